@@ -1,0 +1,227 @@
+"""Synthetic inputs for the SUNK-tagging path: assemblies, exact SUNK sets, ONT-like reads.
+
+Nothing here is on the product hot path.  It exists because the reference ships no
+read data (`.test/data/*.ONT.fa.gz` are absent) and because the
+benchmark configurations of BASELINE.json are defined on synthetic surrogates
+(SURVEY.md §8d, Appendix B).  The SUNK definition below restates, with NumPy, what
+`workflow/rules/defineSUNKs.smk:22-127` obtains from jellyfish/mrsfast/bedtools:
+
+* canonical k-mers with count == 1 over all contigs of both haplotypes
+  (`jellyfish count -C`, `-U 1`; defineSUNKs.smk:39,59),
+* their exact positions (`mrsfast -e 0`, defineSUNKs.smk:101),
+* groups = merged overlapping / book-ended `[start, start+k)` intervals, group
+  id = start of the merged interval (`bedtools merge`, defineSUNKs.smk:124-126).
+"""
+from __future__ import annotations
+
+import gzip
+import io
+from dataclasses import dataclass
+from typing import Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+_ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
+_CODE = np.zeros(256, dtype=np.uint8)  # every byte that is not C/G/T/U maps to 0 ('A')
+for _ch, _v in ((b"Cc", 1), (b"Gg", 2), (b"TtUu", 3)):
+    for _b in _ch:
+        _CODE[_b] = _v
+_IS_ACGT = np.zeros(256, dtype=bool)
+for _b in b"ACGTacgt":
+    _IS_ACGT[_b] = True
+
+
+def ascii_to_codes(seq: bytes | np.ndarray) -> np.ndarray:
+    a = np.frombuffer(seq, dtype=np.uint8) if isinstance(seq, (bytes, bytearray)) else seq
+    return _CODE[a]
+
+
+def codes_to_ascii(codes: np.ndarray) -> bytes:
+    return _ASCII[codes].tobytes()
+
+
+def revcomp_codes(codes: np.ndarray) -> np.ndarray:
+    return (3 - codes[::-1]).astype(np.uint8)
+
+
+def canonical_codes(codes: np.ndarray, k: int) -> np.ndarray:
+    """Canonical 2-bit k-mer code (min of forward and reverse complement, first base
+    most significant) for every window of `codes`; length len-k+1 (empty if len<k)."""
+    n = len(codes) - k + 1
+    if n <= 0:
+        return np.zeros(0, dtype=np.uint64)
+    fwd = np.zeros(n, dtype=np.uint64)
+    rc = np.zeros(n, dtype=np.uint64)
+    c64 = codes.astype(np.uint64)
+    for j in range(k):
+        w = c64[j:j + n]
+        fwd = (fwd << np.uint64(2)) | w
+        rc |= (np.uint64(3) - w) << np.uint64(2 * j)
+    return np.minimum(fwd, rc)
+
+
+def decode_kmer(code: int, k: int) -> str:
+    return "".join("ACGT"[(code >> (2 * (k - 1 - j))) & 3] for j in range(k))
+
+
+@dataclass
+class SunkSet:
+    """SUNKs of an assembly.  Arrays are in `kmer.loc` row order: (contig, start) ascending."""
+    k: int
+    contig_names: List[str]
+    contig_id: np.ndarray  # u32 per SUNK
+    start: np.ndarray      # i64 per SUNK, 0-based
+    code: np.ndarray       # u64 canonical code per SUNK
+    group: np.ndarray      # i64 per SUNK (start of merged interval)
+
+    def __len__(self) -> int:
+        return len(self.code)
+
+    def db_lines(self) -> Iterable[str]:
+        """`jellyfish dump -c`-like list: one canonical k-mer per line (ascending code)."""
+        for c in np.sort(self.code):
+            yield decode_kmer(int(c), self.k)
+
+    def write_db(self, path: str) -> None:
+        with open(path, "w") as f:
+            for s in self.db_lines():
+                f.write(s + "\n")
+
+    def write_loc(self, path: str) -> None:
+        with open(path, "w") as f:
+            for ci, st, cd, g in zip(self.contig_id, self.start, self.code, self.group):
+                f.write(f"{self.contig_names[ci]}\t{int(st)}\t{decode_kmer(int(cd), self.k)}\t{int(g)}\n")
+
+
+def define_sunks(contigs: Sequence[Tuple[str, bytes]], k: int) -> SunkSet:
+    """Exact SUNK set of `contigs` [(name, ascii sequence)] (both haplotypes together)."""
+    codes_all, cid_all, pos_all = [], [], []
+    for ci, (_, seq) in enumerate(contigs):
+        a = np.frombuffer(seq, dtype=np.uint8)
+        cods = _CODE[a]
+        canon = canonical_codes(cods, k)
+        n = len(canon)
+        if n == 0:
+            continue
+        # windows containing a non-ACGT byte are not k-mers (jellyfish skips them)
+        bad = np.concatenate(([0], np.cumsum(~_IS_ACGT[a])))
+        ok = (bad[k:k + n] - bad[:n]) == 0
+        idx = np.nonzero(ok)[0]
+        codes_all.append(canon[idx])
+        cid_all.append(np.full(len(idx), ci, dtype=np.uint32))
+        pos_all.append(idx.astype(np.int64))
+    codes = np.concatenate(codes_all) if codes_all else np.zeros(0, np.uint64)
+    cid = np.concatenate(cid_all) if cid_all else np.zeros(0, np.uint32)
+    pos = np.concatenate(pos_all) if pos_all else np.zeros(0, np.int64)
+    _, first, counts = np.unique(codes, return_index=True, return_counts=True)
+    keep = np.sort(first[counts == 1])  # original order = (contig, pos) ascending
+    codes, cid, pos = codes[keep], cid[keep], pos[keep]
+    group = pos.copy()
+    if len(pos):
+        new = np.ones(len(pos), dtype=bool)
+        new[1:] = (cid[1:] != cid[:-1]) | ((pos[1:] - pos[:-1]) > k)
+        gstart = np.where(new, pos, 0)
+        group = np.maximum.accumulate(np.where(new, np.arange(len(pos)), 0))
+        group = pos[group]
+        del gstart
+    return SunkSet(k, [n for n, _ in contigs], cid, pos, codes, group.astype(np.int64))
+
+
+# ----------------------------------------------------------------------------------
+# genomes
+# ----------------------------------------------------------------------------------
+
+def genome_config2(seed: int = 20, length: int = 5_000_000, n_families: int = 5,
+                   family_len: int = 3000, n_copies: int = 500,
+                   rng: np.random.Generator | None = None) -> Tuple[np.ndarray, np.random.Generator]:
+    """SURVEY.md Appendix B genome: uniform ACGT with pasted repeat-family copies."""
+    rng = rng or np.random.default_rng(seed)
+    seq = rng.integers(0, 4, length, dtype=np.uint8)
+    fams = [rng.integers(0, 4, family_len).astype(np.uint8) for _ in range(n_families)]
+    for c in range(n_copies):
+        p = int(rng.integers(0, length - family_len))
+        seq[p:p + family_len] = fams[c % n_families]
+    return seq, rng
+
+
+def read_fasta(path: str) -> List[Tuple[str, bytes]]:
+    op = gzip.open if path.endswith(".gz") else open
+    out, name, chunks = [], None, []
+    with op(path, "rb") as f:
+        for line in f:
+            line = line.rstrip()
+            if line.startswith(b">"):
+                if name is not None:
+                    out.append((name, b"".join(chunks)))
+                name, chunks = line[1:].split()[0].decode(), []
+            else:
+                chunks.append(line)
+    if name is not None:
+        out.append((name, b"".join(chunks)))
+    return out
+
+
+# ----------------------------------------------------------------------------------
+# reads
+# ----------------------------------------------------------------------------------
+
+def lognormal_lengths(rng: np.random.Generator, n: int, median: float = 20000.0, sigma: float = 0.7,
+                      lo: int = 1000, hi: int = 400000) -> np.ndarray:
+    return np.clip(rng.lognormal(np.log(median), sigma, n).astype(np.int64), lo, hi)
+
+
+def mutate(rng: np.random.Generator, codes: np.ndarray, sub: float, dele: float, ins: float) -> np.ndarray:
+    """ONT-like errors: substitution / deletion / duplicated-base insertion per position."""
+    n = len(codes)
+    x = rng.random(n)
+    out = codes.copy()
+    s = x < sub
+    out[s] = rng.integers(0, 4, int(s.sum()), dtype=np.uint8)
+    rep = np.ones(n, dtype=np.int64)
+    rep[(x >= sub) & (x < sub + dele)] = 0
+    rep[(x >= sub + dele) & (x < sub + dele + ins)] = 2
+    return np.repeat(out, rep)
+
+
+def simulate_reads(rng: np.random.Generator, contigs: Sequence[np.ndarray], lengths: Sequence[int],
+                   sub: float = 0.02, dele: float = 0.02, ins: float = 0.02,
+                   p_reverse: float = 0.5) -> List[np.ndarray]:
+    """Reads (2-bit code arrays) drawn uniformly from `contigs` (code arrays)."""
+    sizes = np.array([len(c) for c in contigs], dtype=np.float64)
+    reads = []
+    for ln in lengths:
+        ci = int(rng.choice(len(contigs), p=sizes / sizes.sum())) if len(contigs) > 1 else 0
+        c = contigs[ci]
+        ln = int(min(ln, len(c) - 1))
+        st = int(rng.integers(0, len(c) - ln))
+        r = c[st:st + ln]
+        if rng.random() < p_reverse:
+            r = revcomp_codes(r)
+        reads.append(mutate(rng, r, sub, dele, ins))
+    return reads
+
+
+def write_fasta(path: str, names: Sequence[str], reads: Sequence[np.ndarray], width: int = 0,
+                fastq: bool = False) -> None:
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "wb") as f:
+        for n, r in zip(names, reads):
+            s = r if isinstance(r, (bytes, bytearray)) else codes_to_ascii(r)
+            if fastq:
+                f.write(b"@" + n.encode() + b"\n" + s + b"\n+\n" + b"#" * len(s) + b"\n")
+            elif width:
+                f.write(b">" + n.encode() + b"\n")
+                for i in range(0, len(s), width):
+                    f.write(s[i:i + width] + b"\n")
+            else:
+                f.write(b">" + n.encode() + b"\n" + s + b"\n")
+
+
+def config2(seed: int = 20, n_reads: int = 10000, k: int = 20, median: float = 20000.0):
+    """BASELINE.json configs[1]: 5 Mb contig, 10 k reads (N50 ~ 30 kb), k = 20."""
+    seq, rng = genome_config2(seed)
+    sunks = define_sunks([("ctg5M", codes_to_ascii(seq))], k)
+    lens = lognormal_lengths(rng, n_reads, median)
+    reads = simulate_reads(rng, [seq], lens)
+    names = [f"r{i}" for i in range(n_reads)]
+    return seq, sunks, names, reads
