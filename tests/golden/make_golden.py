@@ -12,6 +12,7 @@ Cases:
   kat1   tagger quirks Q1 (deflated pos) / Q2 (carry across reads), FASTA + FASTQ(.gz)
   kat2   encoding edge cases: lower case, multi-line FASTA, N->A, duplicate loc key (last wins)
   kat2_missing  k-mer in db but not in loc -> exit code 1
+  short  reads shorter than k (Q6: one 'A'-padded window each)
   kat3-5 diag_filter_v3 / diag_filter_step2: band strictness, fai restriction, tie order, median truncation
   multi_k{20,21,25,31}  3 contigs with repeats, reads on both strands with errors
   amy    cfg 1: real AMY-locus assemblies (.test/data/AMY.hap{1,2}.fa.gz), simulated ONT reads
@@ -164,6 +165,35 @@ def case_kat2(root):
     assert m.tag("reads.fa") == 1
     m.meta["k"] = k
     m.finish()
+
+
+def case_short(root):
+    """Q6: reads shorter than k (the empty read included) still yield ONE window, padded with
+    'A' -- found while building these fixtures; SURVEY.md says otherwise (its KAT-1 r6 simply
+    does not complete to a SUNK)."""
+    c = Case(root, "short")
+    k = 20
+    rnd = random.Random(5)
+    body = "".join(rnd.choice("CGT") for _ in range(400))
+    kms = [body[j * 30:j * 30 + k - j] + "A" * j for j in range(0, 8)]
+    kms += ["C" + "A" * 19, "A" * 20, "GT" + "A" * 18]
+    c.write("db", "".join(canon(x) + "\n" for x in kms))
+    c.write("loc", "".join(f"c{j}\t{j * 100}\t{canon(x)}\t{j * 100}\n" for j, x in enumerate(kms)))
+    longread = "".join(rnd.choice("CGT") for _ in range(5000))
+    recs = []
+    for rep in range(2):
+        for j in range(1, 8):
+            recs.append((f"long{rep}_{j}", longread))
+            recs.append((f"s{rep}_{j}", kms[j][:k - j]))
+    recs += [("one", "C"), ("L2", longread), ("empty", ""), ("two", "GT"), ("empty2", ""), ("empty3", ""),
+             ("one2", "C"), ("n1", "N"), ("x", kms[6][:6] + "A" * 14 + "C"), ("last_empty", "")]
+    c.write("reads.fa", "".join(f">{n}\n{s}\n" for n, s in recs))
+    c.write("reads.fq", "".join(f"@{n}\n{s}\n+\n{'#' * len(s)}\n" for n, s in recs))
+    assert c.tag("reads.fa") == 0
+    assert c.tag("reads.fq", out="expected_fq.sunkpos") == 0
+    c.rlen("reads.fa")
+    c.meta["k"] = k
+    c.finish()
 
 
 def case_diag(root):
@@ -335,6 +365,7 @@ def case_amy(root):
 def build(root):
     case_kat1(root)
     case_kat2(root)
+    case_short(root)
     case_diag(root)
     case_tie(root)
     for k in (20, 21, 25, 31):
