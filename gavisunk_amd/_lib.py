@@ -1,0 +1,105 @@
+"""ctypes binding of libgavisunk.so (include/gavisunk.h).  No fallback: if the library is not
+built, importing the engine fails with instructions instead of silently computing on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgavisunk.so")
+
+GS_OK, GS_E_ARG, GS_E_KEYERROR, GS_E_CAPACITY, GS_E_NODEVICE, GS_E_IO, GS_E_NOMEM = 0, -1, -2, -3, -4, -5, -6
+GS_NONE = 0xFFFFFFFF
+GS_MISSING = 0xFFFFFFFE
+
+
+class GsError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"libgavisunk: {msg} (status {status})")
+        self.status = status
+        self.msg = msg
+
+
+class GsHit(C.Structure):
+    _fields_ = [("read", C.c_uint32), ("pos", C.c_uint32), ("payload", C.c_uint32)]
+
+
+class GsCounters(C.Structure):
+    _fields_ = [("windows", C.c_uint64), ("raw_hits", C.c_uint64), ("emitted", C.c_uint64), ("tiles", C.c_uint64),
+                ("launches", C.c_uint64), ("probe_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# name -> (restype, argtypes): every symbol include/gavisunk.h declares
+P, U32, U64, I = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+SIGNATURES = {
+    "gs_last_error": (C.c_char_p, []),
+    "gs_version": (C.c_char_p, []),
+    "gs_device_count": (I, []),
+    "gs_sunkdb_load": (I, [C.c_char_p, C.c_char_p, C.POINTER(P)]),
+    "gs_sunkdb_free": (None, [P]),
+    "gs_sunkdb_k": (I, [P]),
+    "gs_sunkdb_n_keys": (U64, [P]),
+    "gs_sunkdb_keys": (P, [P]),
+    "gs_sunkdb_key_row": (P, [P]),
+    "gs_sunkdb_key_loc": (P, [P]),
+    "gs_sunkdb_n_rows": (U64, [P]),
+    "gs_sunkdb_row_contig": (P, [P]),
+    "gs_sunkdb_row_start": (P, [P]),
+    "gs_sunkdb_row_group": (P, [P]),
+    "gs_sunkdb_row_loc": (P, [P]),
+    "gs_sunkdb_n_contigs": (U32, [P]),
+    "gs_sunkdb_contig_name": (C.c_char_p, [P, U32]),
+    "gs_fastx_open": (I, [C.c_char_p, C.POINTER(P)]),
+    "gs_fastx_close": (None, [P]),
+    "gs_fastx_next_batch": (I, [P, U64, U32, C.POINTER(P)]),
+    "gs_batch_free": (None, [P]),
+    "gs_batch_n_reads": (U32, [P]),
+    "gs_batch_n_bases": (U64, [P]),
+    "gs_batch_words": (P, [P]),
+    "gs_batch_n_words": (U64, [P]),
+    "gs_batch_word_off": (P, [P]),
+    "gs_batch_len": (P, [P]),
+    "gs_batch_name": (C.c_char_p, [P, U32]),
+    "gs_batch_from_ascii": (I, [P, P, U32, C.POINTER(P)]),
+    "gs_table_create": (I, [I, I, U64, P, P, P, C.POINTER(P)]),
+    "gs_table_destroy": (None, [P]),
+    "gs_table_bytes": (U64, [P]),
+    "gs_reads_upload": (I, [I, P, U64, P, P, U32, I, C.POINTER(P)]),
+    "gs_reads_destroy": (None, [P]),
+    "gs_reads_n_bases": (U64, [P]),
+    "gs_reads_n_windows": (U64, [P]),
+    "gs_tag": (I, [P, P, U32, P, U64, C.POINTER(U64), C.POINTER(U32), C.POINTER(GsCounters)]),
+    "gs_tag_launch": (I, [P, P, U32]),
+    "gs_tag_finish": (I, [P, P, P, U64, C.POINTER(U64), C.POINTER(U32), C.POINTER(GsCounters)]),
+    "gs_tag_phase1": (I, [P, P, C.POINTER(U32), C.POINTER(U32)]),
+    "gs_tag_phase2": (I, [P, P, U32]),
+    "gs_tag_hits_to_host": (I, [P, P, P, U64, C.POINTER(U64)]),
+    "gs_tag_hits_to_device": (I, [P, P, P, U64, C.POINTER(U64)]),
+    "gs_counters_reset": (None, [P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m gavisunk_amd.build` "
+                "(hipcc, gfx950).  gavisunk_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != GS_OK:
+        raise GsError(status, lib().gs_last_error().decode(errors="replace"))

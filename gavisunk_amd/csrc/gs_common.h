@@ -1,0 +1,59 @@
+// Internal declarations shared by the host (gs_host.cpp) and device (gs_device.hip) halves of
+// libgavisunk.so.  The public contract is include/gavisunk.h.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "gavisunk.h"
+
+namespace gs {
+
+void set_error(const char *fmt, ...);
+
+// nim-kmer 0.2.6 `encode` byte table (A/a 0, C/c 1, G/g 2, T/t/U/u 3, everything else 0).
+struct EncodeTable {
+    uint8_t v[256];
+    constexpr EncodeTable() : v{} {
+        v['C'] = v['c'] = 1;
+        v['G'] = v['g'] = 2;
+        v['T'] = v['t'] = v['U'] = v['u'] = 3;
+    }
+};
+inline constexpr EncodeTable kEncode{};
+
+inline uint8_t enc(uint8_t c) { return kEncode.v[c]; }
+
+inline uint64_t encode_kmer(const char *s, size_t n) {
+    uint64_t c = 0;
+    for (size_t i = 0; i < n; i++) c = (c << 2) | kEncode.v[(uint8_t)s[i]];
+    return c;
+}
+
+constexpr int kTileWindows = 2048;  // windows per tile = 64 lanes x 32 windows (one 64-bit word per lane)
+constexpr int kTileWords = 64;
+
+}  // namespace gs
+
+struct gs_sunkdb {
+    int k = 0;
+    std::vector<uint64_t> keys;     // distinct db codes, first-seen order
+    std::vector<uint32_t> key_row;  // winning loc row or GS_MISSING
+    std::vector<uint32_t> key_loc;  // dense (contig, group) id or GS_MISSING
+    std::vector<uint32_t> row_contig;
+    std::vector<int64_t> row_start;
+    std::vector<int64_t> row_group;
+    std::vector<uint32_t> row_loc;
+    std::vector<std::string> contigs;
+};
+
+struct gs_batch {
+    std::vector<uint64_t> words;
+    std::vector<uint64_t> word_off;  // n_reads + 1
+    std::vector<uint32_t> len;
+    std::vector<char> names;         // NUL-terminated, back to back
+    std::vector<uint64_t> name_off;
+    uint64_t bases = 0;
+};

@@ -1,0 +1,887 @@
+// Device half of libgavisunk.so: the SUNK tagger of GAVISUNK (workflow/src/kmerpos_annot3.nim)
+// as hand-written HIP for gfx950 (MI355X, wave64).  Pure integer / indexing work, HBM-bound.
+//
+// Data layout in HBM
+//   reads   2 bits/base, 32 bases per uint64 (first base most significant); every read starts
+//           on a word boundary and is followed by >= 1 zero word.
+//   tiles   a read is cut into tiles of 2048 windows = 64 words; one wavefront owns one tile,
+//           lane l owns word l = windows [32 l, 32 l + 32) of the tile and rolls one canonical
+//           k-mer code across them.
+//   table   open-addressed, linear probing, 16-byte slots {key u64, loc u32, payload u32},
+//           load <= 0.5; hash = (key * golden) >> shift.
+//
+// The pass (one `gs_tag`):
+//   k_probe    every window -> canonical code -> table probe.  Per lane a 32-bit raw-hit mask and
+//              a 32-bit "location changed" mask; per tile {n_raw, first loc, last loc} and the
+//              ordered list of candidates (hits whose loc differs from the previous raw hit of
+//              the tile; the tile's first raw hit is always a candidate).
+//   scan A     over tiles: raw-hit prefix and the loc carried into each tile
+//              (`prevLoc` of kmerpos_annot3.nim:82-84 crosses reads, so the scan is global).
+//   k_resolve  drops a tile's first candidate when it equals the carried loc.
+//   scan B     emitted-hit prefix.
+//   k_emit     pos = window - (raw hits before it in the read - emitted hits before it in the
+//              read)  [`continue` at kmerpos_annot3.nim:92 skips `inc i` at :96], payload by
+//              re-probing the (rare) emitted windows; writes gs_hit in stream order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "gs_common.h"
+
+using namespace gs;
+
+namespace {
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GS_E_NODEVICE;                                                             \
+        }                                                                                     \
+    } while (0)
+
+struct __align__(16) Slot {
+    uint64_t key;
+    uint32_t loc;
+    uint32_t payload;
+};
+constexpr uint64_t kEmptyKey = ~0ULL;  // never a canonical code (k < 32: too wide; k = 32: poly-T is not canonical)
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ULL;
+
+struct TableView {
+    const Slot *slots;
+    uint64_t mask;
+    int shift;
+    int k;
+};
+
+struct ReadsView {
+    const uint64_t *words;
+    const uint64_t *read_word_off;  // per read
+    const uint32_t *read_nwin;      // per read: max(len - k + 1, 1)   (Q6: short reads give one window)
+    const uint32_t *read_tile0;     // per read: first tile
+    const uint32_t *tile_read;      // per tile
+    uint32_t n_tiles;
+};
+
+struct TileArrays {
+    uint32_t *n_raw, *n_cand, *first_loc, *last_loc, *cand_off, *n_emit, *carry_loc;
+    uint64_t *raw_prefix, *emit_prefix;
+};
+
+__device__ __forceinline__ uint64_t revpairs(uint64_t x) {
+    x = __brevll(x);
+    return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+}
+
+// canonical code of the window that starts at base `b` (0..31) of the 64-base string (a:b2)
+__device__ __forceinline__ uint64_t canon_at(uint64_t a, uint64_t b2, uint64_t ra, uint64_t rb, int b, int k,
+                                             uint64_t kmask) {
+    const int s = 2 * b;
+    const uint64_t f = (s ? ((a << s) | (b2 >> (64 - s))) : a) >> (64 - 2 * k);
+    const uint64_t r = (s ? ((ra >> s) | (rb << (64 - s))) : ra) & kmask;
+    return f < r ? f : r;
+}
+
+__device__ __forceinline__ uint64_t slot_of(uint64_t key, int shift) { return (key * kGolden) >> shift; }
+
+__device__ __forceinline__ Slot load_slot(const Slot *p) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+    Slot s;
+    s.key = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    s.loc = v.z;
+    s.payload = v.w;
+    return s;
+}
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t &total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_probe: one wavefront per tile
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_probe(TableView tab, ReadsView rd, TileArrays ta, uint32_t *cand,
+                                               uint32_t cand_cap, uint32_t *g_cand_count,
+                                               unsigned long long *g_err_pos) {
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= rd.n_tiles) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t r = rd.tile_read[tile];
+    const uint32_t tin = tile - rd.read_tile0[r];
+    const uint64_t wbase = rd.read_word_off[r] + (uint64_t)tin * kTileWords;
+    const uint32_t nwin = rd.read_nwin[r];
+    const uint32_t w0 = tin * kTileWindows + lane * 32;
+    const uint32_t nvalid = nwin > w0 ? min(nwin - w0, 32u) : 0u;
+    const uint32_t vmask = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
+
+    const int k = tab.k;
+    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    uint64_t a = 0, b2 = 0;
+    if (nvalid) {
+        a = rd.words[wbase + lane];
+        b2 = rd.words[wbase + lane + 1];
+    }
+    const uint64_t ra = ~revpairs(a), rb = ~revpairs(b2);
+
+    uint32_t raw = 0, chg = 0;  // raw-hit mask, "loc differs from the previous raw hit of this lane" mask
+    uint32_t first_loc = GS_NONE, prev = GS_NONE;
+    bool missing = false;
+    uint32_t missing_bit = 0;
+
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint64_t c[8], h[8];
+        Slot s[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c[j] = canon_at(a, b2, ra, rb, g * 8 + j, k, kmask);
+            h[j] = slot_of(c[j], tab.shift);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = load_slot(tab.slots + h[j]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int bb = g * 8 + j;
+            Slot cur = s[j];
+            uint64_t hh = h[j];
+            while (cur.key != c[j] && cur.key != kEmptyKey) {
+                hh = (hh + 1) & tab.mask;
+                cur = load_slot(tab.slots + hh);
+            }
+            if (cur.key == c[j] && ((vmask >> bb) & 1u)) {
+                raw |= 1u << bb;
+                if (prev == GS_NONE) {
+                    first_loc = cur.loc;
+                } else if (cur.loc != prev) {
+                    chg |= 1u << bb;
+                }
+                prev = cur.loc;
+                if (cur.loc == GS_MISSING && !missing) {
+                    missing = true;
+                    missing_bit = bb;
+                }
+            }
+        }
+    }
+    if (missing) atomicMin(g_err_pos, ((unsigned long long)tile << 32) | (uint32_t)(lane * 32 + missing_bit));
+
+    // loc of the nearest raw hit in a lower lane of this tile
+    const unsigned long long ne = __ballot(raw != 0);
+    const unsigned long long below = ne & ((1ULL << lane) - 1ULL);
+    const int src = below ? 63 - __clzll((long long)below) : -1;
+    const uint32_t prev_lane_loc = __shfl(prev, src < 0 ? 0 : src);
+    if (raw && (src < 0 || first_loc != prev_lane_loc)) chg |= 1u << (__ffs(raw) - 1);
+
+    uint32_t tot_raw, tot_cand;
+    const uint32_t ex_raw = wave_excl_scan(__popc(raw), lane, tot_raw);
+    const uint32_t ex_cand = wave_excl_scan(__popc(chg), lane, tot_cand);
+
+    uint32_t off = 0;
+    if (lane == 0 && tot_cand) off = atomicAdd(g_cand_count, tot_cand);
+    off = __shfl(off, 0);
+    if (tot_cand && (uint64_t)off + tot_cand <= cand_cap) {
+        uint32_t m = chg, i = 0;
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            const uint32_t woff = lane * 32 + bit;
+            const uint32_t rank = ex_raw + __popc(raw & ((1u << bit) - 1u));
+            cand[off + ex_cand + i] = (rank << 16) | woff;
+            i++;
+        }
+    }
+    if (ne) {
+        const int lo = __ffsll((unsigned long long)ne) - 1, hi = 63 - __clzll((long long)ne);
+        const uint32_t fl = __shfl(first_loc, lo), ll = __shfl(prev, hi);
+        if (lane == 0) {
+            ta.first_loc[tile] = fl;
+            ta.last_loc[tile] = ll;
+        }
+    }
+    if (lane == 0) {
+        ta.n_raw[tile] = tot_raw;
+        ta.n_cand[tile] = tot_cand;
+        ta.cand_off[tile] = off;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// tile scans (3 launches each): exclusive scan of {sum, last non-empty loc}
+// ------------------------------------------------------------------------------------------
+struct Agg {
+    uint64_t sum;
+    uint32_t loc;
+    uint32_t has;
+};
+__device__ __forceinline__ Agg combine(const Agg &l, const Agg &r) {
+    Agg o;
+    o.sum = l.sum + r.sum;
+    o.has = l.has | r.has;
+    o.loc = r.has ? r.loc : l.loc;
+    return o;
+}
+__device__ __forceinline__ Agg agg_shfl_up(const Agg &a, int d) {
+    Agg o;
+    o.sum = __shfl_up((unsigned long long)a.sum, d);
+    o.loc = __shfl_up(a.loc, d);
+    o.has = __shfl_up(a.has, d);
+    return o;
+}
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanBlock = kScanThreads * kScanItems;
+
+// mode 0: element = {n_raw[t], last_loc[t], n_raw[t] > 0};  mode 1: element = {n_emit[t], -, 0}
+__device__ __forceinline__ Agg scan_elem(const TileArrays &ta, uint32_t t, uint32_t n, int mode) {
+    Agg e{0, GS_NONE, 0};
+    if (t < n) {
+        if (mode == 0) {
+            const uint32_t nr = ta.n_raw[t];
+            e.sum = nr;
+            e.has = nr ? 1u : 0u;
+            e.loc = nr ? ta.last_loc[t] : GS_NONE;
+        } else {
+            e.sum = ta.n_emit[t];
+        }
+    }
+    return e;
+}
+
+// Exclusive block scan of per-thread aggregates; returns the thread's exclusive prefix and the block total.
+__device__ __forceinline__ Agg block_excl_scan(const Agg &mine, Agg &block_total) {
+    __shared__ Agg wave_tot[kScanThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Agg inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Agg y = agg_shfl_up(inc, d);
+        if (lane >= d) inc = combine(y, inc);
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    Agg pre{0, GS_NONE, 0};
+    for (int w = 0; w < wave; w++) pre = combine(pre, wave_tot[w]);
+    Agg tot{0, GS_NONE, 0};
+    for (int w = 0; w < kScanThreads / 64; w++) tot = combine(tot, wave_tot[w]);
+    block_total = tot;
+    Agg prev = agg_shfl_up(inc, 1);
+    if (lane == 0) prev = Agg{0, GS_NONE, 0};
+    __syncthreads();
+    return combine(pre, prev);
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_reduce(TileArrays ta, uint32_t n, int mode, Agg *block_agg) {
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
+    Agg a{0, GS_NONE, 0};
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) a = combine(a, scan_elem(ta, base + i, n, mode));
+    Agg tot;
+    block_excl_scan(a, tot);
+    if (threadIdx.x == 0) block_agg[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of block aggregates in place, seeded with `seed_loc` (the carry-in)
+__global__ __launch_bounds__(kScanThreads) void k_scan_blocks(Agg *block_agg, uint32_t nblocks, const uint32_t *seed_loc,
+                                                              Agg *grand_total) {
+    Agg run{0, GS_NONE, 0};
+    if (seed_loc && *seed_loc != GS_NONE) {
+        run.loc = *seed_loc;
+        run.has = 1;
+    }
+    for (uint32_t base = 0; base < nblocks; base += kScanThreads) {
+        const uint32_t i = base + threadIdx.x;
+        Agg mine = i < nblocks ? block_agg[i] : Agg{0, GS_NONE, 0};
+        Agg tot;
+        Agg ex = block_excl_scan(mine, tot);
+        if (i < nblocks) block_agg[i] = combine(run, ex);
+        run = combine(run, tot);
+    }
+    if (threadIdx.x == 0) *grand_total = run;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(TileArrays ta, uint32_t n, int mode, const Agg *block_agg) {
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
+    Agg e[kScanItems];
+    Agg a{0, GS_NONE, 0};
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        e[i] = scan_elem(ta, base + i, n, mode);
+        a = combine(a, e[i]);
+    }
+    Agg tot;
+    Agg run = combine(block_agg[blockIdx.x], block_excl_scan(a, tot));
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        const uint32_t t = base + i;
+        if (t < n) {
+            if (mode == 0) {
+                ta.raw_prefix[t] = run.sum;
+                const uint32_t carry = run.has ? run.loc : GS_NONE;
+                ta.carry_loc[t] = carry;
+                // k_resolve fused: the tile's first candidate is suppressed when it repeats the carried loc
+                const uint32_t nr = ta.n_raw[t];
+                const uint32_t supp = (nr && carry != GS_NONE && ta.first_loc[t] == carry) ? 1u : 0u;
+                ta.n_emit[t] = ta.n_cand[t] - supp;
+            } else {
+                ta.emit_prefix[t] = run.sum;
+            }
+        }
+        run = combine(run, e[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_emit: one thread per tile
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit(TableView tab, ReadsView rd, TileArrays ta, const uint32_t *cand,
+                                              uint32_t cand_cap, gs_hit *hits, uint64_t hit_cap) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= rd.n_tiles) return;
+    const uint32_t nc = ta.n_cand[tile];
+    if (!nc) return;
+    const uint32_t ne = ta.n_emit[tile];
+    const uint32_t supp = nc - ne;
+    const uint32_t off = ta.cand_off[tile];
+    if ((uint64_t)off + nc > cand_cap) return;  // overflowed pass; the host re-runs with a larger buffer
+    const uint32_t r = rd.tile_read[tile];
+    const uint32_t t0 = rd.read_tile0[r];
+    const uint32_t tin = tile - t0;
+    const uint64_t raw_before = ta.raw_prefix[tile] - ta.raw_prefix[t0];
+    const uint64_t emit_before = ta.emit_prefix[tile] - ta.emit_prefix[t0];
+    const uint64_t out0 = ta.emit_prefix[tile];
+    const uint64_t rwoff = rd.read_word_off[r];
+    const int k = tab.k;
+    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    for (uint32_t j = supp; j < nc; j++) {
+        const uint32_t cv = cand[off + j];
+        const uint32_t woff = cv & 0xFFFFu, rank = cv >> 16;
+        const uint32_t w = tin * kTileWindows + woff;
+        const uint64_t suppressed_before = (raw_before + rank) - (emit_before + (j - supp));
+        const uint64_t o = out0 + (j - supp);
+        if (o >= hit_cap) return;
+        // payload: re-probe this one window
+        const uint64_t wi = rwoff + (w >> 5);
+        const uint64_t a = rd.words[wi], b2 = rd.words[wi + 1];
+        const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(w & 31u), k, kmask);
+        uint64_t hh = slot_of(c, tab.shift);
+        Slot cur = load_slot(tab.slots + hh);
+        while (cur.key != c && cur.key != kEmptyKey) {
+            hh = (hh + 1) & tab.mask;
+            cur = load_slot(tab.slots + hh);
+        }
+        gs_hit hrec;
+        hrec.read = r;
+        hrec.pos = (uint32_t)(w - suppressed_before);
+        hrec.payload = cur.payload;
+        hits[o] = hrec;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// table build
+// ------------------------------------------------------------------------------------------
+__global__ void k_table_fill(Slot *slots, uint64_t cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        uint4 v;
+        v.x = 0xFFFFFFFFu;
+        v.y = 0xFFFFFFFFu;
+        v.z = GS_NONE;
+        v.w = 0;
+        *reinterpret_cast<uint4 *>(slots + i) = v;
+    }
+}
+
+__global__ void k_table_insert(Slot *slots, uint64_t mask, int shift, const uint64_t *keys, const uint32_t *loc,
+                               const uint32_t *payload, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    uint64_t h = slot_of(key, shift);
+    for (;;) {
+        unsigned long long *kp = reinterpret_cast<unsigned long long *>(&slots[h].key);
+        const unsigned long long old = atomicCAS(kp, (unsigned long long)kEmptyKey, (unsigned long long)key);
+        if (old == kEmptyKey || old == key) {  // keys are distinct; `old == key` only on a re-run
+            slots[h].loc = loc[i];
+            slots[h].payload = payload[i];
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+template <typename T>
+int dev_alloc(T **p, uint64_t n) {
+    *p = nullptr;
+    HIP_TRY(hipMalloc((void **)p, std::max<uint64_t>(n, 1) * sizeof(T)));
+    return GS_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// handles
+// ==========================================================================================
+struct gs_table {
+    int device = 0;
+    int k = 0;
+    uint64_t n = 0, cap = 0;
+    int shift = 0;
+    Slot *slots = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // scalars on device
+    uint32_t *d_cand_count = nullptr;
+    unsigned long long *d_err_pos = nullptr;
+    uint32_t *d_carry_in = nullptr;
+    Agg *d_totals = nullptr;  // [0] scan A grand total, [1] scan B grand total
+    gs_counters ctr{};
+    bool pass_pending = false;
+    uint32_t last_carry_in = GS_NONE;
+    // outcome of the last settled pass
+    const struct gs_reads *settled_reads = nullptr;
+    uint64_t res_n = 0;
+    uint32_t res_carry = GS_NONE;
+    bool res_keyerr = false;
+};
+
+struct gs_reads {
+    int device = 0;
+    int k = 0;
+    uint32_t n_reads = 0;
+    uint32_t n_tiles = 0;
+    uint64_t n_bases = 0, n_windows = 0, n_words = 0;
+    uint64_t *words = nullptr;
+    uint64_t *read_word_off = nullptr;
+    uint32_t *read_nwin = nullptr, *read_tile0 = nullptr, *tile_read = nullptr;
+    TileArrays ta{};
+    Agg *block_agg = nullptr;
+    uint32_t n_scan_blocks = 0;
+    uint32_t *cand = nullptr;
+    uint32_t cand_cap = 0;
+    gs_hit *hits = nullptr;
+    uint64_t hit_cap = 0;
+};
+
+namespace {
+
+TableView view(const gs_table *t) { return TableView{t->slots, t->cap - 1, t->shift, t->k}; }
+ReadsView view(const gs_reads *r) {
+    return ReadsView{r->words, r->read_word_off, r->read_nwin, r->read_tile0, r->tile_read, r->n_tiles};
+}
+
+int ensure_out_buffers(gs_reads *r, uint32_t cand_cap) {
+    if (r->cand && r->cand_cap >= cand_cap) return GS_OK;
+    if (r->cand) (void)hipFree(r->cand);
+    if (r->hits) (void)hipFree(r->hits);
+    r->cand = nullptr;
+    r->hits = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&r->cand, cand_cap))) return rc;
+    if ((rc = dev_alloc(&r->hits, cand_cap))) return rc;
+    r->cand_cap = cand_cap;
+    r->hit_cap = cand_cap;
+    return GS_OK;
+}
+
+int launch_phase1(gs_table *t, gs_reads *r) {
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipMemsetAsync(t->d_cand_count, 0, sizeof(uint32_t), t->stream));
+    HIP_TRY(hipMemsetAsync(t->d_err_pos, 0xFF, sizeof(unsigned long long), t->stream));
+    HIP_TRY(hipEventRecord(t->ev[0], t->stream));
+    if (r->n_tiles) {
+        const uint32_t blocks = (r->n_tiles + 3) / 4;
+        hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(256), 0, t->stream, view(t), view(r), r->ta, r->cand,
+                           r->cand_cap, t->d_cand_count, t->d_err_pos);
+    }
+    HIP_TRY(hipEventRecord(t->ev[1], t->stream));
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+int launch_scan(gs_table *t, gs_reads *r, int mode) {
+    const uint32_t nb = r->n_scan_blocks;
+    if (!r->n_tiles) {
+        Agg z{0, GS_NONE, 0};
+        if (mode == 0 && t->last_carry_in != GS_NONE) {
+            z.loc = t->last_carry_in;
+            z.has = 1;
+        }
+        HIP_TRY(hipMemcpyAsync(t->d_totals + mode, &z, sizeof z, hipMemcpyHostToDevice, t->stream));
+        return GS_OK;
+    }
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanThreads), 0, t->stream, r->ta, r->n_tiles, mode, r->block_agg);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanThreads), 0, t->stream, r->block_agg, nb,
+                       mode == 0 ? t->d_carry_in : (const uint32_t *)nullptr, t->d_totals + mode);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanThreads), 0, t->stream, r->ta, r->n_tiles, mode, r->block_agg);
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
+    HIP_TRY(hipSetDevice(t->device));
+    t->last_carry_in = carry_in;
+    HIP_TRY(hipMemcpyAsync(t->d_carry_in, &t->last_carry_in, sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+    int rc;
+    if ((rc = launch_scan(t, r, 0))) return rc;
+    if ((rc = launch_scan(t, r, 1))) return rc;
+    if (r->n_tiles) {
+        hipLaunchKernelGGL(k_emit, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, view(t), view(r), r->ta,
+                           r->cand, r->cand_cap, r->hits, r->hit_cap);
+    }
+    HIP_TRY(hipEventRecord(t->ev[2], t->stream));
+    HIP_TRY(hipGetLastError());
+    t->pass_pending = true;
+    t->settled_reads = nullptr;
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const uint32_t *loc, const uint32_t *payload,
+                    gs_table **out) {
+    if (!out || k < 1 || k > 32 || (n && (!keys || !loc || !payload))) {
+        set_error("gs_table_create: bad argument (k must be 1..32)");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_table_create: HIP device %d not available (%d devices) -- there is no CPU fallback", device,
+                  gs_device_count());
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    auto *t = new gs_table();
+    t->device = device;
+    t->k = k;
+    t->n = n;
+    uint64_t cap = 1024;
+    int lg = 10;
+    while (cap < 2 * n) {
+        cap <<= 1;
+        lg++;
+    }
+    t->cap = cap;
+    t->shift = 64 - lg;
+    int rc;
+    if ((rc = dev_alloc(&t->slots, cap))) return rc;
+    HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    for (auto &e : t->ev) HIP_TRY(hipEventCreate(&e));
+    if ((rc = dev_alloc(&t->d_cand_count, 1))) return rc;
+    if ((rc = dev_alloc(&t->d_err_pos, 1))) return rc;
+    if ((rc = dev_alloc(&t->d_carry_in, 1))) return rc;
+    if ((rc = dev_alloc(&t->d_totals, 2))) return rc;
+    hipLaunchKernelGGL(k_table_fill, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, t->stream, t->slots, cap);
+    if (n) {
+        uint64_t *dk;
+        uint32_t *dl, *dp;
+        if ((rc = dev_alloc(&dk, n)) || (rc = dev_alloc(&dl, n)) || (rc = dev_alloc(&dp, n))) return rc;
+        HIP_TRY(hipMemcpyAsync(dk, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(dl, loc, n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(dp, payload, n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+        hipLaunchKernelGGL(k_table_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, t->slots, cap - 1,
+                           t->shift, dk, dl, dp, n);
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        (void)hipFree(dk);
+        (void)hipFree(dl);
+        (void)hipFree(dp);
+    }
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    HIP_TRY(hipGetLastError());
+    *out = t;
+    return GS_OK;
+}
+
+void gs_table_destroy(gs_table *t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    (void)hipFree(t->slots);
+    (void)hipFree(t->d_cand_count);
+    (void)hipFree(t->d_err_pos);
+    (void)hipFree(t->d_carry_in);
+    (void)hipFree(t->d_totals);
+    for (auto &e : t->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+}
+
+uint64_t gs_table_bytes(const gs_table *t) { return t ? t->cap * sizeof(Slot) : 0; }
+
+int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off, const uint32_t *len,
+                    uint32_t n_reads, int k, gs_reads **out) {
+    if (!out || k < 1 || k > 32 || (n_reads && (!words || !word_off || !len))) {
+        set_error("gs_reads_upload: bad argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_reads_upload: HIP device %d not available -- there is no CPU fallback", device);
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    auto *r = new gs_reads();
+    r->device = device;
+    r->k = k;
+    r->n_reads = n_reads;
+    r->n_words = n_words;
+    std::vector<uint32_t> nwin(n_reads), tile0(n_reads);
+    std::vector<uint32_t> tile_read;
+    uint64_t tiles = 0;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        const uint32_t l = len[i];
+        // the kernel reads words [w, w+1] of a window's first base: check the packing promise
+        const uint64_t have = word_off[i + 1] - word_off[i];
+        if (have < (uint64_t)(l + 31) / 32 + 1) {
+            set_error("gs_reads_upload: read %u has %llu words for %u bases; need ceil(len/32)+1", i,
+                      (unsigned long long)have, l);
+            delete r;
+            return GS_E_ARG;
+        }
+        nwin[i] = l >= (uint32_t)k ? l - (uint32_t)k + 1 : 1u;  // Q6: a short read still yields one window
+        tile0[i] = (uint32_t)tiles;
+        const uint32_t nt = (nwin[i] + kTileWindows - 1) / kTileWindows;
+        tiles += nt;
+        if (tiles > 0xFFFF0000ull) {
+            set_error("gs_reads_upload: batch too large (%llu tiles); split it", (unsigned long long)tiles);
+            delete r;
+            return GS_E_ARG;
+        }
+        tile_read.insert(tile_read.end(), nt, i);
+        r->n_bases += l;
+        r->n_windows += nwin[i];
+    }
+    r->n_tiles = (uint32_t)tiles;
+    int rc;
+    // +2 zero words of slack: the last lane of the last tile loads one word past its own
+    if ((rc = dev_alloc(&r->words, n_words + 2))) return rc;
+    HIP_TRY(hipMemset(r->words, 0, (n_words + 2) * sizeof(uint64_t)));
+    if ((rc = dev_alloc(&r->read_word_off, (uint64_t)n_reads + 1))) return rc;
+    if ((rc = dev_alloc(&r->read_nwin, n_reads)) || (rc = dev_alloc(&r->read_tile0, n_reads)) ||
+        (rc = dev_alloc(&r->tile_read, tiles)))
+        return rc;
+    if (n_words) HIP_TRY(hipMemcpy(r->words, words, n_words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (n_reads) {
+        HIP_TRY(hipMemcpy(r->read_word_off, word_off, ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(r->read_nwin, nwin.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(r->read_tile0, tile0.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (tiles) HIP_TRY(hipMemcpy(r->tile_read, tile_read.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+    TileArrays &ta = r->ta;
+    if ((rc = dev_alloc(&ta.n_raw, tiles)) || (rc = dev_alloc(&ta.n_cand, tiles)) || (rc = dev_alloc(&ta.first_loc, tiles)) ||
+        (rc = dev_alloc(&ta.last_loc, tiles)) || (rc = dev_alloc(&ta.cand_off, tiles)) || (rc = dev_alloc(&ta.n_emit, tiles)) ||
+        (rc = dev_alloc(&ta.carry_loc, tiles)) || (rc = dev_alloc(&ta.raw_prefix, tiles)) ||
+        (rc = dev_alloc(&ta.emit_prefix, tiles)))
+        return rc;
+    r->n_scan_blocks = (uint32_t)((tiles + kScanBlock - 1) / kScanBlock);
+    if ((rc = dev_alloc(&r->block_agg, r->n_scan_blocks))) return rc;
+    const uint64_t want = std::min<uint64_t>(4 * tiles + 65536, 0xFFFFFFFFull);
+    if ((rc = ensure_out_buffers(r, (uint32_t)want))) return rc;
+    *out = r;
+    return GS_OK;
+}
+
+void gs_reads_destroy(gs_reads *r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(r->words);
+    (void)hipFree(r->read_word_off);
+    (void)hipFree(r->read_nwin);
+    (void)hipFree(r->read_tile0);
+    (void)hipFree(r->tile_read);
+    TileArrays &ta = r->ta;
+    (void)hipFree(ta.n_raw);
+    (void)hipFree(ta.n_cand);
+    (void)hipFree(ta.first_loc);
+    (void)hipFree(ta.last_loc);
+    (void)hipFree(ta.cand_off);
+    (void)hipFree(ta.n_emit);
+    (void)hipFree(ta.carry_loc);
+    (void)hipFree(ta.raw_prefix);
+    (void)hipFree(ta.emit_prefix);
+    (void)hipFree(r->block_agg);
+    (void)hipFree(r->cand);
+    (void)hipFree(r->hits);
+    delete r;
+}
+
+uint64_t gs_reads_n_bases(const gs_reads *r) { return r ? r->n_bases : 0; }
+uint64_t gs_reads_n_windows(const gs_reads *r) { return r ? r->n_windows : 0; }
+
+static int check_pair(const gs_table *t, const gs_reads *r, const char *who) {
+    if (!t || !r) {
+        set_error("%s: null handle", who);
+        return GS_E_ARG;
+    }
+    if (t->device != r->device || t->k != r->k) {
+        set_error("%s: table (device %d, k %d) and reads (device %d, k %d) do not match", who, t->device, t->k,
+                  r->device, r->k);
+        return GS_E_ARG;
+    }
+    return GS_OK;
+}
+
+int gs_tag_launch(gs_table *t, gs_reads *r, uint32_t carry_in) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_launch"))) return rc;
+    if ((rc = launch_phase1(t, r))) return rc;
+    return launch_phase2(t, r, carry_in);
+}
+
+int gs_tag_phase1(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_loc) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_phase1"))) return rc;
+    if ((rc = launch_phase1(t, r))) return rc;
+    // summary = scan A with no carry-in; cheap, and phase 2 redoes it with the true carry
+    t->last_carry_in = GS_NONE;
+    HIP_TRY(hipMemcpyAsync(t->d_carry_in, &t->last_carry_in, sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+    if ((rc = launch_scan(t, r, 0))) return rc;
+    Agg tot;
+    HIP_TRY(hipMemcpyAsync(&tot, t->d_totals, sizeof tot, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    if (has_raw) *has_raw = tot.has;
+    if (last_loc) *last_loc = tot.has ? tot.loc : GS_NONE;
+    return GS_OK;
+}
+
+int gs_tag_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_phase2"))) return rc;
+    return launch_phase2(t, r, carry_in);
+}
+
+// Waits for the pass and caches its outcome in the table handle (idempotent until the next launch).
+// A candidate-buffer overflow (more location changes than budgeted) grows the buffer and re-runs.
+static int settle(gs_table *t, gs_reads *r) {
+    if (!t->pass_pending) {
+        if (t->settled_reads == r) return GS_OK;
+        set_error("no tagging pass was launched for this (table, reads) pair");
+        return GS_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(t->device));
+    for (int attempt = 0; attempt < 8; attempt++) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        uint32_t ncand = 0;
+        unsigned long long err = ~0ULL;
+        Agg tot[2];
+        HIP_TRY(hipMemcpy(&ncand, t->d_cand_count, sizeof ncand, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&err, t->d_err_pos, sizeof err, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tot, t->d_totals, sizeof tot, hipMemcpyDeviceToHost));
+        if (ncand > r->cand_cap) {
+            int rc;
+            if ((rc = ensure_out_buffers(r, (uint32_t)std::min<uint64_t>((uint64_t)ncand + 65536, 0xFFFFFFFFull)))) return rc;
+            if ((rc = launch_phase1(t, r))) return rc;
+            if ((rc = launch_phase2(t, r, t->last_carry_in))) return rc;
+            continue;
+        }
+        float ms01 = 0, ms02 = 0;
+        HIP_TRY(hipEventElapsedTime(&ms01, t->ev[0], t->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms02, t->ev[0], t->ev[2]));
+        t->ctr.probe_ms += ms01;
+        t->ctr.total_ms += ms02;
+        t->ctr.launches += 1;
+        t->ctr.windows = r->n_windows;
+        t->ctr.tiles = r->n_tiles;
+        t->ctr.raw_hits = tot[0].sum;
+        t->ctr.emitted = tot[1].sum;
+        t->res_n = tot[1].sum;
+        t->res_carry = tot[0].has ? tot[0].loc : GS_NONE;
+        t->res_keyerr = err != ~0ULL;
+        if (t->res_keyerr) {
+            // hits emitted before the offending window = emit_prefix of its tile + its earlier candidates
+            const uint32_t tile = (uint32_t)(err >> 32), woff = (uint32_t)err;
+            uint64_t ep = 0;
+            uint32_t nc = 0, ne = 0, off = 0;
+            HIP_TRY(hipMemcpy(&ep, r->ta.emit_prefix + tile, sizeof ep, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&nc, r->ta.n_cand + tile, sizeof nc, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&ne, r->ta.n_emit + tile, sizeof ne, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&off, r->ta.cand_off + tile, sizeof off, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> cv(nc);
+            if (nc) HIP_TRY(hipMemcpy(cv.data(), r->cand + off, nc * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            uint64_t before = 0;
+            for (uint32_t j = nc - ne; j < nc; j++)
+                if ((cv[j] & 0xFFFFu) < woff) before++;
+            t->res_n = ep + before;
+        }
+        t->pass_pending = false;
+        t->settled_reads = r;
+        return GS_OK;
+    }
+    set_error("gs_tag: candidate buffer kept overflowing");
+    return GS_E_NOMEM;
+}
+
+static int copy_hits(gs_table *t, gs_reads *r, void *out, uint64_t cap, uint64_t *n_out, hipMemcpyKind kind) {
+    int rc;
+    if ((rc = settle(t, r))) return rc;
+    if (n_out) *n_out = t->res_n;
+    if (out) {
+        if (t->res_n > cap) {
+            set_error("%llu hits do not fit in cap = %llu", (unsigned long long)t->res_n, (unsigned long long)cap);
+            return GS_E_CAPACITY;
+        }
+        if (t->res_n) HIP_TRY(hipMemcpy(out, r->hits, t->res_n * sizeof(gs_hit), kind));
+    }
+    if (t->res_keyerr) {
+        set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
+        return GS_E_KEYERROR;
+    }
+    return GS_OK;
+}
+
+int gs_tag_finish(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uint64_t *n_out, uint32_t *carry_out,
+                  gs_counters *ctr) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_finish"))) return rc;
+    if ((rc = settle(t, r))) return rc;
+    if (carry_out) *carry_out = t->res_carry;
+    if (ctr) *ctr = t->ctr;
+    return copy_hits(t, r, out, cap, n_out, hipMemcpyDeviceToHost);
+}
+
+int gs_tag(gs_table *t, gs_reads *r, uint32_t carry_in, gs_hit *out, uint64_t cap, uint64_t *n_out, uint32_t *carry_out,
+           gs_counters *ctr) {
+    int rc = gs_tag_launch(t, r, carry_in);
+    if (rc) return rc;
+    return gs_tag_finish(t, r, out, cap, n_out, carry_out, ctr);
+}
+
+int gs_tag_hits_to_host(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uint64_t *n_out) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_hits_to_host"))) return rc;
+    return copy_hits(t, r, out, cap, n_out, hipMemcpyDeviceToHost);
+}
+
+int gs_tag_hits_to_device(gs_table *t, gs_reads *r, void *dst, uint64_t cap, uint64_t *n_out) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_hits_to_device"))) return rc;
+    return copy_hits(t, r, dst, cap, n_out, hipMemcpyDeviceToDevice);
+}
+
+void gs_counters_reset(gs_table *t) {
+    if (t) t->ctr = gs_counters{};
+}
+
+}  // extern "C"

@@ -1,0 +1,476 @@
+// Host half of libgavisunk.so: the file formats on either side of the tagging path.
+//   SUNK list + loc table loader  <- kmerpos_annot3.nim:20-69
+//   FASTA/FASTQ(.gz) reader + 2-bit packer  <- `readfq(reads)`, kmerpos_annot3.nim:85, rlen.nim:13
+// Native C++ because the reference's counterpart is native (Nim); no GPU involved here.
+#include <zlib.h>
+
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+
+#include "gs_common.h"
+
+namespace gs {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// ---------------------------------------------------------------------------------- line reader
+class LineReader {
+   public:
+    explicit LineReader(const char *path) {
+        f_ = gzopen(path, "rb");  // transparently reads plain files too
+        if (f_) gzbuffer(f_, 1 << 20);
+        buf_.resize(1 << 20);
+    }
+    ~LineReader() {
+        if (f_) gzclose(f_);
+    }
+    bool ok() const { return f_ != nullptr; }
+    // Next line without its '\n' (and without a trailing '\r'); false at EOF.
+    bool next(std::string &line) {
+        line.clear();
+        bool any = false;
+        for (;;) {
+            if (pos_ == end_) {
+                int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
+                if (n <= 0) {
+                    if (any && !line.empty() && line.back() == '\r') line.pop_back();
+                    return any;
+                }
+                pos_ = 0;
+                end_ = (size_t)n;
+            }
+            const char *p = buf_.data() + pos_;
+            const char *nl = (const char *)memchr(p, '\n', end_ - pos_);
+            any = true;
+            if (nl) {
+                line.append(p, nl - p);
+                pos_ = (size_t)(nl - buf_.data()) + 1;
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                return true;
+            }
+            line.append(p, end_ - pos_);
+            pos_ = end_;
+        }
+    }
+
+   private:
+    gzFile f_ = nullptr;
+    std::vector<char> buf_;
+    size_t pos_ = 0, end_ = 0;
+};
+
+// ---------------------------------------------------------------------------------- u64 -> u32 map
+class CodeMap {
+   public:
+    void reserve(uint64_t n) {
+        uint64_t cap = 64;
+        while (cap < 2 * n + 2) cap <<= 1;
+        rehash(cap);
+    }
+    // returns reference to the value slot; `fresh` tells whether the key was new
+    uint32_t &at(uint64_t key, bool &fresh) {
+        if ((count_ + 1) * 2 > key_.size()) rehash(key_.empty() ? 64 : key_.size() * 2);
+        uint64_t h = mix(key) & mask_;
+        while (key_[h] != kEmpty && key_[h] != key) h = (h + 1) & mask_;
+        fresh = key_[h] == kEmpty;
+        if (fresh) {
+            key_[h] = key;
+            count_++;
+        }
+        return val_[h];
+    }
+    bool get(uint64_t key, uint32_t &v) const {
+        if (key_.empty()) return false;
+        uint64_t h = mix(key) & mask_;
+        while (key_[h] != kEmpty) {
+            if (key_[h] == key) {
+                v = val_[h];
+                return true;
+            }
+            h = (h + 1) & mask_;
+        }
+        return false;
+    }
+
+   private:
+    static constexpr uint64_t kEmpty = ~0ULL;
+    static uint64_t mix(uint64_t x) {
+        x *= 0x9E3779B97F4A7C15ULL;
+        return x ^ (x >> 29);
+    }
+    void rehash(uint64_t cap) {
+        std::vector<uint64_t> ok;
+        std::vector<uint32_t> ov;
+        ok.swap(key_);
+        ov.swap(val_);
+        key_.assign(cap, kEmpty);
+        val_.assign(cap, 0);
+        mask_ = cap - 1;
+        for (size_t i = 0; i < ok.size(); i++)
+            if (ok[i] != kEmpty) {
+                uint64_t h = mix(ok[i]) & mask_;
+                while (key_[h] != kEmpty) h = (h + 1) & mask_;
+                key_[h] = ok[i];
+                val_[h] = ov[i];
+            }
+    }
+    std::vector<uint64_t> key_;
+    std::vector<uint32_t> val_;
+    uint64_t mask_ = 0, count_ = 0;
+};
+
+static bool parse_i64(const char *b, const char *e, int64_t &v) {
+    if (b == e) return false;
+    bool neg = false;
+    if (*b == '-' || *b == '+') {
+        neg = *b == '-';
+        b++;
+    }
+    if (b == e) return false;
+    int64_t x = 0;
+    for (; b < e; b++) {
+        if (*b < '0' || *b > '9') return false;
+        x = x * 10 + (*b - '0');
+    }
+    v = neg ? -x : x;
+    return true;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+const char *gs_last_error(void) { return g_err.c_str(); }
+const char *gs_version(void) { return "gavisunk_amd 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------- sunkdb
+int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
+    if (!db_path || !loc_path || !out) {
+        set_error("gs_sunkdb_load: null argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    auto *d = new gs_sunkdb();
+    std::string line;
+    CodeMap keymap;  // db code -> key index
+    {
+        LineReader r(db_path);
+        if (!r.ok()) {
+            set_error("cannot open the file %s", db_path);
+            delete d;
+            return GS_E_IO;
+        }
+        bool first = true;
+        while (r.next(line)) {
+            if (first) {  // k = len(first line), kmerpos_annot3.nim:28-38
+                d->k = (int)line.size();
+                first = false;
+            }
+            const uint64_t code = encode_kmer(line.data(), line.size());
+            bool fresh;
+            uint32_t &slot = keymap.at(code, fresh);
+            if (fresh) {
+                slot = (uint32_t)d->keys.size();
+                d->keys.push_back(code);
+            }
+        }
+        if (d->k < 1 || d->k > 32) {
+            set_error("%s: k = %d is outside 1..32 (2 bits per base in a uint64)", db_path, d->k);
+            delete d;
+            return GS_E_ARG;
+        }
+    }
+    CodeMap rowmap;  // loc code -> last row with that code
+    {
+        LineReader r(loc_path);
+        if (!r.ok()) {
+            set_error("cannot open the file %s", loc_path);
+            delete d;
+            return GS_E_IO;
+        }
+        std::unordered_map<std::string, uint32_t> contig_id;
+        struct PairHash {
+            size_t operator()(const std::pair<uint32_t, int64_t> &p) const {
+                return std::hash<uint64_t>()(((uint64_t)p.first << 40) ^ (uint64_t)p.second * 0x9E3779B97F4A7C15ULL);
+            }
+        };
+        std::unordered_map<std::pair<uint32_t, int64_t>, uint32_t, PairHash> locmap;
+        uint64_t lineno = 0;
+        std::string name;
+        while (r.next(line)) {
+            lineno++;
+            if (line.empty()) continue;
+            const char *p = line.data(), *e = p + line.size();
+            const char *f[4];
+            const char *fe[4];
+            int nf = 0;
+            const char *s = p;
+            for (const char *q = p;; q++) {
+                if (q == e || *q == '\t') {
+                    if (nf < 4) {
+                        f[nf] = s;
+                        fe[nf] = q;
+                    }
+                    nf++;
+                    s = q + 1;
+                    if (q == e) break;
+                }
+            }
+            int64_t start, group;
+            if (nf < 4 || !parse_i64(f[1], fe[1], start) || !parse_i64(f[3], fe[3], group)) {
+                set_error("%s:%llu: expected `chrom<TAB>start<TAB>kmer<TAB>group`", loc_path, (unsigned long long)lineno);
+                delete d;
+                return GS_E_IO;
+            }
+            name.assign(f[0], fe[0] - f[0]);
+            auto it = contig_id.find(name);
+            uint32_t cid;
+            if (it == contig_id.end()) {
+                cid = (uint32_t)d->contigs.size();
+                contig_id.emplace(name, cid);
+                d->contigs.push_back(name);
+            } else {
+                cid = it->second;
+            }
+            const uint32_t row = (uint32_t)d->row_contig.size();
+            d->row_contig.push_back(cid);
+            d->row_start.push_back(start);
+            d->row_group.push_back(group);
+            auto key = std::make_pair(cid, group);
+            auto lt = locmap.find(key);
+            uint32_t lid;
+            if (lt == locmap.end()) {
+                lid = (uint32_t)locmap.size();
+                locmap.emplace(key, lid);
+            } else {
+                lid = lt->second;
+            }
+            d->row_loc.push_back(lid);
+            bool fresh;
+            rowmap.at(encode_kmer(f[2], fe[2] - f[2]), fresh) = row;  // later row overwrites (:68)
+        }
+    }
+    d->key_row.resize(d->keys.size());
+    d->key_loc.resize(d->keys.size());
+    for (size_t i = 0; i < d->keys.size(); i++) {
+        uint32_t row;
+        if (rowmap.get(d->keys[i], row)) {
+            d->key_row[i] = row;
+            d->key_loc[i] = d->row_loc[row];
+        } else {
+            d->key_row[i] = GS_MISSING;
+            d->key_loc[i] = GS_MISSING;
+        }
+    }
+    *out = d;
+    return GS_OK;
+}
+
+void gs_sunkdb_free(gs_sunkdb *db) { delete db; }
+int gs_sunkdb_k(const gs_sunkdb *db) { return db->k; }
+uint64_t gs_sunkdb_n_keys(const gs_sunkdb *db) { return db->keys.size(); }
+const uint64_t *gs_sunkdb_keys(const gs_sunkdb *db) { return db->keys.data(); }
+const uint32_t *gs_sunkdb_key_row(const gs_sunkdb *db) { return db->key_row.data(); }
+const uint32_t *gs_sunkdb_key_loc(const gs_sunkdb *db) { return db->key_loc.data(); }
+uint64_t gs_sunkdb_n_rows(const gs_sunkdb *db) { return db->row_contig.size(); }
+const uint32_t *gs_sunkdb_row_contig(const gs_sunkdb *db) { return db->row_contig.data(); }
+const int64_t *gs_sunkdb_row_start(const gs_sunkdb *db) { return db->row_start.data(); }
+const int64_t *gs_sunkdb_row_group(const gs_sunkdb *db) { return db->row_group.data(); }
+const uint32_t *gs_sunkdb_row_loc(const gs_sunkdb *db) { return db->row_loc.data(); }
+uint32_t gs_sunkdb_n_contigs(const gs_sunkdb *db) { return (uint32_t)db->contigs.size(); }
+const char *gs_sunkdb_contig_name(const gs_sunkdb *db, uint32_t c) {
+    return c < db->contigs.size() ? db->contigs[c].c_str() : nullptr;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------- fastx
+struct gs_fastx {
+    LineReader reader;
+    std::string pending;  // a header line already consumed from the stream
+    bool have_pending = false;
+    bool eof = false;
+    explicit gs_fastx(const char *p) : reader(p) {}
+};
+
+namespace gs {
+
+// Appends one read (ASCII, possibly in several pieces) to a batch, packing as it goes.
+class Packer {
+   public:
+    explicit Packer(gs_batch *b) : b_(b) {}
+    void begin(const char *name, size_t name_len) {
+        b_->name_off.push_back(b_->names.size());
+        b_->names.insert(b_->names.end(), name, name + name_len);
+        b_->names.push_back('\0');
+        cur_ = 0;
+        nb_ = 0;
+        len_ = 0;
+    }
+    void add(const char *s, size_t n) {
+        for (size_t i = 0; i < n; i++) {
+            cur_ = (cur_ << 2) | enc((uint8_t)s[i]);
+            if (++nb_ == 32) {
+                b_->words.push_back(cur_);
+                cur_ = 0;
+                nb_ = 0;
+            }
+        }
+        len_ += n;
+    }
+    void end() {
+        if (nb_) b_->words.push_back(cur_ << (2 * (32 - nb_)));
+        b_->words.push_back(0);  // >= 1 zero word after every read ('A' padding, Q6)
+        b_->word_off.push_back(b_->words.size());
+        b_->len.push_back((uint32_t)len_);
+        b_->bases += len_;
+    }
+
+   private:
+    gs_batch *b_;
+    uint64_t cur_ = 0;
+    int nb_ = 0;
+    size_t len_ = 0;
+};
+
+}  // namespace gs
+
+extern "C" {
+
+int gs_fastx_open(const char *path, gs_fastx **out) {
+    if (!path || !out) {
+        set_error("gs_fastx_open: null argument");
+        return GS_E_ARG;
+    }
+    auto *fx = new gs_fastx(path);
+    if (!fx->reader.ok()) {
+        set_error("cannot open the file %s", path);
+        delete fx;
+        *out = nullptr;
+        return GS_E_IO;
+    }
+    *out = fx;
+    return GS_OK;
+}
+
+void gs_fastx_close(gs_fastx *fx) { delete fx; }
+
+int gs_fastx_next_batch(gs_fastx *fx, uint64_t max_bases, uint32_t max_reads, gs_batch **out) {
+    if (!fx || !out) {
+        set_error("gs_fastx_next_batch: null argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    if (fx->eof && !fx->have_pending) return GS_OK;
+    auto *b = new gs_batch();
+    b->word_off.push_back(0);
+    Packer pk(b);
+    std::string line;
+    uint32_t n = 0;
+    while (n < max_reads && (n == 0 || b->bases < max_bases)) {
+        // locate a header: kseq scans for the next '>' or '@'
+        std::string hdr;
+        bool got = false;
+        if (fx->have_pending) {
+            hdr.swap(fx->pending);
+            fx->have_pending = false;
+            got = true;
+        } else {
+            while (fx->reader.next(line)) {
+                size_t p = line.find_first_of(">@");
+                if (p != std::string::npos) {
+                    hdr = line.substr(p);
+                    got = true;
+                    break;
+                }
+            }
+        }
+        if (!got) {
+            fx->eof = true;
+            break;
+        }
+        // name = up to the first whitespace
+        size_t ne = 1;
+        while (ne < hdr.size() && !isspace((unsigned char)hdr[ne])) ne++;
+        pk.begin(hdr.data() + 1, ne - 1);
+        size_t seqlen = 0;
+        char stop = 0;
+        while (fx->reader.next(line)) {
+            if (!line.empty() && (line[0] == '>' || line[0] == '@' || line[0] == '+')) {
+                stop = line[0];
+                break;
+            }
+            pk.add(line.data(), line.size());
+            seqlen += line.size();
+        }
+        pk.end();
+        n++;
+        if (stop == '>' || stop == '@') {
+            fx->pending = line;
+            fx->have_pending = true;
+        } else if (stop == '+') {  // FASTQ: qualities span as many bytes as the sequence
+            size_t q = 0;
+            while (q < seqlen && fx->reader.next(line)) q += line.size();
+            if (seqlen > 0 && q < seqlen) {
+                fx->eof = true;  // truncated record: kseq stops here
+                break;
+            }
+        } else {
+            fx->eof = true;
+            break;
+        }
+    }
+    if (n == 0) {
+        delete b;
+        return GS_OK;
+    }
+    *out = b;
+    return GS_OK;
+}
+
+int gs_batch_from_ascii(const uint8_t *seq, const uint64_t *off, uint32_t n_reads, gs_batch **out) {
+    if (!off || !out || (!seq && n_reads && off[n_reads] > 0)) {
+        set_error("gs_batch_from_ascii: null argument");
+        return GS_E_ARG;
+    }
+    auto *b = new gs_batch();
+    b->word_off.push_back(0);
+    b->words.reserve(off[n_reads] / 32 + 2ull * n_reads + 2);
+    Packer pk(b);
+    char nm[32];
+    for (uint32_t r = 0; r < n_reads; r++) {
+        int l = snprintf(nm, sizeof nm, "%u", r);
+        pk.begin(nm, (size_t)l);
+        pk.add((const char *)seq + off[r], off[r + 1] - off[r]);
+        pk.end();
+    }
+    *out = b;
+    return GS_OK;
+}
+
+void gs_batch_free(gs_batch *b) { delete b; }
+uint32_t gs_batch_n_reads(const gs_batch *b) { return (uint32_t)b->len.size(); }
+uint64_t gs_batch_n_bases(const gs_batch *b) { return b->bases; }
+const uint64_t *gs_batch_words(const gs_batch *b) { return b->words.data(); }
+uint64_t gs_batch_n_words(const gs_batch *b) { return b->words.size(); }
+const uint64_t *gs_batch_word_off(const gs_batch *b) { return b->word_off.data(); }
+const uint32_t *gs_batch_len(const gs_batch *b) { return b->len.data(); }
+const char *gs_batch_name(const gs_batch *b, uint32_t r) {
+    return r < b->name_off.size() ? b->names.data() + b->name_off[r] : nullptr;
+}
+
+}  // extern "C"

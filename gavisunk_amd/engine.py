@@ -1,0 +1,191 @@
+"""Host-side mirror of the reference's tagging programs on top of the C-ABI.
+
+`SunkDB`      = what kmerpos_annot3.nim:20-69 loads (SUNK list + loc table)
+`ReadBatch`   = records of `readfq(reads)` (kmerpos_annot3.nim:85), 2-bit packed
+`Tagger`      = the main loop kmerpos_annot3.nim:82-96 on one GPU, batch after batch with the
+                `prevLoc` carry threaded through
+All compute happens in libgavisunk.so's HIP kernels; nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import GS_MISSING, GS_NONE, GsCounters, GsError, GsHit, check, lib
+
+HIT_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u4"), ("payload", "<u4")])
+assert HIT_DTYPE.itemsize == C.sizeof(GsHit)
+
+
+def _view(ptr: int, n: int, dtype) -> np.ndarray:
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class SunkDB:
+    """Parsed `<kmers.db>` + `<kmer.loc>` (native parser, gs_sunkdb_load)."""
+
+    def __init__(self, db_path: str, loc_path: str):
+        h = C.c_void_p()
+        check(lib().gs_sunkdb_load(db_path.encode(), loc_path.encode(), C.byref(h)))
+        self._h = h
+        L = lib()
+        self.k = L.gs_sunkdb_k(h)
+        nk, nr = L.gs_sunkdb_n_keys(h), L.gs_sunkdb_n_rows(h)
+        self.keys = _view(L.gs_sunkdb_keys(h), nk, np.uint64)
+        self.key_row = _view(L.gs_sunkdb_key_row(h), nk, np.uint32)
+        self.key_loc = _view(L.gs_sunkdb_key_loc(h), nk, np.uint32)
+        self.row_contig = _view(L.gs_sunkdb_row_contig(h), nr, np.uint32)
+        self.row_start = _view(L.gs_sunkdb_row_start(h), nr, np.int64)
+        self.row_group = _view(L.gs_sunkdb_row_group(h), nr, np.int64)
+        self.row_loc = _view(L.gs_sunkdb_row_loc(h), nr, np.uint32)
+        self.contigs = [L.gs_sunkdb_contig_name(h, i).decode() for i in range(L.gs_sunkdb_n_contigs(h))]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_sunkdb_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class ReadBatch:
+    """Host-side packed batch (gs_batch)."""
+
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+        L = lib()
+        self.n_reads = L.gs_batch_n_reads(handle)
+        self.n_bases = L.gs_batch_n_bases(handle)
+        self.n_words = L.gs_batch_n_words(handle)
+        self.words = _view(L.gs_batch_words(handle), self.n_words, np.uint64)
+        self.word_off = _view(L.gs_batch_word_off(handle), self.n_reads + 1, np.uint64)
+        self.len = _view(L.gs_batch_len(handle), self.n_reads, np.uint32)
+
+    @property
+    def names(self) -> List[str]:
+        L = lib()
+        return [L.gs_batch_name(self._h, i).decode() for i in range(self.n_reads)]
+
+    @classmethod
+    def from_ascii(cls, seqs: Sequence[bytes]) -> "ReadBatch":
+        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        if len(seqs):
+            off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+        buf = np.frombuffer(b"".join(seqs), dtype=np.uint8) if len(seqs) else np.zeros(1, np.uint8)
+        return cls.from_concat(buf, off)
+
+    @classmethod
+    def from_concat(cls, buf: np.ndarray, off: np.ndarray) -> "ReadBatch":
+        buf = np.ascontiguousarray(buf, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        h = C.c_void_p()
+        check(lib().gs_batch_from_ascii(buf.ctypes.data, off.ctypes.data, len(off) - 1, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_batch_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def read_batches(path: str, max_bases: int = 1 << 30, max_reads: int = 1 << 22) -> Iterator[ReadBatch]:
+    """Iterates a FASTA/FASTQ(.gz) file in packed batches (native parser, kseq semantics)."""
+    fx = C.c_void_p()
+    check(lib().gs_fastx_open(path.encode(), C.byref(fx)))
+    try:
+        while True:
+            b = C.c_void_p()
+            check(lib().gs_fastx_next_batch(fx, max_bases, max_reads, C.byref(b)))
+            if not b:
+                break
+            yield ReadBatch(b)
+    finally:
+        lib().gs_fastx_close(fx)
+
+
+class DeviceTable:
+    """SUNK hash table resident on one GPU (gs_table)."""
+
+    def __init__(self, k: int, keys: np.ndarray, loc: np.ndarray, payload: np.ndarray, device: int = 0):
+        keys = np.ascontiguousarray(keys, np.uint64)
+        loc = np.ascontiguousarray(loc, np.uint32)
+        payload = np.ascontiguousarray(payload, np.uint32)
+        assert len(keys) == len(loc) == len(payload)
+        h = C.c_void_p()
+        check(lib().gs_table_create(device, k, len(keys), keys.ctypes.data, loc.ctypes.data, payload.ctypes.data,
+                                    C.byref(h)))
+        self._h, self.k, self.device, self.n = h, k, device, len(keys)
+
+    @classmethod
+    def from_db(cls, db: SunkDB, device: int = 0) -> "DeviceTable":
+        return cls(db.k, db.keys, db.key_loc, db.key_row, device)
+
+    @property
+    def nbytes(self) -> int:
+        return lib().gs_table_bytes(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_table_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class DeviceReads:
+    """Packed reads resident on one GPU (gs_reads)."""
+
+    def __init__(self, batch: ReadBatch, k: int, device: int = 0):
+        h = C.c_void_p()
+        check(lib().gs_reads_upload(device, batch.words.ctypes.data if batch.n_words else None, batch.n_words,
+                                    batch.word_off.ctypes.data, batch.len.ctypes.data if batch.n_reads else None,
+                                    batch.n_reads, k, C.byref(h)))
+        self._h, self.k, self.device = h, k, device
+        self.n_reads, self.n_bases = batch.n_reads, batch.n_bases
+        self.n_windows = lib().gs_reads_n_windows(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_reads_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def tag(table: DeviceTable, reads: DeviceReads, carry_in: int = GS_NONE):
+    """One tagging pass -> (status, hits[HIT_DTYPE], carry_out, counters dict).
+    status is GS_OK or GS_E_KEYERROR (then hits = those emitted before the offending window)."""
+    L = lib()
+    check(L.gs_tag_launch(table._h, reads._h, carry_in))
+    n = C.c_uint64(0)
+    carry = C.c_uint32(GS_NONE)
+    ctr = GsCounters()
+    st = L.gs_tag_finish(table._h, reads._h, None, 0, C.byref(n), C.byref(carry), C.byref(ctr))
+    if st not in (_lib.GS_OK, _lib.GS_E_KEYERROR):
+        check(st)
+    out = np.zeros(n.value, dtype=HIT_DTYPE)
+    if n.value:
+        st2 = L.gs_tag_hits_to_host(table._h, reads._h, out.ctypes.data, n.value, None)
+        if st2 not in (_lib.GS_OK, _lib.GS_E_KEYERROR):
+            check(st2)
+    return st, out, carry.value, ctr.as_dict()
+
+
+def format_sunkpos(hits: np.ndarray, names: Sequence[str], db: SunkDB) -> str:
+    """Rows of the reference's output file: name, i, chrom, start, group (kmerpos_annot3.nim:93)."""
+    rows = hits["payload"]
+    contig = db.row_contig[rows]
+    start = db.row_start[rows]
+    group = db.row_group[rows]
+    cn = db.contigs
+    return "".join(f"{names[r]}\t{p}\t{cn[c]}\t{s}\t{g}\n"
+                   for r, p, c, s, g in zip(hits["read"].tolist(), hits["pos"].tolist(), contig.tolist(),
+                                            start.tolist(), group.tolist()))

@@ -1,0 +1,171 @@
+/*
+ * gavisunk.h -- C-ABI of the MI355X-native SUNK-tagging engine (libgavisunk.so).
+ *
+ * Drop-in boundary.  GAVISUNK has no FFI: its hot path is four single-threaded Nim programs
+ * invoked by Snakemake shell lines (workflow/rules/tagONT.smk:36,73,92,110) plus one Python
+ * script (tagONT.smk:189).  The entry points below are what a binding for that path has to
+ * reach; every one cites the reference code it replaces.  The Python host stubs in
+ * gavisunk_amd/ (same positional argv as the reference programs) call them through ctypes;
+ * INTEGRATION.md shows the one-line change per Snakemake rule.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every function returns 0 or a negative
+ *     gs_status, and gs_last_error() (thread-local) explains the last failure;
+ *   - the caller owns every host buffer it passes; the library owns device memory behind the
+ *     opaque handles; one handle lives on one GPU; a handle is not thread-safe, distinct
+ *     handles may be used from distinct threads;
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point
+ *     fails with GS_E_NODEVICE.
+ */
+#ifndef GAVISUNK_H
+#define GAVISUNK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gs_status {
+    GS_OK = 0,
+    GS_E_ARG = -1,       /* bad argument */
+    GS_E_KEYERROR = -2,  /* a read hit a k-mer that is in the db but has no loc row: the
+                            reference dies with KeyError, exit 1 (kmerpos_annot3.nim:90) */
+    GS_E_CAPACITY = -3,  /* output buffer too small; *n_out holds the size needed */
+    GS_E_NODEVICE = -4,  /* no HIP device / HIP runtime error */
+    GS_E_IO = -5,        /* file cannot be opened or parsed (kmerpos_annot3.nim:59-60) */
+    GS_E_NOMEM = -6
+} gs_status;
+
+#define GS_NONE 0xFFFFFFFFu    /* "no previous location" (prevLoc before the first hit) */
+#define GS_MISSING 0xFFFFFFFEu /* loc id of a db k-mer without a loc row */
+
+const char *gs_last_error(void);
+const char *gs_version(void);
+int gs_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side parsing (native, like the reference's Nim programs).  No GPU needed.
+ * ---------------------------------------------------------------------------------------- */
+
+/* The SUNK list + location table as the reference loads them:
+ *   db  : one k-mer per line, k = length of line 1          (kmerpos_annot3.nim:20-38)
+ *   loc : TSV chrom, start, kmer, group; a later row with the same k-mer overwrites an
+ *         earlier one                                        (kmerpos_annot3.nim:53-69)
+ * Both plain or gzip.  `encode` semantics: A/a 0, C/c 1, G/g 2, T/t/U/u 3, any other byte 0,
+ * first base most significant (nim-kmer 0.2.6 `encode`, call sites kmerpos_annot3.nim:24,68). */
+typedef struct gs_sunkdb gs_sunkdb;
+int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out);
+void gs_sunkdb_free(gs_sunkdb *db);
+int gs_sunkdb_k(const gs_sunkdb *db);
+/* Keys of the tagger's table = distinct db k-mers.  Arrays are valid until gs_sunkdb_free. */
+uint64_t gs_sunkdb_n_keys(const gs_sunkdb *db);
+const uint64_t *gs_sunkdb_keys(const gs_sunkdb *db);     /* code of each key (as in the db; canonical there) */
+const uint32_t *gs_sunkdb_key_row(const gs_sunkdb *db);  /* winning loc row of the key, GS_MISSING if none */
+const uint32_t *gs_sunkdb_key_loc(const gs_sunkdb *db);  /* dense id of that row's (chrom, group), GS_MISSING if none */
+/* loc rows (file order) */
+uint64_t gs_sunkdb_n_rows(const gs_sunkdb *db);
+const uint32_t *gs_sunkdb_row_contig(const gs_sunkdb *db);
+const int64_t *gs_sunkdb_row_start(const gs_sunkdb *db);
+const int64_t *gs_sunkdb_row_group(const gs_sunkdb *db);
+const uint32_t *gs_sunkdb_row_loc(const gs_sunkdb *db);  /* dense (chrom, group) id per row */
+uint32_t gs_sunkdb_n_contigs(const gs_sunkdb *db);
+const char *gs_sunkdb_contig_name(const gs_sunkdb *db, uint32_t contig);
+
+/* FASTA/FASTQ reader with kseq semantics, plain or gzip, multi-line records; name = header up
+ * to the first whitespace (the reference iterates `readfq(reads)`, kmerpos_annot3.nim:85,
+ * rlen.nim:13).  A batch holds whole records, 2-bit packed for the device:
+ *   words    : uint64, 32 bases per word, first base in the two most significant bits; each
+ *              read starts on a word boundary and is followed by >= 1 zero word
+ *   word_off : n_reads+1 offsets into `words`;  len : bases per read (what `rlen` prints). */
+typedef struct gs_fastx gs_fastx;
+typedef struct gs_batch gs_batch;
+int gs_fastx_open(const char *path, gs_fastx **out);
+void gs_fastx_close(gs_fastx *fx);
+/* Reads records until `max_bases` bases or `max_reads` records are in the batch (at least
+ * one record).  *out = NULL at end of file. */
+int gs_fastx_next_batch(gs_fastx *fx, uint64_t max_bases, uint32_t max_reads, gs_batch **out);
+void gs_batch_free(gs_batch *b);
+uint32_t gs_batch_n_reads(const gs_batch *b);
+uint64_t gs_batch_n_bases(const gs_batch *b);
+const uint64_t *gs_batch_words(const gs_batch *b);
+uint64_t gs_batch_n_words(const gs_batch *b);
+const uint64_t *gs_batch_word_off(const gs_batch *b);
+const uint32_t *gs_batch_len(const gs_batch *b);
+const char *gs_batch_name(const gs_batch *b, uint32_t read);
+/* A batch from memory: ASCII bases of all reads back to back, off[n_reads+1] in bases.
+ * Packing applies the `encode` table above. */
+int gs_batch_from_ascii(const uint8_t *seq, const uint64_t *off, uint32_t n_reads, gs_batch **out);
+
+/* ------------------------------------------------------------------------------------------
+ * Device side.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Device-resident SUNK table: open-addressed hash, built on the GPU.  Replaces
+ * `uniqueKmers: HashSet[uint64]` + `coords: Table[uint64, coord]`
+ * (kmerpos_annot3.nim:20-26, 44-69).
+ *   keys[n]    distinct canonical codes (2 bits/base, k <= 32)
+ *   loc[n]     dense id of the key's (chrom, group) -- what `curLoc == prevLoc` compares
+ *              (kmerpos_annot3.nim:91-92) -- or GS_MISSING
+ *   payload[n] what a hit reports for this key (the host stubs pass the loc row) */
+typedef struct gs_table gs_table;
+int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const uint32_t *loc,
+                    const uint32_t *payload, gs_table **out);
+void gs_table_destroy(gs_table *t);
+uint64_t gs_table_bytes(const gs_table *t);
+
+/* Device-resident batch of packed reads (+ the per-tile index the kernels need). */
+typedef struct gs_reads gs_reads;
+int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off,
+                    const uint32_t *len, uint32_t n_reads, int k, gs_reads **out);
+void gs_reads_destroy(gs_reads *r);
+uint64_t gs_reads_n_bases(const gs_reads *r);
+uint64_t gs_reads_n_windows(const gs_reads *r);
+
+/* One emitted hit = one row of the reference's output `name \t i \t chrom \t start \t group`
+ * (kmerpos_annot3.nim:93): read = index of the read in the batch, pos = the reference's `i`
+ * (window index minus the suppressed hits before it in the same read, kmerpos_annot3.nim:92,96),
+ * payload = the key's payload (loc row). */
+typedef struct gs_hit {
+    uint32_t read;
+    uint32_t pos;
+    uint32_t payload;
+} gs_hit;
+
+typedef struct gs_counters {
+    uint64_t windows;      /* windows examined (= hash probes) */
+    uint64_t raw_hits;     /* windows found in the SUNK set */
+    uint64_t emitted;      /* rows of output */
+    uint64_t tiles;        /* 2048-window tiles */
+    uint64_t launches;     /* tag passes accumulated in the two times below */
+    double probe_ms;       /* HIP-event time of the probe kernel, summed over `launches` */
+    double total_ms;       /* HIP-event time of the whole pass (all kernels), summed */
+} gs_counters;
+
+/* The tagger's main loop (kmerpos_annot3.nim:82-96) over a resident batch.
+ *   carry_in  : loc id of the last raw hit before this batch in the same input file
+ *               (`prevLoc` is never reset between reads), GS_NONE at the start of a file;
+ *   carry_out : the same for the next batch.
+ * gs_tag = gs_tag_launch + gs_tag_finish.  gs_tag_launch only enqueues the kernels on the
+ * table's stream; gs_tag_finish waits for them and copies the hit list out (`out` may be
+ * NULL to just count).  On GS_E_KEYERROR, *n_out = hits emitted before the offending window. */
+int gs_tag(gs_table *t, gs_reads *r, uint32_t carry_in, gs_hit *out, uint64_t cap, uint64_t *n_out,
+           uint32_t *carry_out, gs_counters *ctr);
+int gs_tag_launch(gs_table *t, gs_reads *r, uint32_t carry_in);
+int gs_tag_finish(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uint64_t *n_out,
+                  uint32_t *carry_out, gs_counters *ctr);
+/* Split pass for read-sharded multi-GPU runs (the shard's carry-in is not known until the
+ * summaries of the shards before it have been exchanged): phase 1 probes and reports whether
+ * the shard has a raw hit and the loc id of its last one; phase 2 takes the carry-in. */
+int gs_tag_phase1(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_loc);
+int gs_tag_phase2(gs_table *t, gs_reads *r, uint32_t carry_in);
+/* Copy the emitted hits of the last pass again, to host memory or into caller-provided DEVICE
+ * memory (for a collective); n_out as in gs_tag_finish. */
+int gs_tag_hits_to_host(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uint64_t *n_out);
+int gs_tag_hits_to_device(gs_table *t, gs_reads *r, void *dst_device, uint64_t cap, uint64_t *n_out);
+void gs_counters_reset(gs_table *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAVISUNK_H */

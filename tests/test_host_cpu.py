@@ -1,0 +1,117 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol
+include/gavisunk.h declares, the native parsers agree with the oracle's, and compute entry
+points fail loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, TAG_CASES
+from gavisunk_amd import _lib, engine, rlen
+from oracle import oracle
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gavisunk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) > 30
+    L = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in _lib.lib().gs_version()
+
+
+@pytest.mark.parametrize("name", TAG_CASES)
+def test_sunkdb_loader_matches_oracle(golden, name):
+    c = golden(name)
+    run = c.meta["tag"][0]
+    db = engine.SunkDB(c.path(run["db"]), c.path(run["loc"]))
+    k, codes = oracle.load_db(c.path(run["db"]))
+    cn, cid, start, code, group = oracle.load_loc(c.path(run["loc"]))
+    assert db.k == k
+    assert set(db.keys.tolist()) == set(codes.tolist())
+    assert db.contigs == cn
+    assert np.array_equal(db.row_contig, cid) and np.array_equal(db.row_start, start)
+    assert np.array_equal(db.row_group, group)
+    last = {}
+    for i, cd in enumerate(code.tolist()):
+        last[cd] = i  # later row wins
+    for key, row, loc in zip(db.keys.tolist(), db.key_row.tolist(), db.key_loc.tolist()):
+        if key in last:
+            assert row == last[key]
+            assert loc == db.row_loc[row]
+        else:
+            assert row == _lib.GS_MISSING and loc == _lib.GS_MISSING
+    # dense loc ids identify (contig, group) pairs
+    pairs = {}
+    for l, cc, g in zip(db.row_loc.tolist(), cid.tolist(), group.tolist()):
+        assert pairs.setdefault(l, (cc, g)) == (cc, g)
+    assert len(set(pairs.values())) == len(pairs)
+
+
+def _unpack(words, word_off, length, r):
+    w = words[int(word_off[r]):int(word_off[r + 1])]
+    bases = np.zeros(len(w) * 32, dtype=np.uint8)
+    for j in range(32):
+        bases[j::32] = (w >> np.uint64(62 - 2 * j)) & np.uint64(3)
+    return bases[:length], bases[length:]
+
+
+@pytest.mark.parametrize("name", ["kat1", "kat2", "short", "multi_k20", "amy"])
+def test_fastx_parser_and_packing_match_oracle(golden, name):
+    c = golden(name)
+    for run in c.meta["tag"]:
+        path = c.path(run["reads"])
+        names, seqs = oracle.parse_reads(path)
+        got_names, got_len, n = [], [], 0
+        for batch in engine.read_batches(path, max_bases=50_000, max_reads=7):  # small: many batches
+            got_names += batch.names
+            got_len += batch.len.tolist()
+            for r in range(batch.n_reads):
+                bases, pad = _unpack(batch.words, batch.word_off, int(batch.len[r]), r)
+                exp = oracle.lib() and np.frombuffer(seqs[n + r], dtype=np.uint8)
+                from gavisunk_amd import synth
+                assert np.array_equal(bases, synth.ascii_to_codes(exp))
+                assert len(pad) >= 32 and not pad.any()  # >= one zero word after each read
+            n += batch.n_reads
+        assert got_names == names
+        assert got_len == [len(s) for s in seqs]
+
+
+@pytest.mark.parametrize("name", ["kat1", "kat2", "short", "multi_k20", "amy"])
+def test_rlen_cli_matches_reference(golden, name, tmp_path):
+    c = golden(name)
+    for run in c.meta["rlen"]:
+        out = tmp_path / "o.rlen"
+        assert rlen.main([c.path(run["reads"]), str(out)]) == 0
+        assert out.read_text() == c.text(run["out"])
+
+
+def test_batch_from_ascii_roundtrip():
+    rng = np.random.default_rng(0)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTNacgtu", dtype=np.uint8), n).tobytes()) for n in (0, 1, 31, 32, 33, 64, 1000)]
+    b = engine.ReadBatch.from_ascii(seqs)
+    from gavisunk_amd import synth
+    for r, s in enumerate(seqs):
+        bases, pad = _unpack(b.words, b.word_off, len(s), r)
+        assert np.array_equal(bases, synth.ascii_to_codes(s))
+        assert not pad.any()
+
+
+def test_missing_file_is_an_io_error(tmp_path):
+    with pytest.raises(_lib.GsError) as e:
+        engine.SunkDB(str(tmp_path / "nope.db"), str(tmp_path / "nope.loc"))
+    assert e.value.status == _lib.GS_E_IO
+
+
+@pytest.mark.skipif(_lib.lib().gs_device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback_without_gpu():
+    keys = np.array([1, 2, 3], dtype=np.uint64)
+    with pytest.raises(_lib.GsError) as e:
+        engine.DeviceTable(20, keys, np.zeros(3, np.uint32), np.zeros(3, np.uint32))
+    assert e.value.status == _lib.GS_E_NODEVICE
+    assert "no CPU fallback" in e.value.msg
