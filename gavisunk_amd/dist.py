@@ -1,0 +1,101 @@
+"""Read-sharded multi-GPU tagging: one process per GPU, `torch.distributed` (backend "nccl" =
+RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+The reference has no distributed runtime; its only parallelism is Snakemake's per-chunk scatter
+(workflow/Snakefile:23-24, tagONT.smk:19-37).  Here ONE input file is cut into contiguous
+blocks of reads, one block per rank, with the SUNK table replicated.  Reads are independent
+except for `prevLoc` (kmerpos_annot3.nim:82-84), which the reference never resets between
+reads; so the path has exactly one exchange step:
+
+  phase 1  every rank probes its shard and learns {has a raw hit?, loc of its last raw hit}
+  exchange all_gather of that 2-word summary (8 bytes per rank: latency-bound, not link-bound)
+  phase 2  every rank resolves its carry-in = last loc of the nearest earlier shard that has a
+           raw hit, and finishes its pass
+  gather   per-rank hit buffers (12 B per output row) are concatenated on rank 0 in shard order:
+           counts first, then one padded all_gather-free `gather`.
+
+Nothing here computes on the CPU: the tagging itself is engine.DeviceTable / engine.DeviceReads.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import GS_NONE
+
+
+def shard_bounds(n_reads: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block of reads of `rank` (sizes differ by at most one read)."""
+    base, rem = divmod(n_reads, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def resolve_carry(summaries: Sequence[Tuple[int, int]], rank: int, carry0: int = GS_NONE) -> int:
+    """Carry-in of `rank` from the (has_raw, last_loc) summaries of all ranks: the last loc of the
+    nearest earlier shard with a raw hit, else the carry into the whole file."""
+    for r in range(rank - 1, -1, -1):
+        has, loc = summaries[r]
+        if has:
+            return int(loc)
+    return int(carry0)
+
+
+def exchange_summaries(has_raw: int, last_loc: int, device=None) -> List[Tuple[int, int]]:
+    """all_gather of the per-shard phase-1 summary."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    mine = torch.tensor([int(has_raw), int(last_loc)], dtype=torch.int64, device=device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [(int(t[0].item()), int(t[1].item())) for t in out]
+
+
+def gather_hits(local_hits, read_offset: int, dst: int = 0):
+    """Concatenate per-rank hit buffers on rank `dst` in shard order.
+
+    local_hits: int32/uint32-viewable torch tensor of shape [n, 3] (read, pos, payload) on the
+    rank's device; read indices are local to the shard and are shifted by `read_offset`.
+    Returns the [N, 3] tensor on rank dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = local_hits.device
+    n_local = torch.tensor([local_hits.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.empty_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    padded = torch.zeros((width, 3), dtype=torch.int32, device=dev)
+    if local_hits.shape[0]:
+        padded[: local_hits.shape[0]] = local_hits.to(torch.int32)
+        padded[: local_hits.shape[0], 0] += int(read_offset)
+    if rank == dst:
+        bufs = [torch.empty_like(padded) for _ in range(world)]
+        dist.gather(padded, bufs, dst=dst)
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    dist.gather(padded, None, dst=dst)
+    return None
+
+
+def broadcast_array(arr: Optional[np.ndarray], dtype, device=None, src: int = 0) -> np.ndarray:
+    """Replicate a host array from rank `src` through the collective backend (the SUNK table's key /
+    loc / payload arrays: built once, broadcast, every rank then builds its own device table)."""
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank()
+    n = torch.tensor([len(arr) if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src)
+    nbytes = int(n.item()) * np.dtype(dtype).itemsize
+    if rank == src:
+        raw = np.ascontiguousarray(arr, dtype=dtype).view(np.uint8)
+        t = torch.from_numpy(raw.copy()).to(device) if device is not None else torch.from_numpy(raw.copy())
+    else:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy().view(dtype)
