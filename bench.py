@@ -236,9 +236,9 @@ def main():
                        "reads_per_gpu": a.reads, "bases_per_gpu": n_bases, "sunks": int(len(keys)),
                        "windows": c["windows"], "raw_hits": c["raw_hits"], "emitted_rows": c["emitted"],
                        "h_raw": round(h_raw, 5), "h_emit": round(h_emit, 7), "tiles": c["tiles"],
-                       "table_MiB": round(table.nbytes / 2**20, 1),
+                       "table_MiB": round(table.nbytes / 2**20, 1), "table_layout": table.layout,
                        "parallelism": f"read-sharded x{world}, table replicated"},
-            "roofline": {"bound": "hbm", "kernel": "k_probe", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_probe_part+k_merge_part+k_probe" if table.layout.startswith("compact") else "k_probe", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "alg_bytes_per_base": round(bpb, 3), "kernel_ms": round(probe_s * 1e3, 4),
                          "pass_ms": round(pass_s * 1e3, 4),

@@ -109,13 +109,11 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_
 }
 
 // ------------------------------------------------------------------------------------------
-// k_probe: one wavefront per tile
+// probe_tile / k_probe: one wavefront per tile (generic 16-byte-slot table in HBM)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_probe(TableView tab, ReadsView rd, TileArrays ta, uint32_t *cand,
-                                               uint32_t cand_cap, uint32_t *g_cand_count,
-                                               unsigned long long *g_err_pos) {
-    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= rd.n_tiles) return;
+__device__ __forceinline__ void probe_tile(const TableView &tab, const ReadsView &rd, const TileArrays &ta,
+                                           uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
+                                           unsigned long long *g_err_pos, uint32_t tile) {
     const int lane = threadIdx.x & 63;
     const uint32_t r = rd.tile_read[tile];
     const uint32_t tin = tile - rd.read_tile0[r];
@@ -127,11 +125,9 @@ __global__ __launch_bounds__(256) void k_probe(TableView tab, ReadsView rd, Tile
 
     const int k = tab.k;
     const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
-    uint64_t a = 0, b2 = 0;
-    if (nvalid) {
-        a = rd.words[wbase + lane];
-        b2 = rd.words[wbase + lane + 1];
-    }
+    // unconditional: the buffer carries kTileWords + 2 words of slack, windows past the read are masked
+    const uint64_t a = rd.words[wbase + lane];
+    const uint64_t b2 = rd.words[wbase + lane + 1];
     const uint64_t ra = ~revpairs(a), rb = ~revpairs(b2);
 
     uint32_t raw = 0, chg = 0;  // raw-hit mask, "loc differs from the previous raw hit of this lane" mask
@@ -214,6 +210,301 @@ __global__ __launch_bounds__(256) void k_probe(TableView tab, ReadsView rd, Tile
         ta.n_cand[tile] = tot_cand;
         ta.cand_off[tile] = off;
     }
+}
+
+
+__global__ __launch_bounds__(256) void k_probe(TableView tab, ReadsView rd, TileArrays ta, uint32_t *cand,
+                                               uint32_t cand_cap, uint32_t *g_cand_count,
+                                               unsigned long long *g_err_pos, const uint32_t *tile_list,
+                                               const uint32_t *tile_list_n) {
+    // whole batch (tile_list == nullptr: one wave per tile) or a list of tiles (grid-stride)
+    const uint32_t n_items = tile_list ? *tile_list_n : rd.n_tiles;
+    for (uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6); item < n_items; item += gridDim.x * 4)
+        probe_tile(tab, rd, ta, cand, cand_cap, g_cand_count, g_err_pos, tile_list ? tile_list[item] : item);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Small-table fast path: an exact compact table that lives in the L2 caches.
+//
+// MI355X has 8 XCDs with a private 4 MiB L2 each, and workgroup b is dispatched to XCD b % 8
+// (observed, used for speed only: any other placement gives the same results, slower).  Random
+// probes that hit L2 run at ~270 G/s chip-wide; past L2 they run at ~55 G/s whatever the table
+// size (profiles/r01/ubench_*.txt).  So the key space is cut into 8 partitions by a cheap
+// strand-symmetric function of the k-mer, partition p is only ever probed by workgroups with
+// blockIdx % 8 == p, and each XCD's L2 holds just its eighth of the table:
+//
+//   part(c)   = ((lo32(c) + lo32(revcomp c)) * 0x9E3779B1) >> 29        (same for both strands)
+//   y         = hmix(c)                      a bijection on 2k-bit codes
+//   bucket    = y >> rembits                 (2^qb buckets of 4 x 32-bit slots per partition)
+//   slot      = (y & remmask) << locbits | loc        0xFFFFFFFF = empty
+//
+// (partition, bucket, remainder) identifies the key exactly, so a match is a true hit.  A key
+// whose home bucket is full at build time is left out; a lookup that finds a full bucket without
+// a match falls back to the generic table, so the pair stays exact.
+//
+// k_probe_part  grid = 8 x ceil(tiles/4): wave (tile, p) rebuilds the tile's 2048 window codes,
+//               keeps the ~1/8 that belong to partition p (compacted through an LDS queue so the
+//               probe loop runs with full waves), probes, and writes a run-length summary of its
+//               hits: up to 3 runs {loc, first window, last window, count}.
+// k_merge_part  per tile, merges the 8 summaries.  If runs of different loc never overlap in
+//               window range the interleaving of the partitions does not matter and the tile's
+//               {n_raw, first/last loc, candidates} follow exactly; otherwise the tile is queued
+//               for the generic probe_tile (k_probe with a tile list).
+// ------------------------------------------------------------------------------------------
+constexpr uint64_t kMixA = 0xD6E8FEB86659FD93ULL, kMixB = 0xCA9B0DBC1D2E4F67ULL;
+constexpr uint32_t kPartMul = 0x9E3779B1u;
+constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+constexpr int kMaxRuns = 3;
+
+__host__ __device__ __forceinline__ uint64_t hmix(uint64_t c, int k, uint64_t kmask) {
+    uint64_t y = (c * kMixA) & kmask;
+    y ^= y >> k;
+    return (y * kMixB) & kmask;
+}
+
+struct CompactView {
+    const uint4 *buckets;  // [8 << qb]
+    int qb, rembits, locbits;
+};
+
+struct __align__(16) PartRec {
+    uint32_t head;  // nruns | complex << 8 | n_hits << 16
+    uint32_t run[kMaxRuns][3];  // loc, first | last << 16, count
+    uint32_t pad[2];
+};
+
+struct PartState {  // wave-uniform run-length state
+    uint32_t nruns = 0, complex = 0, have = 0, hits = 0;
+    uint32_t cur_loc = 0, cur_first = 0, cur_last = 0, cur_cnt = 0;
+    uint32_t run[kMaxRuns][3];
+    __device__ __forceinline__ void push() {
+        if (nruns < (uint32_t)kMaxRuns) {
+#pragma unroll
+            for (int i = 0; i < kMaxRuns; i++)
+                if ((uint32_t)i == nruns) {
+                    run[i][0] = cur_loc;
+                    run[i][1] = cur_first | (cur_last << 16);
+                    run[i][2] = cur_cnt;
+                }
+            nruns++;
+        } else {
+            complex = 1;
+        }
+    }
+};
+
+__device__ __forceinline__ unsigned long long lowmask64(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1ULL); }
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_probe_part(CompactView ct, TableView tab, ReadsView rd, PartRec *recs,
+                                                    unsigned long long *g_err_pos) {
+    __shared__ uint64_t sA[4][kTileWords + 2], sRA[4][kTileWords + 2];
+    __shared__ uint16_t sQ[4][kTileWindows];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t p = blockIdx.x & 7u;
+    const uint32_t tile = (blockIdx.x >> 3) * 4 + wave;
+    if (tile >= rd.n_tiles) return;  // waves are independent: no workgroup barrier below
+    const uint32_t r = rd.tile_read[tile];
+    const uint32_t tin = tile - rd.read_tile0[r];
+    const uint64_t wbase = rd.read_word_off[r] + (uint64_t)tin * kTileWords;
+    const uint32_t nwin = rd.read_nwin[r];
+    const uint32_t w0 = tin * kTileWindows + lane * 32;
+    const uint32_t nvalid = nwin > w0 ? min(nwin - w0, 32u) : 0u;
+    const uint32_t vmask = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
+    const int k = KT ? KT : tab.k;
+    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+
+    const uint64_t a = __builtin_nontemporal_load(rd.words + wbase + lane);
+    const uint64_t b2 = __builtin_nontemporal_load(rd.words + wbase + lane + 1);
+    const uint64_t ra = ~revpairs(a), rb = ~revpairs(b2);
+    sA[wave][lane] = a;
+    sRA[wave][lane] = ra;
+    if (lane == 63) {
+        sA[wave][64] = b2;
+        sRA[wave][64] = rb;
+    }
+
+    // which of my 32 windows belong to partition p  (needs only the low words of both strands)
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 0; b < 32; b++) {
+        const int s = 2 * b;
+        const uint64_t f = (s ? ((a << s) | (b2 >> (64 - s))) : a) >> (64 - 2 * k);
+        const uint64_t rr = s ? ((ra >> s) | (rb << (64 - s))) : ra;
+        const uint32_t t = ((uint32_t)f + (uint32_t)rr) * kPartMul;
+        m |= ((t >> 29) == p ? 1u : 0u) << b;
+    }
+    m &= vmask;
+
+    uint32_t total;
+    const uint32_t base = wave_excl_scan(__popc(m), lane, total);
+    {
+        uint32_t mm = m, i = base;
+        while (mm) {
+            const int bit = __ffs(mm) - 1;
+            mm &= mm - 1;
+            sQ[wave][i++] = (uint16_t)(lane * 32 + bit);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const uint64_t remmask = (1ULL << ct.rembits) - 1ULL;
+    const uint32_t locmask = (1u << ct.locbits) - 1u;
+    PartState st;
+    for (uint32_t j0 = 0; j0 < total; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        bool hit = false;
+        uint32_t loc = 0, woff = 0;
+        if (j < total) {
+            woff = sQ[wave][j];
+            const int wl = woff >> 5, s = 2 * (woff & 31u);
+            const uint64_t qa = sA[wave][wl], qb2 = sA[wave][wl + 1];
+            const uint64_t qra = sRA[wave][wl], qrb = sRA[wave][wl + 1];
+            const uint64_t f = ((qa << s) | ((qb2 >> 1) >> (63 - s))) >> (64 - 2 * k);
+            const uint64_t rr = ((qra >> s) | ((qrb << 1) << (63 - s))) & kmask;
+            const uint64_t c = f < rr ? f : rr;
+            const uint64_t y = hmix(c, k, kmask);
+            const uint32_t rem = (uint32_t)(y & remmask);
+            const uint64_t bidx = ((uint64_t)p << ct.qb) | (y >> ct.rembits);
+            const uint4 bk = ct.buckets[bidx];
+            const uint32_t sl[4] = {bk.x, bk.y, bk.z, bk.w};
+            bool full = true;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (sl[i] == kEmptySlot) {
+                    full = false;
+                } else if ((sl[i] >> ct.locbits) == rem) {
+                    hit = true;
+                    loc = sl[i] & locmask;
+                }
+            }
+            if (!hit && full) {  // overflowed bucket: the generic table decides
+                uint64_t hh = slot_of(c, tab.shift);
+                Slot cur = load_slot(tab.slots + hh);
+                while (cur.key != c && cur.key != kEmptyKey) {
+                    hh = (hh + 1) & tab.mask;
+                    cur = load_slot(tab.slots + hh);
+                }
+                if (cur.key == c) {
+                    hit = true;
+                    loc = cur.loc;
+                }
+            }
+        }
+        const unsigned long long hb = __ballot(hit);
+        if (!hb) continue;
+        const unsigned long long below = hb & lowmask64(lane);
+        const int src = below ? 63 - __clzll((long long)below) : -1;
+        const uint32_t ploc = __shfl(loc, src < 0 ? 0 : src);
+        const bool start = hit && (src < 0 ? (!st.have || loc != st.cur_loc) : (loc != ploc));
+        unsigned long long sb = __ballot(start);
+        int lo = 0;
+        while (sb) {  // wave-uniform; almost always 0 or 1 iterations
+            const int sl_ = __ffsll(sb) - 1;
+            sb &= sb - 1;
+            const unsigned long long seg = hb & lowmask64(sl_) & ~lowmask64(lo);
+            if (st.have) {
+                if (seg) {
+                    st.cur_cnt += __popcll(seg);
+                    st.cur_last = __shfl(woff, 63 - __clzll((long long)seg));
+                }
+                st.push();
+            }
+            st.cur_loc = __shfl(loc, sl_);
+            st.cur_first = __shfl(woff, sl_);
+            st.cur_last = st.cur_first;
+            st.cur_cnt = 0;
+            st.have = 1;
+            lo = sl_;
+        }
+        const unsigned long long seg = hb & ~lowmask64(lo);
+        st.cur_cnt += __popcll(seg);
+        st.cur_last = __shfl(woff, 63 - __clzll((long long)seg));
+        st.hits += __popcll(hb);
+    }
+    if (st.have) st.push();
+    if (lane == 0) {
+        PartRec rec;
+        rec.head = st.nruns | (st.complex << 8) | (st.hits << 16);
+#pragma unroll
+        for (int i = 0; i < kMaxRuns; i++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) rec.run[i][q] = (uint32_t)i < st.nruns ? st.run[i][q] : 0u;
+        rec.pad[0] = rec.pad[1] = 0;
+        recs[(uint64_t)tile * 8 + p] = rec;
+    }
+    (void)g_err_pos;  // the compact table is only built when no key lacks a loc row
+}
+
+__global__ __launch_bounds__(256) void k_merge_part(const PartRec *recs, uint32_t n_tiles, TileArrays ta, uint32_t *cand,
+                                                    uint32_t cand_cap, uint32_t *g_cand_count, uint32_t *complex_list,
+                                                    uint32_t *complex_n) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles) return;
+    uint32_t rl[8 * kMaxRuns], rf[8 * kMaxRuns], rla[8 * kMaxRuns], rc[8 * kMaxRuns];
+    int n = 0;
+    bool complex = false;
+    uint32_t hits = 0;
+    for (int p = 0; p < 8; p++) {
+        const PartRec rec = recs[(uint64_t)tile * 8 + p];
+        const uint32_t nr = rec.head & 0xFFu;
+        complex |= ((rec.head >> 8) & 1u) != 0;
+        hits += rec.head >> 16;
+        for (uint32_t i = 0; i < nr && i < (uint32_t)kMaxRuns; i++) {
+            rl[n] = rec.run[i][0];
+            rf[n] = rec.run[i][1] & 0xFFFFu;
+            rla[n] = rec.run[i][1] >> 16;
+            rc[n] = rec.run[i][2];
+            n++;
+        }
+    }
+    // insertion sort by first window
+    for (int i = 1; i < n && !complex; i++) {
+        const uint32_t l = rl[i], f = rf[i], la = rla[i], c = rc[i];
+        int j = i - 1;
+        while (j >= 0 && rf[j] > f) {
+            rl[j + 1] = rl[j]; rf[j + 1] = rf[j]; rla[j + 1] = rla[j]; rc[j + 1] = rc[j];
+            j--;
+        }
+        rl[j + 1] = l; rf[j + 1] = f; rla[j + 1] = la; rc[j + 1] = c;
+    }
+    // groups of equal loc must not overlap a run of another loc
+    uint32_t cw[8 * kMaxRuns], cr[8 * kMaxRuns];  // candidate window, rank
+    int ncand = 0;
+    uint32_t seen = 0, cur_loc = 0, cur_max = 0;
+    for (int i = 0; i < n && !complex; i++) {
+        if (i == 0 || rl[i] != cur_loc) {
+            if (i && rf[i] <= cur_max) {
+                complex = true;
+                break;
+            }
+            cw[ncand] = rf[i];
+            cr[ncand] = seen;
+            ncand++;
+            cur_loc = rl[i];
+            cur_max = rla[i];
+        } else {
+            cur_max = max(cur_max, rla[i]);
+        }
+        seen += rc[i];
+    }
+    if (complex) {
+        complex_list[atomicAdd(complex_n, 1u)] = tile;
+        return;
+    }
+    ta.n_raw[tile] = hits;
+    ta.n_cand[tile] = (uint32_t)ncand;
+    uint32_t off = 0;
+    if (ncand) {
+        off = atomicAdd(g_cand_count, (uint32_t)ncand);
+        if ((uint64_t)off + ncand <= cand_cap)
+            for (int i = 0; i < ncand; i++) cand[off + i] = (cr[i] << 16) | cw[i];
+        ta.first_loc[tile] = rl[0];
+        ta.last_loc[tile] = cur_loc;
+    }
+    ta.cand_off[tile] = off;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -440,6 +731,12 @@ struct gs_table {
     uint64_t n = 0, cap = 0;
     int shift = 0;
     Slot *slots = nullptr;
+    // small-table fast path (exact compact table resident in the XCD-partitioned L2s)
+    bool compact = false;
+    uint4 *cbuckets = nullptr;
+    int c_qb = 0, c_rembits = 0, c_locbits = 0;
+    uint64_t c_overflow = 0;
+    uint32_t *d_complex_n = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // scalars on device
@@ -473,6 +770,8 @@ struct gs_reads {
     uint32_t cand_cap = 0;
     gs_hit *hits = nullptr;
     uint64_t hit_cap = 0;
+    PartRec *part_recs = nullptr;      // [n_tiles * 8], fast path only
+    uint32_t *complex_list = nullptr;  // [n_tiles]
 };
 
 namespace {
@@ -498,13 +797,36 @@ int ensure_out_buffers(gs_reads *r, uint32_t cand_cap) {
 
 int launch_phase1(gs_table *t, gs_reads *r) {
     HIP_TRY(hipSetDevice(t->device));
+    if (t->compact && r->n_tiles && !r->part_recs) {
+        int rc;
+        if ((rc = dev_alloc(&r->part_recs, (uint64_t)r->n_tiles * 8))) return rc;
+        if ((rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
+    }
     HIP_TRY(hipMemsetAsync(t->d_cand_count, 0, sizeof(uint32_t), t->stream));
     HIP_TRY(hipMemsetAsync(t->d_err_pos, 0xFF, sizeof(unsigned long long), t->stream));
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     if (r->n_tiles) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
-        hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(256), 0, t->stream, view(t), view(r), r->ta, r->cand,
-                           r->cand_cap, t->d_cand_count, t->d_err_pos);
+        if (t->compact) {
+            HIP_TRY(hipMemsetAsync(t->d_complex_n, 0, sizeof(uint32_t), t->stream));
+            const CompactView cv{t->cbuckets, t->c_qb, t->c_rembits, t->c_locbits};
+            if (t->k == 20)
+                hipLaunchKernelGGL(k_probe_part<20>, dim3(blocks * 8), dim3(256), 0, t->stream, cv, view(t), view(r),
+                                   r->part_recs, t->d_err_pos);
+            else
+                hipLaunchKernelGGL(k_probe_part<0>, dim3(blocks * 8), dim3(256), 0, t->stream, cv, view(t), view(r),
+                                   r->part_recs, t->d_err_pos);
+            hipLaunchKernelGGL(k_merge_part, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, r->part_recs,
+                               r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list, t->d_complex_n);
+            // tiles whose partition summaries cannot be merged exactly: generic probe, grid-stride over the list
+            hipLaunchKernelGGL(k_probe, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), view(r),
+                               r->ta, r->cand, r->cand_cap, t->d_cand_count, t->d_err_pos,
+                               (const uint32_t *)r->complex_list, (const uint32_t *)t->d_complex_n);
+        } else {
+            hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(256), 0, t->stream, view(t), view(r), r->ta, r->cand,
+                               r->cand_cap, t->d_cand_count, t->d_err_pos, (const uint32_t *)nullptr,
+                               (const uint32_t *)nullptr);
+        }
     }
     HIP_TRY(hipEventRecord(t->ev[1], t->stream));
     HIP_TRY(hipGetLastError());
@@ -546,6 +868,60 @@ int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
     t->pass_pending = true;
     t->settled_reads = nullptr;
     return GS_OK;
+}
+
+}  // namespace
+
+namespace {
+
+uint64_t revcomp_code(uint64_t c, int k) {
+    uint64_t r = 0;
+    for (int i = 0; i < k; i++) {
+        r = (r << 2) | (3 - (c & 3));
+        c >>= 2;
+    }
+    return r;
+}
+
+// Host build of the compact table; returns false when the fast path does not apply
+// (k < 16, a key without loc row, remainder + loc do not fit 32 bits, or more than 32 MiB).
+bool build_compact(int k, uint64_t n, const uint64_t *keys, const uint32_t *loc, std::vector<uint32_t> &slots, int &qb,
+                   int &rembits, int &locbits, uint64_t &overflow) {
+    const char *env = getenv("GAVISUNK_TABLE");
+    if (env && !strcmp(env, "generic")) return false;
+    if (k < 16 || n == 0) return false;
+    uint32_t maxloc = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (loc[i] >= GS_MISSING) return false;
+        maxloc = std::max(maxloc, loc[i]);
+    }
+    locbits = 1;
+    while ((1ull << locbits) < (uint64_t)maxloc + 2) locbits++;  // the all-ones loc stays unused
+    qb = 10;
+    while ((32ull << qb) < (uint64_t)(2.2 * (double)n)) qb++;
+    while (2 * k - qb + locbits > 32) qb++;
+    if ((128ull << qb) > (32ull << 20)) return false;  // 8 partitions x 2^qb buckets x 16 B must sit in 8 x 4 MiB of L2
+    rembits = 2 * k - qb;
+    if (rembits < 1) return false;
+    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    const uint64_t remmask = (1ULL << rembits) - 1;
+    slots.assign((size_t)32 << qb, kEmptySlot);
+    overflow = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t c = keys[i];
+        const uint32_t p = (((uint32_t)c + (uint32_t)revcomp_code(c, k)) * kPartMul) >> 29;
+        const uint64_t y = hmix(c, k, kmask);
+        const uint64_t b = ((uint64_t)p << qb) | (y >> rembits);
+        const uint32_t v = ((uint32_t)(y & remmask) << locbits) | loc[i];
+        uint32_t *bk = &slots[b * 4];
+        int j = 0;
+        while (j < 4 && bk[j] != kEmptySlot) j++;
+        if (j < 4)
+            bk[j] = v;
+        else
+            overflow++;  // stays in the generic table only; lookups of a full bucket fall back to it
+    }
+    return true;
 }
 
 }  // namespace
@@ -608,8 +984,30 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     }
     HIP_TRY(hipStreamSynchronize(t->stream));
     HIP_TRY(hipGetLastError());
+    {
+        std::vector<uint32_t> cs;
+        if (build_compact(k, n, keys, loc, cs, t->c_qb, t->c_rembits, t->c_locbits, t->c_overflow)) {
+            uint32_t *d = nullptr;
+            if ((rc = dev_alloc(&d, cs.size()))) return rc;
+            HIP_TRY(hipMemcpy(d, cs.data(), cs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            t->cbuckets = reinterpret_cast<uint4 *>(d);
+            if ((rc = dev_alloc(&t->d_complex_n, 1))) return rc;
+            t->compact = true;
+        }
+    }
     *out = t;
     return GS_OK;
+}
+
+const char *gs_table_layout(const gs_table *t) {
+    static thread_local char buf[160];
+    if (!t) return "";
+    if (t->compact)
+        snprintf(buf, sizeof buf, "compact-l2: 8 partitions x 2^%d buckets x 4 x u32 (%d-bit remainder, %d-bit loc), %llu overflow keys; generic 16 B table behind it",
+                 t->c_qb, t->c_rembits, t->c_locbits, (unsigned long long)t->c_overflow);
+    else
+        snprintf(buf, sizeof buf, "generic: open-addressed 16 B slots in HBM");
+    return buf;
 }
 
 void gs_table_destroy(gs_table *t) {
@@ -617,6 +1015,8 @@ void gs_table_destroy(gs_table *t) {
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)hipFree(t->slots);
+    (void)hipFree(t->cbuckets);
+    (void)hipFree(t->d_complex_n);
     (void)hipFree(t->d_cand_count);
     (void)hipFree(t->d_err_pos);
     (void)hipFree(t->d_carry_in);
@@ -627,7 +1027,9 @@ void gs_table_destroy(gs_table *t) {
     delete t;
 }
 
-uint64_t gs_table_bytes(const gs_table *t) { return t ? t->cap * sizeof(Slot) : 0; }
+uint64_t gs_table_bytes(const gs_table *t) {
+    return t ? t->cap * sizeof(Slot) + (t->compact ? (128ull << t->c_qb) : 0) : 0;
+}
 
 int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off, const uint32_t *len,
                     uint32_t n_reads, int k, gs_reads **out) {
@@ -674,9 +1076,10 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
     }
     r->n_tiles = (uint32_t)tiles;
     int rc;
-    // +2 zero words of slack: the last lane of the last tile loads one word past its own
-    if ((rc = dev_alloc(&r->words, n_words + 2))) return rc;
-    HIP_TRY(hipMemset(r->words, 0, (n_words + 2) * sizeof(uint64_t)));
+    // zero slack after the last read: every lane of a tile loads words [l, l+1] unconditionally
+    const uint64_t slack = kTileWords + 2;
+    if ((rc = dev_alloc(&r->words, n_words + slack))) return rc;
+    HIP_TRY(hipMemset(r->words, 0, (n_words + slack) * sizeof(uint64_t)));
     if ((rc = dev_alloc(&r->read_word_off, (uint64_t)n_reads + 1))) return rc;
     if ((rc = dev_alloc(&r->read_nwin, n_reads)) || (rc = dev_alloc(&r->read_tile0, n_reads)) ||
         (rc = dev_alloc(&r->tile_read, tiles)))
@@ -724,6 +1127,8 @@ void gs_reads_destroy(gs_reads *r) {
     (void)hipFree(r->block_agg);
     (void)hipFree(r->cand);
     (void)hipFree(r->hits);
+    (void)hipFree(r->part_recs);
+    (void)hipFree(r->complex_list);
     delete r;
 }
 

@@ -132,6 +132,10 @@ class DeviceTable:
     def nbytes(self) -> int:
         return lib().gs_table_bytes(self._h)
 
+    @property
+    def layout(self) -> str:
+        return lib().gs_table_layout(self._h).decode()
+
     def close(self):
         if getattr(self, "_h", None):
             lib().gs_table_destroy(self._h)

@@ -113,6 +113,9 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
                     const uint32_t *payload, gs_table **out);
 void gs_table_destroy(gs_table *t);
 uint64_t gs_table_bytes(const gs_table *t);
+/* Human-readable description of the layout chosen for this table (small tables get an exact
+ * compact copy that stays resident in the XCD-partitioned L2; GAVISUNK_TABLE=generic disables it). */
+const char *gs_table_layout(const gs_table *t);
 
 /* Device-resident batch of packed reads (+ the per-tile index the kernels need). */
 typedef struct gs_reads gs_reads;

@@ -12,6 +12,14 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "generic"], autouse=True)
+def table_layout(request, monkeypatch):
+    """Every test runs twice: with the layout the library picks (small k<=20 tables get the exact
+    compact copy probed out of the XCD-partitioned L2) and with the generic HBM table forced."""
+    monkeypatch.setenv("GAVISUNK_TABLE", request.param)
+    return request.param
+
+
 def _oracle_hits(k, keys, key_loc_pairs, seqs, prev=oracle.NONE):
     """Oracle run where every key is its own loc row; chrom = 0, group = loc id."""
     t = oracle.Table(k, keys, keys, np.zeros(len(keys), np.uint32), key_loc_pairs.astype(np.int64))
@@ -57,7 +65,7 @@ def test_cli_matches_reference_binary(golden, name, tmp_path):
             assert got.startswith(exp)
 
 
-@pytest.mark.parametrize("k", [11, 20, 21, 25, 31, 32])
+@pytest.mark.parametrize("k", [11, 16, 18, 20, 21, 25, 31, 32])
 @pytest.mark.parametrize("seed", [1, 2])
 def test_random_inputs_match_oracle(k, seed):
     keys, loc, seqs = _random_case(seed * 100 + k, k)
@@ -142,6 +150,37 @@ def test_empty_and_tiny_batches():
     # Q6: empty / short reads yield one A-padded window each -> poly-A hits; repeats are suppressed
     assert h["read"].tolist() == [0] and h["pos"].tolist() == [0] and carry == 0
     assert ctr["windows"] == 3 + (40 - k + 1) and ctr["raw_hits"] == 3
+
+
+def test_layout_selection(table_layout):
+    keys, loc, _ = _random_case(3, 20)
+    tab = engine.DeviceTable(20, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    assert tab.layout.startswith("compact-l2" if table_layout == "auto" else "generic")
+    tab.close()
+    keys, loc, _ = _random_case(3, 25)
+    tab = engine.DeviceTable(25, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    assert tab.layout.startswith("generic")  # 50-bit keys do not fit the 32-bit compact slots
+    tab.close()
+
+
+def test_spurious_hit_inside_a_run_takes_the_exact_fallback():
+    """A read that walks along one location group with single hits of another group sprinkled
+    inside it: the partition summaries overlap, so those tiles must go through the generic
+    probe; the answer must not change."""
+    k = 20
+    rng = np.random.default_rng(77)
+    g = rng.integers(0, 4, 60_000, dtype=np.uint8)
+    codes, first = np.unique(synth.canonical_codes(g, k), return_index=True)
+    loc = np.zeros(len(codes), dtype=np.uint32)
+    odd = rng.random(len(codes)) < 0.002
+    loc[odd] = 1 + (first[odd] % 5).astype(np.uint32)
+    seqs = [synth.codes_to_ascii(g), synth.codes_to_ascii(synth.revcomp_codes(g[1000:50_000]))]
+    rc, oh, _, octr = _oracle_hits(k, codes, loc, seqs)
+    st, gh, _, ctr = _engine_hits(k, codes, loc, seqs)
+    assert st == 0 and ctr["raw_hits"] == octr["raw_hits"]
+    assert len(gh) == len(oh) > 100
+    assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"])
+    assert np.array_equal(gh["payload"], oh["row"])
 
 
 def test_deterministic_across_runs():
