@@ -230,42 +230,82 @@ __global__ __launch_bounds__(256) void k_probe(TableView tab, ReadsView rd, Tile
 // MI355X has 8 XCDs with a private 4 MiB L2 each, and workgroup b is dispatched to XCD b % 8
 // (observed, used for speed only: any other placement gives the same results, slower).  Random
 // probes that hit L2 run at ~270 G/s chip-wide; past L2 they run at ~55 G/s whatever the table
-// size (profiles/r01/ubench_*.txt).  So the key space is cut into 8 partitions by a cheap
-// strand-symmetric function of the k-mer, partition p is only ever probed by workgroups with
-// blockIdx % 8 == p, and each XCD's L2 holds just its eighth of the table:
+// size (profiles/r01/ubench_*.txt).  So the key space is cut into 16 partitions, 8 of them live
+// at a time (two passes over the tiles), partition p is only probed by workgroups with
+// blockIdx % 8 == p % 8, and each XCD's L2 holds one 1/16 slice of the table at a time.
 //
-//   part(c)   = ((lo32(c) + lo32(revcomp c)) * 0x9E3779B1) >> 29        (same for both strands)
-//   y         = hmix(c)                      a bijection on 2k-bit codes
-//   bucket    = y >> rembits                 (2^qb buckets of 4 x 32-bit slots per partition)
-//   slot      = (y & remmask) << locbits | loc        0xFFFFFFFF = empty
+// The partition function is strand-symmetric, costs a few bit-parallel operations for all 32
+// windows of a lane at once, and is "free" in key bits.  With x_i the i-th base of a window,
 //
-// (partition, bucket, remainder) identifies the key exactly, so a match is a true hit.  A key
-// whose home bucket is full at build time is left out; a lookup that finds a full bucket without
-// a match falls back to the generic table, so the pair stays exact.
+//   part = (x_0 ^ x_{k-1}) << 2 | (x_1 ^ x_{k-2})
 //
-// k_probe_part  grid = 8 x ceil(tiles/4): wave (tile, p) rebuilds the tile's 2048 window codes,
-//               keeps the ~1/8 that belong to partition p (compacted through an LDS queue so the
-//               probe loop runs with full waves), probes, and writes a run-length summary of its
-//               hits: up to 3 runs {loc, first window, last window, count}.
-// k_merge_part  per tile, merges the 8 summaries.  If runs of different loc never overlap in
+// is the same for a k-mer and its reverse complement, and given `part` the last two bases follow
+// from the first two, so the table only has to store the canonical code without them:
+//
+//   key~      = canonical code >> 4                       (2k-4 bits)
+//   y         = hmix(key~)                                a bijection on (2k-4)-bit values
+//   bucket    = y >> rembits                              2^qb buckets of 4 x 32-bit slots per partition
+//   slot      = flag << 31 | (y & remmask) << locbits | loc        0xFFFFFFFF = empty
+//
+// (partition, bucket, remainder) identifies the key exactly, so a match is a true hit.  A key whose
+// home bucket is full at build time stays in the generic table only and the bucket gets its
+// overflow flag (bit 31 of slot 0); a lookup that finds no match in a flagged bucket asks the
+// generic table, every other lookup without a match is an exact miss.
+//
+// k_probe_part  grid = 16 x ceil(tiles/4): wave (tile, p) finds which of the tile's 2048 windows
+//               belong to partition p with ~40 bit-parallel operations per lane, compacts them
+//               through an LDS queue so the probe loop runs with full waves and four bucket loads
+//               in flight per lane, and writes a run-length summary of its hits: up to 3 runs
+//               {loc, first window, last window, count}.
+// k_merge_part  per tile, merges the 16 summaries.  If runs of different loc never overlap in
 //               window range the interleaving of the partitions does not matter and the tile's
 //               {n_raw, first/last loc, candidates} follow exactly; otherwise the tile is queued
 //               for the generic probe_tile (k_probe with a tile list).
 // ------------------------------------------------------------------------------------------
-constexpr uint64_t kMixA = 0xD6E8FEB86659FD93ULL, kMixB = 0xCA9B0DBC1D2E4F67ULL;
-constexpr uint32_t kPartMul = 0x9E3779B1u;
 constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
 constexpr int kMaxRuns = 3;
+constexpr int kNPart = 16;  // key-space partitions; 8 are live at a time (one per XCD), kNPart / 8 passes
+constexpr int kPipe = 4;    // bucket loads in flight per lane in the probe loop
+constexpr int kPartTiles = 4;  // tiles per wave in k_probe_part
 
-__host__ __device__ __forceinline__ uint64_t hmix(uint64_t c, int k, uint64_t kmask) {
-    uint64_t y = (c * kMixA) & kmask;
-    y ^= y >> k;
-    return (y * kMixB) & kmask;
+// Bijection on `kbits`-bit keys, cheap in 32-bit arithmetic, returning the pair (bucket, remainder)
+// with bucket in [0, 2^qb) taken from the best-mixed bits.  kbits = 2k - 4 in [28, 60], qb <= 20.
+struct BucketRem {
+    uint32_t bucket;
+    uint32_t rem;  // kbits - qb bits
+};
+__host__ __device__ __forceinline__ BucketRem hmix2(uint64_t key, int kbits, int qb) {
+    const int lbits = kbits < 32 ? kbits : 32;  // low part that gets mixed
+    const uint32_t lmask = lbits == 32 ? 0xFFFFFFFFu : ((1u << lbits) - 1u);
+    const uint32_t hi = (uint32_t)(key >> lbits);  // kbits - lbits bits, passes through
+    uint32_t l = (uint32_t)key & lmask;
+    l = (l * 0x9E3779B1u) & lmask;
+    l ^= l >> (lbits / 2);
+    l = (l * 0x85EBCA6Bu) & lmask;
+    l ^= l >> (lbits / 2 + 1);
+    l = (l ^ (hi * 0xC2B2AE35u)) & lmask;
+    BucketRem o;
+    o.bucket = l >> (lbits - qb);
+    o.rem = ((l & ((1u << (lbits - qb)) - 1u)) << (kbits - lbits)) | hi;
+    return o;
+}
+// second-chance bucket of a key (same partition): bucket ^ (odd, non-zero function of the remainder)
+__host__ __device__ __forceinline__ uint32_t alt_bucket(uint32_t bucket, uint32_t rem, int qb) {
+    return bucket ^ ((((rem + 1u) * 0x9E3779B1u) >> (32 - qb)) | 1u);
 }
 
+// partition of a canonical (or not: it is strand-symmetric) 2k-bit code
+__host__ __device__ __forceinline__ uint32_t part_of(uint64_t c, int k) {
+    const uint32_t x0 = (uint32_t)(c >> (2 * k - 2)) & 3u, x1 = (uint32_t)(c >> (2 * k - 4)) & 3u;
+    const uint32_t xl = (uint32_t)c & 3u, xl2 = (uint32_t)(c >> 2) & 3u;
+    return ((x0 ^ xl) << 2) | (x1 ^ xl2);
+}
+
+// slot = [ flags(2, slot 0 only) | alt(1) | rem | loc ];  flags: bit 31 = a key of this bucket lives in its
+// second-chance bucket, bit 30 = a key of this bucket lives in the generic table only
 struct CompactView {
-    const uint4 *buckets;  // [8 << qb]
-    int qb, rembits, locbits;
+    const uint4 *buckets;  // [kNPart << qb]
+    int qb, rembits, locbits, has_flag;
 };
 
 struct __align__(16) PartRec {
@@ -274,168 +314,332 @@ struct __align__(16) PartRec {
     uint32_t pad[2];
 };
 
-struct PartState {  // wave-uniform run-length state
-    uint32_t nruns = 0, complex = 0, have = 0, hits = 0;
-    uint32_t cur_loc = 0, cur_first = 0, cur_last = 0, cur_cnt = 0;
-    uint32_t run[kMaxRuns][3];
-    __device__ __forceinline__ void push() {
+struct __align__(16) TileDesc {
+    uint64_t wbase;      // first word of the tile
+    uint32_t nwin_left;  // windows of the read from the tile's first window on
+    uint32_t read;
+};
+
+// wave-uniform run-length state of one (tile, partition); completed runs go to LDS
+struct PartState {
+    uint32_t nruns, complex, have, hits, cur_loc, cur_first, cur_last, cur_cnt;
+    __device__ __forceinline__ void reset() { nruns = complex = have = hits = cur_loc = cur_first = cur_last = cur_cnt = 0; }
+    __device__ __forceinline__ void push(uint32_t (*runs)[3], int lane) {
         if (nruns < (uint32_t)kMaxRuns) {
-#pragma unroll
-            for (int i = 0; i < kMaxRuns; i++)
-                if ((uint32_t)i == nruns) {
-                    run[i][0] = cur_loc;
-                    run[i][1] = cur_first | (cur_last << 16);
-                    run[i][2] = cur_cnt;
-                }
+            if (lane == 0) {
+                runs[nruns][0] = cur_loc;
+                runs[nruns][1] = cur_first | (cur_last << 16);
+                runs[nruns][2] = cur_cnt;
+            }
             nruns++;
         } else {
             complex = 1;
         }
     }
-};
-
-__device__ __forceinline__ unsigned long long lowmask64(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1ULL); }
-
-template <int KT>
-__global__ __launch_bounds__(256) void k_probe_part(CompactView ct, TableView tab, ReadsView rd, PartRec *recs,
-                                                    unsigned long long *g_err_pos) {
-    __shared__ uint64_t sA[4][kTileWords + 2], sRA[4][kTileWords + 2];
-    __shared__ uint16_t sQ[4][kTileWindows];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t p = blockIdx.x & 7u;
-    const uint32_t tile = (blockIdx.x >> 3) * 4 + wave;
-    if (tile >= rd.n_tiles) return;  // waves are independent: no workgroup barrier below
-    const uint32_t r = rd.tile_read[tile];
-    const uint32_t tin = tile - rd.read_tile0[r];
-    const uint64_t wbase = rd.read_word_off[r] + (uint64_t)tin * kTileWords;
-    const uint32_t nwin = rd.read_nwin[r];
-    const uint32_t w0 = tin * kTileWindows + lane * 32;
-    const uint32_t nvalid = nwin > w0 ? min(nwin - w0, 32u) : 0u;
-    const uint32_t vmask = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
-    const int k = KT ? KT : tab.k;
-    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
-
-    const uint64_t a = __builtin_nontemporal_load(rd.words + wbase + lane);
-    const uint64_t b2 = __builtin_nontemporal_load(rd.words + wbase + lane + 1);
-    const uint64_t ra = ~revpairs(a), rb = ~revpairs(b2);
-    sA[wave][lane] = a;
-    sRA[wave][lane] = ra;
-    if (lane == 63) {
-        sA[wave][64] = b2;
-        sRA[wave][64] = rb;
-    }
-
-    // which of my 32 windows belong to partition p  (needs only the low words of both strands)
-    uint32_t m = 0;
-#pragma unroll
-    for (int b = 0; b < 32; b++) {
-        const int s = 2 * b;
-        const uint64_t f = (s ? ((a << s) | (b2 >> (64 - s))) : a) >> (64 - 2 * k);
-        const uint64_t rr = s ? ((ra >> s) | (rb << (64 - s))) : ra;
-        const uint32_t t = ((uint32_t)f + (uint32_t)rr) * kPartMul;
-        m |= ((t >> 29) == p ? 1u : 0u) << b;
-    }
-    m &= vmask;
-
-    uint32_t total;
-    const uint32_t base = wave_excl_scan(__popc(m), lane, total);
-    {
-        uint32_t mm = m, i = base;
-        while (mm) {
-            const int bit = __ffs(mm) - 1;
-            mm &= mm - 1;
-            sQ[wave][i++] = (uint16_t)(lane * 32 + bit);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    const uint64_t remmask = (1ULL << ct.rembits) - 1ULL;
-    const uint32_t locmask = (1u << ct.locbits) - 1u;
-    PartState st;
-    for (uint32_t j0 = 0; j0 < total; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        bool hit = false;
-        uint32_t loc = 0, woff = 0;
-        if (j < total) {
-            woff = sQ[wave][j];
-            const int wl = woff >> 5, s = 2 * (woff & 31u);
-            const uint64_t qa = sA[wave][wl], qb2 = sA[wave][wl + 1];
-            const uint64_t qra = sRA[wave][wl], qrb = sRA[wave][wl + 1];
-            const uint64_t f = ((qa << s) | ((qb2 >> 1) >> (63 - s))) >> (64 - 2 * k);
-            const uint64_t rr = ((qra >> s) | ((qrb << 1) << (63 - s))) & kmask;
-            const uint64_t c = f < rr ? f : rr;
-            const uint64_t y = hmix(c, k, kmask);
-            const uint32_t rem = (uint32_t)(y & remmask);
-            const uint64_t bidx = ((uint64_t)p << ct.qb) | (y >> ct.rembits);
-            const uint4 bk = ct.buckets[bidx];
-            const uint32_t sl[4] = {bk.x, bk.y, bk.z, bk.w};
-            bool full = true;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (sl[i] == kEmptySlot) {
-                    full = false;
-                } else if ((sl[i] >> ct.locbits) == rem) {
-                    hit = true;
-                    loc = sl[i] & locmask;
-                }
-            }
-            if (!hit && full) {  // overflowed bucket: the generic table decides
-                uint64_t hh = slot_of(c, tab.shift);
-                Slot cur = load_slot(tab.slots + hh);
-                while (cur.key != c && cur.key != kEmptyKey) {
-                    hh = (hh + 1) & tab.mask;
-                    cur = load_slot(tab.slots + hh);
-                }
-                if (cur.key == c) {
-                    hit = true;
-                    loc = cur.loc;
-                }
-            }
-        }
+    // fold one ordered group of <= 64 items (one per lane) into the run list
+    __device__ __forceinline__ void step(bool hit, uint32_t loc, uint32_t woff, int lane, uint32_t (*runs)[3]) {
         const unsigned long long hb = __ballot(hit);
-        if (!hb) continue;
-        const unsigned long long below = hb & lowmask64(lane);
+        if (!hb) return;
+        const int first_lane = __ffsll(hb) - 1, last_lane = 63 - __clzll((long long)hb);
+        const uint32_t loc0 = __shfl(loc, first_lane);
+        hits += __popcll(hb);
+        if (!__ballot(hit && loc != loc0)) {  // the usual case: every hit of the group has the same loc
+            if (!(have && cur_loc == loc0)) {
+                if (have) push(runs, lane);
+                cur_loc = loc0;
+                cur_first = __shfl(woff, first_lane);
+                cur_cnt = 0;
+                have = 1;
+            }
+            cur_cnt += __popcll(hb);
+            cur_last = __shfl(woff, last_lane);
+            return;
+        }
+        const unsigned long long below = hb & (lane ? (~0ULL >> (64 - lane)) : 0ULL);
         const int src = below ? 63 - __clzll((long long)below) : -1;
         const uint32_t ploc = __shfl(loc, src < 0 ? 0 : src);
-        const bool start = hit && (src < 0 ? (!st.have || loc != st.cur_loc) : (loc != ploc));
+        const bool start = hit && (src < 0 ? (!have || loc != cur_loc) : (loc != ploc));
         unsigned long long sb = __ballot(start);
         int lo = 0;
-        while (sb) {  // wave-uniform; almost always 0 or 1 iterations
-            const int sl_ = __ffsll(sb) - 1;
+        while (sb) {  // wave-uniform
+            const int sl = __ffsll(sb) - 1;
             sb &= sb - 1;
-            const unsigned long long seg = hb & lowmask64(sl_) & ~lowmask64(lo);
-            if (st.have) {
+            const unsigned long long seg = hb & ((1ULL << sl) - 1ULL) & ~((1ULL << lo) - 1ULL);
+            if (have) {
                 if (seg) {
-                    st.cur_cnt += __popcll(seg);
-                    st.cur_last = __shfl(woff, 63 - __clzll((long long)seg));
+                    cur_cnt += __popcll(seg);
+                    cur_last = __shfl(woff, 63 - __clzll((long long)seg));
                 }
-                st.push();
+                push(runs, lane);
             }
-            st.cur_loc = __shfl(loc, sl_);
-            st.cur_first = __shfl(woff, sl_);
-            st.cur_last = st.cur_first;
-            st.cur_cnt = 0;
-            st.have = 1;
-            lo = sl_;
+            cur_loc = __shfl(loc, sl);
+            cur_first = __shfl(woff, sl);
+            cur_last = cur_first;
+            cur_cnt = 0;
+            have = 1;
+            lo = sl;
         }
-        const unsigned long long seg = hb & ~lowmask64(lo);
-        st.cur_cnt += __popcll(seg);
-        st.cur_last = __shfl(woff, 63 - __clzll((long long)seg));
-        st.hits += __popcll(hb);
+        const unsigned long long seg = hb & ~((1ULL << lo) - 1ULL);
+        cur_cnt += __popcll(seg);
+        cur_last = __shfl(woff, 63 - __clzll((long long)seg));
     }
-    if (st.have) st.push();
-    if (lane == 0) {
-        PartRec rec;
-        rec.head = st.nruns | (st.complex << 8) | (st.hits << 16);
+};
+
+// A wave works on NT consecutive tiles of one partition per pass over its phases, so that every
+// phase has NT (or more) independent memory requests in flight per lane: descriptors, words,
+// first-chance buckets, second-chance buckets.  DBG: timing experiments (1 = no bucket loads,
+// 2 = stop after the queue); results are wrong for DBG != 0.
+template <int KT, int NT, int DBG>
+__global__ __launch_bounds__(256) void k_probe_part(CompactView ct, TableView tab, const uint64_t *__restrict__ words,
+                                                    const TileDesc *__restrict__ tdesc, uint32_t n_tiles, PartRec *recs) {
+    static_assert(NT == 2 || NT == 4, "tile index takes 2 bits of a queue entry");
+    constexpr int QCAP = 1024;  // queue window (items); more items are handled window by window
+    constexpr int PCAP = 128;   // deferred (second-chance / generic) lookups per flush
+    // queue entry: woff[0:11) | tile[11:13) | hit[13] | loc[14:32)
+    __shared__ uint64_t sA[4][NT][kTileWords + 2];
+    __shared__ uint32_t sQ[4][QCAP];
+    __shared__ uint32_t sP[4][PCAP][3];
+    __shared__ uint32_t sRun[4][kMaxRuns][3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nbatch = (n_tiles + NT - 1) / NT;
+    const uint32_t groups = (nbatch + 3) / 4;
+    // blocks [pass * 8 * groups, (pass + 1) * 8 * groups) work on partitions pass * 8 + (b % 8): dispatch order
+    // keeps one 1/kNPart slice of the table hot in each XCD's L2 at a time
+    const uint32_t pass = blockIdx.x / (8u * groups);
+    const uint32_t bip = blockIdx.x - pass * 8u * groups;
+    const uint32_t p = pass * 8u + (bip & 7u);
+    const uint32_t batch = (bip >> 3) * 4 + wave;
+    if (batch >= nbatch) return;  // waves are independent: no workgroup barrier below
+    const uint32_t tile0 = batch * NT;
+    const int k = KT ? KT : tab.k;
+    const uint32_t wlane = (uint32_t)lane * 32u;
+
+    uint64_t m[NT];
+    uint32_t ex[NT], tot[NT];
+    {
+        TileDesc td[NT];
 #pragma unroll
-        for (int i = 0; i < kMaxRuns; i++)
+        for (int q = 0; q < NT; q++) {
+            td[q] = tdesc[min(tile0 + q, n_tiles - 1)];
+            if (tile0 + q >= n_tiles) td[q].nwin_left = 0;
+        }
+        uint64_t a[NT], b2[NT];
 #pragma unroll
-            for (int q = 0; q < 3; q++) rec.run[i][q] = (uint32_t)i < st.nruns ? st.run[i][q] : 0u;
-        rec.pad[0] = rec.pad[1] = 0;
-        recs[(uint64_t)tile * 8 + p] = rec;
+        for (int q = 0; q < NT; q++) {
+            a[q] = __builtin_nontemporal_load(words + td[q].wbase + lane);
+            b2[q] = __builtin_nontemporal_load(words + td[q].wbase + lane + 1);
+        }
+        // Which of my 32 windows of each tile belong to partition p, all at once.  Base j of the 64-base string
+        // (a:b2) sits at bits 127-2j, 126-2j.  W1 field b = x_b ^ x_{b+k-1}; W2 field b+1 = x_{b+1} ^ x_{b+k-2}.
+        const int s1 = 2 * (k - 1), s2 = 2 * (k - 3);
+        const uint64_t t1 = (uint64_t)(p >> 2) * 0x5555555555555555ULL, t2 = (uint64_t)(p & 3u) * 0x5555555555555555ULL;
+        uint32_t cnt[NT];
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+            sA[wave][q][lane] = a[q];
+            if (lane == 63) sA[wave][q][64] = b2[q];
+            const uint32_t nvalid = td[q].nwin_left > wlane ? min(td[q].nwin_left - wlane, 32u) : 0u;
+            const uint64_t w1 = a[q] ^ ((a[q] << s1) | (b2[q] >> (64 - s1)));
+            const uint64_t w2h = a[q] ^ ((a[q] << s2) | (b2[q] >> (64 - s2)));
+            const uint64_t w2l = b2[q] ^ (b2[q] << s2);
+            const uint64_t w2s = (w2h << 2) | (w2l >> 62);
+            const uint64_t e = (w1 ^ t1) | (w2s ^ t2);
+            uint64_t mm = ~(e | (e >> 1)) & 0x5555555555555555ULL;  // bit 62-2b set <=> window b is in partition p
+            mm &= nvalid >= 32 ? ~0ULL : ~(~0ULL >> (2 * nvalid));
+            m[q] = mm;
+            cnt[q] = __popcll(mm);
+        }
+        // per-tile exclusive prefix over lanes, two tiles per 32-bit scan (counts < 2^16)
+#pragma unroll
+        for (int q = 0; q < NT; q += 2) {
+            const uint32_t packed = cnt[q] | (cnt[q + 1] << 16);
+            uint32_t t;
+            const uint32_t e2 = wave_excl_scan(packed, lane, t);
+            ex[q] = e2 & 0xFFFFu;
+            tot[q] = t & 0xFFFFu;
+            ex[q + 1] = e2 >> 16;
+            tot[q + 1] = t >> 16;
+        }
     }
-    (void)g_err_pos;  // the compact table is only built when no key lacks a loc row
+    uint32_t vbase[NT + 1];  // the tiles' item lists back to back
+    vbase[0] = 0;
+#pragma unroll
+    for (int q = 0; q < NT; q++) vbase[q + 1] = vbase[q] + tot[q];
+    const uint32_t V = vbase[NT];
+    if (DBG == 2) {
+        if (lane == 0)
+            for (int q = 0; q < NT; q++)
+                if (tile0 + q < n_tiles) recs[(uint64_t)(tile0 + q) * kNPart + p].head = 0;
+        return;
+    }
+
+    const int kbits = 2 * k - 4;
+    const uint64_t keymask = (1ULL << kbits) - 1ULL;
+    const uint32_t locmask = (1u << ct.locbits) - 1u;
+    const uint32_t tagmask = (1u << (ct.rembits + 1)) - 1u;  // remainder + alt bit
+    const uint4 *part_buckets = ct.buckets + ((uint64_t)p << ct.qb);
+    uint32_t (*runs)[3] = sRun[wave];
+    PartState st;
+    st.reset();
+    int cur_q = 0;
+
+    auto canon_of = [&](uint32_t entry) -> uint64_t {  // canonical code of the window a queue entry names
+        const uint32_t q = (entry >> 11) & (uint32_t)(NT - 1), woff = entry & 2047u;
+        const int wl = woff >> 5, sh = 2 * (woff & 31u);
+        const uint64_t qa = sA[wave][q][wl], qb2 = sA[wave][q][wl + 1];
+        const uint64_t f = ((qa << sh) | ((qb2 >> 1) >> (63 - sh))) >> (64 - 2 * k);
+        const uint64_t rr = (~revpairs(f)) >> (64 - 2 * k);  // reverse complement of the window itself
+        return f < rr ? f : rr;
+    };
+    auto match4 = [&](const uint4 &b, uint32_t want, uint32_t &l) -> uint32_t {  // branch-free bucket compare
+        const uint32_t sl[4] = {b.x, b.y, b.z, b.w};
+        uint32_t h = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t eq = (((sl[i] >> ct.locbits) & tagmask) == want) & (sl[i] != kEmptySlot);
+            h |= eq;
+            l = eq ? (sl[i] & locmask) : l;
+        }
+        return h;
+    };
+    auto finish_tile = [&](int q) {  // wave-uniform
+        if (st.have) st.push(runs, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (tile0 + q < n_tiles && lane < 3) {
+            const uint32_t nr = st.nruns;
+            uint4 v;
+            if (lane == 0)
+                v = make_uint4(nr | (st.complex << 8) | (st.hits << 16), nr > 0 ? runs[0][0] : 0u, nr > 0 ? runs[0][1] : 0u,
+                               nr > 0 ? runs[0][2] : 0u);
+            else if (lane == 1)
+                v = make_uint4(nr > 1 ? runs[1][0] : 0u, nr > 1 ? runs[1][1] : 0u, nr > 1 ? runs[1][2] : 0u,
+                               nr > 2 ? runs[2][0] : 0u);
+            else
+                v = make_uint4(nr > 2 ? runs[2][1] : 0u, nr > 2 ? runs[2][2] : 0u, 0u, 0u);
+            reinterpret_cast<uint4 *>(recs + (uint64_t)(tile0 + q) * kNPart + p)[lane] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        st.reset();
+    };
+
+    for (uint32_t vlo = 0; vlo < V; vlo += QCAP) {
+        const uint32_t nitems = min(V - vlo, (uint32_t)QCAP);
+        // queue window [vlo, vlo + nitems): one entry per matching window, in (tile, window) order
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+            uint64_t mm = m[q];
+            uint32_t v = vbase[q] + ex[q] - vlo;  // wraps below the window: the unsigned compare rejects it
+            while (mm) {
+                const int pb = __clzll((long long)mm);  // 1, 3, 5, ... (window b at bit 62-2b)
+                mm &= ~(0x8000000000000000ULL >> pb);
+                if (v < nitems) sQ[wave][v] = ((uint32_t)q << 11) | (wlane + (uint32_t)(pb >> 1));
+                v++;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        const uint32_t ngroups = (nitems + 63u) / 64u;
+        uint32_t npend = 0;  // wave-uniform
+        auto flush_pending = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j0 = 0; j0 < npend; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool on = j < npend;
+                const uint32_t meta = sP[wave][on ? j : 0][0], tg = sP[wave][on ? j : 0][1], bkt = sP[wave][on ? j : 0][2];
+                const uint32_t idx = meta & 1023u;
+                uint32_t h = 0, l = 0;
+                if (on && (meta & 1024u)) {  // second-chance bucket
+                    const uint4 b = part_buckets[alt_bucket(bkt, tg, ct.qb)];
+                    h = match4(b, tg | (1u << ct.rembits), l);
+                }
+                if (on && !h && (meta & 2048u)) {  // rare: both buckets were full at build time
+                    const uint64_t c = canon_of(sQ[wave][idx]);
+                    uint64_t hh = slot_of(c, tab.shift);
+                    Slot cur = load_slot(tab.slots + hh);
+                    while (cur.key != c && cur.key != kEmptyKey) {
+                        hh = (hh + 1) & tab.mask;
+                        cur = load_slot(tab.slots + hh);
+                    }
+                    if (cur.key == c) {
+                        h = 1;
+                        l = cur.loc;
+                    }
+                }
+                if (on && h) sQ[wave][idx] |= (1u << 13) | (l << 14);
+            }
+            npend = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        for (uint32_t g0 = 0; g0 < ngroups; g0 += kPipe) {
+            // Straight-line per-lane code: lanes past the end compute on harmless values (every LDS and bucket
+            // index they form is in range) and are masked out at the end.
+            uint32_t entry[kPipe], tag[kPipe], bkt[kPipe];
+            uint4 bk[kPipe];
+#pragma unroll
+            for (int u = 0; u < kPipe; u++) {
+                if (g0 + u < ngroups) {  // wave-uniform
+                    entry[u] = sQ[wave][(g0 + u) * 64 + lane];
+                    const BucketRem br = hmix2((canon_of(entry[u]) >> 4) & keymask, kbits, ct.qb);
+                    tag[u] = br.rem;
+                    bkt[u] = br.bucket;
+                    bk[u] = DBG == 1 ? make_uint4(kEmptySlot, kEmptySlot, kEmptySlot, br.rem) : part_buckets[br.bucket];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kPipe; u++) {
+                if (g0 + u >= ngroups) break;  // wave-uniform
+                const uint32_t idx = (g0 + u) * 64 + lane;
+                const uint32_t live = idx < nitems;
+                uint32_t l = 0;
+                const uint32_t h = match4(bk[u], tag[u], l) & live;
+                const uint32_t full = max(max(bk[u].x, bk[u].y), max(bk[u].z, bk[u].w)) != kEmptySlot;
+                const uint32_t miss_full = live & (h ^ 1u) & full;
+                const uint32_t again = ct.has_flag ? (miss_full & (bk[u].x >> 31)) : 0u;
+                const uint32_t generic = ct.has_flag ? (miss_full & ((bk[u].x >> 30) & 1u)) : miss_full;
+                if (h) sQ[wave][idx] = entry[u] | (1u << 13) | (l << 14);
+                const unsigned long long pb = __ballot((again | generic) != 0);
+                if (pb) {  // a few lanes per group at most: park them, resolve them together later
+                    const uint32_t np = __popcll(pb);
+                    if (npend + np > (uint32_t)PCAP) flush_pending();
+                    if (again | generic) {
+                        const uint32_t slot = npend + __popcll(pb & (lane ? (~0ULL >> (64 - lane)) : 0ULL));
+                        sP[wave][slot][0] = idx | (again << 10) | (generic << 11);
+                        sP[wave][slot][1] = tag[u];
+                        sP[wave][slot][2] = bkt[u];
+                    }
+                    npend += np;
+                }
+            }
+        }
+        if (npend) flush_pending();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // run-length pass over the resolved entries, tile by tile (a group of 64 may straddle tiles)
+        for (uint32_t g = 0; g < ngroups; g++) {
+            const uint32_t idx = g * 64 + lane;
+            const uint32_t e = idx < nitems ? sQ[wave][idx] : 0u;
+            const bool hit = ((e >> 13) & 1u) != 0;
+            const int myq = (int)((e >> 11) & (uint32_t)(NT - 1));
+            const uint32_t vfirst = vlo + g * 64u, vlast = vlo + min(g * 64u + 63u, nitems - 1u);
+            int qlo = 0, qhi = 0;
+#pragma unroll
+            for (int i = 1; i < NT; i++) {
+                qlo += vfirst >= vbase[i] ? 1 : 0;
+                qhi += vlast >= vbase[i] ? 1 : 0;
+            }
+            for (int q = qlo; q <= qhi; q++) {  // wave-uniform
+                while (cur_q < q) finish_tile(cur_q++);
+                st.step(hit && myq == q, e >> 14, e & 2047u, lane, runs);
+            }
+        }
+    }
+    while (cur_q < NT) finish_tile(cur_q++);
 }
 
 __global__ __launch_bounds__(256) void k_merge_part(const PartRec *recs, uint32_t n_tiles, TileArrays ta, uint32_t *cand,
@@ -443,12 +647,12 @@ __global__ __launch_bounds__(256) void k_merge_part(const PartRec *recs, uint32_
                                                     uint32_t *complex_n) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= n_tiles) return;
-    uint32_t rl[8 * kMaxRuns], rf[8 * kMaxRuns], rla[8 * kMaxRuns], rc[8 * kMaxRuns];
+    uint32_t rl[kNPart * kMaxRuns], rf[kNPart * kMaxRuns], rla[kNPart * kMaxRuns], rc[kNPart * kMaxRuns];
     int n = 0;
     bool complex = false;
     uint32_t hits = 0;
-    for (int p = 0; p < 8; p++) {
-        const PartRec rec = recs[(uint64_t)tile * 8 + p];
+    for (int p = 0; p < kNPart; p++) {
+        const PartRec rec = recs[(uint64_t)tile * kNPart + p];
         const uint32_t nr = rec.head & 0xFFu;
         complex |= ((rec.head >> 8) & 1u) != 0;
         hits += rec.head >> 16;
@@ -471,7 +675,7 @@ __global__ __launch_bounds__(256) void k_merge_part(const PartRec *recs, uint32_
         rl[j + 1] = l; rf[j + 1] = f; rla[j + 1] = la; rc[j + 1] = c;
     }
     // groups of equal loc must not overlap a run of another loc
-    uint32_t cw[8 * kMaxRuns], cr[8 * kMaxRuns];  // candidate window, rank
+    uint32_t cw[kNPart * kMaxRuns], cr[kNPart * kMaxRuns];  // candidate window, rank
     int ncand = 0;
     uint32_t seen = 0, cur_loc = 0, cur_max = 0;
     for (int i = 0; i < n && !complex; i++) {
@@ -734,7 +938,7 @@ struct gs_table {
     // small-table fast path (exact compact table resident in the XCD-partitioned L2s)
     bool compact = false;
     uint4 *cbuckets = nullptr;
-    int c_qb = 0, c_rembits = 0, c_locbits = 0;
+    int c_qb = 0, c_rembits = 0, c_locbits = 0, c_has_flag = 0;
     uint64_t c_overflow = 0;
     uint32_t *d_complex_n = nullptr;
     hipStream_t stream = nullptr;
@@ -770,7 +974,8 @@ struct gs_reads {
     uint32_t cand_cap = 0;
     gs_hit *hits = nullptr;
     uint64_t hit_cap = 0;
-    PartRec *part_recs = nullptr;      // [n_tiles * 8], fast path only
+    TileDesc *tile_desc = nullptr;     // [n_tiles]
+    PartRec *part_recs = nullptr;      // [n_tiles * kNPart], fast path only
     uint32_t *complex_list = nullptr;  // [n_tiles]
 };
 
@@ -799,7 +1004,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
     HIP_TRY(hipSetDevice(t->device));
     if (t->compact && r->n_tiles && !r->part_recs) {
         int rc;
-        if ((rc = dev_alloc(&r->part_recs, (uint64_t)r->n_tiles * 8))) return rc;
+        if ((rc = dev_alloc(&r->part_recs, (uint64_t)r->n_tiles * kNPart))) return rc;
         if ((rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
     }
     HIP_TRY(hipMemsetAsync(t->d_cand_count, 0, sizeof(uint32_t), t->stream));
@@ -809,13 +1014,22 @@ int launch_phase1(gs_table *t, gs_reads *r) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
         if (t->compact) {
             HIP_TRY(hipMemsetAsync(t->d_complex_n, 0, sizeof(uint32_t), t->stream));
-            const CompactView cv{t->cbuckets, t->c_qb, t->c_rembits, t->c_locbits};
-            if (t->k == 20)
-                hipLaunchKernelGGL(k_probe_part<20>, dim3(blocks * 8), dim3(256), 0, t->stream, cv, view(t), view(r),
-                                   r->part_recs, t->d_err_pos);
+            const CompactView cv{t->cbuckets, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag};
+            const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
+            const int mode = dbg ? atoi(dbg) : 0;
+            const uint32_t pblocks = ((r->n_tiles + kPartTiles - 1) / kPartTiles + 3) / 4 * kNPart;
+#define GS_LAUNCH_PART(KT, DBG)                                                                                   \
+    hipLaunchKernelGGL((k_probe_part<KT, kPartTiles, DBG>), dim3(pblocks), dim3(256), 0, t->stream, cv, view(t),  \
+                       (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->part_recs)
+            if (t->k == 20 && mode == 0)
+                GS_LAUNCH_PART(20, 0);
+            else if (t->k == 20 && mode == 1)
+                GS_LAUNCH_PART(20, 1);
+            else if (t->k == 20 && mode == 2)
+                GS_LAUNCH_PART(20, 2);
             else
-                hipLaunchKernelGGL(k_probe_part<0>, dim3(blocks * 8), dim3(256), 0, t->stream, cv, view(t), view(r),
-                                   r->part_recs, t->d_err_pos);
+                GS_LAUNCH_PART(0, 0);
+#undef GS_LAUNCH_PART
             hipLaunchKernelGGL(k_merge_part, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, r->part_recs,
                                r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list, t->d_complex_n);
             // tiles whose partition summaries cannot be merged exactly: generic probe, grid-stride over the list
@@ -884,9 +1098,9 @@ uint64_t revcomp_code(uint64_t c, int k) {
 }
 
 // Host build of the compact table; returns false when the fast path does not apply
-// (k < 16, a key without loc row, remainder + loc do not fit 32 bits, or more than 32 MiB).
+// (k < 16, a key without loc row, remainder + loc do not fit 32 bits, or slices too large for L2).
 bool build_compact(int k, uint64_t n, const uint64_t *keys, const uint32_t *loc, std::vector<uint32_t> &slots, int &qb,
-                   int &rembits, int &locbits, uint64_t &overflow) {
+                   int &rembits, int &locbits, int &has_flag, uint64_t &overflow) {
     const char *env = getenv("GAVISUNK_TABLE");
     if (env && !strcmp(env, "generic")) return false;
     if (k < 16 || n == 0) return false;
@@ -897,29 +1111,40 @@ bool build_compact(int k, uint64_t n, const uint64_t *keys, const uint32_t *loc,
     }
     locbits = 1;
     while ((1ull << locbits) < (uint64_t)maxloc + 2) locbits++;  // the all-ones loc stays unused
-    qb = 10;
-    while ((32ull << qb) < (uint64_t)(2.2 * (double)n)) qb++;
-    while (2 * k - qb + locbits > 32) qb++;
-    if ((128ull << qb) > (32ull << 20)) return false;  // 8 partitions x 2^qb buckets x 16 B must sit in 8 x 4 MiB of L2
-    rembits = 2 * k - qb;
-    if (rembits < 1) return false;
-    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
-    const uint64_t remmask = (1ULL << rembits) - 1;
-    slots.assign((size_t)32 << qb, kEmptySlot);
+    if (locbits > 18) return false;  // a queue entry of k_probe_part keeps the loc in 18 bits
+    const int kbits = 2 * k - 4;
+    qb = 8;
+    while (((uint64_t)(4 * kNPart) << qb) < (uint64_t)(2.2 * (double)n)) qb++;
+    while (kbits - qb + locbits > 32) qb++;
+    // 8 live slices of 2^qb buckets x 16 B share 8 x 4 MiB of L2 with the read stream: keep a slice <= 2 MiB
+    if ((16ull << qb) > (2ull << 20) || kbits - qb < 1 || qb > 20 || (kbits >= 32 && qb > 32 - 1)) return false;
+    rembits = kbits - qb;
+    has_flag = rembits + 1 + locbits <= 30;
+    slots.assign((size_t)(4 * kNPart) << qb, kEmptySlot);
     overflow = 0;
+    const uint64_t keymask = (1ULL << kbits) - 1;
+    auto place = [&](uint64_t bucket, uint32_t v) {
+        uint32_t *bk = &slots[bucket * 4];
+        for (int j = 0; j < 4; j++)
+            if (bk[j] == kEmptySlot) {
+                bk[j] = v;
+                return true;
+            }
+        return false;
+    };
     for (uint64_t i = 0; i < n; i++) {
         const uint64_t c = keys[i];
-        const uint32_t p = (((uint32_t)c + (uint32_t)revcomp_code(c, k)) * kPartMul) >> 29;
-        const uint64_t y = hmix(c, k, kmask);
-        const uint64_t b = ((uint64_t)p << qb) | (y >> rembits);
-        const uint32_t v = ((uint32_t)(y & remmask) << locbits) | loc[i];
-        uint32_t *bk = &slots[b * 4];
-        int j = 0;
-        while (j < 4 && bk[j] != kEmptySlot) j++;
-        if (j < 4)
-            bk[j] = v;
-        else
-            overflow++;  // stays in the generic table only; lookups of a full bucket fall back to it
+        const BucketRem br = hmix2((c >> 4) & keymask, kbits, qb);
+        const uint64_t pbase = (uint64_t)part_of(c, k) << qb;
+        const uint32_t v = (br.rem << locbits) | loc[i];
+        if (place(pbase + br.bucket, v)) continue;
+        uint32_t *home = &slots[(pbase + br.bucket) * 4];
+        if (has_flag && place(pbase + alt_bucket(br.bucket, br.rem, qb), v | (1u << (rembits + locbits)))) {
+            home[0] |= 0x80000000u;  // some key of this bucket lives in its second-chance bucket
+            continue;
+        }
+        overflow++;  // stays in the generic table only
+        if (has_flag) home[0] |= 0x40000000u;
     }
     return true;
 }
@@ -986,7 +1211,7 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     HIP_TRY(hipGetLastError());
     {
         std::vector<uint32_t> cs;
-        if (build_compact(k, n, keys, loc, cs, t->c_qb, t->c_rembits, t->c_locbits, t->c_overflow)) {
+        if (build_compact(k, n, keys, loc, cs, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_overflow)) {
             uint32_t *d = nullptr;
             if ((rc = dev_alloc(&d, cs.size()))) return rc;
             HIP_TRY(hipMemcpy(d, cs.data(), cs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1003,8 +1228,8 @@ const char *gs_table_layout(const gs_table *t) {
     static thread_local char buf[160];
     if (!t) return "";
     if (t->compact)
-        snprintf(buf, sizeof buf, "compact-l2: 8 partitions x 2^%d buckets x 4 x u32 (%d-bit remainder, %d-bit loc), %llu overflow keys; generic 16 B table behind it",
-                 t->c_qb, t->c_rembits, t->c_locbits, (unsigned long long)t->c_overflow);
+        snprintf(buf, sizeof buf, "compact-l2: 16 partitions x 2^%d buckets x 4 x u32 (%d-bit remainder, %d-bit loc%s), %llu keys only in the generic 16 B table behind it",
+                 t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag ? ", second-chance buckets" : "", (unsigned long long)t->c_overflow);
     else
         snprintf(buf, sizeof buf, "generic: open-addressed 16 B slots in HBM");
     return buf;
@@ -1028,7 +1253,7 @@ void gs_table_destroy(gs_table *t) {
 }
 
 uint64_t gs_table_bytes(const gs_table *t) {
-    return t ? t->cap * sizeof(Slot) + (t->compact ? (128ull << t->c_qb) : 0) : 0;
+    return t ? t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)(16 * kNPart) << t->c_qb) : 0) : 0;
 }
 
 int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off, const uint32_t *len,
@@ -1050,6 +1275,7 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
     r->n_words = n_words;
     std::vector<uint32_t> nwin(n_reads), tile0(n_reads);
     std::vector<uint32_t> tile_read;
+    std::vector<TileDesc> tdesc;
     uint64_t tiles = 0;
     for (uint32_t i = 0; i < n_reads; i++) {
         const uint32_t l = len[i];
@@ -1071,6 +1297,8 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
             return GS_E_ARG;
         }
         tile_read.insert(tile_read.end(), nt, i);
+        for (uint32_t q = 0; q < nt; q++)
+            tdesc.push_back(TileDesc{word_off[i] + (uint64_t)q * kTileWords, nwin[i] - q * kTileWindows, i});
         r->n_bases += l;
         r->n_windows += nwin[i];
     }
@@ -1091,6 +1319,8 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
         HIP_TRY(hipMemcpy(r->read_tile0, tile0.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (tiles) HIP_TRY(hipMemcpy(r->tile_read, tile_read.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(&r->tile_desc, tiles))) return rc;
+    if (tiles) HIP_TRY(hipMemcpy(r->tile_desc, tdesc.data(), tiles * sizeof(TileDesc), hipMemcpyHostToDevice));
     TileArrays &ta = r->ta;
     if ((rc = dev_alloc(&ta.n_raw, tiles)) || (rc = dev_alloc(&ta.n_cand, tiles)) || (rc = dev_alloc(&ta.first_loc, tiles)) ||
         (rc = dev_alloc(&ta.last_loc, tiles)) || (rc = dev_alloc(&ta.cand_off, tiles)) || (rc = dev_alloc(&ta.n_emit, tiles)) ||
@@ -1127,6 +1357,7 @@ void gs_reads_destroy(gs_reads *r) {
     (void)hipFree(r->block_agg);
     (void)hipFree(r->cand);
     (void)hipFree(r->hits);
+    (void)hipFree(r->tile_desc);
     (void)hipFree(r->part_recs);
     (void)hipFree(r->complex_list);
     delete r;
