@@ -50,6 +50,7 @@ struct __align__(16) Slot {
 };
 constexpr uint64_t kEmptyKey = ~0ULL;  // never a canonical code (k < 32: too wide; k = 32: poly-T is not canonical)
 constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ULL;
+constexpr int kDirectCand = 4;  // candidate slots every tile owns in the candidate buffer
 
 struct TableView {
     const Slot *slots;
@@ -183,9 +184,13 @@ __device__ __forceinline__ void probe_tile(const TableView &tab, const ReadsView
     const uint32_t ex_raw = wave_excl_scan(__popc(raw), lane, tot_raw);
     const uint32_t ex_cand = wave_excl_scan(__popc(chg), lane, tot_cand);
 
-    uint32_t off = 0;
-    if (lane == 0 && tot_cand) off = atomicAdd(g_cand_count, tot_cand);
-    off = __shfl(off, 0);
+    // up to kDirectCand candidates go to the tile's own slots; longer lists (rare) are allocated with one atomic
+    // (a single counter word sustains only ~90 returning atomics per microsecond on this chip)
+    uint32_t off = tile * kDirectCand;
+    if (tot_cand > (uint32_t)kDirectCand) {
+        if (lane == 0) off = rd.n_tiles * kDirectCand + atomicAdd(g_cand_count, tot_cand);
+        off = __shfl(off, 0);
+    }
     if (tot_cand && (uint64_t)off + tot_cand <= cand_cap) {
         uint32_t m = chg, i = 0;
         while (m) {
@@ -265,8 +270,6 @@ __global__ __launch_bounds__(256) void k_probe(TableView tab, ReadsView rd, Tile
 constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
 constexpr int kMaxRuns = 3;
 constexpr int kNPart = 16;  // key-space partitions; 8 are live at a time (one per XCD), kNPart / 8 passes
-constexpr int kPipe = 4;    // bucket loads in flight per lane in the probe loop
-constexpr int kPartTiles = 4;  // tiles per wave in k_probe_part
 
 // Bijection on `kbits`-bit keys, cheap in 32-bit arithmetic, returning the pair (bucket, remainder)
 // with bucket in [0, 2^qb) taken from the best-mixed bits.  kbits = 2k - 4 in [28, 60], qb <= 20.
@@ -389,7 +392,7 @@ struct PartState {
 // phase has NT (or more) independent memory requests in flight per lane: descriptors, words,
 // first-chance buckets, second-chance buckets.  DBG: timing experiments (1 = no bucket loads,
 // 2 = stop after the queue); results are wrong for DBG != 0.
-template <int KT, int NT, int DBG>
+template <int KT, int NT, int kPipe, int DBG>
 __global__ __launch_bounds__(256) void k_probe_part(CompactView ct, TableView tab, const uint64_t *__restrict__ words,
                                                     const TileDesc *__restrict__ tdesc, uint32_t n_tiles, PartRec *recs) {
     static_assert(NT == 2 || NT == 4, "tile index takes 2 bits of a queue entry");
@@ -642,73 +645,114 @@ __global__ __launch_bounds__(256) void k_probe_part(CompactView ct, TableView ta
     while (cur_q < NT) finish_tile(cur_q++);
 }
 
+// One wave merges 4 tiles: 16 lanes per tile, one partition summary (<= 3 runs) per lane.  The runs are
+// peeled loc by loc in order of first window: for the loc of the earliest remaining run, its hull
+// [min first, max last] and hit count over all remaining runs with that loc (three 16-lane reductions).
+// If the hulls are pairwise disjoint the order of hits across partitions is decided without knowing it:
+// the tile's raw hits are hull after hull, one candidate (location change) at each hull's first window,
+// with rank = hits of the earlier hulls.  Anything else (overlapping hulls, > 4 locs, a summary that
+// overflowed) is queued for the exact generic probe.
+constexpr int kMaxHulls = 4;
 __global__ __launch_bounds__(256) void k_merge_part(const PartRec *recs, uint32_t n_tiles, TileArrays ta, uint32_t *cand,
                                                     uint32_t cand_cap, uint32_t *g_cand_count, uint32_t *complex_list,
                                                     uint32_t *complex_n) {
-    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= n_tiles) return;
-    uint32_t rl[kNPart * kMaxRuns], rf[kNPart * kMaxRuns], rla[kNPart * kMaxRuns], rc[kNPart * kMaxRuns];
-    int n = 0;
-    bool complex = false;
-    uint32_t hits = 0;
-    for (int p = 0; p < kNPart; p++) {
-        const PartRec rec = recs[(uint64_t)tile * kNPart + p];
-        const uint32_t nr = rec.head & 0xFFu;
-        complex |= ((rec.head >> 8) & 1u) != 0;
-        hits += rec.head >> 16;
-        for (uint32_t i = 0; i < nr && i < (uint32_t)kMaxRuns; i++) {
-            rl[n] = rec.run[i][0];
-            rf[n] = rec.run[i][1] & 0xFFFFu;
-            rla[n] = rec.run[i][1] >> 16;
-            rc[n] = rec.run[i][2];
-            n++;
-        }
+    const int lane = threadIdx.x & 63, part = lane & 15;
+    const uint32_t tile = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool on = tile < n_tiles;
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
+    if (on) {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(recs + (uint64_t)tile * kNPart + part);
+        r0 = rp[0];
+        r1 = rp[1];
+        r2 = rp[2];
     }
-    // insertion sort by first window
-    for (int i = 1; i < n && !complex; i++) {
-        const uint32_t l = rl[i], f = rf[i], la = rla[i], c = rc[i];
-        int j = i - 1;
-        while (j >= 0 && rf[j] > f) {
-            rl[j + 1] = rl[j]; rf[j + 1] = rf[j]; rla[j + 1] = rla[j]; rc[j + 1] = rc[j];
-            j--;
-        }
-        rl[j + 1] = l; rf[j + 1] = f; rla[j + 1] = la; rc[j + 1] = c;
+    const uint32_t nr = r0.x & 0xFFu;
+    uint32_t rloc[kMaxRuns] = {r0.y, r1.x, r1.w};
+    uint32_t rfl[kMaxRuns] = {r0.z, r1.y, r2.x};  // first | last << 16
+    uint32_t rcnt[kMaxRuns] = {r0.w, r1.z, r2.y};
+    uint32_t alive = nr >= 3 ? 7u : (nr == 2 ? 3u : (nr == 1 ? 1u : 0u));
+    uint32_t bad = (r0.x >> 8) & 1u, total = r0.x >> 16;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        bad |= __shfl_xor(bad, d, 16);
+        total += __shfl_xor(total, d, 16);
     }
-    // groups of equal loc must not overlap a run of another loc
-    uint32_t cw[kNPart * kMaxRuns], cr[kNPart * kMaxRuns];  // candidate window, rank
-    int ncand = 0;
-    uint32_t seen = 0, cur_loc = 0, cur_max = 0;
-    for (int i = 0; i < n && !complex; i++) {
-        if (i == 0 || rl[i] != cur_loc) {
-            if (i && rf[i] <= cur_max) {
-                complex = true;
-                break;
+    uint32_t hull_loc[kMaxHulls], hull_first[kMaxHulls], hull_rank[kMaxHulls];
+    uint32_t nh = 0, seen = 0, max_last = 0;
+#pragma unroll
+    for (int it = 0; it <= kMaxHulls; it++) {
+        // earliest remaining run of the tile -> its loc
+        uint32_t key = 0xFFFFFFFFu;  // first << 16 | lane-local tie breaker is irrelevant: equal firsts share... see below
+        uint32_t kloc = 0;
+#pragma unroll
+        for (int i = 0; i < kMaxRuns; i++) {
+            const uint32_t f = rfl[i] & 0xFFFFu;
+            if (((alive >> i) & 1u) && f < key) {
+                key = f;
+                kloc = rloc[i];
             }
-            cw[ncand] = rf[i];
-            cr[ncand] = seen;
-            ncand++;
-            cur_loc = rl[i];
-            cur_max = rla[i];
-        } else {
-            cur_max = max(cur_max, rla[i]);
         }
-        seen += rc[i];
+        // argmin over 16 lanes of (first, loc): two windows are never equal across partitions, so `first` alone decides
+        uint32_t best = key, bloc = kloc;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const uint32_t ob = __shfl_xor(best, d, 16), ol = __shfl_xor(bloc, d, 16);
+            if (ob < best) {
+                best = ob;
+                bloc = ol;
+            }
+        }
+        if (best == 0xFFFFFFFFu) continue;  // nothing left in this tile (other tiles of the wave may go on)
+        if (it == kMaxHulls) {
+            bad = 1;
+            continue;
+        }
+        uint32_t hl = 0, hc = 0;  // hull end and hits of loc `bloc`
+#pragma unroll
+        for (int i = 0; i < kMaxRuns; i++)
+            if (((alive >> i) & 1u) && rloc[i] == bloc) {
+                hl = max(hl, rfl[i] >> 16);
+                hc += rcnt[i];
+                alive &= ~(1u << i);
+            }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            hl = max(hl, (uint32_t)__shfl_xor(hl, d, 16));
+            hc += __shfl_xor(hc, d, 16);
+        }
+        if (nh && best <= max_last) bad = 1;  // this hull starts inside an earlier one
+        max_last = max(max_last, hl);
+#pragma unroll
+        for (int i = 0; i < kMaxHulls; i++)
+            if ((uint32_t)i == nh) {
+                hull_loc[i] = bloc;
+                hull_first[i] = best;
+                hull_rank[i] = seen;
+            }
+        nh++;
+        seen += hc;
     }
-    if (complex) {
-        complex_list[atomicAdd(complex_n, 1u)] = tile;
-        return;
+    if (on && part == 0) {
+        if (bad) {
+            complex_list[atomicAdd(complex_n, 1u)] = tile;
+        } else {
+            ta.n_raw[tile] = total;
+            ta.n_cand[tile] = nh;
+            static_assert(kMaxHulls <= kDirectCand, "a merged tile's candidates live in its own slots");
+            const uint32_t off = tile * kDirectCand;
+            if (nh) {
+#pragma unroll
+                for (int i = 0; i < kMaxHulls; i++)
+                    if ((uint32_t)i < nh) cand[off + i] = (hull_rank[i] << 16) | hull_first[i];
+                ta.first_loc[tile] = hull_loc[0];
+                uint32_t ll = hull_loc[0];
+#pragma unroll
+                for (int i = 1; i < kMaxHulls; i++) ll = (uint32_t)i < nh ? hull_loc[i] : ll;
+                ta.last_loc[tile] = ll;
+            }
+            ta.cand_off[tile] = off;
+        }
     }
-    ta.n_raw[tile] = hits;
-    ta.n_cand[tile] = (uint32_t)ncand;
-    uint32_t off = 0;
-    if (ncand) {
-        off = atomicAdd(g_cand_count, (uint32_t)ncand);
-        if ((uint64_t)off + ncand <= cand_cap)
-            for (int i = 0; i < ncand; i++) cand[off + i] = (cr[i] << 16) | cw[i];
-        ta.first_loc[tile] = rl[0];
-        ta.last_loc[tile] = cur_loc;
-    }
-    ta.cand_off[tile] = off;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1017,20 +1061,30 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             const CompactView cv{t->cbuckets, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag};
             const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
             const int mode = dbg ? atoi(dbg) : 0;
-            const uint32_t pblocks = ((r->n_tiles + kPartTiles - 1) / kPartTiles + 3) / 4 * kNPart;
-#define GS_LAUNCH_PART(KT, DBG)                                                                                   \
-    hipLaunchKernelGGL((k_probe_part<KT, kPartTiles, DBG>), dim3(pblocks), dim3(256), 0, t->stream, cv, view(t),  \
+            const char *env_nt = getenv("GAVISUNK_PART_TILES"), *env_pipe = getenv("GAVISUNK_PART_PIPE");  // tuning experiments
+            const int nt = env_nt ? atoi(env_nt) : 4, pipe = env_pipe ? atoi(env_pipe) : 4;
+            const uint32_t pblocks = ((r->n_tiles + nt - 1) / nt + 3) / 4 * kNPart;
+#define GS_LAUNCH_PART(KT, NT, PIPE, DBG)                                                                           \
+    hipLaunchKernelGGL((k_probe_part<KT, NT, PIPE, DBG>), dim3(pblocks), dim3(256), 0, t->stream, cv, view(t),      \
                        (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->part_recs)
-            if (t->k == 20 && mode == 0)
-                GS_LAUNCH_PART(20, 0);
-            else if (t->k == 20 && mode == 1)
-                GS_LAUNCH_PART(20, 1);
-            else if (t->k == 20 && mode == 2)
-                GS_LAUNCH_PART(20, 2);
+            if (t->k != 20)
+                GS_LAUNCH_PART(0, 4, 4, 0);
+            else if (mode == 1)
+                GS_LAUNCH_PART(20, 4, 4, 1);
+            else if (mode == 2)
+                GS_LAUNCH_PART(20, 4, 4, 2);
+            else if (nt == 2 && pipe == 4)
+                GS_LAUNCH_PART(20, 2, 4, 0);
+            else if (nt == 2 && pipe == 8)
+                GS_LAUNCH_PART(20, 2, 8, 0);
+            else if (nt == 4 && pipe == 8)
+                GS_LAUNCH_PART(20, 4, 8, 0);
+            else if (nt == 4 && pipe == 2)
+                GS_LAUNCH_PART(20, 4, 2, 0);
             else
-                GS_LAUNCH_PART(0, 0);
+                GS_LAUNCH_PART(20, 4, 4, 0);
 #undef GS_LAUNCH_PART
-            hipLaunchKernelGGL(k_merge_part, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, r->part_recs,
+            hipLaunchKernelGGL(k_merge_part, dim3((r->n_tiles + 15) / 16), dim3(256), 0, t->stream, (const PartRec *)r->part_recs,
                                r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list, t->d_complex_n);
             // tiles whose partition summaries cannot be merged exactly: generic probe, grid-stride over the list
             hipLaunchKernelGGL(k_probe, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), view(r),
@@ -1291,7 +1345,7 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
         tile0[i] = (uint32_t)tiles;
         const uint32_t nt = (nwin[i] + kTileWindows - 1) / kTileWindows;
         tiles += nt;
-        if (tiles > 0xFFFF0000ull) {
+        if (tiles > 0x20000000ull) {
             set_error("gs_reads_upload: batch too large (%llu tiles); split it", (unsigned long long)tiles);
             delete r;
             return GS_E_ARG;
@@ -1329,7 +1383,7 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
         return rc;
     r->n_scan_blocks = (uint32_t)((tiles + kScanBlock - 1) / kScanBlock);
     if ((rc = dev_alloc(&r->block_agg, r->n_scan_blocks))) return rc;
-    const uint64_t want = std::min<uint64_t>(4 * tiles + 65536, 0xFFFFFFFFull);
+    const uint64_t want = std::min<uint64_t>((kDirectCand + 2) * tiles + 65536, 0xFFFFFFFFull);
     if ((rc = ensure_out_buffers(r, (uint32_t)want))) return rc;
     *out = r;
     return GS_OK;
@@ -1425,9 +1479,9 @@ static int settle(gs_table *t, gs_reads *r) {
         HIP_TRY(hipMemcpy(&ncand, t->d_cand_count, sizeof ncand, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(&err, t->d_err_pos, sizeof err, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(tot, t->d_totals, sizeof tot, hipMemcpyDeviceToHost));
-        if (ncand > r->cand_cap) {
+        if ((uint64_t)r->n_tiles * kDirectCand + ncand > r->cand_cap) {
             int rc;
-            if ((rc = ensure_out_buffers(r, (uint32_t)std::min<uint64_t>((uint64_t)ncand + 65536, 0xFFFFFFFFull)))) return rc;
+            if ((rc = ensure_out_buffers(r, (uint32_t)std::min<uint64_t>((uint64_t)r->n_tiles * kDirectCand + ncand + 65536, 0xFFFFFFFFull)))) return rc;
             if ((rc = launch_phase1(t, r))) return rc;
             if ((rc = launch_phase2(t, r, t->last_carry_in))) return rc;
             continue;
