@@ -323,6 +323,10 @@ struct __align__(16) TileDesc {
     uint32_t read;
 };
 
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int uniform_lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, uniform_lane);
+}
+
 // wave-uniform run-length state of one (tile, partition); completed runs go to LDS
 struct PartState {
     uint32_t nruns, complex, have, hits, cur_loc, cur_first, cur_last, cur_cnt;
@@ -344,18 +348,18 @@ struct PartState {
         const unsigned long long hb = __ballot(hit);
         if (!hb) return;
         const int first_lane = __ffsll(hb) - 1, last_lane = 63 - __clzll((long long)hb);
-        const uint32_t loc0 = __shfl(loc, first_lane);
+        const uint32_t loc0 = lane_value(loc, first_lane);
         hits += __popcll(hb);
         if (!__ballot(hit && loc != loc0)) {  // the usual case: every hit of the group has the same loc
             if (!(have && cur_loc == loc0)) {
                 if (have) push(runs, lane);
                 cur_loc = loc0;
-                cur_first = __shfl(woff, first_lane);
+                cur_first = lane_value(woff, first_lane);
                 cur_cnt = 0;
                 have = 1;
             }
             cur_cnt += __popcll(hb);
-            cur_last = __shfl(woff, last_lane);
+            cur_last = lane_value(woff, last_lane);
             return;
         }
         const unsigned long long below = hb & (lane ? (~0ULL >> (64 - lane)) : 0ULL);
@@ -371,12 +375,12 @@ struct PartState {
             if (have) {
                 if (seg) {
                     cur_cnt += __popcll(seg);
-                    cur_last = __shfl(woff, 63 - __clzll((long long)seg));
+                    cur_last = lane_value(woff, 63 - __clzll((long long)seg));
                 }
                 push(runs, lane);
             }
-            cur_loc = __shfl(loc, sl);
-            cur_first = __shfl(woff, sl);
+            cur_loc = lane_value(loc, sl);
+            cur_first = lane_value(woff, sl);
             cur_last = cur_first;
             cur_cnt = 0;
             have = 1;
@@ -384,7 +388,7 @@ struct PartState {
         }
         const unsigned long long seg = hb & ~((1ULL << lo) - 1ULL);
         cur_cnt += __popcll(seg);
-        cur_last = __shfl(woff, 63 - __clzll((long long)seg));
+        cur_last = lane_value(woff, 63 - __clzll((long long)seg));
     }
 };
 
@@ -396,8 +400,8 @@ template <int KT, int NT, int kPipe, int DBG>
 __global__ __launch_bounds__(256) void k_probe_part(CompactView ct, TableView tab, const uint64_t *__restrict__ words,
                                                     const TileDesc *__restrict__ tdesc, uint32_t n_tiles, PartRec *recs) {
     static_assert(NT == 2 || NT == 4, "tile index takes 2 bits of a queue entry");
-    constexpr int QCAP = 1024;  // queue window (items); more items are handled window by window
-    constexpr int PCAP = 128;   // deferred (second-chance / generic) lookups per flush
+    constexpr int QCAP = 640;  // queue window (items); more items are handled window by window
+    constexpr int PCAP = 64;   // deferred (second-chance / generic) lookups per flush
     // queue entry: woff[0:11) | tile[11:13) | hit[13] | loc[14:32)
     __shared__ uint64_t sA[4][NT][kTileWords + 2];
     __shared__ uint32_t sQ[4][QCAP];
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(256) void k_probe_part(CompactView ct, TableView ta
                 const uint32_t j = j0 + lane;
                 const bool on = j < npend;
                 const uint32_t meta = sP[wave][on ? j : 0][0], tg = sP[wave][on ? j : 0][1], bkt = sP[wave][on ? j : 0][2];
-                const uint32_t idx = meta & 1023u;
+                const uint32_t idx = meta & 1023u;  // QCAP <= 1024
                 uint32_t h = 0, l = 0;
                 if (on && (meta & 1024u)) {  // second-chance bucket
                     const uint4 b = part_buckets[alt_bucket(bkt, tg, ct.qb)];
