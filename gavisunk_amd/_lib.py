@@ -80,6 +80,20 @@ SIGNATURES = {
     "gs_tag_hits_to_host": (I, [P, P, P, U64, C.POINTER(U64)]),
     "gs_tag_hits_to_device": (I, [P, P, P, U64, C.POINTER(U64)]),
     "gs_counters_reset": (None, [P]),
+    "gs_sunkpos_load": (I, [C.c_char_p, C.POINTER(P)]),
+    "gs_sunkpos_free": (None, [P]),
+    "gs_sunkpos_n_rows": (U64, [P]),
+    "gs_sunkpos_n_segs": (U32, [P]),
+    "gs_sunkpos_row_seg": (P, [P]),
+    "gs_sunkpos_row_pos": (P, [P]),
+    "gs_sunkpos_row_contig": (P, [P]),
+    "gs_sunkpos_row_start": (P, [P]),
+    "gs_sunkpos_row_group": (P, [P]),
+    "gs_sunkpos_seg_name": (C.c_char_p, [P, U32]),
+    "gs_sunkpos_n_contigs": (U32, [P]),
+    "gs_sunkpos_contig_name": (C.c_char_p, [P, U32]),
+    "gs_sunkpos_row_text": (P, [P, U64, C.POINTER(U32)]),
+    "gs_diag_filter": (I, [I, P, P, P, P, P, P]),
 }
 
 _lib = None

@@ -57,3 +57,11 @@ struct gs_batch {
     std::vector<uint64_t> name_off;
     uint64_t bases = 0;
 };
+
+struct gs_sunkpos {
+    std::vector<uint32_t> row_seg, row_contig;
+    std::vector<int64_t> row_pos, row_start, row_group;
+    std::vector<uint64_t> row_text_off;  // n_rows + 1 offsets into `text`
+    std::vector<char> text;              // rows back to back, '\0' after each
+    std::vector<std::string> seg_names, contigs;
+};

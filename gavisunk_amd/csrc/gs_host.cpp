@@ -474,3 +474,99 @@ const char *gs_batch_name(const gs_batch *b, uint32_t r) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------- sunkpos
+extern "C" {
+
+int gs_sunkpos_load(const char *path, gs_sunkpos **out) {
+    if (!path || !out) {
+        set_error("gs_sunkpos_load: null argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    LineReader r(path);
+    if (!r.ok()) {
+        set_error("cannot open the file %s", path);
+        return GS_E_IO;
+    }
+    auto *d = new gs_sunkpos();
+    std::unordered_map<std::string, uint32_t> contig_id;
+    std::string line, name, prev;
+    bool first = true;
+    uint64_t lineno = 0;
+    d->row_text_off.push_back(0);
+    while (r.next(line)) {
+        lineno++;
+        if (line.empty()) continue;
+        const char *p = line.data(), *e = p + line.size();
+        const char *f[5], *fe[5];
+        int nf = 0;
+        const char *s0 = p;
+        for (const char *q = p;; q++) {
+            if (q == e || *q == '\t') {
+                if (nf < 5) {
+                    f[nf] = s0;
+                    fe[nf] = q;
+                }
+                nf++;
+                s0 = q + 1;
+                if (q == e) break;
+            }
+        }
+        int64_t pos, start, group;
+        if (nf < 5 || !parse_i64(f[1], fe[1], pos) || !parse_i64(f[3], fe[3], start) || !parse_i64(f[4], fe[4], group)) {
+            set_error("%s:%llu: expected `rname<TAB>pos<TAB>contig<TAB>start<TAB>group`", path, (unsigned long long)lineno);
+            delete d;
+            return GS_E_IO;
+        }
+        name.assign(f[0], fe[0] - f[0]);
+        if (first || name != prev) {  // the reference flushes on every change of name (diag_filter_v3.nim:64)
+            d->seg_names.push_back(name);
+            prev = name;
+            first = false;
+        }
+        name.assign(f[2], fe[2] - f[2]);
+        auto it = contig_id.find(name);
+        uint32_t cid;
+        if (it == contig_id.end()) {
+            cid = (uint32_t)d->contigs.size();
+            contig_id.emplace(name, cid);
+            d->contigs.push_back(name);
+        } else {
+            cid = it->second;
+        }
+        d->row_seg.push_back((uint32_t)d->seg_names.size() - 1);
+        d->row_pos.push_back(pos);
+        d->row_contig.push_back(cid);
+        d->row_start.push_back(start);
+        d->row_group.push_back(group);
+        d->text.insert(d->text.end(), line.begin(), line.end());
+        d->text.push_back('\0');
+        d->row_text_off.push_back(d->text.size());
+    }
+    *out = d;
+    return GS_OK;
+}
+
+void gs_sunkpos_free(gs_sunkpos *s) { delete s; }
+uint64_t gs_sunkpos_n_rows(const gs_sunkpos *s) { return s->row_seg.size(); }
+uint32_t gs_sunkpos_n_segs(const gs_sunkpos *s) { return (uint32_t)s->seg_names.size(); }
+const uint32_t *gs_sunkpos_row_seg(const gs_sunkpos *s) { return s->row_seg.data(); }
+const int64_t *gs_sunkpos_row_pos(const gs_sunkpos *s) { return s->row_pos.data(); }
+const uint32_t *gs_sunkpos_row_contig(const gs_sunkpos *s) { return s->row_contig.data(); }
+const int64_t *gs_sunkpos_row_start(const gs_sunkpos *s) { return s->row_start.data(); }
+const int64_t *gs_sunkpos_row_group(const gs_sunkpos *s) { return s->row_group.data(); }
+const char *gs_sunkpos_seg_name(const gs_sunkpos *s, uint32_t seg) {
+    return seg < s->seg_names.size() ? s->seg_names[seg].c_str() : nullptr;
+}
+uint32_t gs_sunkpos_n_contigs(const gs_sunkpos *s) { return (uint32_t)s->contigs.size(); }
+const char *gs_sunkpos_contig_name(const gs_sunkpos *s, uint32_t c) {
+    return c < s->contigs.size() ? s->contigs[c].c_str() : nullptr;
+}
+const char *gs_sunkpos_row_text(const gs_sunkpos *s, uint64_t row, uint32_t *len) {
+    if (row >= s->row_seg.size()) return nullptr;
+    if (len) *len = (uint32_t)(s->row_text_off[row + 1] - s->row_text_off[row] - 1);
+    return s->text.data() + s->row_text_off[row];
+}
+
+}  // extern "C"

@@ -193,3 +193,48 @@ def format_sunkpos(hits: np.ndarray, names: Sequence[str], db: SunkDB) -> str:
     return "".join(f"{names[r]}\t{p}\t{cn[c]}\t{s}\t{g}\n"
                    for r, p, c, s, g in zip(hits["read"].tolist(), hits["pos"].tolist(), contig.tolist(),
                                             start.tolist(), group.tolist()))
+
+
+class SunkPos:
+    """Parsed `.sunkpos` file (native parser, gs_sunkpos_load)."""
+
+    def __init__(self, path: str):
+        h = C.c_void_p()
+        check(lib().gs_sunkpos_load(path.encode(), C.byref(h)))
+        self._h = h
+        L = lib()
+        self.n_rows, self.n_segs = L.gs_sunkpos_n_rows(h), L.gs_sunkpos_n_segs(h)
+        self.row_seg = _view(L.gs_sunkpos_row_seg(h), self.n_rows, np.uint32)
+        self.row_pos = _view(L.gs_sunkpos_row_pos(h), self.n_rows, np.int64)
+        self.row_contig = _view(L.gs_sunkpos_row_contig(h), self.n_rows, np.uint32)
+        self.row_start = _view(L.gs_sunkpos_row_start(h), self.n_rows, np.int64)
+        self.row_group = _view(L.gs_sunkpos_row_group(h), self.n_rows, np.int64)
+        self.contigs = [L.gs_sunkpos_contig_name(h, i).decode() for i in range(L.gs_sunkpos_n_contigs(h))]
+
+    def seg_name(self, seg: int) -> str:
+        return lib().gs_sunkpos_seg_name(self._h, seg).decode()
+
+    def row_text(self, row: int) -> bytes:
+        n = C.c_uint32(0)
+        p = lib().gs_sunkpos_row_text(self._h, row, C.byref(n))
+        return C.string_at(p, n.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_sunkpos_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def diag_filter(sp: SunkPos, fai_contigs, device: int = 0):
+    """gs_diag_filter -> (best_contig[seg], best_good[seg], best_dir[seg], keep[row])."""
+    fai = set(fai_contigs)
+    in_fai = np.array([1 if c in fai else 0 for c in sp.contigs] + [0], dtype=np.uint8)
+    bc = np.zeros(max(sp.n_segs, 1), np.uint32)
+    bg = np.zeros(max(sp.n_segs, 1), np.uint32)
+    bd = np.zeros(max(sp.n_segs, 1), np.uint8)
+    keep = np.zeros(max(sp.n_rows, 1), np.uint8)
+    check(lib().gs_diag_filter(device, sp._h, in_fai.ctypes.data, bc.ctypes.data, bg.ctypes.data, bd.ctypes.data,
+                               keep.ctypes.data))
+    return bc[: sp.n_segs], bg[: sp.n_segs], bd[: sp.n_segs], keep[: sp.n_rows]

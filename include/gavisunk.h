@@ -168,6 +168,43 @@ int gs_tag_hits_to_host(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uin
 int gs_tag_hits_to_device(gs_table *t, gs_reads *r, void *dst_device, uint64_t cap, uint64_t *n_out);
 void gs_counters_reset(gs_table *t);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Diagonal filter (workflow/src/diag_filter_v3.nim + diag_filter_step2.nim).
+ * ---------------------------------------------------------------------------------------- */
+
+/* A `.sunkpos` file (rows `rname \t pos \t contig \t start \t group`, plain or gzip) parsed into
+ * arrays.  `seg` numbers the runs of consecutive rows with the same rname: the reference flushes
+ * whenever the name changes (diag_filter_v3.nim:64), so a name that comes back later is a new read. */
+typedef struct gs_sunkpos gs_sunkpos;
+int gs_sunkpos_load(const char *path, gs_sunkpos **out);
+void gs_sunkpos_free(gs_sunkpos *s);
+uint64_t gs_sunkpos_n_rows(const gs_sunkpos *s);
+uint32_t gs_sunkpos_n_segs(const gs_sunkpos *s);
+const uint32_t *gs_sunkpos_row_seg(const gs_sunkpos *s);
+const int64_t *gs_sunkpos_row_pos(const gs_sunkpos *s);
+const uint32_t *gs_sunkpos_row_contig(const gs_sunkpos *s);
+const int64_t *gs_sunkpos_row_start(const gs_sunkpos *s);
+const int64_t *gs_sunkpos_row_group(const gs_sunkpos *s);
+const char *gs_sunkpos_seg_name(const gs_sunkpos *s, uint32_t seg);
+uint32_t gs_sunkpos_n_contigs(const gs_sunkpos *s);
+const char *gs_sunkpos_contig_name(const gs_sunkpos *s, uint32_t contig);
+/* the text of row i (without newline), for step 2's verbatim copy-through */
+const char *gs_sunkpos_row_text(const gs_sunkpos *s, uint64_t row, uint32_t *len);
+
+/* Per segment (read): the contig with the most distinct SUNK groups within 2500 bp of the median
+ * diagonal, trying `pos+start` ("-") then `start-pos` ("+") per contig; ties go to the contig
+ * with fewer hits, then to the first contig in the slot order of Nim's Table[string, ...]
+ * (diag_filter_v3.nim:76-138).  Only contigs with in_fai[contig] != 0 count (:147-150).
+ *   best_contig[seg] = contig id or GS_NONE when the read prints nothing (maxgood <= 1, :141)
+ *   best_good[seg]   = maxgood,  best_dir[seg] = '-' or '+'
+ *   keep[row]        = 1 when diag_filter_step2 keeps the row (contig == best contig of its read,
+ *                      diag_filter_step2.nim:45-64)
+ * The per-(read, contig) statistics and the selection run on the GPU; the host walks the rows once
+ * to lay out segments and to replay the Table's slot order (a serial hash-table emulation). */
+int gs_diag_filter(int device, const gs_sunkpos *s, const uint8_t *in_fai, uint32_t *best_contig,
+                   uint32_t *best_good, uint8_t *best_dir, uint8_t *keep);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,108 @@
+"""World-size-2 (and 3) `gloo` test of the read-sharded multi-GPU protocol (gavisunk_amd/dist.py) on CPU.
+
+There is no CPU tagging path in the product, so here the per-shard "device" work is played by
+the oracle; what is under test is the host logic that makes N shards equal one file: shard
+bounds, the carry exchange (all_gather of {has_raw, last_loc}), carry resolution, the gather of
+hit buffers in shard order with read-index offsets, and the table broadcast."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gavisunk_amd import dist as gdist
+from gavisunk_amd import synth
+from gavisunk_amd._lib import GS_NONE
+from oracle import oracle
+
+
+def _case():
+    k = 20
+    rng = np.random.default_rng(11)
+    g = rng.integers(0, 4, 40_000, dtype=np.uint8)
+    sunks = synth.define_sunks([("c", synth.codes_to_ascii(g))], k)
+    loc = (sunks.start // 700).astype(np.uint32)  # coarse groups: carries across reads do happen
+    lens = synth.lognormal_lengths(rng, 41, median=900, sigma=0.7, lo=1, hi=20000)
+    reads = [synth.codes_to_ascii(r) for r in synth.simulate_reads(rng, [g], lens, sub=0.005, dele=0.005, ins=0.005)]
+    return k, sunks.code, loc, reads
+
+
+def _oracle_shard(k, keys, loc, seqs, carry_loc):
+    """Oracle stand-in for gs_tag_phase1/phase2 on one shard; locs play the role of loc rows."""
+    t = oracle.Table(k, keys, keys, np.zeros(len(keys), np.uint32), loc.astype(np.int64))
+    buf, off = oracle.concat_reads(seqs)
+    prev = oracle.NONE
+    if carry_loc != GS_NONE:
+        prev = int(np.nonzero(loc == carry_loc)[0][0])  # any row of that loc
+    rc, hits, prev_out, ctr = t.tag(buf, off, prev_row=prev)
+    assert rc == 0
+    last_loc = int(loc[prev_out]) if prev_out != oracle.NONE else GS_NONE
+    has_raw = int(ctr["raw_hits"] > 0)
+    return hits, has_raw, (last_loc if has_raw else GS_NONE)
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k, keys, loc, reads = _case()
+        # table arrays travel from rank 0 through the collective backend
+        keys_b = gdist.broadcast_array(keys if rank == 0 else None, np.uint64)
+        loc_b = gdist.broadcast_array(loc if rank == 0 else None, np.uint32)
+        assert np.array_equal(keys_b, keys) and np.array_equal(loc_b, loc)
+        lo, hi = gdist.shard_bounds(len(reads), world, rank)
+        shard = reads[lo:hi]
+        # phase 1 (no carry known yet): summary of the shard
+        _, has_raw, last_loc = _oracle_shard(k, keys_b, loc_b, shard, GS_NONE)
+        summ = gdist.exchange_summaries(has_raw, last_loc)
+        carry = gdist.resolve_carry(summ, rank)
+        # phase 2 with the resolved carry
+        hits, _, _ = _oracle_shard(k, keys_b, loc_b, shard, carry)
+        local = torch.from_numpy(np.stack([hits["read"], hits["pos"], hits["row"]], axis=1).astype(np.int32)).reshape(-1, 3)
+        allhits = gdist.gather_hits(local, lo)
+        if rank == 0:
+            np.save(out_path, allhits.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_run_equals_single_file(world, tmp_path):
+    out = str(tmp_path / "hits.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    k, keys, loc, reads = _case()
+    whole, _, _ = _oracle_shard(k, keys, loc, reads, GS_NONE)
+    assert len(whole) > 20
+    assert np.array_equal(got[:, 0], whole["read"].astype(np.int32))
+    assert np.array_equal(got[:, 1], whole["pos"].astype(np.int32))
+    # same loc per row (rows of equal loc are interchangeable for the stand-in carry)
+    assert np.array_equal(loc[got[:, 2]], loc[whole["row"]])
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 64, 1001):
+        for w in (1, 2, 3, 8):
+            b = [gdist.shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_resolve_carry():
+    s = [(0, GS_NONE), (1, 5), (0, GS_NONE), (1, 9)]
+    assert gdist.resolve_carry(s, 0) == GS_NONE
+    assert gdist.resolve_carry(s, 0, carry0=3) == 3
+    assert gdist.resolve_carry(s, 1) == GS_NONE
+    assert gdist.resolve_carry(s, 2) == 5
+    assert gdist.resolve_carry(s, 3) == 5
