@@ -94,6 +94,7 @@ SIGNATURES = {
     "gs_sunkpos_contig_name": (C.c_char_p, [P, U32]),
     "gs_sunkpos_row_text": (P, [P, U64, C.POINTER(U32)]),
     "gs_diag_filter": (I, [I, P, P, P, P, P, P]),
+    "gs_pair_component": (I, [I, U32, P, P, P, P, P, P]),
 }
 
 _lib = None

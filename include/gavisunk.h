@@ -205,6 +205,22 @@ const char *gs_sunkpos_row_text(const gs_sunkpos *s, uint64_t row, uint32_t *len
 int gs_diag_filter(int device, const gs_sunkpos *s, const uint8_t *in_fai, uint32_t *best_contig,
                    uint32_t *best_good, uint8_t *best_dir, uint8_t *keep);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Inter-SUNK distance test (workflow/scripts/process-by-contig_lowmem_AR.py:135-200).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Per read: all pairs of its SUNK hits whose distance on the read is within (0.9, 1.1) of their
+ * distance on the contig (fp64, as scipy.pdist + numpy compute it, :140-147), restricted to the
+ * majority orientation (:150-153), cleaned of IDs seen at several read positions (:160-181), then
+ * the largest connected component of the ID graph; its IDs in vertex insertion order (:189-198).
+ *   read_off[n_reads+1] : row ranges; rows of a read sorted by `start` (stable) and de-duplicated,
+ *                         i.e. `sub` of the script (lines 50-108 are file-level filtering, host side)
+ *   out_n[r]            : number of IDs kept for read r (0 = the read prints nothing)
+ *   out_ids             : n_rows slots; read r's IDs start at out_ids[read_off[r]] */
+int gs_pair_component(int device, uint32_t n_reads, const uint64_t *read_off, const int64_t *pos,
+                      const int64_t *start, const int64_t *id, uint32_t *out_n, int64_t *out_ids);
+
 #ifdef __cplusplus
 }
 #endif

@@ -403,9 +403,7 @@ def pair_component_read(ids: Sequence[int], pos: Sequence[int], start: Sequence[
         return []
     ones = sum(1 for m, s in zip(mask, sign) if m and s == 1)
     zeros = sum(1 for m, s in zip(mask, sign) if m and s == 0)
-    true_orient = 1 if ones > zeros else 0                         # :150-152 argmax, tie -> 0
-    if zeros == 0:
-        true_orient = 1
+    true_orient = 1 if ones > zeros else 0                         # :150-152 argmax over sorted [0, 1], tie -> 0
     edges = [(ids[i], ids[j], pos[i], pos[j]) for (i, j), m, s in zip(pairs, mask, sign)
              if m and s == true_orient]                            # :153-158
     # multipos clean-up (:160-181)
@@ -462,3 +460,70 @@ def pair_component_read(ids: Sequence[int], pos: Sequence[int], start: Sequence[
             label_order.append(r)
     best_root = max(label_order, key=lambda r: (size[r], -label_order.index(r)))
     return [verts[i] for i in range(len(verts)) if roots[i] == best_root]
+
+
+def process_by_contig(sunkpos_text: str, rlen_text: str, bad_text: str) -> Tuple[str, str]:
+    """process-by-contig_lowmem_AR.py:50-260 on the contents of its input files -> (tsv, bed).
+    Plain-Python restatement (dicts and lists instead of pandas); PARITY UNPINNED, see module header."""
+    rows = parse_sunkpos(sunkpos_text)                                   # :60
+    contig = rows[0][2]                                                  # :62
+    bad = set(bad_text.splitlines())                                     # :67-68
+    rows = [r for r in rows if f"{r[2]}:{r[4]}" not in bad]              # :69-72
+    ids_of: Dict[str, set] = {}
+    for r in rows:
+        ids_of.setdefault(r[0], set()).add(r[4])
+    multi = {n for n, s in ids_of.items() if len(s) > 1}                 # :91
+    if not multi:
+        return f"{contig}\n", ""                                         # :92-94
+    rows = [r for r in rows if r[0] in multi]
+    rows.sort(key=lambda r: (r[0], r[3]))                                # :100 (stable)
+    seen, ded = set(), []
+    for r in rows:                                                       # :104
+        if r not in seen:
+            seen.add(r)
+            ded.append(r)
+    rlen = {}
+    for ln in rlen_text.splitlines():
+        f = ln.split("\t")
+        if len(f) >= 2:
+            rlen[f[0]] = int(f[1])
+    sub = [r for r in ded if rlen.get(r[0], -1) >= 10000]                # :106-108
+    groups: Dict[str, list] = {}
+    for r in sub:
+        groups.setdefault(r[0], []).append(r)
+    outputs = []
+    for rname in sorted(groups):                                         # :135 groupby -> sorted keys
+        g = groups[rname]
+        ids = pair_component_read([r[4] for r in g], [r[1] for r in g], [r[3] for r in g])
+        if ids:
+            outputs.append((rname, ids))
+    if not outputs:
+        return f"{contig}\n", ""                                         # :202-204
+    tsv = "".join(f"{i}\t{rname}\n" for rname, ids in outputs for i in ids)  # :206-207
+    # contig-wide graph (:219-260)
+    vid: Dict[int, int] = {}
+    verts: List[int] = []
+    parent: List[int] = []
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    for _, ids in outputs:
+        for a, b in itertools.combinations(ids, 2):
+            for v in (a, b):
+                if v not in vid:
+                    vid[v] = len(verts)
+                    verts.append(v)
+                    parent.append(len(parent))
+            ra, rb = find(vid[a]), find(vid[b])
+            if ra != rb:
+                parent[max(ra, rb)] = min(ra, rb)
+    comps: Dict[int, list] = {}
+    for i, v in enumerate(verts):
+        comps.setdefault(find(i), []).append(v)
+    regs = sorted((min(c), max(c)) for c in comps.values() if len(c) > 2)
+    bed = "".join(f"{contig}\t{s}\t{e}\n" for s, e in regs)
+    return tsv, bed
