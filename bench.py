@@ -119,9 +119,13 @@ def main():
         import torch.distributed as dist
         from gavisunk_amd import dist as gdist
 
-        torch.cuda.set_device(device)
-        tdev = torch.device("cuda", device)
-        dist.init_process_group("nccl", device_id=tdev)
+        backend = os.environ.get("GAVISUNK_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 path on one GPU
+        if backend == "nccl":
+            torch.cuda.set_device(device)
+            tdev = torch.device("cuda", device)
+            dist.init_process_group("nccl", device_id=tdev)
+        else:
+            dist.init_process_group(backend)
 
     k = 20
     # ---- inputs (synthetic; SURVEY.md Appendix B recipe) --------------------------------
@@ -163,6 +167,7 @@ def main():
     if world > 1:
         import torch
         hit_buf = torch.empty((max(dev_reads.n_windows // 64, 1 << 20), 3), dtype=torch.int32, device=tdev)
+        on_gpu = tdev is not None
     n_hits = C.c_uint64(0)
     carry = C.c_uint32(0)
     ctr = _lib.GsCounters()
@@ -181,14 +186,16 @@ def main():
         summ = gdist.exchange_summaries(has.value, last.value, tdev)
         _lib.check(L.gs_tag_phase2(table._h, dev_reads._h, gdist.resolve_carry(summ, rank)))
         _lib.check(L.gs_tag_finish(table._h, dev_reads._h, None, 0, C.byref(n_hits), C.byref(carry), C.byref(ctr)))
-        _lib.check(L.gs_tag_hits_to_device(table._h, dev_reads._h, hit_buf.data_ptr(), hit_buf.shape[0], None))
+        copy = L.gs_tag_hits_to_device if on_gpu else L.gs_tag_hits_to_host
+        _lib.check(copy(table._h, dev_reads._h, hit_buf.data_ptr(), hit_buf.shape[0], None))
         return gdist.gather_hits(hit_buf[: n_hits.value], read_lo)
 
     def sync():
         if world > 1:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if tdev is not None:
+                torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
