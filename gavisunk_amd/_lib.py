@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgavisunk.so")
+LIB_PATH = os.environ.get("GAVISUNK_LIB") or os.path.join(HERE, "libgavisunk.so")  # override: tuning experiments
 
 GS_OK, GS_E_ARG, GS_E_KEYERROR, GS_E_CAPACITY, GS_E_NODEVICE, GS_E_IO, GS_E_NOMEM = 0, -1, -2, -3, -4, -5, -6
 GS_NONE = 0xFFFFFFFF

@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256) void k_probe(TableView tab, ReadsView rd, Tile
 //               for the generic probe_tile (k_probe with a tile list).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+#ifndef GS_PART_WAVES
+#define GS_PART_WAVES 6  // waves per SIMD k_probe_part is compiled for (register budget); 6 x pipe 2 measured best
+#endif
 constexpr int kMaxRuns = 3;
 constexpr int kNPart = 16;  // key-space partitions; 8 are live at a time (one per XCD), kNPart / 8 passes
 
@@ -397,7 +400,7 @@ struct PartState {
 // first-chance buckets, second-chance buckets.  DBG: timing experiments (1 = no bucket loads,
 // 2 = stop after the queue); results are wrong for DBG != 0.
 template <int KT, int NT, int kPipe, int DBG>
-__global__ __launch_bounds__(256) void k_probe_part(CompactView ct, TableView tab, const uint64_t *__restrict__ words,
+__global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView ct, TableView tab, const uint64_t *__restrict__ words,
                                                     const TileDesc *__restrict__ tdesc, uint32_t n_tiles, PartRec *recs) {
     static_assert(NT == 2 || NT == 4, "tile index takes 2 bits of a queue entry");
     constexpr int QCAP = 640;  // queue window (items); more items are handled window by window
@@ -1066,7 +1069,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
             const int mode = dbg ? atoi(dbg) : 0;
             const char *env_nt = getenv("GAVISUNK_PART_TILES"), *env_pipe = getenv("GAVISUNK_PART_PIPE");  // tuning experiments
-            const int nt = env_nt ? atoi(env_nt) : 4, pipe = env_pipe ? atoi(env_pipe) : 4;
+            const int nt = env_nt ? atoi(env_nt) : 4, pipe = env_pipe ? atoi(env_pipe) : 2;
             const uint32_t pblocks = ((r->n_tiles + nt - 1) / nt + 3) / 4 * kNPart;
 #define GS_LAUNCH_PART(KT, NT, PIPE, DBG)                                                                           \
     hipLaunchKernelGGL((k_probe_part<KT, NT, PIPE, DBG>), dim3(pblocks), dim3(256), 0, t->stream, cv, view(t),      \
