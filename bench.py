@@ -225,6 +225,15 @@ def main():
         pass_s = c["total_ms"] / max(c["launches"], 1) / 1e3
         bpb = alg_bytes_per_base(h_raw, h_emit)
         achieved = n_bases * bpb / probe_s / 1e9
+        # HBM-side bytes per launch come from a separate rocprofv3 --pmc run (never collected inside the bench);
+        # they are quoted only for the exact workload they were measured on
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
+            if table.layout.startswith("compact") and a.reads == 10000 and a.seed == 20 and world == 1:
+                traffic = tj["k_probe_part"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "ONT bases/sec SUNK-tagged (k=20), bit-exact hit list",
             "value": total_bases * a.steps / dt,
@@ -246,7 +255,9 @@ def main():
                        "table_MiB": round(table.nbytes / 2**20, 1), "table_layout": table.layout,
                        "parallelism": f"read-sharded x{world}, table replicated"},
             "roofline": {"bound": "hbm", "kernel": "k_probe_part+k_merge_part+k_probe" if table.layout.startswith("compact") else "k_probe", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from profiles/r01/traffic.json (PMC run, gfx950-corrected)" if traffic else None,
+                         "alg_bytes_per_launch": int(n_bases * bpb),
                          "alg_bytes_per_base": round(bpb, 3), "kernel_ms": round(probe_s * 1e3, 4),
                          "pass_ms": round(pass_s * 1e3, 4),
                          "kernel_bases_per_s": n_bases / probe_s},
