@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "gs_common.h"
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        const uint32_t ngroups = (nitems + 63u) / 64u;
+        const uint32_t ngroups = DBG == 6 ? 0u : (nitems + 63u) / 64u;
         uint32_t npend = 0;  // wave-uniform
         auto flush_pending = [&]() {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -585,14 +586,15 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
             __builtin_amdgcn_wave_barrier();
         };
 
-        for (uint32_t g0 = 0; g0 < ngroups; g0 += kPipe) {
+        auto chunk = [&](uint32_t g0, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;  // all kPipe groups exist: no guards, so the compiler can interleave them
             // Straight-line per-lane code: lanes past the end compute on harmless values (every LDS and bucket
             // index they form is in range) and are masked out at the end.
             uint32_t entry[kPipe], tag[kPipe], bkt[kPipe];
             uint4 bk[kPipe];
 #pragma unroll
             for (int u = 0; u < kPipe; u++) {
-                if (g0 + u < ngroups) {  // wave-uniform
+                if (FULL || g0 + u < ngroups) {  // wave-uniform
                     entry[u] = sQ[wave][(g0 + u) * 64 + lane];
                     const BucketRem br = hmix2((canon_of(entry[u]) >> 4) & keymask, kbits, ct.qb);
                     tag[u] = br.rem;
@@ -602,8 +604,12 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
             }
 #pragma unroll
             for (int u = 0; u < kPipe; u++) {
-                if (g0 + u >= ngroups) break;  // wave-uniform
+                if (!FULL && g0 + u >= ngroups) break;  // wave-uniform
                 const uint32_t idx = (g0 + u) * 64 + lane;
+                if (DBG == 4) {
+                    if ((bk[u].x ^ bk[u].y ^ bk[u].z ^ bk[u].w) == 0x12345u) sQ[wave][idx] = 1;
+                    continue;
+                }
                 const uint32_t live = idx < nitems;
                 uint32_t l = 0;
                 const uint32_t h = match4(bk[u], tag[u], l) & live;
@@ -625,13 +631,18 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
                     npend += np;
                 }
             }
+        };
+        {
+            uint32_t g0 = 0;
+            for (; g0 + kPipe <= ngroups; g0 += kPipe) chunk(g0, std::true_type{});
+            if (g0 < ngroups) chunk(g0, std::false_type{});
         }
         if (npend) flush_pending();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
         // run-length pass over the resolved entries, tile by tile (a group of 64 may straddle tiles)
-        for (uint32_t g = 0; g < ngroups; g++) {
+        for (uint32_t g = 0; g < (DBG >= 3 ? 0u : ngroups); g++) {
             const uint32_t idx = g * 64 + lane;
             const uint32_t e = idx < nitems ? sQ[wave][idx] : 0u;
             const bool hit = ((e >> 13) & 1u) != 0;
@@ -1080,6 +1091,14 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                 GS_LAUNCH_PART(20, 4, 4, 1);
             else if (mode == 2)
                 GS_LAUNCH_PART(20, 4, 4, 2);
+            else if (mode == 3)
+                GS_LAUNCH_PART(20, 4, 2, 3);
+            else if (mode == 4)
+                GS_LAUNCH_PART(20, 4, 2, 4);
+            else if (mode == 5)
+                GS_LAUNCH_PART(20, 4, 2, 1);
+            else if (mode == 6)
+                GS_LAUNCH_PART(20, 4, 2, 6);
             else if (nt == 2 && pipe == 4)
                 GS_LAUNCH_PART(20, 2, 4, 0);
             else if (nt == 2 && pipe == 8)
