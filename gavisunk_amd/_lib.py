@@ -95,6 +95,7 @@ SIGNATURES = {
     "gs_sunkpos_row_text": (P, [P, U64, C.POINTER(U32)]),
     "gs_diag_filter": (I, [I, P, P, P, P, P, P]),
     "gs_pair_component": (I, [I, U32, P, P, P, P, P, P]),
+    "gs_key_histogram": (I, [I, U64, P, U32, P, P, P, U32]),
 }
 
 _lib = None

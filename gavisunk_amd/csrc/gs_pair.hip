@@ -260,3 +260,48 @@ extern "C" int gs_pair_component(int device, uint32_t n_reads, const uint64_t *r
     if (n_rows) HIP_TRY(hipMemcpy(out_ids, d_out, n_rows * sizeof(int64_t), hipMemcpyDeviceToHost));
     return GS_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Bad-SUNK histogram (workflow/scripts/badsunks_AR.py:20-51):
+// reads per `chrom:ID` key, then the histogram of those counts (its arg-max is the script's "mean coverage").
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ void k_key_count(const uint32_t *row_key, uint64_t n_rows, uint32_t *key_count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows) atomicAdd(&key_count[row_key[i]], 1u);
+}
+__global__ void k_count_hist(const uint32_t *key_count, const uint8_t *key_sel, uint32_t n_keys, uint32_t *hist,
+                             uint32_t hist_len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_keys && key_sel[i]) atomicAdd(&hist[min(key_count[i], hist_len - 1)], 1u);
+}
+}  // namespace
+
+extern "C" int gs_key_histogram(int device, uint64_t n_rows, const uint32_t *row_key, uint32_t n_keys,
+                                const uint8_t *key_sel, uint32_t *key_count, uint32_t *hist, uint32_t hist_len) {
+    if ((n_rows && !row_key) || !key_sel || !key_count || !hist || hist_len < 2) {
+        set_error("gs_key_histogram: bad argument");
+        return GS_E_ARG;
+    }
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_key_histogram: HIP device %d not available -- there is no CPU fallback", device);
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    DevBuf db;
+    int rc;
+    uint32_t *d_rk, *d_kc, *d_h;
+    uint8_t *d_sel;
+    if ((rc = db.put(&d_rk, row_key, n_rows)) || (rc = db.put(&d_kc, (const uint32_t *)nullptr, n_keys)) ||
+        (rc = db.put(&d_h, (const uint32_t *)nullptr, hist_len)) || (rc = db.put(&d_sel, key_sel, n_keys)))
+        return rc;
+    HIP_TRY(hipMemset(d_kc, 0, std::max<uint64_t>(n_keys, 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(d_h, 0, hist_len * sizeof(uint32_t)));
+    if (n_rows) hipLaunchKernelGGL(k_key_count, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, 0, d_rk, n_rows, d_kc);
+    if (n_keys) hipLaunchKernelGGL(k_count_hist, dim3((n_keys + 255) / 256), dim3(256), 0, 0, d_kc, d_sel, n_keys, d_h, hist_len);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (n_keys) HIP_TRY(hipMemcpy(key_count, d_kc, n_keys * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hist, d_h, hist_len * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return GS_OK;
+}

@@ -221,6 +221,16 @@ int gs_diag_filter(int device, const gs_sunkpos *s, const uint8_t *in_fai, uint3
 int gs_pair_component(int device, uint32_t n_reads, const uint64_t *read_off, const int64_t *pos,
                       const int64_t *start, const int64_t *id, uint32_t *out_n, int64_t *out_ids);
 
+
+/* Bad-SUNK histogram (workflow/scripts/badsunks_AR.py:20-51).
+ *   row_key[n_rows]  dense id of each .sunkpos row's `chrom:ID`
+ *   key_sel[n_keys]  1 for keys on this haplotype's contigs ("correct_hap", :31-34)
+ *   key_count[n_keys] <- reads per key (`value_counts`, :23-24)
+ *   hist[hist_len]    <- number of selected keys per count (last bin = that count or more); its arg-max is
+ *                        the script's "mean coverage" = mode of the counts (:43) */
+int gs_key_histogram(int device, uint64_t n_rows, const uint32_t *row_key, uint32_t n_keys, const uint8_t *key_sel,
+                     uint32_t *key_count, uint32_t *hist, uint32_t hist_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -527,3 +527,22 @@ def process_by_contig(sunkpos_text: str, rlen_text: str, bad_text: str) -> Tuple
     regs = sorted((min(c), max(c)) for c in comps.values() if len(c) > 2)
     bed = "".join(f"{contig}\t{s}\t{e}\n" for s, e in regs)
     return tsv, bed
+
+
+def badsunks(fai1_text: str, fai2_text: str, sunkpos1_text: str, sunkpos2_text: str) -> set:
+    """badsunks_AR.py:20-103 (PARITY UNPINNED: the script does not run under pandas 2.x, SURVEY.md 8c);
+    restated from the source text.  Returns the set the script writes (in arbitrary order) to <outpath>."""
+    from collections import Counter
+
+    def one(fai_text, sp_text):
+        contigs = {ln.split("\t")[0] for ln in fai_text.splitlines() if ln.strip()}
+        cnt = Counter(f"{r[2]}:{r[4]}" for r in parse_sunkpos(sp_text))       # :22-24
+        own = {k: v for k, v in cnt.items() if k.rsplit(":", 1)[0] in contigs}    # :29-34 (split on the first ':' there;
+        other = {k: v for k, v in cnt.items() if k not in own}                    #  contig names carry no ':')
+        hist = Counter(own.values())
+        top = max(hist.values())
+        meancov = min(c for c, n in hist.items() if n == top)                     # :43 mode().values[0]
+        limit = meancov + (meancov ** 0.5) * 4                                    # :46
+        return ({k for k, v in own.items() if v > limit or v < 2} |               # :48
+                {k for k, v in other.items() if v > limit})                       # :51
+    return one(fai1_text, sunkpos1_text) | one(fai2_text, sunkpos2_text)          # :97

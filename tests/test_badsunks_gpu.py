@@ -1,0 +1,39 @@
+"""Bad-SUNK caller (next row N2): GPU histogram behind the badsunks stub vs the oracle restatement."""
+import numpy as np
+import pytest
+
+from gavisunk_amd import badsunks
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _synthetic(seed, own, other):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for r in range(600):
+        for _ in range(int(rng.integers(1, 30))):
+            c = own[int(rng.integers(0, len(own)))] if rng.random() < 0.8 else other[int(rng.integers(0, len(other)))]
+            g = int(rng.zipf(1.4)) % 400 * 1000
+            rows.append(f"r{r}\t{int(rng.integers(0, 50000))}\t{c}\t{g + 5}\t{g}\n")
+    return "".join(rows)
+
+
+def test_matches_oracle(tmp_path, golden):
+    fai1 = "h1a\t10\nh1b\t10\n"
+    fai2 = "h2a\t10\n"
+    sp1 = _synthetic(1, ["h1a", "h1b"], ["h2a"])
+    sp2 = _synthetic(2, ["h2a"], ["h1a", "h1b"])
+    p = {n: tmp_path / n for n in ("f1", "f2", "s1", "s2", "out")}
+    p["f1"].write_text(fai1), p["f2"].write_text(fai2), p["s1"].write_text(sp1), p["s2"].write_text(sp2)
+    assert badsunks.main([str(p["f1"]), str(p["f2"]), str(p["s1"]), str(p["s2"]), str(p["out"])]) == 0
+    got = set(p["out"].read_text().split())
+    exp = oracle.badsunks(fai1, fai2, sp1, sp2)
+    assert got == exp and len(exp) > 20
+    # and on a reference-made .sunkpos (AMY locus): hap1 reads against both haplotype roles
+    c = golden("amy")
+    sp = c.text("expected.sunkpos")
+    fai = c.text("fai")
+    p["s1"].write_text(sp), p["f1"].write_text(fai), p["f2"].write_text("AMY_CHM1\t467195\t10\t60\t61\n"), p["s2"].write_text(sp)
+    assert badsunks.main([str(p["f1"]), str(p["f2"]), str(p["s1"]), str(p["s2"]), str(p["out"])]) == 0
+    assert set(p["out"].read_text().split()) == oracle.badsunks(fai, "AMY_CHM1\t467195\t10\t60\t61\n", sp, sp)
