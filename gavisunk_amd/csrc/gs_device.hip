@@ -641,6 +641,55 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
+        if (V <= (uint32_t)QCAP && DBG < 3) {
+            // Usual case, the whole batch sits in this window: run-length pass tile by tile, three groups of 64
+            // entries at a time.  The group descriptors (hit ballot, first/last hit, "all the same loc") are
+            // independent of each other, only their merge into the run list is sequential and it is scalar.
+            for (int q = 0; q < NT; q++) {
+                const uint32_t n = tot[q], base = vbase[q];
+                for (uint32_t j0 = 0; j0 < n; j0 += 192) {
+                    uint32_t e[3];
+                    unsigned long long hb[3], nb[3];
+                    uint32_t floc[3], fw[3], lw[3];
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+                        const uint32_t j = j0 + u * 64 + lane;
+                        e[u] = j < n ? sQ[wave][base + j] : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+                        const bool hit = ((e[u] >> 13) & 1u) != 0;
+                        hb[u] = __ballot(hit);
+                        const int fl = hb[u] ? __ffsll(hb[u]) - 1 : 0, ll = hb[u] ? 63 - __clzll((long long)hb[u]) : 0;
+                        floc[u] = lane_value(e[u] >> 14, fl);
+                        fw[u] = lane_value(e[u] & 2047u, fl);
+                        lw[u] = lane_value(e[u] & 2047u, ll);
+                        nb[u] = __ballot(hit && (e[u] >> 14) != floc[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+                        if (!hb[u]) continue;
+                        if (nb[u]) {  // a location change inside the group: the general fold
+                            st.step(((e[u] >> 13) & 1u) != 0, e[u] >> 14, e[u] & 2047u, lane, runs);
+                            continue;
+                        }
+                        const uint32_t c = (uint32_t)__popcll(hb[u]);
+                        if (!(st.have && st.cur_loc == floc[u])) {
+                            if (st.have) st.push(runs, lane);
+                            st.cur_loc = floc[u];
+                            st.cur_first = fw[u];
+                            st.cur_cnt = 0;
+                            st.have = 1;
+                        }
+                        st.cur_cnt += c;
+                        st.cur_last = lw[u];
+                        st.hits += c;
+                    }
+                }
+                finish_tile(q);
+            }
+            cur_q = NT;
+        } else {
         // run-length pass over the resolved entries, tile by tile (a group of 64 may straddle tiles)
         for (uint32_t g = 0; g < (DBG >= 3 ? 0u : ngroups); g++) {
             const uint32_t idx = g * 64 + lane;
@@ -658,6 +707,7 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
                 while (cur_q < q) finish_tile(cur_q++);
                 st.step(hit && myq == q, e >> 14, e & 2047u, lane, runs);
             }
+        }
         }
     }
     while (cur_q < NT) finish_tile(cur_q++);
