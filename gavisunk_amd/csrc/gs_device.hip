@@ -110,12 +110,112 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_
     return x - v;
 }
 
+#ifndef GS_PART_WAVES
+#define GS_PART_WAVES 6  // waves per SIMD k_probe_part is compiled for (register budget); 6 x pipe 2 measured best
+#endif
+constexpr int kMaxRuns = 3;
+constexpr int kNPart = 16;  // key-space partitions; 8 are live at a time (one per XCD), kNPart / 8 passes
+constexpr uint32_t kEmptySlot32 = 0xFFFFFFFFu;
+
+// Bijection on `kbits`-bit keys, cheap in 32-bit arithmetic, returning the pair (bucket, remainder)
+// with bucket in [0, 2^qb) taken from the best-mixed bits.  kbits = 2k - 4 in [28, 60], qb <= 20.
+struct BucketRem {
+    uint32_t bucket;
+    uint32_t rem;  // kbits - qb bits
+};
+__host__ __device__ __forceinline__ BucketRem hmix2(uint64_t key, int kbits, int qb) {
+    const int lbits = kbits < 32 ? kbits : 32;  // low part that gets mixed
+    const uint32_t lmask = lbits == 32 ? 0xFFFFFFFFu : ((1u << lbits) - 1u);
+    const uint32_t hi = (uint32_t)(key >> lbits);  // kbits - lbits bits, passes through
+    uint32_t l = (uint32_t)key & lmask;
+    l = (l * 0x9E3779B1u) & lmask;
+    l ^= l >> (lbits / 2);
+    l = (l * 0x85EBCA6Bu) & lmask;
+    l ^= l >> (lbits / 2 + 1);
+    l = (l ^ (hi * 0xC2B2AE35u)) & lmask;
+    BucketRem o;
+    o.bucket = l >> (lbits - qb);
+    o.rem = ((l & ((1u << (lbits - qb)) - 1u)) << (kbits - lbits)) | hi;
+    return o;
+}
+// second-chance bucket of a key (same partition): bucket ^ (odd, non-zero function of the remainder)
+__host__ __device__ __forceinline__ uint32_t alt_bucket(uint32_t bucket, uint32_t rem, int qb) {
+    return bucket ^ ((((rem + 1u) * 0x9E3779B1u) >> (32 - qb)) | 1u);
+}
+
+// partition of a canonical (or not: it is strand-symmetric) 2k-bit code
+__host__ __device__ __forceinline__ uint32_t part_of(uint64_t c, int k) {
+    const uint32_t x0 = (uint32_t)(c >> (2 * k - 2)) & 3u, x1 = (uint32_t)(c >> (2 * k - 4)) & 3u;
+    const uint32_t xl = (uint32_t)c & 3u, xl2 = (uint32_t)(c >> 2) & 3u;
+    return ((x0 ^ xl) << 2) | (x1 ^ xl2);
+}
+
+// slot = [ flags(2, slot 0 only) | alt(1) | rem | loc ];  flags: bit 31 = a key of this bucket lives in its
+// second-chance bucket, bit 30 = a key of this bucket lives in the generic table only
+struct CompactView {
+    const uint4 *buckets;  // [kNPart << qb]
+    int qb, rembits, locbits, has_flag;
+};
+
+
+// Exact lookup in the compact table (any size: resident in L2 slices or out in HBM).  Returns hit / loc; a key
+// that overflowed both of its buckets at build time is found in the generic table.
+__device__ __forceinline__ bool compact_lookup(const CompactView &ct, const TableView &tab, uint64_t c, int k,
+                                               uint32_t &loc) {
+    const int kbits = 2 * k - 4;
+    const uint64_t keymask = (1ULL << kbits) - 1ULL;
+    const uint32_t locmask = (1u << ct.locbits) - 1u, tagmask = (1u << (ct.rembits + 1)) - 1u;
+    const BucketRem br = hmix2((c >> 4) & keymask, kbits, ct.qb);
+    const uint4 *pb = ct.buckets + ((uint64_t)part_of(c, k) << ct.qb);
+    const uint4 b = pb[br.bucket];
+    const uint32_t sl[4] = {b.x, b.y, b.z, b.w};
+    bool hit = false, full = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (sl[i] == kEmptySlot32) full = false;
+        else if (((sl[i] >> ct.locbits) & tagmask) == br.rem) {
+            hit = true;
+            loc = sl[i] & locmask;
+        }
+    }
+    if (hit || !full) return hit;
+    bool generic = !ct.has_flag;
+    if (ct.has_flag) {
+        generic = ((sl[0] >> 30) & 1u) != 0;
+        if (sl[0] >> 31) {
+            const uint4 b2 = pb[alt_bucket(br.bucket, br.rem, ct.qb)];
+            const uint32_t s2[4] = {b2.x, b2.y, b2.z, b2.w};
+            const uint32_t want = br.rem | (1u << ct.rembits);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (s2[i] != kEmptySlot32 && ((s2[i] >> ct.locbits) & tagmask) == want) {
+                    hit = true;
+                    loc = s2[i] & locmask;
+                }
+            if (hit) return true;
+        }
+    }
+    if (!generic) return false;
+    uint64_t hh = slot_of(c, tab.shift);
+    Slot cur = load_slot(tab.slots + hh);
+    while (cur.key != c && cur.key != kEmptyKey) {
+        hh = (hh + 1) & tab.mask;
+        cur = load_slot(tab.slots + hh);
+    }
+    if (cur.key == c) {
+        loc = cur.loc;
+        return true;
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------
 // probe_tile / k_probe: one wavefront per tile (generic 16-byte-slot table in HBM)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void probe_tile(const TableView &tab, const ReadsView &rd, const TileArrays &ta,
-                                           uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
-                                           unsigned long long *g_err_pos, uint32_t tile) {
+template <bool COMPACT>
+__device__ __forceinline__ void probe_tile(const TableView &tab, const CompactView &ct, const ReadsView &rd,
+                                           const TileArrays &ta, uint32_t *cand, uint32_t cand_cap,
+                                           uint32_t *g_cand_count, unsigned long long *g_err_pos, uint32_t tile) {
     const int lane = threadIdx.x & 63;
     const uint32_t r = rd.tile_read[tile];
     const uint32_t tin = tile - rd.read_tile0[r];
@@ -137,37 +237,79 @@ __device__ __forceinline__ void probe_tile(const TableView &tab, const ReadsView
     bool missing = false;
     uint32_t missing_bit = 0;
 
+    if (COMPACT) {
+        // compact table out in HBM: one 16-byte bucket load per window (one 64-byte line from the fabric), 8 in flight
+        const int kbits = 2 * k - 4;
+        const uint64_t keymask = (1ULL << kbits) - 1ULL;
+        const uint32_t locmask = (1u << ct.locbits) - 1u, tagmask = (1u << (ct.rembits + 1)) - 1u;
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        uint64_t c[8], h[8];
-        Slot s[8];
+        for (int g = 0; g < 4; g++) {
+            uint64_t c[8];
+            uint32_t tag[8];
+            uint4 bk[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c[j] = canon_at(a, b2, ra, rb, g * 8 + j, k, kmask);
-            h[j] = slot_of(c[j], tab.shift);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = load_slot(tab.slots + h[j]);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int bb = g * 8 + j;
-            Slot cur = s[j];
-            uint64_t hh = h[j];
-            while (cur.key != c[j] && cur.key != kEmptyKey) {
-                hh = (hh + 1) & tab.mask;
-                cur = load_slot(tab.slots + hh);
+            for (int j = 0; j < 8; j++) {
+                c[j] = canon_at(a, b2, ra, rb, g * 8 + j, k, kmask);
+                const BucketRem br = hmix2((c[j] >> 4) & keymask, kbits, ct.qb);
+                tag[j] = br.rem;
+                bk[j] = ct.buckets[((uint64_t)part_of(c[j], k) << ct.qb) + br.bucket];
             }
-            if (cur.key == c[j] && ((vmask >> bb) & 1u)) {
-                raw |= 1u << bb;
-                if (prev == GS_NONE) {
-                    first_loc = cur.loc;
-                } else if (cur.loc != prev) {
-                    chg |= 1u << bb;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int bb = g * 8 + j;
+                const uint32_t sl[4] = {bk[j].x, bk[j].y, bk[j].z, bk[j].w};
+                uint32_t h = 0, l = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t eq = (((sl[i] >> ct.locbits) & tagmask) == tag[j]) & (sl[i] != kEmptySlot32);
+                    h |= eq;
+                    l = eq ? sl[i] : l;
                 }
-                prev = cur.loc;
-                if (cur.loc == GS_MISSING && !missing) {
-                    missing = true;
-                    missing_bit = bb;
+                uint32_t loc = l & locmask;
+                bool hit = h != 0;
+                const bool full = max(max(sl[0], sl[1]), max(sl[2], sl[3])) != kEmptySlot32;
+                if (!hit && full && ((vmask >> bb) & 1u)) hit = compact_lookup(ct, tab, c[j], k, loc);  // second chance / generic
+                if (hit && ((vmask >> bb) & 1u)) {
+                    raw |= 1u << bb;
+                    if (prev == GS_NONE) first_loc = loc;
+                    else if (loc != prev) chg |= 1u << bb;
+                    prev = loc;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            uint64_t c[8], h[8];
+            Slot s[8];
+    #pragma unroll
+            for (int j = 0; j < 8; j++) {
+                c[j] = canon_at(a, b2, ra, rb, g * 8 + j, k, kmask);
+                h[j] = slot_of(c[j], tab.shift);
+            }
+    #pragma unroll
+            for (int j = 0; j < 8; j++) s[j] = load_slot(tab.slots + h[j]);
+    #pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int bb = g * 8 + j;
+                Slot cur = s[j];
+                uint64_t hh = h[j];
+                while (cur.key != c[j] && cur.key != kEmptyKey) {
+                    hh = (hh + 1) & tab.mask;
+                    cur = load_slot(tab.slots + hh);
+                }
+                if (cur.key == c[j] && ((vmask >> bb) & 1u)) {
+                    raw |= 1u << bb;
+                    if (prev == GS_NONE) {
+                        first_loc = cur.loc;
+                    } else if (cur.loc != prev) {
+                        chg |= 1u << bb;
+                    }
+                    prev = cur.loc;
+                    if (cur.loc == GS_MISSING && !missing) {
+                        missing = true;
+                        missing_bit = bb;
+                    }
                 }
             }
         }
@@ -219,14 +361,15 @@ __device__ __forceinline__ void probe_tile(const TableView &tab, const ReadsView
 }
 
 
-__global__ __launch_bounds__(256) void k_probe(TableView tab, ReadsView rd, TileArrays ta, uint32_t *cand,
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void k_probe(TableView tab, CompactView ct, ReadsView rd, TileArrays ta, uint32_t *cand,
                                                uint32_t cand_cap, uint32_t *g_cand_count,
                                                unsigned long long *g_err_pos, const uint32_t *tile_list,
                                                const uint32_t *tile_list_n) {
     // whole batch (tile_list == nullptr: one wave per tile) or a list of tiles (grid-stride)
     const uint32_t n_items = tile_list ? *tile_list_n : rd.n_tiles;
     for (uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6); item < n_items; item += gridDim.x * 4)
-        probe_tile(tab, rd, ta, cand, cand_cap, g_cand_count, g_err_pos, tile_list ? tile_list[item] : item);
+        probe_tile<COMPACT>(tab, ct, rd, ta, cand, cand_cap, g_cand_count, g_err_pos, tile_list ? tile_list[item] : item);
 }
 
 
@@ -268,52 +411,7 @@ __global__ __launch_bounds__(256) void k_probe(TableView tab, ReadsView rd, Tile
 //               {n_raw, first/last loc, candidates} follow exactly; otherwise the tile is queued
 //               for the generic probe_tile (k_probe with a tile list).
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
-#ifndef GS_PART_WAVES
-#define GS_PART_WAVES 6  // waves per SIMD k_probe_part is compiled for (register budget); 6 x pipe 2 measured best
-#endif
-constexpr int kMaxRuns = 3;
-constexpr int kNPart = 16;  // key-space partitions; 8 are live at a time (one per XCD), kNPart / 8 passes
-
-// Bijection on `kbits`-bit keys, cheap in 32-bit arithmetic, returning the pair (bucket, remainder)
-// with bucket in [0, 2^qb) taken from the best-mixed bits.  kbits = 2k - 4 in [28, 60], qb <= 20.
-struct BucketRem {
-    uint32_t bucket;
-    uint32_t rem;  // kbits - qb bits
-};
-__host__ __device__ __forceinline__ BucketRem hmix2(uint64_t key, int kbits, int qb) {
-    const int lbits = kbits < 32 ? kbits : 32;  // low part that gets mixed
-    const uint32_t lmask = lbits == 32 ? 0xFFFFFFFFu : ((1u << lbits) - 1u);
-    const uint32_t hi = (uint32_t)(key >> lbits);  // kbits - lbits bits, passes through
-    uint32_t l = (uint32_t)key & lmask;
-    l = (l * 0x9E3779B1u) & lmask;
-    l ^= l >> (lbits / 2);
-    l = (l * 0x85EBCA6Bu) & lmask;
-    l ^= l >> (lbits / 2 + 1);
-    l = (l ^ (hi * 0xC2B2AE35u)) & lmask;
-    BucketRem o;
-    o.bucket = l >> (lbits - qb);
-    o.rem = ((l & ((1u << (lbits - qb)) - 1u)) << (kbits - lbits)) | hi;
-    return o;
-}
-// second-chance bucket of a key (same partition): bucket ^ (odd, non-zero function of the remainder)
-__host__ __device__ __forceinline__ uint32_t alt_bucket(uint32_t bucket, uint32_t rem, int qb) {
-    return bucket ^ ((((rem + 1u) * 0x9E3779B1u) >> (32 - qb)) | 1u);
-}
-
-// partition of a canonical (or not: it is strand-symmetric) 2k-bit code
-__host__ __device__ __forceinline__ uint32_t part_of(uint64_t c, int k) {
-    const uint32_t x0 = (uint32_t)(c >> (2 * k - 2)) & 3u, x1 = (uint32_t)(c >> (2 * k - 4)) & 3u;
-    const uint32_t xl = (uint32_t)c & 3u, xl2 = (uint32_t)(c >> 2) & 3u;
-    return ((x0 ^ xl) << 2) | (x1 ^ xl2);
-}
-
-// slot = [ flags(2, slot 0 only) | alt(1) | rem | loc ];  flags: bit 31 = a key of this bucket lives in its
-// second-chance bucket, bit 30 = a key of this bucket lives in the generic table only
-struct CompactView {
-    const uint4 *buckets;  // [kNPart << qb]
-    int qb, rembits, locbits, has_flag;
-};
+constexpr uint32_t kEmptySlot = kEmptySlot32;
 
 struct __align__(16) PartRec {
     uint32_t head;  // nruns | complex << 8 | n_hits << 16
@@ -1029,6 +1127,33 @@ __global__ void k_table_insert(Slot *slots, uint64_t mask, int shift, const uint
     }
 }
 
+// Compact-table build on the GPU: first free slot of the home bucket, else of the second-chance bucket (alt bit),
+// else the key stays in the generic table only; the home bucket's slot 0 carries the two overflow flags.
+__global__ void k_compact_insert(uint32_t *slots, int k, int qb, int rembits, int locbits, int has_flag,
+                                 const uint64_t *keys, const uint32_t *loc, uint64_t n, unsigned long long *overflow) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c = keys[i];
+    const int kbits = 2 * k - 4;
+    const BucketRem br = hmix2((c >> 4) & ((1ULL << kbits) - 1ULL), kbits, qb);
+    const uint64_t pbase = (uint64_t)part_of(c, k) << qb;
+    const uint32_t v = (br.rem << locbits) | loc[i];
+    uint32_t *home = slots + (pbase + br.bucket) * 4;
+    for (int j = 0; j < 4; j++)
+        if (atomicCAS(home + j, kEmptySlot32, v) == kEmptySlot32) return;
+    if (has_flag) {
+        uint32_t *alt = slots + (pbase + alt_bucket(br.bucket, br.rem, qb)) * 4;
+        const uint32_t va = v | (1u << (rembits + locbits));
+        for (int j = 0; j < 4; j++)
+            if (atomicCAS(alt + j, kEmptySlot32, va) == kEmptySlot32) {
+                atomicOr(home, 0x80000000u);
+                return;
+            }
+        atomicOr(home, 0x40000000u);
+    }
+    atomicAdd(overflow, 1ULL);
+}
+
 template <typename T>
 int dev_alloc(T **p, uint64_t n) {
     *p = nullptr;
@@ -1048,7 +1173,7 @@ struct gs_table {
     int shift = 0;
     Slot *slots = nullptr;
     // small-table fast path (exact compact table resident in the XCD-partitioned L2s)
-    bool compact = false;
+    int compact = 0;  // 0 generic only, 1 compact-l2, 2 compact-hbm
     uint4 *cbuckets = nullptr;
     int c_qb = 0, c_rembits = 0, c_locbits = 0, c_has_flag = 0;
     uint64_t c_overflow = 0;
@@ -1114,7 +1239,7 @@ int ensure_out_buffers(gs_reads *r, uint32_t cand_cap) {
 
 int launch_phase1(gs_table *t, gs_reads *r) {
     HIP_TRY(hipSetDevice(t->device));
-    if (t->compact && r->n_tiles && !r->part_recs) {
+    if (t->compact == 1 && r->n_tiles && !r->part_recs) {
         int rc;
         if ((rc = dev_alloc(&r->part_recs, (uint64_t)r->n_tiles * kNPart))) return rc;
         if ((rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
@@ -1124,9 +1249,9 @@ int launch_phase1(gs_table *t, gs_reads *r) {
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     if (r->n_tiles) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
-        if (t->compact) {
+        const CompactView cv{t->cbuckets, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag};
+        if (t->compact == 1) {
             HIP_TRY(hipMemsetAsync(t->d_complex_n, 0, sizeof(uint32_t), t->stream));
-            const CompactView cv{t->cbuckets, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag};
             const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
             const int mode = dbg ? atoi(dbg) : 0;
             const char *env_nt = getenv("GAVISUNK_PART_TILES"), *env_pipe = getenv("GAVISUNK_PART_PIPE");  // tuning experiments
@@ -1163,11 +1288,15 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             hipLaunchKernelGGL(k_merge_part, dim3((r->n_tiles + 15) / 16), dim3(256), 0, t->stream, (const PartRec *)r->part_recs,
                                r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list, t->d_complex_n);
             // tiles whose partition summaries cannot be merged exactly: generic probe, grid-stride over the list
-            hipLaunchKernelGGL(k_probe, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), view(r),
-                               r->ta, r->cand, r->cand_cap, t->d_cand_count, t->d_err_pos,
+            hipLaunchKernelGGL(k_probe<false>, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), cv,
+                               view(r), r->ta, r->cand, r->cand_cap, t->d_cand_count, t->d_err_pos,
                                (const uint32_t *)r->complex_list, (const uint32_t *)t->d_complex_n);
+        } else if (t->compact == 2) {
+            hipLaunchKernelGGL(k_probe<true>, dim3(blocks), dim3(256), 0, t->stream, view(t), cv, view(r), r->ta, r->cand,
+                               r->cand_cap, t->d_cand_count, t->d_err_pos, (const uint32_t *)nullptr,
+                               (const uint32_t *)nullptr);
         } else {
-            hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(256), 0, t->stream, view(t), view(r), r->ta, r->cand,
+            hipLaunchKernelGGL(k_probe<false>, dim3(blocks), dim3(256), 0, t->stream, view(t), cv, view(r), r->ta, r->cand,
                                r->cand_cap, t->d_cand_count, t->d_err_pos, (const uint32_t *)nullptr,
                                (const uint32_t *)nullptr);
         }
@@ -1227,56 +1356,33 @@ uint64_t revcomp_code(uint64_t c, int k) {
     return r;
 }
 
-// Host build of the compact table; returns false when the fast path does not apply
-// (k < 16, a key without loc row, remainder + loc do not fit 32 bits, or slices too large for L2).
-bool build_compact(int k, uint64_t n, const uint64_t *keys, const uint32_t *loc, std::vector<uint32_t> &slots, int &qb,
-                   int &rembits, int &locbits, int &has_flag, uint64_t &overflow) {
+// Layout choice for the exact compact copy of the table (32-bit slots):
+//   1 = "compact-l2":  a 1/16 slice fits the L2 of an XCD next to the read stream (<= 2 MiB)  -> k_probe_part
+//   2 = "compact-hbm": larger; probed with one 16-byte bucket load per window                    -> k_probe<true>
+//   0 = generic 16-byte slots only (k < 16, a key without loc row, or remainder + loc do not fit 32 bits)
+int choose_compact(int k, uint64_t n, uint64_t generic_bytes, const uint32_t *loc, int &qb, int &rembits, int &locbits,
+                   int &has_flag) {
     const char *env = getenv("GAVISUNK_TABLE");
-    if (env && !strcmp(env, "generic")) return false;
-    if (k < 16 || n == 0) return false;
+    if (env && !strcmp(env, "generic")) return 0;
+    if (k < 16 || n == 0) return 0;
     uint32_t maxloc = 0;
     for (uint64_t i = 0; i < n; i++) {
-        if (loc[i] >= GS_MISSING) return false;
+        if (loc[i] >= GS_MISSING) return 0;
         maxloc = std::max(maxloc, loc[i]);
     }
     locbits = 1;
     while ((1ull << locbits) < (uint64_t)maxloc + 2) locbits++;  // the all-ones loc stays unused
-    if (locbits > 18) return false;  // a queue entry of k_probe_part keeps the loc in 18 bits
     const int kbits = 2 * k - 4;
     qb = 8;
     while (((uint64_t)(4 * kNPart) << qb) < (uint64_t)(2.2 * (double)n)) qb++;
     while (kbits - qb + locbits > 32) qb++;
-    // 8 live slices of 2^qb buckets x 16 B share 8 x 4 MiB of L2 with the read stream: keep a slice <= 2 MiB
-    if ((16ull << qb) > (2ull << 20) || kbits - qb < 1 || qb > 20 || (kbits >= 32 && qb > 32 - 1)) return false;
+    if (kbits - qb < 1 || qb > 28 || qb >= (kbits < 32 ? kbits : 32)) return 0;
+    // forcing the remainder into 32 bits can blow a small table up: never larger than the generic one (or 32 MiB)
+    if (((uint64_t)(16 * kNPart) << qb) > std::max<uint64_t>(generic_bytes, 32ull << 20)) return 0;
     rembits = kbits - qb;
     has_flag = rembits + 1 + locbits <= 30;
-    slots.assign((size_t)(4 * kNPart) << qb, kEmptySlot);
-    overflow = 0;
-    const uint64_t keymask = (1ULL << kbits) - 1;
-    auto place = [&](uint64_t bucket, uint32_t v) {
-        uint32_t *bk = &slots[bucket * 4];
-        for (int j = 0; j < 4; j++)
-            if (bk[j] == kEmptySlot) {
-                bk[j] = v;
-                return true;
-            }
-        return false;
-    };
-    for (uint64_t i = 0; i < n; i++) {
-        const uint64_t c = keys[i];
-        const BucketRem br = hmix2((c >> 4) & keymask, kbits, qb);
-        const uint64_t pbase = (uint64_t)part_of(c, k) << qb;
-        const uint32_t v = (br.rem << locbits) | loc[i];
-        if (place(pbase + br.bucket, v)) continue;
-        uint32_t *home = &slots[(pbase + br.bucket) * 4];
-        if (has_flag && place(pbase + alt_bucket(br.bucket, br.rem, qb), v | (1u << (rembits + locbits)))) {
-            home[0] |= 0x80000000u;  // some key of this bucket lives in its second-chance bucket
-            continue;
-        }
-        overflow++;  // stays in the generic table only
-        if (has_flag) home[0] |= 0x40000000u;
-    }
-    return true;
+    const bool l2 = (16ull << qb) <= (2ull << 20) && locbits <= 18 && !(env && !strcmp(env, "compact-hbm"));
+    return l2 ? 1 : 2;
 }
 
 }  // namespace
@@ -1339,16 +1445,31 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     }
     HIP_TRY(hipStreamSynchronize(t->stream));
     HIP_TRY(hipGetLastError());
-    {
-        std::vector<uint32_t> cs;
-        if (build_compact(k, n, keys, loc, cs, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_overflow)) {
-            uint32_t *d = nullptr;
-            if ((rc = dev_alloc(&d, cs.size()))) return rc;
-            HIP_TRY(hipMemcpy(d, cs.data(), cs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            t->cbuckets = reinterpret_cast<uint4 *>(d);
-            if ((rc = dev_alloc(&t->d_complex_n, 1))) return rc;
-            t->compact = true;
-        }
+    t->compact = choose_compact(k, n, cap * sizeof(Slot), loc, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
+    if (t->compact) {
+        const uint64_t nslots = (uint64_t)(4 * kNPart) << t->c_qb;
+        uint32_t *d = nullptr;
+        if ((rc = dev_alloc(&d, nslots))) return rc;
+        HIP_TRY(hipMemsetAsync(d, 0xFF, nslots * sizeof(uint32_t), t->stream));
+        uint64_t *dk;
+        uint32_t *dl;
+        unsigned long long *dov;
+        if ((rc = dev_alloc(&dk, n)) || (rc = dev_alloc(&dl, n)) || (rc = dev_alloc(&dov, 1))) return rc;
+        HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
+        HIP_TRY(hipMemcpyAsync(dk, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(dl, loc, n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+        hipLaunchKernelGGL(k_compact_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, d, k, t->c_qb,
+                           t->c_rembits, t->c_locbits, t->c_has_flag, dk, dl, n, dov);
+        unsigned long long ov = 0;
+        HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        HIP_TRY(hipGetLastError());
+        (void)hipFree(dk);
+        (void)hipFree(dl);
+        (void)hipFree(dov);
+        t->c_overflow = ov;
+        t->cbuckets = reinterpret_cast<uint4 *>(d);
+        if ((rc = dev_alloc(&t->d_complex_n, 1))) return rc;
     }
     *out = t;
     return GS_OK;
@@ -1358,8 +1479,9 @@ const char *gs_table_layout(const gs_table *t) {
     static thread_local char buf[160];
     if (!t) return "";
     if (t->compact)
-        snprintf(buf, sizeof buf, "compact-l2: 16 partitions x 2^%d buckets x 4 x u32 (%d-bit remainder, %d-bit loc%s), %llu keys only in the generic 16 B table behind it",
-                 t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag ? ", second-chance buckets" : "", (unsigned long long)t->c_overflow);
+        snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x u32 (%d-bit remainder, %d-bit loc%s), %llu keys only in the generic 16 B table behind it",
+                 t->compact == 1 ? "compact-l2" : "compact-hbm", t->c_qb, t->c_rembits, t->c_locbits,
+                 t->c_has_flag ? ", second-chance buckets" : "", (unsigned long long)t->c_overflow);
     else
         snprintf(buf, sizeof buf, "generic: open-addressed 16 B slots in HBM");
     return buf;

@@ -15,8 +15,8 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int sh) {
     for (int it = 0; it < N; it++) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            if (OP == 0) a[i] = a[i] * 0x9E3779B1u + 1u;                    // v_mul_lo_u32 (+add)
-            if (OP == 1) a[i] = __umul24(a[i], 0x9E3779u) + 1u;              // v_mul_u32_u24 / v_mad_u32_u24
+            if (OP == 0) a[i] = (a[i] * a[(i + 1) & 7]) ^ 0x9E3779B1u;        // v_mul_lo_u32 (+xor), data-dependent
+            if (OP == 1) a[i] = __umul24(a[i], a[(i + 1) & 7]) ^ 0x9E3779B1u;  // v_mul_u32_u24 (+xor), data-dependent
             if (OP == 2) b[i] = (b[i] << (sh & 63)) + 1;                     // v_lshlrev_b64 variable
             if (OP == 3) a[i] = (a[i] << (sh & 31)) + 1u;                    // v_lshlrev_b32 variable (+add)
             if (OP == 4) a[i] = __builtin_amdgcn_alignbit(a[i], a[(i + 1) & 7], sh) ^ 1u;  // v_alignbit_b32
@@ -51,7 +51,7 @@ int run(const char *name, uint32_t *out) {
 
 int main() {
     uint32_t *out; CK(hipMalloc(&out, 4));
-    run<0>("v_mul_lo_u32 + add", out); run<1>("v_mad_u32_u24", out); run<2>("v_lshlrev_b64 var + add64", out);
+    run<0>("v_mul_lo_u32 + xor", out); run<1>("v_mul_u32_u24 + xor", out); run<2>("v_lshlrev_b64 var + add64", out);
     run<3>("v_lshlrev_b32 var + add", out); run<4>("v_alignbit_b32 + xor", out); run<5>("v_bfrev_b32 + add", out);
     run<6>("min u64 + add64", out); run<7>("v_readlane + add", out); run<8>("ballot + bcnt + add", out); run<9>("shift, xor, add", out);
     return 0;
