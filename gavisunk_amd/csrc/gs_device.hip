@@ -153,7 +153,8 @@ __host__ __device__ __forceinline__ uint32_t part_of(uint64_t c, int k) {
 // slot = [ flags(2, slot 0 only) | alt(1) | rem | loc ];  flags: bit 31 = a key of this bucket lives in its
 // second-chance bucket, bit 30 = a key of this bucket lives in the generic table only
 struct CompactView {
-    const uint4 *buckets;  // [kNPart << qb]
+    const uint4 *buckets;     // [kNPart << qb]
+    const uint32_t *payload;  // one per slot (what a hit on that slot reports)
     int qb, rembits, locbits, has_flag;
 };
 
@@ -161,7 +162,7 @@ struct CompactView {
 // Exact lookup in the compact table (any size: resident in L2 slices or out in HBM).  Returns hit / loc; a key
 // that overflowed both of its buckets at build time is found in the generic table.
 __device__ __forceinline__ bool compact_lookup(const CompactView &ct, const TableView &tab, uint64_t c, int k,
-                                               uint32_t &loc) {
+                                               uint32_t &loc, uint32_t *payload = nullptr) {
     const int kbits = 2 * k - 4;
     const uint64_t keymask = (1ULL << kbits) - 1ULL;
     const uint32_t locmask = (1u << ct.locbits) - 1u, tagmask = (1u << (ct.rembits + 1)) - 1u;
@@ -176,6 +177,7 @@ __device__ __forceinline__ bool compact_lookup(const CompactView &ct, const Tabl
         else if (((sl[i] >> ct.locbits) & tagmask) == br.rem) {
             hit = true;
             loc = sl[i] & locmask;
+            if (payload) *payload = ct.payload[(uint64_t)(pb - ct.buckets + br.bucket) * 4 + i];
         }
     }
     if (hit || !full) return hit;
@@ -183,7 +185,8 @@ __device__ __forceinline__ bool compact_lookup(const CompactView &ct, const Tabl
     if (ct.has_flag) {
         generic = ((sl[0] >> 30) & 1u) != 0;
         if (sl[0] >> 31) {
-            const uint4 b2 = pb[alt_bucket(br.bucket, br.rem, ct.qb)];
+            const uint32_t ab = alt_bucket(br.bucket, br.rem, ct.qb);
+            const uint4 b2 = pb[ab];
             const uint32_t s2[4] = {b2.x, b2.y, b2.z, b2.w};
             const uint32_t want = br.rem | (1u << ct.rembits);
 #pragma unroll
@@ -191,6 +194,7 @@ __device__ __forceinline__ bool compact_lookup(const CompactView &ct, const Tabl
                 if (s2[i] != kEmptySlot32 && ((s2[i] >> ct.locbits) & tagmask) == want) {
                     hit = true;
                     loc = s2[i] & locmask;
+                    if (payload) *payload = ct.payload[(uint64_t)(pb - ct.buckets + ab) * 4 + i];
                 }
             if (hit) return true;
         }
@@ -204,6 +208,7 @@ __device__ __forceinline__ bool compact_lookup(const CompactView &ct, const Tabl
     }
     if (cur.key == c) {
         loc = cur.loc;
+        if (payload) *payload = cur.payload;
         return true;
     }
     return false;
@@ -1050,8 +1055,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(TileArrays ta, uint
 // ------------------------------------------------------------------------------------------
 // k_emit: one thread per tile
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_emit(TableView tab, ReadsView rd, TileArrays ta, const uint32_t *cand,
-                                              uint32_t cand_cap, gs_hit *hits, uint64_t hit_cap) {
+__global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, int compact, ReadsView rd, TileArrays ta,
+                                              const uint32_t *cand, uint32_t cand_cap, gs_hit *hits, uint64_t hit_cap) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= rd.n_tiles) return;
     const uint32_t nc = ta.n_cand[tile];
@@ -1080,16 +1085,22 @@ __global__ __launch_bounds__(256) void k_emit(TableView tab, ReadsView rd, TileA
         const uint64_t wi = rwoff + (w >> 5);
         const uint64_t a = rd.words[wi], b2 = rd.words[wi + 1];
         const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(w & 31u), k, kmask);
-        uint64_t hh = slot_of(c, tab.shift);
-        Slot cur = load_slot(tab.slots + hh);
-        while (cur.key != c && cur.key != kEmptyKey) {
-            hh = (hh + 1) & tab.mask;
-            cur = load_slot(tab.slots + hh);
+        uint32_t payload = 0, loc_unused = 0;
+        if (compact) {
+            compact_lookup(ct, tab, c, k, loc_unused, &payload);
+        } else {
+            uint64_t hh = slot_of(c, tab.shift);
+            Slot cur = load_slot(tab.slots + hh);
+            while (cur.key != c && cur.key != kEmptyKey) {
+                hh = (hh + 1) & tab.mask;
+                cur = load_slot(tab.slots + hh);
+            }
+            payload = cur.payload;
         }
         gs_hit hrec;
         hrec.read = r;
         hrec.pos = (uint32_t)(w - suppressed_before);
-        hrec.payload = cur.payload;
+        hrec.payload = payload;
         hits[o] = hrec;
     }
 }
@@ -1129,8 +1140,9 @@ __global__ void k_table_insert(Slot *slots, uint64_t mask, int shift, const uint
 
 // Compact-table build on the GPU: first free slot of the home bucket, else of the second-chance bucket (alt bit),
 // else the key stays in the generic table only; the home bucket's slot 0 carries the two overflow flags.
-__global__ void k_compact_insert(uint32_t *slots, int k, int qb, int rembits, int locbits, int has_flag,
-                                 const uint64_t *keys, const uint32_t *loc, uint64_t n, unsigned long long *overflow) {
+__global__ void k_compact_insert(uint32_t *slots, uint32_t *slot_payload, int k, int qb, int rembits, int locbits,
+                                 int has_flag, const uint64_t *keys, const uint32_t *loc, const uint32_t *payload, uint64_t n,
+                                 unsigned long long *overflow, uint32_t *overflow_list) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t c = keys[i];
@@ -1140,18 +1152,42 @@ __global__ void k_compact_insert(uint32_t *slots, int k, int qb, int rembits, in
     const uint32_t v = (br.rem << locbits) | loc[i];
     uint32_t *home = slots + (pbase + br.bucket) * 4;
     for (int j = 0; j < 4; j++)
-        if (atomicCAS(home + j, kEmptySlot32, v) == kEmptySlot32) return;
+        if (atomicCAS(home + j, kEmptySlot32, v) == kEmptySlot32) {
+            slot_payload[(home - slots) + j] = payload[i];
+            return;
+        }
     if (has_flag) {
         uint32_t *alt = slots + (pbase + alt_bucket(br.bucket, br.rem, qb)) * 4;
         const uint32_t va = v | (1u << (rembits + locbits));
         for (int j = 0; j < 4; j++)
             if (atomicCAS(alt + j, kEmptySlot32, va) == kEmptySlot32) {
+                slot_payload[(alt - slots) + j] = payload[i];
                 atomicOr(home, 0x80000000u);
                 return;
             }
         atomicOr(home, 0x40000000u);
     }
-    atomicAdd(overflow, 1ULL);
+    overflow_list[atomicAdd(overflow, 1ULL)] = (uint32_t)i;  // goes to the (small) generic table
+}
+
+// generic-table insert of a subset of the keys (those the compact table could not take)
+__global__ void k_table_insert_list(Slot *slots, uint64_t mask, int shift, const uint64_t *keys, const uint32_t *loc,
+                                    const uint32_t *payload, const uint32_t *list, uint64_t n_list) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_list) return;
+    const uint32_t i = list[t];
+    const uint64_t key = keys[i];
+    uint64_t h = slot_of(key, shift);
+    for (;;) {
+        unsigned long long *kp = reinterpret_cast<unsigned long long *>(&slots[h].key);
+        const unsigned long long old = atomicCAS(kp, (unsigned long long)kEmptyKey, (unsigned long long)key);
+        if (old == kEmptyKey || old == key) {
+            slots[h].loc = loc[i];
+            slots[h].payload = payload[i];
+            return;
+        }
+        h = (h + 1) & mask;
+    }
 }
 
 template <typename T>
@@ -1175,6 +1211,7 @@ struct gs_table {
     // small-table fast path (exact compact table resident in the XCD-partitioned L2s)
     int compact = 0;  // 0 generic only, 1 compact-l2, 2 compact-hbm
     uint4 *cbuckets = nullptr;
+    uint32_t *cpayload = nullptr;  // payload per compact slot
     int c_qb = 0, c_rembits = 0, c_locbits = 0, c_has_flag = 0;
     uint64_t c_overflow = 0;
     uint32_t *d_complex_n = nullptr;
@@ -1249,7 +1286,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     if (r->n_tiles) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
-        const CompactView cv{t->cbuckets, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag};
+        const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag};
         if (t->compact == 1) {
             HIP_TRY(hipMemsetAsync(t->d_complex_n, 0, sizeof(uint32_t), t->stream));
             const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
@@ -1288,7 +1325,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             hipLaunchKernelGGL(k_merge_part, dim3((r->n_tiles + 15) / 16), dim3(256), 0, t->stream, (const PartRec *)r->part_recs,
                                r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list, t->d_complex_n);
             // tiles whose partition summaries cannot be merged exactly: generic probe, grid-stride over the list
-            hipLaunchKernelGGL(k_probe<false>, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), cv,
+            hipLaunchKernelGGL(k_probe<true>, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), cv,
                                view(r), r->ta, r->cand, r->cand_cap, t->d_cand_count, t->d_err_pos,
                                (const uint32_t *)r->complex_list, (const uint32_t *)t->d_complex_n);
         } else if (t->compact == 2) {
@@ -1333,7 +1370,8 @@ int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
     if ((rc = launch_scan(t, r, 0))) return rc;
     if ((rc = launch_scan(t, r, 1))) return rc;
     if (r->n_tiles) {
-        hipLaunchKernelGGL(k_emit, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, view(t), view(r), r->ta,
+        const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag};
+        hipLaunchKernelGGL(k_emit, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, view(t), cv, t->compact, view(r), r->ta,
                            r->cand, r->cand_cap, r->hits, r->hit_cap);
     }
     HIP_TRY(hipEventRecord(t->ev[2], t->stream));
@@ -1412,65 +1450,76 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     t->device = device;
     t->k = k;
     t->n = n;
-    uint64_t cap = 1024;
-    int lg = 10;
-    while (cap < 2 * n) {
-        cap <<= 1;
-        lg++;
-    }
-    t->cap = cap;
-    t->shift = 64 - lg;
     int rc;
-    if ((rc = dev_alloc(&t->slots, cap))) return rc;
     HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     for (auto &e : t->ev) HIP_TRY(hipEventCreate(&e));
     if ((rc = dev_alloc(&t->d_cand_count, 1))) return rc;
     if ((rc = dev_alloc(&t->d_err_pos, 1))) return rc;
     if ((rc = dev_alloc(&t->d_carry_in, 1))) return rc;
     if ((rc = dev_alloc(&t->d_totals, 2))) return rc;
-    hipLaunchKernelGGL(k_table_fill, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, t->stream, t->slots, cap);
+    if ((rc = dev_alloc(&t->d_complex_n, 1))) return rc;
+    uint64_t *dk = nullptr;
+    uint32_t *dl = nullptr, *dp = nullptr, *dlist = nullptr;
+    if ((rc = dev_alloc(&dk, n)) || (rc = dev_alloc(&dl, n)) || (rc = dev_alloc(&dp, n))) return rc;
     if (n) {
-        uint64_t *dk;
-        uint32_t *dl, *dp;
-        if ((rc = dev_alloc(&dk, n)) || (rc = dev_alloc(&dl, n)) || (rc = dev_alloc(&dp, n))) return rc;
         HIP_TRY(hipMemcpyAsync(dk, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(dl, loc, n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(dp, payload, n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
-        hipLaunchKernelGGL(k_table_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, t->slots, cap - 1,
-                           t->shift, dk, dl, dp, n);
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        (void)hipFree(dk);
-        (void)hipFree(dl);
-        (void)hipFree(dp);
     }
-    HIP_TRY(hipStreamSynchronize(t->stream));
-    HIP_TRY(hipGetLastError());
-    t->compact = choose_compact(k, n, cap * sizeof(Slot), loc, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
+    auto pow2_cap = [](uint64_t want, int &lg) {
+        uint64_t c = 1024;
+        lg = 10;
+        while (c < want) {
+            c <<= 1;
+            lg++;
+        }
+        return c;
+    };
+    int lg_full;
+    const uint64_t cap_full = pow2_cap(2 * n, lg_full);
+    // The exact compact copy first (when it applies); the generic 16-byte-slot table then only has to hold the
+    // keys the compact one could not take.  Without a compact copy the generic table holds everything.
+    t->compact = choose_compact(k, n, cap_full * sizeof(Slot), loc, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
+    uint64_t n_generic = n;
     if (t->compact) {
         const uint64_t nslots = (uint64_t)(4 * kNPart) << t->c_qb;
         uint32_t *d = nullptr;
-        if ((rc = dev_alloc(&d, nslots))) return rc;
+        unsigned long long *dov = nullptr;
+        if ((rc = dev_alloc(&d, nslots)) || (rc = dev_alloc(&t->cpayload, nslots)) || (rc = dev_alloc(&dov, 1)) ||
+            (rc = dev_alloc(&dlist, n)))
+            return rc;
         HIP_TRY(hipMemsetAsync(d, 0xFF, nslots * sizeof(uint32_t), t->stream));
-        uint64_t *dk;
-        uint32_t *dl;
-        unsigned long long *dov;
-        if ((rc = dev_alloc(&dk, n)) || (rc = dev_alloc(&dl, n)) || (rc = dev_alloc(&dov, 1))) return rc;
         HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
-        HIP_TRY(hipMemcpyAsync(dk, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
-        HIP_TRY(hipMemcpyAsync(dl, loc, n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
-        hipLaunchKernelGGL(k_compact_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, d, k, t->c_qb,
-                           t->c_rembits, t->c_locbits, t->c_has_flag, dk, dl, n, dov);
+        hipLaunchKernelGGL(k_compact_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, d, t->cpayload, k,
+                           t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, dk, dl, dp, n, dov, dlist);
         unsigned long long ov = 0;
         HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         HIP_TRY(hipGetLastError());
-        (void)hipFree(dk);
-        (void)hipFree(dl);
         (void)hipFree(dov);
         t->c_overflow = ov;
         t->cbuckets = reinterpret_cast<uint4 *>(d);
-        if ((rc = dev_alloc(&t->d_complex_n, 1))) return rc;
+        n_generic = ov;
     }
+    int lg;
+    t->cap = pow2_cap(2 * n_generic, lg);
+    t->shift = 64 - lg;
+    if ((rc = dev_alloc(&t->slots, t->cap))) return rc;
+    hipLaunchKernelGGL(k_table_fill, dim3((unsigned)((t->cap + 255) / 256)), dim3(256), 0, t->stream, t->slots, t->cap);
+    if (n_generic) {
+        if (t->compact)
+            hipLaunchKernelGGL(k_table_insert_list, dim3((unsigned)((n_generic + 255) / 256)), dim3(256), 0, t->stream,
+                               t->slots, t->cap - 1, t->shift, dk, dl, dp, dlist, n_generic);
+        else
+            hipLaunchKernelGGL(k_table_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, t->slots,
+                               t->cap - 1, t->shift, dk, dl, dp, n);
+    }
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    HIP_TRY(hipGetLastError());
+    (void)hipFree(dk);
+    (void)hipFree(dl);
+    (void)hipFree(dp);
+    (void)hipFree(dlist);
     *out = t;
     return GS_OK;
 }
@@ -1479,7 +1528,7 @@ const char *gs_table_layout(const gs_table *t) {
     static thread_local char buf[160];
     if (!t) return "";
     if (t->compact)
-        snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x u32 (%d-bit remainder, %d-bit loc%s), %llu keys only in the generic 16 B table behind it",
+        snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x u32 (%d-bit remainder, %d-bit loc%s), %llu overflow keys in a generic 16 B-slot side table",
                  t->compact == 1 ? "compact-l2" : "compact-hbm", t->c_qb, t->c_rembits, t->c_locbits,
                  t->c_has_flag ? ", second-chance buckets" : "", (unsigned long long)t->c_overflow);
     else
@@ -1493,6 +1542,7 @@ void gs_table_destroy(gs_table *t) {
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)hipFree(t->slots);
     (void)hipFree(t->cbuckets);
+    (void)hipFree(t->cpayload);
     (void)hipFree(t->d_complex_n);
     (void)hipFree(t->d_cand_count);
     (void)hipFree(t->d_err_pos);
@@ -1505,7 +1555,7 @@ void gs_table_destroy(gs_table *t) {
 }
 
 uint64_t gs_table_bytes(const gs_table *t) {
-    return t ? t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)(16 * kNPart) << t->c_qb) : 0) : 0;
+    return t ? t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)(32 * kNPart) << t->c_qb) : 0) : 0;  // slots + payloads
 }
 
 int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off, const uint32_t *len,
