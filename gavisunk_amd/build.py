@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgavisunk.so")
-SOURCES = ["gs_device.hip", "gs_filter.hip", "gs_pair.hip", "gs_host.cpp"]
+SOURCES = ["gs_device.hip", "gs_filter.hip", "gs_pair.hip", "gs_sunkdef.hip", "gs_host.cpp"]
 
 
 def hipcc() -> str:

@@ -238,3 +238,23 @@ def diag_filter(sp: SunkPos, fai_contigs, device: int = 0):
     check(lib().gs_diag_filter(device, sp._h, in_fai.ctypes.data, bc.ctypes.data, bg.ctypes.data, bd.ctypes.data,
                                keep.ctypes.data))
     return bc[: sp.n_segs], bg[: sp.n_segs], bd[: sp.n_segs], keep[: sp.n_rows]
+
+
+def define_sunks(contigs, k: int, device: int = 0):
+    """GPU SUNK definition (gs_sunks_define).
+    contigs: [(name, ascii bytes)] of both haplotypes -> synth.SunkSet-like arrays in kmer.loc order."""
+    from .synth import SunkSet
+
+    off = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    if contigs:
+        off[1:] = np.cumsum([len(s) for _, s in contigs], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(s for _, s in contigs), dtype=np.uint8) if contigs else np.zeros(1, np.uint8)
+    h = C.c_void_p()
+    check(lib().gs_sunks_define(device, k, len(contigs), buf.ctypes.data, off.ctypes.data, C.byref(h)))
+    L = lib()
+    n = L.gs_sunkset_n(h)
+    out = SunkSet(k, [nm for nm, _ in contigs],
+                  _view(L.gs_sunkset_contig(h), n, np.uint32).copy(), _view(L.gs_sunkset_start(h), n, np.int64).copy(),
+                  _view(L.gs_sunkset_code(h), n, np.uint64).copy(), _view(L.gs_sunkset_group(h), n, np.int64).copy())
+    L.gs_sunkset_free(h)
+    return out

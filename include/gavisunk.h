@@ -231,6 +231,27 @@ int gs_pair_component(int device, uint32_t n_reads, const uint64_t *read_off, co
 int gs_key_histogram(int device, uint64_t n_rows, const uint32_t *row_key, uint32_t n_keys, const uint8_t *key_sel,
                      uint32_t *key_count, uint32_t *hist, uint32_t hist_len);
 
+
+/* ------------------------------------------------------------------------------------------
+ * SUNK definition on the GPU: the table's input straight from the
+ * assemblies, without the text round trip through jellyfish.db / kmer.loc.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Canonical k-mers that occur exactly once over all contigs (`jellyfish count -C -U 1`,
+ * workflow/rules/defineSUNKs.smk:39; windows containing a non-ACGT byte are not k-mers), their
+ * positions (`mrsfast -e 0`, :101) and groups = merged overlapping or book-ended [start, start+k)
+ * intervals, id = start of the merged interval (`bedtools merge`, :124-126).
+ *   seq/off : ASCII bases of all contigs (hap1 then hap2) back to back, off[n_contigs+1]
+ * Result rows are in `kmer.loc` order, (contig, start) ascending. */
+typedef struct gs_sunkset gs_sunkset;
+int gs_sunks_define(int device, int k, uint32_t n_contigs, const uint8_t *seq, const uint64_t *off, gs_sunkset **out);
+void gs_sunkset_free(gs_sunkset *s);
+uint64_t gs_sunkset_n(const gs_sunkset *s);
+const uint64_t *gs_sunkset_code(const gs_sunkset *s);
+const uint32_t *gs_sunkset_contig(const gs_sunkset *s);
+const int64_t *gs_sunkset_start(const gs_sunkset *s);
+const int64_t *gs_sunkset_group(const gs_sunkset *s);
+
 #ifdef __cplusplus
 }
 #endif
