@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <type_traits>
 #include <vector>
 
@@ -1447,6 +1448,7 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     }
     HIP_TRY(hipSetDevice(device));
     auto *t = new gs_table();
+    std::unique_ptr<gs_table, void (*)(gs_table *)> guard(t, gs_table_destroy);  // frees everything on an early return
     t->device = device;
     t->k = k;
     t->n = n;
@@ -1520,7 +1522,7 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     (void)hipFree(dl);
     (void)hipFree(dp);
     (void)hipFree(dlist);
-    *out = t;
+    *out = guard.release();
     return GS_OK;
 }
 
@@ -1571,6 +1573,7 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
     }
     HIP_TRY(hipSetDevice(device));
     auto *r = new gs_reads();
+    std::unique_ptr<gs_reads, void (*)(gs_reads *)> guard(r, gs_reads_destroy);
     r->device = device;
     r->k = k;
     r->n_reads = n_reads;
@@ -1586,7 +1589,6 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
         if (have < (uint64_t)(l + 31) / 32 + 1) {
             set_error("gs_reads_upload: read %u has %llu words for %u bases; need ceil(len/32)+1", i,
                       (unsigned long long)have, l);
-            delete r;
             return GS_E_ARG;
         }
         nwin[i] = l >= (uint32_t)k ? l - (uint32_t)k + 1 : 1u;  // Q6: a short read still yields one window
@@ -1595,7 +1597,6 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
         tiles += nt;
         if (tiles > 0x20000000ull) {
             set_error("gs_reads_upload: batch too large (%llu tiles); split it", (unsigned long long)tiles);
-            delete r;
             return GS_E_ARG;
         }
         tile_read.insert(tile_read.end(), nt, i);
@@ -1633,7 +1634,7 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
     if ((rc = dev_alloc(&r->block_agg, r->n_scan_blocks))) return rc;
     const uint64_t want = std::min<uint64_t>((kDirectCand + 2) * tiles + 65536, 0xFFFFFFFFull);
     if ((rc = ensure_out_buffers(r, (uint32_t)want))) return rc;
-    *out = r;
+    *out = guard.release();
     return GS_OK;
 }
 

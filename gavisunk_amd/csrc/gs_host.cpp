@@ -4,6 +4,7 @@
 // Native C++ because the reference's counterpart is native (Nim); no GPU involved here.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
@@ -211,6 +212,9 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
         std::unordered_map<std::pair<uint32_t, int64_t>, uint32_t, PairHash> locmap;
         uint64_t lineno = 0;
         std::string name;
+        bool have_last = false;
+        uint32_t last_cid = 0, last_lid = 0;
+        int64_t last_group = 0;
         while (r.next(line)) {
             lineno++;
             if (line.empty()) continue;
@@ -236,29 +240,43 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
                 delete d;
                 return GS_E_IO;
             }
-            name.assign(f[0], fe[0] - f[0]);
-            auto it = contig_id.find(name);
+            // consecutive rows nearly always share the contig and very often the group: skip the hash lookups then
             uint32_t cid;
-            if (it == contig_id.end()) {
-                cid = (uint32_t)d->contigs.size();
-                contig_id.emplace(name, cid);
-                d->contigs.push_back(name);
+            const size_t nlen = (size_t)(fe[0] - f[0]);
+            if (have_last && nlen == name.size() && !memcmp(name.data(), f[0], nlen)) {
+                cid = last_cid;
             } else {
-                cid = it->second;
+                name.assign(f[0], nlen);
+                auto it = contig_id.find(name);
+                if (it == contig_id.end()) {
+                    cid = (uint32_t)d->contigs.size();
+                    contig_id.emplace(name, cid);
+                    d->contigs.push_back(name);
+                } else {
+                    cid = it->second;
+                }
             }
             const uint32_t row = (uint32_t)d->row_contig.size();
             d->row_contig.push_back(cid);
             d->row_start.push_back(start);
             d->row_group.push_back(group);
-            auto key = std::make_pair(cid, group);
-            auto lt = locmap.find(key);
             uint32_t lid;
-            if (lt == locmap.end()) {
-                lid = (uint32_t)locmap.size();
-                locmap.emplace(key, lid);
+            if (have_last && cid == last_cid && group == last_group) {
+                lid = last_lid;
             } else {
-                lid = lt->second;
+                auto key = std::make_pair(cid, group);
+                auto lt = locmap.find(key);
+                if (lt == locmap.end()) {
+                    lid = (uint32_t)locmap.size();
+                    locmap.emplace(key, lid);
+                } else {
+                    lid = lt->second;
+                }
             }
+            have_last = true;
+            last_cid = cid;
+            last_group = group;
+            last_lid = lid;
             d->row_loc.push_back(lid);
             bool fresh;
             rowmap.at(encode_kmer(f[2], fe[2] - f[2]), fresh) = row;  // later row overwrites (:68)
