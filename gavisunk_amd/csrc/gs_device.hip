@@ -606,16 +606,23 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
         const uint64_t rr = (~revpairs(f)) >> (64 - 2 * k);  // reverse complement of the window itself
         return f < rr ? f : rr;
     };
-    auto match4 = [&](const uint4 &b, uint32_t want, uint32_t &l) -> uint32_t {  // branch-free bucket compare
+    // Branch-free bucket compare.  slot ^ (want << locbits) is zero in the tag field exactly for a match.  With the
+    // flag layout an empty slot (all ones) carries alt = 1, rem = all ones: it can only equal a second-chance tag
+    // whose remainder is all ones, so the explicit empty test is needed for second-chance lookups only.
+    const uint32_t fieldmask = tagmask << ct.locbits;
+    auto match4 = [&](const uint4 &b, uint32_t want, uint32_t &l, bool check_empty) -> uint32_t {
         const uint32_t sl[4] = {b.x, b.y, b.z, b.w};
-        uint32_t h = 0;
+        const uint32_t ws = want << ct.locbits;
+        bool h = false;
+        uint32_t pick = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t eq = (((sl[i] >> ct.locbits) & tagmask) == want) & (sl[i] != kEmptySlot);
-            h |= eq;
-            l = eq ? (sl[i] & locmask) : l;
+            const bool eq = (((sl[i] ^ ws) & fieldmask) == 0u) && (!check_empty || sl[i] != kEmptySlot);
+            h = h || eq;
+            pick = eq ? sl[i] : pick;
         }
-        return h;
+        l = h ? (pick & locmask) : l;
+        return h ? 1u : 0u;
     };
     auto finish_tile = [&](int q) {  // wave-uniform
         if (st.have) st.push(runs, lane);
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
                 uint32_t h = 0, l = 0;
                 if (on && (meta & 1024u)) {  // second-chance bucket
                     const uint4 b = part_buckets[alt_bucket(bkt, tg, ct.qb)];
-                    h = match4(b, tg | (1u << ct.rembits), l);
+                    h = match4(b, tg | (1u << ct.rembits), l, true);
                 }
                 if (on && !h && (meta & 2048u)) {  // rare: both buckets were full at build time
                     const uint64_t c = canon_of(sQ[wave][idx]);
@@ -716,7 +723,7 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
                 }
                 const uint32_t live = idx < nitems;
                 uint32_t l = 0;
-                const uint32_t h = match4(bk[u], tag[u], l) & live;
+                const uint32_t h = match4(bk[u], tag[u], l, !ct.has_flag) & live;
                 const uint32_t full = max(max(bk[u].x, bk[u].y), max(bk[u].z, bk[u].w)) != kEmptySlot;
                 const uint32_t miss_full = live & (h ^ 1u) & full;
                 const uint32_t again = ct.has_flag ? (miss_full & (bk[u].x >> 31)) : 0u;
