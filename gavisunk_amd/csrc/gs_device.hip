@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
     constexpr int QCAP = 640;  // queue window (items); more items are handled window by window
     constexpr int PCAP = 64;   // deferred (second-chance / generic) lookups per flush
     // queue entry: woff[0:11) | tile[11:13) | hit[13] | loc[14:32)
-    __shared__ uint64_t sA[4][NT][kTileWords + 2];
+    __shared__ uint32_t sA[4][NT][2 * (kTileWords + 2)];  // the tiles' 2-bit streams as 32-bit words in stream order
     __shared__ uint32_t sQ[4][QCAP];
     __shared__ uint32_t sP[4][PCAP][3];
     __shared__ uint32_t sRun[4][kMaxRuns][3];
@@ -551,8 +551,8 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
         uint32_t cnt[NT];
 #pragma unroll
         for (int q = 0; q < NT; q++) {
-            sA[wave][q][lane] = a[q];
-            if (lane == 63) sA[wave][q][64] = b2[q];
+            reinterpret_cast<uint2 *>(sA[wave][q])[lane] = make_uint2((uint32_t)(a[q] >> 32), (uint32_t)a[q]);
+            if (lane == 63) reinterpret_cast<uint2 *>(sA[wave][q])[64] = make_uint2((uint32_t)(b2[q] >> 32), (uint32_t)b2[q]);
             const uint32_t nvalid = td[q].nwin_left > wlane ? min(td[q].nwin_left - wlane, 32u) : 0u;
             const uint64_t w1 = a[q] ^ ((a[q] << s1) | (b2[q] >> (64 - s1)));
             const uint64_t w2h = a[q] ^ ((a[q] << s2) | (b2[q] >> (64 - s2)));
@@ -600,9 +600,12 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
 
     auto canon_of = [&](uint32_t entry) -> uint64_t {  // canonical code of the window a queue entry names
         const uint32_t q = (entry >> 11) & (uint32_t)(NT - 1), woff = entry & 2047u;
-        const int wl = woff >> 5, sh = 2 * (woff & 31u);
-        const uint64_t qa = sA[wave][q][wl], qb2 = sA[wave][q][wl + 1];
-        const uint64_t f = ((qa << sh) | ((qb2 >> 1) >> (63 - sh))) >> (64 - 2 * k);
+        // the window's 2k <= 64 bits start at bit `ob` (< 32) of three consecutive 32-bit words of the stream
+        const uint32_t i32 = woff >> 4, ob = 2u * (woff & 15u);
+        const uint32_t h0 = sA[wave][q][i32], h1 = sA[wave][q][i32 + 1], h2 = sA[wave][q][i32 + 2];
+        const uint32_t xhi = (uint32_t)(((((uint64_t)h0 << 32) | h1) << ob) >> 32);
+        const uint32_t xlo = (uint32_t)(((((uint64_t)h1 << 32) | h2) << ob) >> 32);
+        const uint64_t f = (((uint64_t)xhi << 32) | xlo) >> (64 - 2 * k);
         const uint64_t rr = (~revpairs(f)) >> (64 - 2 * k);  // reverse complement of the window itself
         return f < rr ? f : rr;
     };
