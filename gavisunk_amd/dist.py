@@ -43,15 +43,16 @@ def resolve_carry(summaries: Sequence[Tuple[int, int]], rank: int, carry0: int =
 
 
 def exchange_summaries(has_raw: int, last_loc: int, device=None) -> List[Tuple[int, int]]:
-    """all_gather of the per-shard phase-1 summary."""
+    """all_gather of the per-shard phase-1 summary (one collective, one device-to-host copy)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size()
     mine = torch.tensor([int(has_raw), int(last_loc)], dtype=torch.int64, device=device)
-    out = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(out, mine)
-    return [(int(t[0].item()), int(t[1].item())) for t in out]
+    out = torch.empty((world, 2), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine.reshape(1, 2))
+    rows = out.cpu().tolist()
+    return [(int(h), int(l)) for h, l in rows]
 
 
 def gather_hits(local_hits, read_offset: int, dst: int = 0):
@@ -59,21 +60,23 @@ def gather_hits(local_hits, read_offset: int, dst: int = 0):
 
     local_hits: int32/uint32-viewable torch tensor of shape [n, 3] (read, pos, payload) on the
     rank's device; read indices are local to the shard and are shifted by `read_offset`.
-    Returns the [N, 3] tensor on rank dst, None elsewhere."""
+    Returns the [N, 3] tensor on rank dst, None elsewhere.  Two collectives: the counts
+    (all_gather, 8 B per rank), then one gather padded to the largest count."""
     import torch
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = local_hits.device
-    n_local = torch.tensor([local_hits.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.empty_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local)
-    counts = [int(c.item()) for c in counts]
+    n = int(local_hits.shape[0])
+    n_local = torch.tensor([[n]], dtype=torch.int64, device=dev)
+    counts_t = torch.empty((world, 1), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts_t, n_local)
+    counts = [int(c[0]) for c in counts_t.cpu().tolist()]
     width = max(max(counts), 1)
     padded = torch.zeros((width, 3), dtype=torch.int32, device=dev)
-    if local_hits.shape[0]:
-        padded[: local_hits.shape[0]] = local_hits.to(torch.int32)
-        padded[: local_hits.shape[0], 0] += int(read_offset)
+    if n:
+        padded[:n] = local_hits.to(torch.int32)
+        padded[:n, 0] += int(read_offset)
     if rank == dst:
         bufs = [torch.empty_like(padded) for _ in range(world)]
         dist.gather(padded, bufs, dst=dst)
