@@ -13,9 +13,13 @@ CPU restatement of GAVISUNK's hot path, used only as the parity checker by tests
 Parity status
   tagger, rlen, diag filter, step 2: PINNED against outputs of the reference's own prebuilt
     binaries (tests/golden/, made by tests/golden/make_golden.py).
-  pair/component stage: PARITY UNPINNED -- the reference script needs graph_tool / seaborn /
-    pandas 1.3, none of which exist in the build image, and the reference ships no expected
-    output for it; the restatement follows the source text line by line (cited below).
+  pair/component stage: PROVISIONALLY PINNED -- the reference script needs graph_tool / seaborn /
+    pandas 1.3.4, none of which exist in the build image, and the reference ships no expected
+    output for it.  tests/golden/pair_* hold outputs of the reference's own script run here under
+    pandas 2.x with a documented graph_tool stand-in (tests/golden/make_golden_pair.py): everything up
+    to the graph calls is the reference's code executing for real; vertex order / largest-component
+    tie rules are the stand-in's.  Exact wherever no tie is involved, unpinned for ties.
+  bad-SUNK caller: PARITY UNPINNED (the script does not run under pandas 2.x); restated from the text.
 """
 from __future__ import annotations
 
