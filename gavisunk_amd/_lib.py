@@ -96,6 +96,7 @@ SIGNATURES = {
     "gs_diag_filter": (I, [I, P, P, P, P, P, P]),
     "gs_pair_component": (I, [I, U32, P, P, P, P, P, P]),
     "gs_key_histogram": (I, [I, U64, P, U32, P, P, P, U32]),
+    "gs_union_regions": (I, [I, U64, P, P, U32, P, P, P, P]),
     "gs_sunks_define": (I, [I, I, U32, P, P, C.POINTER(P)]),
     "gs_sunkset_free": (None, [P]),
     "gs_sunkset_n": (U64, [P]),

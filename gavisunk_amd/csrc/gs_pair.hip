@@ -305,3 +305,89 @@ extern "C" int gs_key_histogram(int device, uint64_t n_rows, const uint32_t *row
     HIP_TRY(hipMemcpy(hist, d_h, hist_len * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return GS_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Contig-wide union of the reads' validated ID sets (process-by-contig_lowmem_AR.py:219-260, SURVEY.md section 8f
+// row N3): connected components of "appears in the same read", components with more than two SUNKs become
+// [min ID, max ID] intervals.  Lock-free union-find (link the larger root under the smaller with atomicCAS),
+// then per-component size / min / max with atomics.
+// ------------------------------------------------------------------------------------------
+namespace {
+__device__ uint32_t uf_root(uint32_t *parent, uint32_t x) {
+    uint32_t p = parent[x];
+    while (p != x) {
+        const uint32_t gp = parent[p];
+        if (gp != p) atomicCAS(&parent[x], p, gp);  // path halving; a stale write only shortens a valid path
+        x = p;
+        p = parent[x];
+    }
+    return x;
+}
+__global__ void k_uf_init(uint32_t *parent, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) parent[i] = i;
+}
+// rows of one read are consecutive; an edge joins row i to row i+1 of the same read
+__global__ void k_uf_union(uint32_t *parent, const uint32_t *row_vertex, const uint32_t *row_read, uint64_t n_rows) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= n_rows || row_read[i] != row_read[i + 1]) return;
+    uint32_t a = uf_root(parent, row_vertex[i]), b = uf_root(parent, row_vertex[i + 1]);
+    while (a != b) {
+        if (a < b) {
+            const uint32_t t = a;
+            a = b;
+            b = t;
+        }
+        const uint32_t old = atomicCAS(&parent[a], a, b);  // hang the larger root under the smaller
+        if (old == a) break;
+        a = uf_root(parent, a);
+        b = uf_root(parent, b);
+    }
+}
+__global__ void k_uf_stats(uint32_t *parent, const long long *vertex_id, uint32_t n, uint32_t *csize, long long *cmin,
+                           long long *cmax) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = uf_root(parent, i);
+    atomicAdd(&csize[r], 1u);
+    atomicMin(&cmin[r], vertex_id[i]);
+    atomicMax(&cmax[r], vertex_id[i]);
+}
+}  // namespace
+
+extern "C" int gs_union_regions(int device, uint64_t n_rows, const uint32_t *row_read, const uint32_t *row_vertex,
+                                uint32_t n_vertices, const int64_t *vertex_id, uint32_t *comp_size, int64_t *comp_min,
+                                int64_t *comp_max) {
+    if ((n_rows && (!row_read || !row_vertex)) || (n_vertices && (!vertex_id || !comp_size || !comp_min || !comp_max))) {
+        set_error("gs_union_regions: null argument");
+        return GS_E_ARG;
+    }
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_union_regions: HIP device %d not available -- there is no CPU fallback", device);
+        return GS_E_NODEVICE;
+    }
+    if (!n_vertices) return GS_OK;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf db;
+    int rc;
+    uint32_t *d_rr, *d_rv, *d_parent, *d_size;
+    long long *d_vid, *d_min, *d_max;
+    if ((rc = db.put(&d_rr, row_read, n_rows)) || (rc = db.put(&d_rv, row_vertex, n_rows)) ||
+        (rc = db.put(&d_parent, (const uint32_t *)nullptr, n_vertices)) || (rc = db.put(&d_size, (const uint32_t *)nullptr, n_vertices)) ||
+        (rc = db.put(&d_vid, (const long long *)vertex_id, n_vertices)) || (rc = db.put(&d_min, (const long long *)nullptr, n_vertices)) ||
+        (rc = db.put(&d_max, (const long long *)nullptr, n_vertices)))
+        return rc;
+    HIP_TRY(hipMemset(d_size, 0, n_vertices * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(d_min, 0x7F, n_vertices * sizeof(long long)));  // 0x7F7F...: above every ID
+    HIP_TRY(hipMemset(d_max, 0x80, n_vertices * sizeof(long long)));  // 0x8080...: below every ID
+    hipLaunchKernelGGL(k_uf_init, dim3((n_vertices + 255) / 256), dim3(256), 0, 0, d_parent, n_vertices);
+    if (n_rows > 1)
+        hipLaunchKernelGGL(k_uf_union, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, 0, d_parent, d_rv, d_rr, n_rows);
+    hipLaunchKernelGGL(k_uf_stats, dim3((n_vertices + 255) / 256), dim3(256), 0, 0, d_parent, d_vid, n_vertices, d_size, d_min, d_max);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(comp_size, d_size, n_vertices * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(comp_min, d_min, n_vertices * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(comp_max, d_max, n_vertices * sizeof(long long), hipMemcpyDeviceToHost));
+    return GS_OK;
+}

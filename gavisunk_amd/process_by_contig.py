@@ -7,7 +7,7 @@
                  largest component                                         -> GPU, gs_pair_component
   lines 206-207  `ID \\t rname` TSV
   lines 219-260  contig-wide union of the reads' ID sets, components with > 2 SUNKs -> `contig start end` BED
-                 (host union-find for now)
+                                                        -> GPU, gs_union_regions
 
 `--minlen` and `--opt_filt` are accepted and ignored, as in the reference (minlen is overwritten with
 10000 at line 106, opt_filt is never read).
@@ -111,33 +111,25 @@ def pair_component(read_off, pos, start, ident, device: int = 0):
     return out_n[:n_reads], out_ids
 
 
-def contig_regions(per_read_ids):
-    """Lines 219-260: union of the reads' ID sets; components with more than two SUNKs -> (start, end)."""
-    vid, verts, parent = {}, [], []
-
-    def find(x):
-        while parent[x] != x:
-            parent[x] = parent[parent[x]]
-            x = parent[x]
-        return x
-
-    for ids in per_read_ids:
-        prev = None
-        for v in ids:
-            if v not in vid:
-                vid[v] = len(verts)
-                verts.append(v)
-                parent.append(len(parent))
-            if prev is not None:
-                a, b = find(vid[prev]), find(vid[v])
-                if a != b:
-                    parent[max(a, b)] = min(a, b)
-            prev = v
-    comps = {}
-    for i, v in enumerate(verts):
-        comps.setdefault(find(i), []).append(v)
-    regs = [(min(c), max(c)) for c in comps.values() if len(c) > 2]
-    return sorted(regs)
+def contig_regions(per_read_ids, device: int = 0):
+    """Lines 219-260: union of the reads' ID sets (GPU union-find, gs_union_regions); components with more than
+    two SUNKs -> (start, end), sorted by start."""
+    ids = np.array([v for r in per_read_ids for v in r], dtype=np.int64)
+    if not len(ids):
+        return []
+    row_read = np.repeat(np.arange(len(per_read_ids), dtype=np.uint32), [len(r) for r in per_read_ids])
+    vertex_id, row_vertex = np.unique(ids, return_inverse=True)
+    row_vertex = np.ascontiguousarray(row_vertex.reshape(-1), np.uint32)
+    row_read = np.ascontiguousarray(row_read, np.uint32)
+    vertex_id = np.ascontiguousarray(vertex_id, np.int64)
+    nv = len(vertex_id)
+    size = np.zeros(nv, np.uint32)
+    cmin = np.zeros(nv, np.int64)
+    cmax = np.zeros(nv, np.int64)
+    _lib.check(_lib.lib().gs_union_regions(device, len(ids), row_read.ctypes.data, row_vertex.ctypes.data, nv,
+                                           vertex_id.ctypes.data, size.ctypes.data, cmin.ctypes.data, cmax.ctypes.data))
+    keep = np.nonzero(size > 2)[0]
+    return sorted((int(cmin[i]), int(cmax[i])) for i in keep)
 
 
 def run(loc, sunkpos, rlen, bad, out_tsv, out_bed, device: int = 0) -> int:
@@ -159,7 +151,7 @@ def run(loc, sunkpos, rlen, bad, out_tsv, out_bed, device: int = 0) -> int:
         for nm, ids in per_read:
             fh.write("".join(f"{i}\t{nm}\n" for i in ids))
     with open(out_bed, "w") as fh:
-        for s, e in contig_regions([ids for _, ids in per_read]):
+        for s, e in contig_regions([ids for _, ids in per_read], device):
             fh.write(f"{contig}\t{s}\t{e}\n")
     return 0
 

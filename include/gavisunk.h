@@ -252,6 +252,17 @@ const uint32_t *gs_sunkset_contig(const gs_sunkset *s);
 const int64_t *gs_sunkset_start(const gs_sunkset *s);
 const int64_t *gs_sunkset_group(const gs_sunkset *s);
 
+
+/* Contig-wide union of the reads' validated SUNK sets (process-by-contig_lowmem_AR.py:219-260; SURVEY.md
+ * section 8f row N3).  Rows = the `ID \t rname` output rows; row_read numbers the reads (rows of a read are
+ * consecutive), row_vertex is the dense index of the row's ID, vertex_id the ID value of each vertex.
+ * Per vertex v that is the root of a component: comp_size[v] = SUNKs in it (0 for non-roots),
+ * comp_min / comp_max = its smallest / largest ID.  Components with comp_size > 2 are the validated
+ * intervals of the BED (:247-251). */
+int gs_union_regions(int device, uint64_t n_rows, const uint32_t *row_read, const uint32_t *row_vertex,
+                     uint32_t n_vertices, const int64_t *vertex_id, uint32_t *comp_size, int64_t *comp_min,
+                     int64_t *comp_max);
+
 #ifdef __cplusplus
 }
 #endif
