@@ -69,6 +69,7 @@ SIGNATURES = {
     "gs_table_bytes": (U64, [P]),
     "gs_table_layout": (C.c_char_p, [P]),
     "gs_reads_upload": (I, [I, P, U64, P, P, U32, I, C.POINTER(P)]),
+    "gs_reads_upload_ascii": (I, [I, P, P, U32, I, C.POINTER(P)]),
     "gs_reads_destroy": (None, [P]),
     "gs_reads_n_bases": (U64, [P]),
     "gs_reads_n_windows": (U64, [P]),

@@ -1570,9 +1570,10 @@ uint64_t gs_table_bytes(const gs_table *t) {
     return t ? t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)(32 * kNPart) << t->c_qb) : 0) : 0;  // slots + payloads
 }
 
-int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off, const uint32_t *len,
-                    uint32_t n_reads, int k, gs_reads **out) {
-    if (!out || k < 1 || k > 32 || (n_reads && (!words || !word_off || !len))) {
+// index building + allocations shared by the two upload entry points; the packed words are zeroed, not filled
+static int reads_setup(int device, uint64_t n_words, const uint64_t *word_off, const uint32_t *len, uint32_t n_reads, int k,
+                       gs_reads **out) {
+    if (!out || k < 1 || k > 32 || (n_reads && (!word_off || !len))) {
         set_error("gs_reads_upload: bad argument");
         return GS_E_ARG;
     }
@@ -1625,7 +1626,6 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
     if ((rc = dev_alloc(&r->read_nwin, n_reads)) || (rc = dev_alloc(&r->read_tile0, n_reads)) ||
         (rc = dev_alloc(&r->tile_read, tiles)))
         return rc;
-    if (n_words) HIP_TRY(hipMemcpy(r->words, words, n_words * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (n_reads) {
         HIP_TRY(hipMemcpy(r->read_word_off, word_off, ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(r->read_nwin, nwin.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1644,6 +1644,97 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
     if ((rc = dev_alloc(&r->block_agg, r->n_scan_blocks))) return rc;
     const uint64_t want = std::min<uint64_t>((kDirectCand + 2) * tiles + 65536, 0xFFFFFFFFull);
     if ((rc = ensure_out_buffers(r, (uint32_t)want))) return rc;
+    *out = guard.release();
+    return GS_OK;
+}
+
+int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off, const uint32_t *len,
+                    uint32_t n_reads, int k, gs_reads **out) {
+    if (n_reads && !words) {
+        set_error("gs_reads_upload: bad argument");
+        return GS_E_ARG;
+    }
+    int rc = reads_setup(device, n_words, word_off, len, n_reads, k, out);
+    if (rc) return rc;
+    if (n_words) {
+        hipError_t e = hipMemcpy((*out)->words, words, n_words * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("hipMemcpy of the packed reads failed: %s", hipGetErrorString(e));
+            gs_reads_destroy(*out);
+            *out = nullptr;
+            return GS_E_NODEVICE;
+        }
+    }
+    return GS_OK;
+}
+
+// 2-bit packing on the device: one thread per output word, 32 source bytes each,
+// nim-kmer's `encode` table (A/a 0, C/c 1, G/g 2, T/t/U/u 3, everything else 0)
+__global__ void k_pack_reads(const uint8_t *seq, const uint64_t *byte_off, const uint64_t *word_off, uint32_t n_reads,
+                             uint64_t n_words, uint64_t *words) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t lo = 0, hi = n_reads;  // read of this word: last r with word_off[r] <= w
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (word_off[mid] <= w) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t len = byte_off[lo + 1] - byte_off[lo];
+    const uint64_t b0 = (w - word_off[lo]) * 32;
+    uint64_t v = 0;
+    if (b0 < len) {
+        const uint8_t *s = seq + byte_off[lo] + b0;
+        const int n = (int)min((uint64_t)32, len - b0);
+        for (int i = 0; i < n; i++) {
+            const uint32_t c = s[i] & 0xDFu;  // upper case
+            const uint64_t code = c == 'C' ? 1u : c == 'G' ? 2u : (c == 'T' || c == 'U') ? 3u : 0u;
+            v |= code << (62 - 2 * i);
+        }
+    }
+    words[w] = v;
+}
+
+int gs_reads_upload_ascii(int device, const uint8_t *seq, const uint64_t *off, uint32_t n_reads, int k, gs_reads **out) {
+    if (!out || (n_reads && (!off || (off[n_reads] && !seq)))) {
+        set_error("gs_reads_upload_ascii: bad argument");
+        return GS_E_ARG;
+    }
+    std::vector<uint64_t> word_off((size_t)n_reads + 1, 0);
+    std::vector<uint32_t> len(n_reads);
+    for (uint32_t i = 0; i < n_reads; i++) {
+        const uint64_t l = off[i + 1] - off[i];
+        if (l > 0xFFFFFFFFull) {
+            set_error("gs_reads_upload_ascii: read %u is longer than 2^32 bases", i);
+            return GS_E_ARG;
+        }
+        len[i] = (uint32_t)l;
+        word_off[i + 1] = word_off[i] + (l + 31) / 32 + 1;
+    }
+    const uint64_t n_words = word_off[n_reads];
+    int rc = reads_setup(device, n_words, word_off.data(), len.data(), n_reads, k, out);
+    if (rc) return rc;
+    if (!n_reads) return GS_OK;
+    std::unique_ptr<gs_reads, void (*)(gs_reads *)> guard(*out, gs_reads_destroy);
+    *out = nullptr;
+    uint8_t *d_seq = nullptr;
+    uint64_t *d_boff = nullptr;
+    const uint64_t nbytes = off[n_reads];
+    if ((rc = dev_alloc(&d_seq, nbytes)) || (rc = dev_alloc(&d_boff, (uint64_t)n_reads + 1))) return rc;
+    hipError_t e = hipSuccess;
+    if (nbytes) e = hipMemcpy(d_seq, seq, nbytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_boff, off, ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, 0, d_seq, d_boff,
+                           guard->read_word_off, n_reads, n_words, guard->words);
+        e = hipDeviceSynchronize();
+    }
+    (void)hipFree(d_seq);
+    (void)hipFree(d_boff);
+    if (e != hipSuccess) {
+        set_error("gs_reads_upload_ascii: %s", hipGetErrorString(e));
+        return GS_E_NODEVICE;
+    }
     *out = guard.release();
     return GS_OK;
 }

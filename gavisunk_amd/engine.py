@@ -156,6 +156,21 @@ class DeviceReads:
         self.n_reads, self.n_bases = batch.n_reads, batch.n_bases
         self.n_windows = lib().gs_reads_n_windows(h)
 
+    @classmethod
+    def from_ascii(cls, seqs: Sequence[bytes], k: int, device: int = 0) -> "DeviceReads":
+        """Upload unpacked reads and pack them on the GPU (gs_reads_upload_ascii)."""
+        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        if len(seqs):
+            off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+        buf = np.frombuffer(b"".join(seqs), dtype=np.uint8) if len(seqs) and off[-1] else np.zeros(1, np.uint8)
+        h = C.c_void_p()
+        check(lib().gs_reads_upload_ascii(device, buf.ctypes.data, off.ctypes.data, len(seqs), k, C.byref(h)))
+        self = cls.__new__(cls)
+        self._h, self.k, self.device = h, k, device
+        self.n_reads, self.n_bases = len(seqs), int(off[-1])
+        self.n_windows = lib().gs_reads_n_windows(h)
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             lib().gs_reads_destroy(self._h)

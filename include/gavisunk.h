@@ -121,6 +121,9 @@ const char *gs_table_layout(const gs_table *t);
 typedef struct gs_reads gs_reads;
 int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off,
                     const uint32_t *len, uint32_t n_reads, int k, gs_reads **out);
+/* The same from unpacked reads: ASCII bases back to back, off[n_reads+1] in bytes; the 2-bit packing (with the
+ * `encode` table above) runs on the GPU. */
+int gs_reads_upload_ascii(int device, const uint8_t *seq, const uint64_t *off, uint32_t n_reads, int k, gs_reads **out);
 void gs_reads_destroy(gs_reads *r);
 uint64_t gs_reads_n_bases(const gs_reads *r);
 uint64_t gs_reads_n_windows(const gs_reads *r);

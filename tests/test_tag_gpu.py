@@ -184,6 +184,48 @@ def test_spurious_hit_inside_a_run_takes_the_exact_fallback():
     assert np.array_equal(gh["payload"], oh["row"])
 
 
+def test_low_complexity_reads_overflow_one_partition():
+    """Homopolymer and short-period repeats put thousands of windows of a tile into ONE key-space partition:
+    the partitioned kernel's queue windows, deferred-lookup list and run summaries all overflow their usual sizes."""
+    k = 20
+    rng = np.random.default_rng(8)
+    g = rng.integers(0, 4, 20_000, dtype=np.uint8)
+    codes = np.unique(synth.canonical_codes(g, k))
+    rep = [b"A" * 9000, b"AC" * 6000, b"ACG" * 3000, b"T" * 5000 + synth.codes_to_ascii(g[:3000]) + b"A" * 4000,
+           b"ACGT" * 2500, synth.codes_to_ascii(g), b"GA" * 2048 + b"A" * 64 + b"GA" * 1000]
+    extra = np.unique(np.concatenate([synth.canonical_codes(synth.ascii_to_codes(r), k) for r in rep[:5] + rep[6:]]))
+    keys = np.unique(np.concatenate([codes, extra]))
+    loc = (np.arange(len(keys)) % 3).astype(np.uint32)  # neighbouring windows keep changing location
+    rc, oh, _, octr = _oracle_hits(k, keys, loc, rep)
+    st, gh, _, ctr = _engine_hits(k, keys, loc, rep)
+    assert st == 0 and rc == 0 and ctr["raw_hits"] == octr["raw_hits"] == ctr["windows"]
+    assert len(gh) == len(oh) > 1000
+    assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"])
+    assert np.array_equal(loc[gh["payload"]], loc[oh["row"]])
+    # and with a single location: nearly everything is suppressed, positions deflate by thousands
+    loc1 = np.zeros(len(keys), dtype=np.uint32)
+    rc, oh, _, _ = _oracle_hits(k, keys, loc1, rep)
+    st, gh, _, _ = _engine_hits(k, keys, loc1, rep)
+    assert len(gh) == len(oh) == 1 and gh["pos"][0] == oh["pos"][0]
+
+
+def test_table_without_keys():
+    st, h, carry, ctr = _engine_hits(20, np.zeros(0, np.uint64), np.zeros(0, np.uint32), [b"ACGT" * 100, b""])
+    assert st == 0 and len(h) == 0 and carry == _lib.GS_NONE and ctr["raw_hits"] == 0
+
+
+def test_device_packing_equals_host_packing():
+    k = 20
+    keys, loc, seqs = _random_case(31, k, n_reads=50)
+    seqs = seqs + [b"", b"acgtn" * 9, b"N" * 70, b"ACGU" * 40]
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    a = engine.tag(tab, engine.DeviceReads(engine.ReadBatch.from_ascii(seqs), k))
+    b = engine.tag(tab, engine.DeviceReads.from_ascii(seqs, k))
+    assert a[0] == b[0] == 0 and a[1].tobytes() == b[1].tobytes() and a[2] == b[2]
+    assert a[3]["windows"] == b[3]["windows"] and a[3]["raw_hits"] == b[3]["raw_hits"]
+    tab.close()
+
+
 def test_deterministic_across_runs():
     k = 20
     keys, loc, seqs = _random_case(21, k, n_reads=50)
