@@ -1,27 +1,31 @@
 // Device half of libgavisunk.so: the SUNK tagger of GAVISUNK (workflow/src/kmerpos_annot3.nim)
-// as hand-written HIP for gfx950 (MI355X, wave64).  Pure integer / indexing work, HBM-bound.
+// as hand-written HIP for gfx950 (MI355X, wave64).  Pure integer / indexing work; see DESIGN.md section 4.
 //
 // Data layout in HBM
 //   reads   2 bits/base, 32 bases per uint64 (first base most significant); every read starts
 //           on a word boundary and is followed by >= 1 zero word.
-//   tiles   a read is cut into tiles of 2048 windows = 64 words; one wavefront owns one tile,
-//           lane l owns word l = windows [32 l, 32 l + 32) of the tile and rolls one canonical
-//           k-mer code across them.
-//   table   open-addressed, linear probing, 16-byte slots {key u64, loc u32, payload u32},
-//           load <= 0.5; hash = (key * golden) >> shift.
+//   tiles   a read is cut into tiles of 2048 windows = 64 words; a wavefront lane owns one word
+//           = windows [32 l, 32 l + 32) of a tile.
+//   tables  (1) compact: exact, 16 partitions x 2^qb buckets x 4 x 32-bit slots [flags|alt|remainder|loc],
+//               built on the GPU, + one payload word per slot;
+//           (2) generic: open-addressed, linear probing, 16-byte slots {key u64, loc u32, payload u32},
+//               load <= 0.5 -- everything when (1) does not apply, else only the keys (1) could not take.
 //
-// The pass (one `gs_tag`):
-//   k_probe    every window -> canonical code -> table probe.  Per lane a 32-bit raw-hit mask and
-//              a 32-bit "location changed" mask; per tile {n_raw, first loc, last loc} and the
-//              ordered list of candidates (hits whose loc differs from the previous raw hit of
-//              the tile; the tile's first raw hit is always a candidate).
-//   scan A     over tiles: raw-hit prefix and the loc carried into each tile
-//              (`prevLoc` of kmerpos_annot3.nim:82-84 crosses reads, so the scan is global).
-//   k_resolve  drops a tile's first candidate when it equals the carried loc.
-//   scan B     emitted-hit prefix.
-//   k_emit     pos = window - (raw hits before it in the read - emitted hits before it in the
-//              read)  [`continue` at kmerpos_annot3.nim:92 skips `inc i` at :96], payload by
-//              re-probing the (rare) emitted windows; writes gs_hit in stream order.
+// One `gs_tag` pass:
+//   phase 1, one of
+//     k_probe<false>   generic table, one wave per tile, 8 probes in flight per lane
+//     k_probe<true>    compact table out in HBM: one 16-byte bucket load (one 64-byte line) per window
+//     k_probe_part + k_merge_part (+ k_probe<true> on the few tiles that cannot be merged)
+//                      compact table resident in the XCD-partitioned L2s
+//   -> per tile {n_raw, first loc, last loc} and the ordered candidates (hits whose loc differs from the
+//      previous raw hit of the tile; the tile's first raw hit is always a candidate)
+//   scan A     over tiles: raw-hit prefix and the loc carried into each tile (`prevLoc` of
+//              kmerpos_annot3.nim:82-84 crosses reads, so the scan is global); drops a tile's first
+//              candidate when it equals the carried loc
+//   scan B     emitted-hit prefix
+//   k_emit     pos = window - (raw hits before it in the read - emitted hits before it in the read)
+//              [`continue` at kmerpos_annot3.nim:92 skips `inc i` at :96], payload by re-probing the
+//              (rare) emitted windows; writes gs_hit in stream order
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
