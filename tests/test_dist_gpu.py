@@ -1,0 +1,80 @@
+"""The read-sharded protocol with the REAL kernels: 2 and 3 processes share the one GPU of the test box (collectives
+over gloo, since RCCL refuses two ranks on one device), each tags its shard with gs_tag_phase1 / phase2, and rank 0's
+gathered hit list must equal a single-process pass over the whole input."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _case():
+    from gavisunk_amd import synth
+
+    k = 20
+    rng = np.random.default_rng(77)
+    g = rng.integers(0, 4, 60_000, dtype=np.uint8)
+    sunks = synth.define_sunks([("c", synth.codes_to_ascii(g))], k)
+    loc = (sunks.start // 900).astype(np.uint32)
+    lens = synth.lognormal_lengths(rng, 53, median=2500, sigma=0.8, lo=1, hi=30000)
+    reads = [synth.codes_to_ascii(r) for r in synth.simulate_reads(rng, [g], lens, sub=0.005, dele=0.005, ins=0.005)]
+    reads[20] = b""  # shards that start or end on reads without raw hits
+    reads[21] = b"ACGT" * 3
+    return k, sunks.code, loc, reads
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gavisunk_amd import _lib, engine
+        from gavisunk_amd import dist as gdist
+
+        L = _lib.lib()
+        k, keys, loc, reads = _case()
+        tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+        lo, hi = gdist.shard_bounds(len(reads), world, rank)
+        dev = engine.DeviceReads(engine.ReadBatch.from_ascii(reads[lo:hi]), k)
+        has, last = C.c_uint32(0), C.c_uint32(0)
+        _lib.check(L.gs_tag_phase1(tab._h, dev._h, C.byref(has), C.byref(last)))
+        summ = gdist.exchange_summaries(has.value, last.value)
+        _lib.check(L.gs_tag_phase2(tab._h, dev._h, gdist.resolve_carry(summ, rank)))
+        n = C.c_uint64(0)
+        _lib.check(L.gs_tag_finish(tab._h, dev._h, None, 0, C.byref(n), None, None))
+        hits = np.zeros(max(n.value, 1), dtype=engine.HIT_DTYPE)
+        _lib.check(L.gs_tag_hits_to_host(tab._h, dev._h, hits.ctypes.data, len(hits), None))
+        hits = hits[: n.value]
+        local = torch.from_numpy(np.stack([hits["read"], hits["pos"], hits["payload"]], axis=1).astype(np.int64).astype(np.int32)).reshape(-1, 3)
+        allhits = gdist.gather_hits(local, lo)
+        if rank == 0:
+            np.save(out_path, allhits.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gpu_run_equals_single_pass(world, tmp_path):
+    from gavisunk_amd import engine
+
+    out = str(tmp_path / "hits.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    k, keys, loc, reads = _case()
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    st, whole, _, _ = engine.tag(tab, engine.DeviceReads(engine.ReadBatch.from_ascii(reads), k))
+    assert st == 0 and len(whole) > 50
+    assert np.array_equal(got[:, 0], whole["read"].astype(np.int32))
+    assert np.array_equal(got[:, 1], whole["pos"].astype(np.int32))
+    assert np.array_equal(got[:, 2], whole["payload"].astype(np.int32))
