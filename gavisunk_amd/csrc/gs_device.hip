@@ -1429,6 +1429,10 @@ int choose_compact(int k, uint64_t n, uint64_t generic_bytes, const uint32_t *lo
     qb = 8;
     while (((uint64_t)(4 * kNPart) << qb) < (uint64_t)(2.2 * (double)n)) qb++;
     while (kbits - qb + locbits > 32) qb++;
+    if (const char *fq = getenv("GAVISUNK_COMPACT_QB")) {  // test knob: an undersized table makes every overflow path busy
+        const int v = atoi(fq);
+        if (v >= 4 && v <= 28 && kbits - v + locbits <= 32) qb = v;
+    }
     if (kbits - qb < 1 || qb > 28 || qb >= (kbits < 32 ? kbits : 32)) return 0;
     // forcing the remainder into 32 bits can blow a small table up: never larger than the generic one (or 32 MiB)
     if (((uint64_t)(16 * kNPart) << qb) > std::max<uint64_t>(generic_bytes, 32ull << 20)) return 0;

@@ -209,6 +209,27 @@ def test_low_complexity_reads_overflow_one_partition():
     assert len(gh) == len(oh) == 1 and gh["pos"][0] == oh["pos"][0]
 
 
+@pytest.mark.parametrize("qb", ["9", "11"])
+def test_undersized_compact_table_uses_every_overflow_path(qb, monkeypatch, table_layout):
+    """With far too few buckets most keys live in their second-chance bucket or only in the generic side table:
+    deferred lookups, their flushes and the generic fallback carry the load, and the answer must not change."""
+    if table_layout == "generic":
+        pytest.skip("needs a compact layout")
+    monkeypatch.setenv("GAVISUNK_COMPACT_QB", qb)
+    k = 20
+    keys, loc, seqs = _random_case(55, k, n_reads=60, glen=60000, median=4000)
+    loc = (loc % 5).astype(np.uint32)
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    assert f"2^{qb} buckets" in tab.layout and "overflow keys" in tab.layout
+    assert int(tab.layout.split("), ")[1].split(" overflow")[0]) > (2000 if qb == "9" else 0)
+    tab.close()
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] and len(gh) == len(oh) > 100
+    assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"])
+    assert np.array_equal(gh["payload"], oh["row"])
+
+
 def test_table_without_keys():
     st, h, carry, ctr = _engine_hits(20, np.zeros(0, np.uint64), np.zeros(0, np.uint32), [b"ACGT" * 100, b""])
     assert st == 0 and len(h) == 0 and carry == _lib.GS_NONE and ctr["raw_hits"] == 0
