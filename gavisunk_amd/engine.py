@@ -9,12 +9,12 @@ All compute happens in libgavisunk.so's HIP kernels; nothing here falls back to 
 from __future__ import annotations
 
 import ctypes as C
-from typing import Iterator, List, Optional, Sequence, Tuple
+from typing import Iterator, List, Sequence
 
 import numpy as np
 
 from . import _lib
-from ._lib import GS_MISSING, GS_NONE, GsCounters, GsError, GsHit, check, lib
+from ._lib import GS_NONE, GsCounters, GsHit, check, lib
 
 HIT_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u4"), ("payload", "<u4")])
 assert HIT_DTYPE.itemsize == C.sizeof(GsHit)

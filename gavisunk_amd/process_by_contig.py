@@ -15,7 +15,6 @@
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import os
 import sys
 

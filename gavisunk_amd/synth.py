@@ -15,7 +15,6 @@ benchmark configurations of BASELINE.json are defined on synthetic surrogates
 from __future__ import annotations
 
 import gzip
-import io
 from dataclasses import dataclass
 from typing import Iterable, List, Sequence, Tuple
 

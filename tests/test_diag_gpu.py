@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import DIAG_CASES
-from gavisunk_amd import _lib, diag_filter_step2, diag_filter_v3, engine
+from gavisunk_amd import diag_filter_step2, diag_filter_v3, engine
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
