@@ -119,10 +119,8 @@ def define_sunks(contigs: Sequence[Tuple[str, bytes]], k: int) -> SunkSet:
     if len(pos):
         new = np.ones(len(pos), dtype=bool)
         new[1:] = (cid[1:] != cid[:-1]) | ((pos[1:] - pos[:-1]) > k)
-        gstart = np.where(new, pos, 0)
-        group = np.maximum.accumulate(np.where(new, np.arange(len(pos)), 0))
-        group = pos[group]
-        del gstart
+        head = np.maximum.accumulate(np.where(new, np.arange(len(pos)), 0))  # index of each run's first SUNK
+        group = pos[head]
     return SunkSet(k, [n for n, _ in contigs], cid, pos, codes, group.astype(np.int64))
 
 
