@@ -380,6 +380,8 @@ def digest(root):
             if f.endswith((".py", ".pyc")) or f == "MD5SUMS":
                 continue
             p = os.path.join(d, f)
+            if os.path.relpath(p, root).startswith(("pair_", "_shim")):  # made by make_golden_pair.py
+                continue
             out[os.path.relpath(p, root)] = hashlib.md5(open(p, "rb").read()).hexdigest()
     return out
 

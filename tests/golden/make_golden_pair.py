@@ -85,6 +85,27 @@ def synth_case(out_name, seed, n_reads):
 if __name__ == "__main__":
     if not os.path.exists(REF_SCRIPT):
         sys.exit("reference tree not present")
+    if "--check" in sys.argv:  # regenerate into a temp dir and compare with the committed files
+        import filecmp
+        import shutil
+        import tempfile
+
+        keep = HERE
+        with tempfile.TemporaryDirectory() as t:
+            for d in ("amy", "multi_k20", "multi_k25"):
+                shutil.copytree(os.path.join(keep, d), os.path.join(t, d))
+            shutil.copytree(os.path.join(keep, "_shim"), os.path.join(t, "_shim"))
+            HERE = t
+            synth_case("pair_synth_src", 9, 150)
+            bad = []
+            for args in (("amy", "pair_amy", False, 7), ("multi_k20", "pair_multi_k20", True, 0),
+                         ("multi_k25", "pair_multi_k25", True, 5), ("pair_synth_src", "pair_synth", False, 11)):
+                run_case(*args)
+                for f in os.listdir(os.path.join(t, args[1])):
+                    if f != "case.json" and not filecmp.cmp(os.path.join(t, args[1], f), os.path.join(keep, args[1], f), shallow=False):
+                        bad.append(f"{args[1]}/{f}")
+        print("pair goldens reproduce" if not bad else f"MISMATCH: {bad}")
+        sys.exit(1 if bad else 0)
     synth_case("pair_synth_src", 9, 150)
     for args in (("amy", "pair_amy", False, 7), ("multi_k20", "pair_multi_k20", True, 0), ("multi_k25", "pair_multi_k25", True, 5),
                  ("pair_synth_src", "pair_synth", False, 11)):
