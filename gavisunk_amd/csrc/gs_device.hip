@@ -126,7 +126,7 @@ constexpr uint32_t kEmptySlot32 = 0xFFFFFFFFu;
 // with bucket in [0, 2^qb) taken from the best-mixed bits.  kbits = 2k - 4 in [28, 60], qb <= 20.
 struct BucketRem {
     uint32_t bucket;
-    uint32_t rem;  // kbits - qb bits
+    uint64_t rem;  // kbits - qb bits (fits 32 bits whenever the 32-bit slot format is in use)
 };
 __host__ __device__ __forceinline__ BucketRem hmix2(uint64_t key, int kbits, int qb) {
     const int lbits = kbits < 32 ? kbits : 32;  // low part that gets mixed
@@ -140,12 +140,13 @@ __host__ __device__ __forceinline__ BucketRem hmix2(uint64_t key, int kbits, int
     l = (l ^ (hi * 0xC2B2AE35u)) & lmask;
     BucketRem o;
     o.bucket = l >> (lbits - qb);
-    o.rem = ((l & ((1u << (lbits - qb)) - 1u)) << (kbits - lbits)) | hi;
+    o.rem = ((uint64_t)(l & ((1u << (lbits - qb)) - 1u)) << (kbits - lbits)) | hi;
     return o;
 }
 // second-chance bucket of a key (same partition): bucket ^ (odd, non-zero function of the remainder)
-__host__ __device__ __forceinline__ uint32_t alt_bucket(uint32_t bucket, uint32_t rem, int qb) {
-    return bucket ^ ((((rem + 1u) * 0x9E3779B1u) >> (32 - qb)) | 1u);
+__host__ __device__ __forceinline__ uint32_t alt_bucket(uint32_t bucket, uint64_t rem, int qb) {
+    const uint32_t r = (uint32_t)rem ^ (uint32_t)(rem >> 32);
+    return bucket ^ ((((r + 1u) * 0x9E3779B1u) >> (32 - qb)) | 1u);
 }
 
 // partition of a canonical (or not: it is strand-symmetric) 2k-bit code
@@ -158,9 +159,9 @@ __host__ __device__ __forceinline__ uint32_t part_of(uint64_t c, int k) {
 // slot = [ flags(2, slot 0 only) | alt(1) | rem | loc ];  flags: bit 31 = a key of this bucket lives in its
 // second-chance bucket, bit 30 = a key of this bucket lives in the generic table only
 struct CompactView {
-    const uint4 *buckets;     // [kNPart << qb]
+    const uint4 *buckets;     // [kNPart << qb] buckets of 4 slots: one uint4 each (32-bit slots) or two (64-bit slots)
     const uint32_t *payload;  // one per slot (what a hit on that slot reports)
-    int qb, rembits, locbits, has_flag;
+    int qb, rembits, locbits, has_flag, w64;
 };
 
 
@@ -170,8 +171,50 @@ __device__ __forceinline__ bool compact_lookup(const CompactView &ct, const Tabl
                                                uint32_t &loc, uint32_t *payload = nullptr) {
     const int kbits = 2 * k - 4;
     const uint64_t keymask = (1ULL << kbits) - 1ULL;
-    const uint32_t locmask = (1u << ct.locbits) - 1u, tagmask = (1u << (ct.rembits + 1)) - 1u;
     const BucketRem br = hmix2((c >> 4) & keymask, kbits, ct.qb);
+    if (ct.w64) {  // 64-bit slots [flags(2) | alt | rem | loc]; always with flags
+        const uint64_t locmask = (1ULL << ct.locbits) - 1ULL, tagmask = (1ULL << (ct.rembits + 1)) - 1ULL;
+        const uint64_t pbase = (uint64_t)part_of(c, k) << ct.qb;
+        const ulonglong2 *b64 = reinterpret_cast<const ulonglong2 *>(ct.buckets);
+        bool full_out = false;
+        auto scan = [&](uint64_t bucket, uint64_t want, uint64_t &s0) -> bool {
+            const ulonglong2 lo = b64[(pbase + bucket) * 2], hi2 = b64[(pbase + bucket) * 2 + 1];
+            const uint64_t sl[4] = {lo.x, lo.y, hi2.x, hi2.y};
+            s0 = sl[0];
+            bool h = false;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (sl[i] != ~0ULL && ((sl[i] >> ct.locbits) & tagmask) == want) {
+                    h = true;
+                    loc = (uint32_t)(sl[i] & locmask);
+                    if (payload) *payload = ct.payload[(pbase + bucket) * 4 + i];
+                }
+            full_out = sl[0] != ~0ULL && sl[1] != ~0ULL && sl[2] != ~0ULL && sl[3] != ~0ULL;
+            return h;
+        };
+        uint64_t s0 = 0;
+        if (scan(br.bucket, br.rem, s0)) return true;
+        if (!full_out) return false;
+        const bool generic = ((s0 >> 62) & 1ULL) != 0;
+        if (s0 >> 63) {
+            uint64_t s1;
+            if (scan(alt_bucket(br.bucket, br.rem, ct.qb), br.rem | (1ULL << ct.rembits), s1)) return true;
+        }
+        if (!generic) return false;
+        uint64_t hh = slot_of(c, tab.shift);
+        Slot cur = load_slot(tab.slots + hh);
+        while (cur.key != c && cur.key != kEmptyKey) {
+            hh = (hh + 1) & tab.mask;
+            cur = load_slot(tab.slots + hh);
+        }
+        if (cur.key == c) {
+            loc = cur.loc;
+            if (payload) *payload = cur.payload;
+            return true;
+        }
+        return false;
+    }
+    const uint32_t locmask = (1u << ct.locbits) - 1u, tagmask = (1u << (ct.rembits + 1)) - 1u;
     const uint4 *pb = ct.buckets + ((uint64_t)part_of(c, k) << ct.qb);
     const uint4 b = pb[br.bucket];
     const uint32_t sl[4] = {b.x, b.y, b.z, b.w};
@@ -179,7 +222,7 @@ __device__ __forceinline__ bool compact_lookup(const CompactView &ct, const Tabl
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if (sl[i] == kEmptySlot32) full = false;
-        else if (((sl[i] >> ct.locbits) & tagmask) == br.rem) {
+        else if (((sl[i] >> ct.locbits) & tagmask) == (uint32_t)br.rem) {
             hit = true;
             loc = sl[i] & locmask;
             if (payload) *payload = ct.payload[(uint64_t)(pb - ct.buckets + br.bucket) * 4 + i];
@@ -193,7 +236,7 @@ __device__ __forceinline__ bool compact_lookup(const CompactView &ct, const Tabl
             const uint32_t ab = alt_bucket(br.bucket, br.rem, ct.qb);
             const uint4 b2 = pb[ab];
             const uint32_t s2[4] = {b2.x, b2.y, b2.z, b2.w};
-            const uint32_t want = br.rem | (1u << ct.rembits);
+            const uint32_t want = (uint32_t)br.rem | (1u << ct.rembits);
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 if (s2[i] != kEmptySlot32 && ((s2[i] >> ct.locbits) & tagmask) == want) {
@@ -247,7 +290,50 @@ __device__ __forceinline__ void probe_tile(const TableView &tab, const CompactVi
     bool missing = false;
     uint32_t missing_bit = 0;
 
-    if (COMPACT) {
+    if (COMPACT && ct.w64) {
+        // 64-bit slots: one 32-byte bucket (two 16-byte loads of one 64-byte line) per window, 4 windows in flight
+        const int kbits = 2 * k - 4;
+        const uint64_t keymask = (1ULL << kbits) - 1ULL;
+        const uint64_t locmask = (1ULL << ct.locbits) - 1ULL, tagmask = (1ULL << (ct.rembits + 1)) - 1ULL;
+        const ulonglong2 *b64 = reinterpret_cast<const ulonglong2 *>(ct.buckets);
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            uint64_t c[4], tag[4];
+            ulonglong2 lo[4], hi[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                c[j] = canon_at(a, b2, ra, rb, g * 4 + j, k, kmask);
+                const BucketRem br = hmix2((c[j] >> 4) & keymask, kbits, ct.qb);
+                tag[j] = br.rem;
+                const uint64_t bi = (((uint64_t)part_of(c[j], k) << ct.qb) + br.bucket) * 2;
+                lo[j] = b64[bi];
+                hi[j] = b64[bi + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int bb = g * 4 + j;
+                const uint64_t sl[4] = {lo[j].x, lo[j].y, hi[j].x, hi[j].y};
+                bool hit = false, full = true;
+                uint64_t l = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (sl[i] == ~0ULL) full = false;
+                    else if (((sl[i] >> ct.locbits) & tagmask) == tag[j]) {
+                        hit = true;
+                        l = sl[i];
+                    }
+                }
+                uint32_t loc = (uint32_t)(l & locmask);
+                if (!hit && full && ((vmask >> bb) & 1u)) hit = compact_lookup(ct, tab, c[j], k, loc);  // second chance / generic
+                if (hit && ((vmask >> bb) & 1u)) {
+                    raw |= 1u << bb;
+                    if (prev == GS_NONE) first_loc = loc;
+                    else if (loc != prev) chg |= 1u << bb;
+                    prev = loc;
+                }
+            }
+        }
+    } else if (COMPACT) {
         // compact table out in HBM: one 16-byte bucket load per window (one 64-byte line from the fabric), 8 in flight
         const int kbits = 2 * k - 4;
         const uint64_t keymask = (1ULL << kbits) - 1ULL;
@@ -261,7 +347,7 @@ __device__ __forceinline__ void probe_tile(const TableView &tab, const CompactVi
             for (int j = 0; j < 8; j++) {
                 c[j] = canon_at(a, b2, ra, rb, g * 8 + j, k, kmask);
                 const BucketRem br = hmix2((c[j] >> 4) & keymask, kbits, ct.qb);
-                tag[j] = br.rem;
+                tag[j] = (uint32_t)br.rem;
                 bk[j] = ct.buckets[((uint64_t)part_of(c[j], k) << ct.qb) + br.bucket];
             }
 #pragma unroll
@@ -715,7 +801,7 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
                 if (FULL || g0 + u < ngroups) {  // wave-uniform
                     entry[u] = sQ[wave][(g0 + u) * 64 + lane];
                     const BucketRem br = hmix2((canon_of(entry[u]) >> 4) & keymask, kbits, ct.qb);
-                    tag[u] = br.rem;
+                    tag[u] = (uint32_t)br.rem;
                     bkt[u] = br.bucket;
                     bk[u] = DBG == 1 ? make_uint4(kEmptySlot, kEmptySlot, kEmptySlot, br.rem) : part_buckets[br.bucket];
                 }
@@ -1185,6 +1271,35 @@ __global__ void k_compact_insert(uint32_t *slots, uint32_t *slot_payload, int k,
     overflow_list[atomicAdd(overflow, 1ULL)] = (uint32_t)i;  // goes to the (small) generic table
 }
 
+// the same with 64-bit slots [flags(2) | alt | rem | loc] (tables whose remainder + loc exceed 32 bits)
+__global__ void k_compact_insert64(unsigned long long *slots, uint32_t *slot_payload, int k, int qb, int rembits, int locbits,
+                                   const uint64_t *keys, const uint32_t *loc, const uint32_t *payload, uint64_t n,
+                                   unsigned long long *overflow, uint32_t *overflow_list) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c = keys[i];
+    const int kbits = 2 * k - 4;
+    const BucketRem br = hmix2((c >> 4) & ((1ULL << kbits) - 1ULL), kbits, qb);
+    const uint64_t pbase = (uint64_t)part_of(c, k) << qb;
+    const unsigned long long v = (br.rem << locbits) | loc[i];
+    unsigned long long *home = slots + (pbase + br.bucket) * 4;
+    for (int j = 0; j < 4; j++)
+        if (atomicCAS(home + j, ~0ULL, v) == ~0ULL) {
+            slot_payload[(home - slots) + j] = payload[i];
+            return;
+        }
+    unsigned long long *alt = slots + (pbase + alt_bucket(br.bucket, br.rem, qb)) * 4;
+    const unsigned long long va = v | (1ULL << (rembits + locbits));
+    for (int j = 0; j < 4; j++)
+        if (atomicCAS(alt + j, ~0ULL, va) == ~0ULL) {
+            slot_payload[(alt - slots) + j] = payload[i];
+            atomicOr(home, 1ULL << 63);
+            return;
+        }
+    atomicOr(home, 1ULL << 62);
+    overflow_list[atomicAdd(overflow, 1ULL)] = (uint32_t)i;
+}
+
 // generic-table insert of a subset of the keys (those the compact table could not take)
 __global__ void k_table_insert_list(Slot *slots, uint64_t mask, int shift, const uint64_t *keys, const uint32_t *loc,
                                     const uint32_t *payload, const uint32_t *list, uint64_t n_list) {
@@ -1227,7 +1342,7 @@ struct gs_table {
     int compact = 0;  // 0 generic only, 1 compact-l2, 2 compact-hbm
     uint4 *cbuckets = nullptr;
     uint32_t *cpayload = nullptr;  // payload per compact slot
-    int c_qb = 0, c_rembits = 0, c_locbits = 0, c_has_flag = 0;
+    int c_qb = 0, c_rembits = 0, c_locbits = 0, c_has_flag = 0, c_w64 = 0;
     uint64_t c_overflow = 0;
     uint32_t *d_complex_n = nullptr;
     hipStream_t stream = nullptr;
@@ -1301,7 +1416,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     if (r->n_tiles) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
-        const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag};
+        const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
         if (t->compact == 1) {
             HIP_TRY(hipMemsetAsync(t->d_complex_n, 0, sizeof(uint32_t), t->stream));
             const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
@@ -1385,7 +1500,7 @@ int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
     if ((rc = launch_scan(t, r, 0))) return rc;
     if ((rc = launch_scan(t, r, 1))) return rc;
     if (r->n_tiles) {
-        const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag};
+        const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
         hipLaunchKernelGGL(k_emit, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, view(t), cv, t->compact, view(r), r->ta,
                            r->cand, r->cand_cap, r->hits, r->hit_cap);
     }
@@ -1409,10 +1524,11 @@ uint64_t revcomp_code(uint64_t c, int k) {
     return r;
 }
 
-// Layout choice for the exact compact copy of the table (32-bit slots):
-//   1 = "compact-l2":  a 1/16 slice fits the L2 of an XCD next to the read stream (<= 2 MiB)  -> k_probe_part
-//   2 = "compact-hbm": larger; probed with one 16-byte bucket load per window                    -> k_probe<true>
-//   0 = generic 16-byte slots only (k < 16, a key without loc row, or remainder + loc do not fit 32 bits)
+// Layout choice for the exact compact copy of the table:
+//   1 = "compact-l2":  32-bit slots, a 1/16 slice fits the L2 of an XCD next to the read stream (<= 2 MiB) -> k_probe_part
+//   2 = "compact-hbm": 32-bit slots, larger; one 16-byte bucket load per window                              -> k_probe<true>
+//   3 = "compact-hbm": 64-bit slots (remainder + loc do not fit 32 bits: long k, many groups, huge tables)    -> k_probe<true>
+//   0 = generic 16-byte slots only (k < 16, or a key without loc row)
 int choose_compact(int k, uint64_t n, uint64_t generic_bytes, const uint32_t *loc, int &qb, int &rembits, int &locbits,
                    int &has_flag) {
     const char *env = getenv("GAVISUNK_TABLE");
@@ -1426,20 +1542,30 @@ int choose_compact(int k, uint64_t n, uint64_t generic_bytes, const uint32_t *lo
     locbits = 1;
     while ((1ull << locbits) < (uint64_t)maxloc + 2) locbits++;  // the all-ones loc stays unused
     const int kbits = 2 * k - 4;
-    qb = 8;
-    while (((uint64_t)(4 * kNPart) << qb) < (uint64_t)(2.2 * (double)n)) qb++;
+    int qb_nat = 8;
+    while (((uint64_t)(4 * kNPart) << qb_nat) < (uint64_t)(2.2 * (double)n)) qb_nat++;
+    const int lbits = kbits < 32 ? kbits : 32;
+    auto valid_qb = [&](int q) { return q >= 4 && q <= 28 && q < lbits && kbits - q >= 1; };
+    // 32-bit slots: with the natural bucket count, or with more buckets (a shorter remainder) while the table stays small
+    qb = qb_nat;
     while (kbits - qb + locbits > 32) qb++;
     if (const char *fq = getenv("GAVISUNK_COMPACT_QB")) {  // test knob: an undersized table makes every overflow path busy
         const int v = atoi(fq);
-        if (v >= 4 && v <= 28 && kbits - v + locbits <= 32) qb = v;
+        if (valid_qb(v) && kbits - v + locbits <= 32) qb = v;
     }
-    if (kbits - qb < 1 || qb > 28 || qb >= (kbits < 32 ? kbits : 32)) return 0;
-    // forcing the remainder into 32 bits can blow a small table up: never larger than the generic one (or 32 MiB)
-    if (((uint64_t)(16 * kNPart) << qb) > std::max<uint64_t>(generic_bytes, 32ull << 20)) return 0;
+    const bool fits32 = valid_qb(qb) && ((uint64_t)(16 * kNPart) << qb) <= std::max<uint64_t>(generic_bytes, 32ull << 20);
+    if (fits32) {
+        rembits = kbits - qb;
+        has_flag = rembits + 1 + locbits <= 30;
+        const bool l2 = (16ull << qb) <= (2ull << 20) && locbits <= 18 && !(env && !strcmp(env, "compact-hbm"));
+        return l2 ? 1 : 2;
+    }
+    // 64-bit slots with the natural bucket count
+    qb = qb_nat;
     rembits = kbits - qb;
-    has_flag = rembits + 1 + locbits <= 30;
-    const bool l2 = (16ull << qb) <= (2ull << 20) && locbits <= 18 && !(env && !strcmp(env, "compact-hbm"));
-    return l2 ? 1 : 2;
+    if (!valid_qb(qb) || rembits + 1 + locbits > 62) return 0;
+    has_flag = 1;
+    return 3;
 }
 
 }  // namespace
@@ -1502,14 +1628,22 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     t->compact = choose_compact(k, n, cap_full * sizeof(Slot), loc, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
     uint64_t n_generic = n;
     if (t->compact) {
+        t->c_w64 = t->compact == 3;
+        if (t->compact == 3) t->compact = 2;  // same probe kernel; the view says which slot width
         const uint64_t nslots = (uint64_t)(4 * kNPart) << t->c_qb;
+        const uint64_t slot_words = t->c_w64 ? 2 * nslots : nslots;  // in uint32 units
         uint32_t *d = nullptr;
         unsigned long long *dov = nullptr;
-        if ((rc = dev_alloc(&d, nslots)) || (rc = dev_alloc(&t->cpayload, nslots)) || (rc = dev_alloc(&dov, 1)) ||
+        if ((rc = dev_alloc(&d, slot_words)) || (rc = dev_alloc(&t->cpayload, nslots)) || (rc = dev_alloc(&dov, 1)) ||
             (rc = dev_alloc(&dlist, n)))
             return rc;
-        HIP_TRY(hipMemsetAsync(d, 0xFF, nslots * sizeof(uint32_t), t->stream));
+        HIP_TRY(hipMemsetAsync(d, 0xFF, slot_words * sizeof(uint32_t), t->stream));
         HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
+        if (t->c_w64)
+            hipLaunchKernelGGL(k_compact_insert64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream,
+                               reinterpret_cast<unsigned long long *>(d), t->cpayload, k, t->c_qb, t->c_rembits, t->c_locbits, dk,
+                               dl, dp, n, dov, dlist);
+        else
         hipLaunchKernelGGL(k_compact_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, d, t->cpayload, k,
                            t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, dk, dl, dp, n, dov, dlist);
         unsigned long long ov = 0;
@@ -1548,8 +1682,8 @@ const char *gs_table_layout(const gs_table *t) {
     static thread_local char buf[160];
     if (!t) return "";
     if (t->compact)
-        snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x u32 (%d-bit remainder, %d-bit loc%s), %llu overflow keys in a generic 16 B-slot side table",
-                 t->compact == 1 ? "compact-l2" : "compact-hbm", t->c_qb, t->c_rembits, t->c_locbits,
+        snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x %s (%d-bit remainder, %d-bit loc%s), %llu overflow keys in a generic 16 B-slot side table",
+                 t->compact == 1 ? "compact-l2" : "compact-hbm", t->c_qb, t->c_w64 ? "u64" : "u32", t->c_rembits, t->c_locbits,
                  t->c_has_flag ? ", second-chance buckets" : "", (unsigned long long)t->c_overflow);
     else
         snprintf(buf, sizeof buf, "generic: open-addressed 16 B slots in HBM");
@@ -1575,7 +1709,7 @@ void gs_table_destroy(gs_table *t) {
 }
 
 uint64_t gs_table_bytes(const gs_table *t) {
-    return t ? t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)(32 * kNPart) << t->c_qb) : 0) : 0;  // slots + payloads
+    return t ? t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)((t->c_w64 ? 48 : 32) * kNPart) << t->c_qb) : 0) : 0;  // slots + payloads
 }
 
 // index building + allocations shared by the two upload entry points; the packed words are zeroed, not filled

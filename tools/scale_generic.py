@@ -9,7 +9,7 @@ from gavisunk_amd import synth, engine, _lib
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 100          # Mb
 n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
-k = 20
+k = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 20
 rng = np.random.default_rng(30)
 t0 = time.perf_counter()
 contigs = [rng.integers(0, 4, G * 1_000_000 // 4, dtype=np.uint8) for _ in range(4)]
