@@ -23,6 +23,8 @@ keep = np.sort(first[counts == 1])
 codes, cid, pos = codes[keep], cid[keep], pos[keep]
 new = np.ones(len(pos), bool); new[1:] = (cid[1:] != cid[:-1]) | ((pos[1:] - pos[:-1]) > k)
 loc = (np.cumsum(new) - 1).astype(np.uint32)
+if "--many-groups" in sys.argv:  # genome-like group counts: a new group every ~200 SUNKs
+    loc = (np.arange(len(pos)) // 200).astype(np.uint32)
 print(f"genome {G} Mb: {len(codes)} SUNKs in {int(loc[-1]) + 1} groups ({time.perf_counter() - t0:.0f} s)", flush=True)
 lens = synth.lognormal_lengths(rng, n_reads, median=19000.0)
 reads = [synth.codes_to_ascii(r) for r in synth.simulate_reads(rng, contigs, lens)]
