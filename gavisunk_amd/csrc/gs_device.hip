@@ -1050,6 +1050,13 @@ __device__ __forceinline__ Agg agg_shfl_up(const Agg &a, int d) {
     return o;
 }
 
+// Scalars of a pass, in one device block: reset with one copy, fetched with one copy into pinned host memory.
+struct PassStatus {
+    unsigned long long err_pos;
+    Agg totals[2];  // [0] scan A grand total, [1] scan B grand total
+    uint32_t cand_count, complex_n, carry_in, pad;
+};
+
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanBlock = kScanThreads * kScanItems;
@@ -1345,6 +1352,9 @@ struct gs_table {
     int c_qb = 0, c_rembits = 0, c_locbits = 0, c_has_flag = 0, c_w64 = 0;
     uint64_t c_overflow = 0;
     uint32_t *d_complex_n = nullptr;
+    PassStatus *d_status = nullptr;       // the five scalars below live in this one block
+    PassStatus *h_status = nullptr;       // pinned: filled by an async copy at the end of a pass
+    PassStatus *h_init = nullptr;         // pinned: template the block is reset from
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // scalars on device
@@ -1411,14 +1421,16 @@ int launch_phase1(gs_table *t, gs_reads *r) {
         if ((rc = dev_alloc(&r->part_recs, (uint64_t)r->n_tiles * kNPart))) return rc;
         if ((rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
     }
-    HIP_TRY(hipMemsetAsync(t->d_cand_count, 0, sizeof(uint32_t), t->stream));
-    HIP_TRY(hipMemsetAsync(t->d_err_pos, 0xFF, sizeof(unsigned long long), t->stream));
+    memset(t->h_init, 0, sizeof(PassStatus));
+    t->h_init->err_pos = ~0ULL;
+    t->h_init->totals[0].loc = t->h_init->totals[1].loc = GS_NONE;
+    t->h_init->carry_in = GS_NONE;
+    HIP_TRY(hipMemcpyAsync(t->d_status, t->h_init, sizeof(PassStatus), hipMemcpyHostToDevice, t->stream));
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     if (r->n_tiles) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
         if (t->compact == 1) {
-            HIP_TRY(hipMemsetAsync(t->d_complex_n, 0, sizeof(uint32_t), t->stream));
             const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
             const int mode = dbg ? atoi(dbg) : 0;
             const char *env_nt = getenv("GAVISUNK_PART_TILES"), *env_pipe = getenv("GAVISUNK_PART_PIPE");  // tuning experiments
@@ -1505,6 +1517,7 @@ int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
                            r->cand, r->cand_cap, r->hits, r->hit_cap);
     }
     HIP_TRY(hipEventRecord(t->ev[2], t->stream));
+    HIP_TRY(hipMemcpyAsync(t->h_status, t->d_status, sizeof(PassStatus), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipGetLastError());
     t->pass_pending = true;
     t->settled_reads = nullptr;
@@ -1599,11 +1612,14 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     int rc;
     HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     for (auto &e : t->ev) HIP_TRY(hipEventCreate(&e));
-    if ((rc = dev_alloc(&t->d_cand_count, 1))) return rc;
-    if ((rc = dev_alloc(&t->d_err_pos, 1))) return rc;
-    if ((rc = dev_alloc(&t->d_carry_in, 1))) return rc;
-    if ((rc = dev_alloc(&t->d_totals, 2))) return rc;
-    if ((rc = dev_alloc(&t->d_complex_n, 1))) return rc;
+    if ((rc = dev_alloc(&t->d_status, 1))) return rc;
+    HIP_TRY(hipHostMalloc((void **)&t->h_status, sizeof(PassStatus), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&t->h_init, sizeof(PassStatus), hipHostMallocDefault));
+    t->d_err_pos = &t->d_status->err_pos;
+    t->d_totals = t->d_status->totals;
+    t->d_cand_count = &t->d_status->cand_count;
+    t->d_complex_n = &t->d_status->complex_n;
+    t->d_carry_in = &t->d_status->carry_in;
     uint64_t *dk = nullptr;
     uint32_t *dl = nullptr, *dp = nullptr, *dlist = nullptr;
     if ((rc = dev_alloc(&dk, n)) || (rc = dev_alloc(&dl, n)) || (rc = dev_alloc(&dp, n))) return rc;
@@ -1697,11 +1713,9 @@ void gs_table_destroy(gs_table *t) {
     (void)hipFree(t->slots);
     (void)hipFree(t->cbuckets);
     (void)hipFree(t->cpayload);
-    (void)hipFree(t->d_complex_n);
-    (void)hipFree(t->d_cand_count);
-    (void)hipFree(t->d_err_pos);
-    (void)hipFree(t->d_carry_in);
-    (void)hipFree(t->d_totals);
+    (void)hipFree(t->d_status);
+    if (t->h_status) (void)hipHostFree(t->h_status);
+    if (t->h_init) (void)hipHostFree(t->h_init);
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -1965,12 +1979,9 @@ static int settle(gs_table *t, gs_reads *r) {
     HIP_TRY(hipSetDevice(t->device));
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(hipStreamSynchronize(t->stream));
-        uint32_t ncand = 0;
-        unsigned long long err = ~0ULL;
-        Agg tot[2];
-        HIP_TRY(hipMemcpy(&ncand, t->d_cand_count, sizeof ncand, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&err, t->d_err_pos, sizeof err, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(tot, t->d_totals, sizeof tot, hipMemcpyDeviceToHost));
+        const uint32_t ncand = t->h_status->cand_count;
+        const unsigned long long err = t->h_status->err_pos;
+        const Agg tot[2] = {t->h_status->totals[0], t->h_status->totals[1]};
         if ((uint64_t)r->n_tiles * kDirectCand + ncand > r->cand_cap) {
             int rc;
             if ((rc = ensure_out_buffers(r, (uint32_t)std::min<uint64_t>((uint64_t)r->n_tiles * kDirectCand + ncand + 65536, 0xFFFFFFFFull)))) return rc;
