@@ -66,6 +66,17 @@ def test_cli_matches_reference_binary(golden, name, tmp_path):
             assert got.startswith(exp)
 
 
+@pytest.mark.parametrize("name", ["kat1", "amy", "multi_k21"])
+def test_cli_in_small_device_batches(golden, name, tmp_path, monkeypatch):
+    """The CLI threads `prevLoc` through device batches: tiny batches must not change a byte."""
+    monkeypatch.setenv("GAVISUNK_BATCH_BASES", "700")
+    c = golden(name)
+    run = c.meta["tag"][0]
+    out = tmp_path / "out.sunkpos"
+    assert kmerpos_annot3.main([c.path(run["reads"]), c.path(run["db"]), c.path(run["loc"]), str(out)]) == run["rc"] == 0
+    assert out.read_text() == c.text(run["out"])
+
+
 @pytest.mark.parametrize("k", [11, 16, 18, 20, 21, 25, 31, 32])
 @pytest.mark.parametrize("seed", [1, 2])
 def test_random_inputs_match_oracle(k, seed):
