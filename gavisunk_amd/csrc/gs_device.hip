@@ -143,10 +143,12 @@ __host__ __device__ __forceinline__ BucketRem hmix2(uint64_t key, int kbits, int
     o.rem = ((uint64_t)(l & ((1u << (lbits - qb)) - 1u)) << (kbits - lbits)) | hi;
     return o;
 }
-// second-chance bucket of a key (same partition): bucket ^ (odd, non-zero function of the remainder)
+// second-chance bucket of a key (same partition): bucket ^ (odd, non-zero function of the remainder).  Only the low
+// bits change, so both buckets of a key lie in the same 1/16 of the partition (the slice one CU stages in LDS).
+__host__ __device__ __forceinline__ int alt_bits(int qb) { return qb - 4 < 1 ? 1 : (qb - 4 > 9 ? 9 : qb - 4); }
 __host__ __device__ __forceinline__ uint32_t alt_bucket(uint32_t bucket, uint64_t rem, int qb) {
     const uint32_t r = (uint32_t)rem ^ (uint32_t)(rem >> 32);
-    return bucket ^ ((((r + 1u) * 0x9E3779B1u) >> (32 - qb)) | 1u);
+    return bucket ^ ((((r + 1u) * 0x9E3779B1u) >> (32 - alt_bits(qb))) | 1u);
 }
 
 // partition of a canonical (or not: it is strand-symmetric) 2k-bit code
@@ -260,6 +262,56 @@ __device__ __forceinline__ bool compact_lookup(const CompactView &ct, const Tabl
         return true;
     }
     return false;
+}
+
+// Per-lane results of one tile (lane = 32 consecutive windows: raw-hit mask, "loc differs from the lane's previous
+// raw hit" mask, loc of the lane's first and last raw hit) -> the tile's {n_raw, n_cand, first/last loc, candidates}.
+__device__ __forceinline__ void tile_summary(uint32_t raw, uint32_t chg, uint32_t first_loc, uint32_t prev, uint32_t tile,
+                                             uint32_t n_tiles, const TileArrays &ta, uint32_t *cand, uint32_t cand_cap,
+                                             uint32_t *g_cand_count) {
+    const int lane = threadIdx.x & 63;
+    // loc of the nearest raw hit in a lower lane of this tile
+    const unsigned long long ne = __ballot(raw != 0);
+    const unsigned long long below = ne & ((1ULL << lane) - 1ULL);
+    const int src = below ? 63 - __clzll((long long)below) : -1;
+    const uint32_t prev_lane_loc = __shfl(prev, src < 0 ? 0 : src);
+    if (raw && (src < 0 || first_loc != prev_lane_loc)) chg |= 1u << (__ffs(raw) - 1);
+
+    uint32_t tot_raw, tot_cand;
+    const uint32_t ex_raw = wave_excl_scan(__popc(raw), lane, tot_raw);
+    const uint32_t ex_cand = wave_excl_scan(__popc(chg), lane, tot_cand);
+
+    // up to kDirectCand candidates go to the tile's own slots; longer lists (rare) are allocated with one atomic
+    // (a single counter word sustains only ~90 returning atomics per microsecond on this chip)
+    uint32_t off = tile * kDirectCand;
+    if (tot_cand > (uint32_t)kDirectCand) {
+        if (lane == 0) off = n_tiles * kDirectCand + atomicAdd(g_cand_count, tot_cand);
+        off = __shfl(off, 0);
+    }
+    if (tot_cand && (uint64_t)off + tot_cand <= cand_cap) {
+        uint32_t m = chg, i = 0;
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            const uint32_t woff = lane * 32 + bit;
+            const uint32_t rank = ex_raw + __popc(raw & ((1u << bit) - 1u));
+            cand[off + ex_cand + i] = (rank << 16) | woff;
+            i++;
+        }
+    }
+    if (ne) {
+        const int lo = __ffsll((unsigned long long)ne) - 1, hi = 63 - __clzll((long long)ne);
+        const uint32_t fl = __shfl(first_loc, lo), ll = __shfl(prev, hi);
+        if (lane == 0) {
+            ta.first_loc[tile] = fl;
+            ta.last_loc[tile] = ll;
+        }
+    }
+    if (lane == 0) {
+        ta.n_raw[tile] = tot_raw;
+        ta.n_cand[tile] = tot_cand;
+        ta.cand_off[tile] = off;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -412,48 +464,7 @@ __device__ __forceinline__ void probe_tile(const TableView &tab, const CompactVi
     }
     if (missing) atomicMin(g_err_pos, ((unsigned long long)tile << 32) | (uint32_t)(lane * 32 + missing_bit));
 
-    // loc of the nearest raw hit in a lower lane of this tile
-    const unsigned long long ne = __ballot(raw != 0);
-    const unsigned long long below = ne & ((1ULL << lane) - 1ULL);
-    const int src = below ? 63 - __clzll((long long)below) : -1;
-    const uint32_t prev_lane_loc = __shfl(prev, src < 0 ? 0 : src);
-    if (raw && (src < 0 || first_loc != prev_lane_loc)) chg |= 1u << (__ffs(raw) - 1);
-
-    uint32_t tot_raw, tot_cand;
-    const uint32_t ex_raw = wave_excl_scan(__popc(raw), lane, tot_raw);
-    const uint32_t ex_cand = wave_excl_scan(__popc(chg), lane, tot_cand);
-
-    // up to kDirectCand candidates go to the tile's own slots; longer lists (rare) are allocated with one atomic
-    // (a single counter word sustains only ~90 returning atomics per microsecond on this chip)
-    uint32_t off = tile * kDirectCand;
-    if (tot_cand > (uint32_t)kDirectCand) {
-        if (lane == 0) off = rd.n_tiles * kDirectCand + atomicAdd(g_cand_count, tot_cand);
-        off = __shfl(off, 0);
-    }
-    if (tot_cand && (uint64_t)off + tot_cand <= cand_cap) {
-        uint32_t m = chg, i = 0;
-        while (m) {
-            const int bit = __ffs(m) - 1;
-            m &= m - 1;
-            const uint32_t woff = lane * 32 + bit;
-            const uint32_t rank = ex_raw + __popc(raw & ((1u << bit) - 1u));
-            cand[off + ex_cand + i] = (rank << 16) | woff;
-            i++;
-        }
-    }
-    if (ne) {
-        const int lo = __ffsll((unsigned long long)ne) - 1, hi = 63 - __clzll((long long)ne);
-        const uint32_t fl = __shfl(first_loc, lo), ll = __shfl(prev, hi);
-        if (lane == 0) {
-            ta.first_loc[tile] = fl;
-            ta.last_loc[tile] = ll;
-        }
-    }
-    if (lane == 0) {
-        ta.n_raw[tile] = tot_raw;
-        ta.n_cand[tile] = tot_cand;
-        ta.cand_off[tile] = off;
-    }
+    tile_summary(raw, chg, first_loc, prev, tile, rd.n_tiles, ta, cand, cand_cap, g_cand_count);
 }
 
 
@@ -1028,6 +1039,398 @@ __global__ __launch_bounds__(256) void k_merge_part(const PartRec *recs, uint32_
 }
 
 // ------------------------------------------------------------------------------------------
+// LDS join (k = 20, 32-bit compact table): the same exact table, probed from LDS.
+//
+// One L2 request per window is itself a wall (~270 G requests/s chip-wide), and finding "the windows of my
+// partition" inside every tile costs more instructions than the probes.  So the windows are routed instead,
+// like the probe side of a radix-partitioned hash join:
+//
+//   k_join_bin    a workgroup takes a batch of 4 tiles (8192 windows): canonical code, hash, and the
+//                 table slice (1 of 256: partition x top 4 bucket bits) of every window; a counting sort
+//                 in LDS groups the 32-bit hashed keys by slice; the batch goes out densely packed:
+//                 item[batch][8192] (+ the window of each item, + start/count per slice).
+//   k_join_segT   transposes the start/count table to [slice][batch] (so that a slice reads it contiguously).
+//   k_join_probe  one workgroup per slice stages its 2^(qb-4) buckets (<= 128 KiB) in LDS and streams the
+//                 slice's items of all batches: one ds_read_b128 per window instead of an L2 request.  A
+//                 wave takes 64 batches at a time and appends its hits {item position, loc + 1} to one
+//                 contiguous stream per (slice, 64 batches), with the start of every 8-batch group noted.
+//   k_join_merge  a workgroup per 8 batches (32 tiles) scatters the hits of the 256 streams into window
+//                 order (LDS, 16 bits per window) and writes the same per-tile summary as probe_tile:
+//                 nothing downstream changes.
+//
+// All traffic is streaming and nothing is written in place (partial-sector writes cost a read-modify-write).
+// Exactness never depends on placement.  Degenerate input (more than 4096 windows of 64 consecutive batches in
+// one slice: homopolymer reads) sends those batches' tiles to the generic exact probe.
+// ------------------------------------------------------------------------------------------
+constexpr int kJoinTiles = 4;
+constexpr int kJoinWin = kJoinTiles * kTileWindows;  // windows per batch
+constexpr int kJoinSlices = 256;                     // kNPart x 16
+constexpr int kJoinSliceBuckets = 8192;              // LDS image of a slice: <= 128 KiB
+constexpr int kJoinOvfMax = 256;                     // overflow keys of a slice kept in LDS
+constexpr uint32_t kJoinChunk = 32768;               // batches per queue buffer
+constexpr uint32_t kJoinHitCap = 4096;               // hit records per (slice, 64 batches): the fast path cannot exceed it
+constexpr int kJoinMergeBatches = 8;                 // batches per k_join_merge workgroup
+
+struct JoinQ {
+    uint32_t *item;   // [batches][kJoinWin]     hashed key (bucket in slice | remainder), grouped by slice
+    uint16_t *woff;   // [batches][kJoinWin]     window of the item inside its batch
+    uint32_t *seg;    // [batches][kJoinSlices]  start | count << 16 of a slice's items inside the batch
+    uint32_t *segT;   // [kJoinSlices][bpad]     the same, transposed (bpad = batches rounded up to 64)
+    uint32_t *hits;   // [kJoinSlices][bpad / 64][kJoinHitCap]  item position (16 bits: batch & 7, index) | (loc + 1) << 16
+    uint32_t *hsub;   // [bpad / 8][kJoinSlices] start | count << 16 of an 8-batch group inside its hit stream
+    uint32_t *gflag;  // [bpad / 64]             1 = degenerate group: its tiles go to the generic probe
+    uint32_t bpad;
+};
+
+template <int KT>
+__global__ __launch_bounds__(1024) void k_join_bin(CompactView ct, const uint64_t *__restrict__ words,
+                                                    const TileDesc *__restrict__ tdesc, uint32_t n_tiles, uint32_t batch0,
+                                                    JoinQ jq) {
+    __shared__ __align__(16) uint32_t dkey[kJoinWin];
+    __shared__ __align__(16) uint16_t dwoff[kJoinWin];
+    __shared__ __align__(16) uint32_t cnt[kJoinSlices];
+    __shared__ __align__(16) uint32_t off[kJoinSlices];
+    constexpr int k = KT;
+    constexpr int kbits = 2 * k - 4;
+    const int tid = threadIdx.x;
+    const uint32_t bl = blockIdx.x;
+    if (tid < kJoinSlices) cnt[tid] = 0;
+    // thread = 8 consecutive windows: word (tid >> 2) of the batch's 256 words, quarter (tid & 3) of it
+    const int q = tid >> 8, l = (tid >> 2) & 63, h = tid & 3;
+    const uint32_t tile = (batch0 + bl) * kJoinTiles + q;
+    TileDesc td = tdesc[min(tile, n_tiles - 1)];
+    if (tile >= n_tiles) td.nwin_left = 0;
+    const uint64_t a = __builtin_nontemporal_load(words + td.wbase + l);
+    const uint64_t b2 = __builtin_nontemporal_load(words + td.wbase + l + 1);
+    __syncthreads();
+    const uint32_t w0 = (uint32_t)l * 32u + (uint32_t)h * 8u;
+    const uint32_t nvalid = td.nwin_left > w0 ? min(td.nwin_left - w0, 8u) : 0u;
+    const int s = 16 * h;
+    const uint64_t X = s ? ((a << s) | (b2 >> (64 - s))) : a;  // my 8 windows start at bases 0..7 of X (8 + k - 1 <= 32 bases)
+    const uint64_t R = ~revpairs(X);                            // base i of X, complemented, at bits 2i+1:2i
+    static_assert(8 + KT - 1 <= 32, "the 8 windows of a thread must fit one 64-bit word");
+    constexpr uint64_t kmask = (1ULL << (2 * k)) - 1ULL, keymask = (1ULL << kbits) - 1ULL;
+    const int sb = ct.qb - 4;  // bucket bits inside a slice; sb + rembits = 32
+    uint32_t item[8], sr[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint64_t f = (X << (2 * j)) >> (64 - 2 * k);
+        const uint64_t r = (R >> (2 * j)) & kmask;
+        const uint64_t c = f < r ? f : r;
+        const BucketRem br = hmix2((c >> 4) & keymask, kbits, ct.qb);
+        const uint32_t slice = (part_of(c, k) << 4) | (br.bucket >> sb);
+        item[j] = ((br.bucket & ((1u << sb) - 1u)) << ct.rembits) | (uint32_t)br.rem;
+        const uint32_t rank = (uint32_t)j < nvalid ? atomicAdd(&cnt[slice], 1u) : 0u;
+        sr[j] = slice | (rank << 8);
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive prefix over the 256 counters, 4 per lane
+        const uint4 c4 = reinterpret_cast<const uint4 *>(cnt)[tid];
+        uint32_t total;
+        const uint32_t ex = wave_excl_scan(c4.x + c4.y + c4.z + c4.w, tid, total);
+        const uint4 o4 = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);
+        reinterpret_cast<uint4 *>(off)[tid] = o4;
+        reinterpret_cast<uint4 *>(jq.seg + (uint64_t)bl * kJoinSlices)[tid] =
+            make_uint4(o4.x | (c4.x << 16), o4.y | (c4.y << 16), o4.z | (c4.z << 16), o4.w | (c4.w << 16));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if ((uint32_t)j < nvalid) {
+            const uint32_t pos = off[sr[j] & 255u] + (sr[j] >> 8);
+            dkey[pos] = item[j];
+            dwoff[pos] = (uint16_t)(((uint32_t)q << 11) | (w0 + (uint32_t)j));
+        }
+    __syncthreads();
+    const uint32_t total = off[kJoinSlices - 1] + cnt[kJoinSlices - 1];
+    uint4 *gk = reinterpret_cast<uint4 *>(jq.item + (uint64_t)bl * kJoinWin);
+    uint4 *gw = reinterpret_cast<uint4 *>(jq.woff + (uint64_t)bl * kJoinWin);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t e4 = (uint32_t)tid + 1024u * (uint32_t)i;
+        if (e4 * 4u < total) gk[e4] = reinterpret_cast<const uint4 *>(dkey)[e4];
+    }
+    if ((uint32_t)tid * 8u < total) gw[tid] = reinterpret_cast<const uint4 *>(dwoff)[tid];
+}
+
+// seg [nb][256] -> segT [256][bpad] in 64 x 64 pieces (batches past nb read as empty); also clears the group flags
+__global__ __launch_bounds__(256) void k_join_segT(JoinQ jq, uint32_t nb) {
+    __shared__ uint32_t tl[64][65];
+    const uint32_t b0 = blockIdx.x * 64u, s0 = blockIdx.y * 64u;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (blockIdx.y == 0 && threadIdx.x == 0) jq.gflag[blockIdx.x] = 0;
+    for (int i = ty; i < 64; i += 4) tl[i][tx] = b0 + i < nb ? jq.seg[(uint64_t)(b0 + i) * kJoinSlices + s0 + tx] : 0u;
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) jq.segT[(uint64_t)(s0 + i) * jq.bpad + b0 + tx] = tl[tx][i];
+}
+
+template <int KT, int PIPE>
+__global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, uint32_t nb, uint32_t reps,
+                                                      const uint64_t *__restrict__ ovf_code,
+                                                      const uint32_t *__restrict__ ovf_loc,
+                                                      const uint32_t *__restrict__ ovf_start) {
+    constexpr int PCAP = 64;  // deferred (second-chance / overflow) lookups resolved together
+    __shared__ uint4 sT[kJoinSliceBuckets];
+    __shared__ uint32_t sBase[16][65];
+    __shared__ unsigned long long sEnd[16][64];
+    __shared__ uint32_t sPend[16][PCAP][2];
+    __shared__ uint32_t sOvfKey[kJoinOvfMax], sOvfLoc[kJoinOvfMax];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t s = blockIdx.x % (uint32_t)kJoinSlices, rep = blockIdx.x / (uint32_t)kJoinSlices;
+    const int sb = ct.qb - 4;
+    const uint32_t n_ovf = ovf_start[s + 1] - ovf_start[s];
+    {
+        const uint4 *src = ct.buckets + ((uint64_t)(s >> 4) << ct.qb) + ((uint64_t)(s & 15u) << sb);
+        for (uint32_t i = tid; i < (1u << sb); i += 1024u) sT[i] = src[i];
+        if ((uint32_t)tid < n_ovf) {
+            sOvfKey[tid] = (uint32_t)ovf_code[ovf_start[s] + tid];  // the item part; the slice part is s
+            sOvfLoc[tid] = ovf_loc[ovf_start[s] + tid];
+        }
+    }
+    __syncthreads();
+    const int rembits = ct.rembits, locbits = ct.locbits;
+    const uint32_t remmask = (1u << rembits) - 1u;
+    const uint32_t locmask = (1u << locbits) - 1u;
+    const uint32_t slot0mask = ct.has_flag ? 0x3FFFFFFFu : 0xFFFFFFFFu;
+    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint32_t ng64 = jq.bpad / 64u;
+
+    // second lookup of a parked item: its second-chance bucket (same slice, alt bit set in the slot), then the slice's
+    // overflow keys; returns loc + 1 or 0
+    auto second = [&](uint32_t key, uint32_t flags) -> uint32_t {
+        const uint32_t bucket = key >> rembits, rem = key & remmask;
+        uint32_t res = 0;
+        if (flags & 1u) {
+            const uint4 b = sT[alt_bucket(bucket, rem, ct.qb)];
+            const uint32_t wa = (rem | (1u << rembits)) << locbits;
+            const uint32_t sl[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t e = (sl[i] ^ wa) & (i == 0 ? slot0mask : 0xFFFFFFFFu);
+                if (sl[i] != kEmptySlot32 && e < locmask) res = e + 1u;
+            }
+        }
+        if (!res && (flags & 2u)) {  // rare: the key overflowed both buckets at build time
+            uint32_t lo = 0, hi = n_ovf;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (sOvfKey[mid] < key) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo < n_ovf && sOvfKey[lo] == key) res = sOvfLoc[lo] + 1u;
+        }
+        return res;
+    };
+
+    const uint32_t ngroups = (nb + 63u) / 64u;
+    for (uint32_t g = rep * 16u + (uint32_t)wave; g < ngroups; g += reps * 16u) {
+        const uint32_t b = g * 64u + (uint32_t)lane;
+        const uint32_t sg = jq.segT[(uint64_t)s * jq.bpad + b];  // batches past nb are empty
+        const uint32_t cnt = sg >> 16, start = sg & 0xFFFFu;
+        uint32_t T;
+        const uint32_t ex = wave_excl_scan(cnt, lane, T);
+        uint32_t *hsub = jq.hsub + (uint64_t)g * 8u * kJoinSlices + s;  // [8 groups of 8 batches][slices]
+        if (T == 0 || T > kJoinHitCap) {
+            if (lane < 8) hsub[(uint32_t)lane * kJoinSlices] = 0u;
+            if (T && lane == 0) jq.gflag[g] = 1u;
+            continue;
+        }
+        // the items of the 64 batches as one stream: position -> batch through a bit vector of segment ends
+        const unsigned long long nz = __ballot(cnt != 0);
+        sEnd[wave][lane] = 0ULL;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (cnt) {
+            sBase[wave][__popcll(nz & lt)] = b * (uint32_t)kJoinWin + start - ex;
+            const uint32_t e = ex + cnt - 1u;
+            atomicOr(&sEnd[wave][e >> 6], 1ULL << (e & 63u));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long word = sEnd[wave][lane];
+        uint32_t unused;
+        const uint32_t before = wave_excl_scan((uint32_t)__popcll(word), lane, unused);
+        const uint32_t wlo = (uint32_t)word, whi = (uint32_t)(word >> 32);
+        const uint32_t nsteps = (T + 63u) / 64u;
+        uint32_t *hout = jq.hits + ((uint64_t)s * ng64 + g) * kJoinHitCap;
+        uint32_t cursor = 0;  // hits written so far (wave-uniform)
+        // hit-stream position where each 8-batch group starts: noted when the item stream crosses its first item
+        int jn = 0;         // next group whose start is not noted yet
+        uint32_t jpos = 0;  // its first item position (= ex of batch 8 jn)
+        uint32_t gstart[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) gstart[j] = 0;
+        for (uint32_t t0 = 0; t0 < nsteps; t0 += PIPE) {
+            uint32_t idx[PIPE], key[PIPE], res[PIPE];
+            int pslot[PIPE];
+#pragma unroll
+            for (int u = 0; u < PIPE; u++) {
+                const uint32_t t = (t0 + (uint32_t)u) & 63u, p = (t0 + (uint32_t)u) * 64u + (uint32_t)lane;
+                const uint32_t sl = lane_value(wlo, (int)t), sh = lane_value(whi, (int)t), sbv = lane_value(before, (int)t);
+                // lanes past T may name one segment past the last: sBase has a spare entry
+                const uint32_t ci = __builtin_amdgcn_mbcnt_hi(sh, __builtin_amdgcn_mbcnt_lo(sl, sbv));
+                idx[u] = sBase[wave][ci] + p;
+                key[u] = p < T ? jq.item[idx[u]] : 0xFFFFFFFFu;
+            }
+            // home buckets; lookups that need a second bucket or the overflow list are parked and resolved together
+            uint32_t npend = 0;  // wave-uniform
+            auto resolve = [&](int upto) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if ((uint32_t)lane < npend) sPend[wave][lane][0] = second(sPend[wave][lane][0], sPend[wave][lane][1]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int v = 0; v < PIPE; v++)
+                    if (v <= upto && pslot[v] >= 0) {
+                        res[v] = sPend[wave][pslot[v]][0];
+                        pslot[v] = -1;
+                    }
+                npend = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            };
+#pragma unroll
+            for (int u = 0; u < PIPE; u++) {
+                const bool live = (t0 + (uint32_t)u) * 64u + (uint32_t)lane < T;
+                const uint32_t bucket = (key[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1), rem = key[u] & remmask;
+                const uint4 bk = sT[bucket];
+                const uint32_t ws = rem << locbits;
+                const uint32_t e0 = (bk.x ^ ws) & slot0mask, e1 = bk.y ^ ws, e2 = bk.z ^ ws, e3 = bk.w ^ ws;
+                const uint32_t m = min(min(e0, e1), min(e2, e3));
+                // a matching slot leaves its loc (< locmask: the all-ones loc is never stored); an empty slot leaves at least locmask
+                const bool hit = live && m < locmask;
+                res[u] = hit ? m + 1u : 0u;
+                const bool full = bk.w != kEmptySlot32;  // slots fill in order
+                const uint32_t again = ct.has_flag ? (bk.x >> 31) : 0u;
+                const uint32_t generic = ct.has_flag ? ((bk.x >> 30) & 1u) : 1u;
+                const bool pend = live && !hit && full && (again | generic) != 0u;
+                pslot[u] = -1;
+                const unsigned long long pb = __ballot(pend);
+                if (pb) {
+                    const uint32_t np = __popcll(pb);
+                    if (npend + np > (uint32_t)PCAP) resolve(u - 1);
+                    if (pend) {
+                        pslot[u] = (int)(npend + (uint32_t)__popcll(pb & lt));
+                        sPend[wave][pslot[u]][0] = key[u];
+                        sPend[wave][pslot[u]][1] = again | (generic << 1);
+                    }
+                    npend += np;
+                }
+            }
+            if (npend) resolve(PIPE - 1);
+#pragma unroll
+            for (int u = 0; u < PIPE; u++) {
+                const unsigned long long hb = __ballot(res[u] != 0);
+                const uint32_t p0 = (t0 + (uint32_t)u) * 64u;
+                // 8-batch groups that start inside [p0, p0 + 64): their hits start after the hits of the lanes before
+                while (jn < 8 && jpos < p0 + 64u) {  // wave-uniform
+                    const uint32_t d = jpos > p0 ? jpos - p0 : 0u;
+                    const uint32_t v = cursor + (uint32_t)__popcll(hb & (d ? (~0ULL >> (64 - d)) : 0ULL));
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (j == jn) gstart[j] = v;
+                    jn++;
+                    jpos = jn < 8 ? lane_value(ex, jn * 8) : 0xFFFFFFFFu;
+                }
+                if (res[u]) hout[cursor + (uint32_t)__popcll(hb & lt)] = (idx[u] & 0xFFFFu) | (res[u] << 16);
+                cursor += (uint32_t)__popcll(hb);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j >= jn) gstart[j] = cursor;  // groups without items
+        gstart[8] = cursor;
+        if (lane < 8) {
+            uint32_t st = 0, en = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (j == lane) {
+                    st = gstart[j];
+                    en = gstart[j + 1];
+                }
+            hsub[(uint32_t)lane * kJoinSlices] = st | ((en - st) << 16);
+        }
+    }
+}
+
+// One workgroup per 8 batches (32 tiles).  loc + 1 per window in LDS, 16 bits each; lane l of the wave that owns a tile
+// reads its 32 windows as one 64-byte row, the 16-byte pieces of a row rotated by l to spread the banks.
+__global__ __launch_bounds__(1024) void k_join_merge(JoinQ jq, uint32_t batch0, uint32_t nb, uint32_t n_tiles, TileArrays ta,
+                                                     uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
+                                                     uint32_t *complex_list, uint32_t *complex_n) {
+    __shared__ __align__(16) uint16_t locat[kJoinMergeBatches * kJoinWin];  // 128 KiB
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t g8 = blockIdx.x, g64 = g8 >> 3;
+    const uint32_t tile_lo = (batch0 + g8 * kJoinMergeBatches) * kJoinTiles;
+    if (jq.gflag[g64]) {  // degenerate group: exact generic probe for these tiles
+        if (tid < kJoinMergeBatches * kJoinTiles && tile_lo + tid < n_tiles) complex_list[atomicAdd(complex_n, 1u)] = tile_lo + tid;
+        return;
+    }
+    // the 16 hit streams this wave scatters (slices wave, wave + 16, ...): start/count first, so that the loads overlap the clear
+    const uint32_t hs_mine = lane < 16 ? jq.hsub[(uint64_t)g8 * kJoinSlices + (uint32_t)wave + 16u * (uint32_t)lane] : 0u;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(locat) / 16 / 1024); i++) reinterpret_cast<uint4 *>(locat)[tid + 1024 * i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t ng64 = jq.bpad / 64u;
+    const uint16_t *woff = jq.woff + (uint64_t)g8 * kJoinMergeBatches * kJoinWin;
+    auto put = [&](uint32_t rec, uint32_t wo) {
+        const uint32_t w = (((rec & 0xFFFFu) >> 13) << 13) | wo;  // window inside the 8 batches
+        locat[(w & ~31u) | ((((w >> 3) + (w >> 5)) & 3u) << 3) | (w & 7u)] = (uint16_t)(rec >> 16);
+    };
+    constexpr int MU = 4;  // streams in flight per wave
+    for (int i0 = 0; i0 < 16; i0 += MU) {
+        uint32_t rec[MU], wo[MU], cnt[MU];
+        const uint32_t *h[MU];
+#pragma unroll
+        for (int u = 0; u < MU; u++) {
+            const uint32_t hs = lane_value(hs_mine, i0 + u);
+            const uint32_t sl = (uint32_t)wave + 16u * (uint32_t)(i0 + u);
+            cnt[u] = hs >> 16;
+            h[u] = jq.hits + ((uint64_t)sl * ng64 + g64) * kJoinHitCap + (hs & 0xFFFFu);
+            rec[u] = (uint32_t)lane < cnt[u] ? h[u][lane] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < MU; u++) wo[u] = rec[u] ? woff[rec[u] & 0xFFFFu] : 0u;
+#pragma unroll
+        for (int u = 0; u < MU; u++)
+            if (rec[u]) put(rec[u], wo[u]);
+#pragma unroll
+        for (int u = 0; u < MU; u++)
+            for (uint32_t j = 64u + (uint32_t)lane; j < cnt[u]; j += 64u) {  // long streams (rare)
+                const uint32_t r2 = h[u][j];
+                put(r2, woff[r2 & 0xFFFFu]);
+            }
+    }
+    __syncthreads();
+    for (int i = 0; i < 2; i++) {
+        const uint32_t tl = (uint32_t)wave * 2u + (uint32_t)i;  // tile inside the group
+        const uint32_t tile = tile_lo + tl;
+        if (tile >= n_tiles) break;
+        uint32_t raw = 0, chg = 0, first_loc = GS_NONE, prev = GS_NONE;
+        const uint4 *row = reinterpret_cast<const uint4 *>(locat + tl * kTileWindows + lane * 32);
+#pragma unroll
+        for (int pc = 0; pc < 4; pc++) {
+            const uint4 v4 = row[(pc + lane) & 3];
+            const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int bb = pc * 8 + c;
+                const uint32_t x = (v[c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
+                if (x) {
+                    const uint32_t loc = x - 1u;
+                    raw |= 1u << bb;
+                    if (prev == GS_NONE) first_loc = loc;
+                    else if (loc != prev) chg |= 1u << bb;
+                    prev = loc;
+                }
+            }
+        }
+        tile_summary(raw, chg, first_loc, prev, tile, n_tiles, ta, cand, cand_cap, g_cand_count);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // tile scans (3 launches each): exclusive scan of {sum, last non-empty loc}
 // ------------------------------------------------------------------------------------------
 struct Agg {
@@ -1351,6 +1754,12 @@ struct gs_table {
     uint32_t *cpayload = nullptr;  // payload per compact slot
     int c_qb = 0, c_rembits = 0, c_locbits = 0, c_has_flag = 0, c_w64 = 0;
     uint64_t c_overflow = 0;
+    // LDS join (k = 20): the compact table's slices are probed from LDS; keys that overflowed both buckets, in
+    // hashed form (slice << 32 | item), sorted
+    int join = 0;
+    uint64_t *j_ovf_code = nullptr;
+    uint32_t *j_ovf_loc = nullptr;
+    uint32_t *j_ovf_start = nullptr;  // [kJoinSlices + 1] first overflow key of every slice
     uint32_t *d_complex_n = nullptr;
     PassStatus *d_status = nullptr;       // the five scalars below live in this one block
     PassStatus *h_status = nullptr;       // pinned: filled by an async copy at the end of a pass
@@ -1391,6 +1800,7 @@ struct gs_reads {
     TileDesc *tile_desc = nullptr;     // [n_tiles]
     PartRec *part_recs = nullptr;      // [n_tiles * kNPart], fast path only
     uint32_t *complex_list = nullptr;  // [n_tiles]
+    JoinQ jq{};                        // LDS join queues for min(batches, kJoinChunk) batches
 };
 
 namespace {
@@ -1416,7 +1826,19 @@ int ensure_out_buffers(gs_reads *r, uint32_t cand_cap) {
 
 int launch_phase1(gs_table *t, gs_reads *r) {
     HIP_TRY(hipSetDevice(t->device));
-    if (t->compact == 1 && r->n_tiles && !r->part_recs) {
+    if (t->compact == 1 && t->join && r->n_tiles && !r->jq.item) {
+        int rc;
+        const uint64_t nb = std::min<uint64_t>(kJoinChunk, (r->n_tiles + kJoinTiles - 1) / kJoinTiles);
+        const uint64_t bpad = (nb + 63) / 64 * 64;
+        r->jq.bpad = (uint32_t)bpad;
+        if ((rc = dev_alloc(&r->jq.item, nb * kJoinWin)) || (rc = dev_alloc(&r->jq.woff, bpad * kJoinWin)) ||
+            (rc = dev_alloc(&r->jq.seg, nb * kJoinSlices)) || (rc = dev_alloc(&r->jq.segT, bpad * kJoinSlices)) ||
+            (rc = dev_alloc(&r->jq.hits, bpad / 64 * kJoinSlices * kJoinHitCap)) ||
+            (rc = dev_alloc(&r->jq.hsub, bpad / 8 * kJoinSlices)) || (rc = dev_alloc(&r->jq.gflag, bpad / 64)) ||
+            (rc = dev_alloc(&r->complex_list, r->n_tiles)))
+            return rc;
+    }
+    if (t->compact == 1 && !t->join && r->n_tiles && !r->part_recs) {
         int rc;
         if ((rc = dev_alloc(&r->part_recs, (uint64_t)r->n_tiles * kNPart))) return rc;
         if ((rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
@@ -1430,7 +1852,37 @@ int launch_phase1(gs_table *t, gs_reads *r) {
     if (r->n_tiles) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
-        if (t->compact == 1) {
+        if (t->compact == 1 && t->join) {
+            const uint32_t n_batches = (r->n_tiles + kJoinTiles - 1) / kJoinTiles;
+            const char *env_reps = getenv("GAVISUNK_JOIN_REPS");  // tuning: workgroups per table slice
+            const uint32_t reps = env_reps ? std::max(1, atoi(env_reps)) : 1u;
+            const char *env_jp = getenv("GAVISUNK_JOIN_PIPE");  // tuning: item loads in flight per lane
+            const int jpipe = env_jp ? atoi(env_jp) : 4;
+            for (uint32_t b0 = 0; b0 < n_batches; b0 += kJoinChunk) {
+                const uint32_t nb = std::min(kJoinChunk, n_batches - b0);
+                const uint32_t ng64 = (nb + 63) / 64;
+                hipLaunchKernelGGL((k_join_bin<20>), dim3(nb), dim3(1024), 0, t->stream, cv, (const uint64_t *)r->words,
+                                   (const TileDesc *)r->tile_desc, r->n_tiles, b0, r->jq);
+                hipLaunchKernelGGL(k_join_segT, dim3(ng64, kJoinSlices / 64), dim3(256), 0, t->stream, r->jq, nb);
+#define GS_LAUNCH_JOIN_PROBE(PIPE)                                                                                        \
+    hipLaunchKernelGGL((k_join_probe<20, PIPE>), dim3(kJoinSlices * reps), dim3(1024), 0, t->stream, cv, r->jq, nb, reps, \
+                       (const uint64_t *)t->j_ovf_code, (const uint32_t *)t->j_ovf_loc, (const uint32_t *)t->j_ovf_start)
+                if (jpipe == 16)
+                    GS_LAUNCH_JOIN_PROBE(16);
+                else if (jpipe == 8)
+                    GS_LAUNCH_JOIN_PROBE(8);
+                else
+                    GS_LAUNCH_JOIN_PROBE(4);
+#undef GS_LAUNCH_JOIN_PROBE
+                hipLaunchKernelGGL(k_join_merge, dim3((nb + kJoinMergeBatches - 1) / kJoinMergeBatches), dim3(1024), 0, t->stream,
+                                   r->jq, b0, nb, r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list,
+                                   t->d_complex_n);
+            }
+            // tiles of degenerate groups (none on ordinary reads): generic exact probe, grid-stride over the list
+            hipLaunchKernelGGL(k_probe<true>, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), cv,
+                               view(r), r->ta, r->cand, r->cand_cap, t->d_cand_count, t->d_err_pos,
+                               (const uint32_t *)r->complex_list, (const uint32_t *)t->d_complex_n);
+        } else if (t->compact == 1) {
             const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
             const int mode = dbg ? atoi(dbg) : 0;
             const char *env_nt = getenv("GAVISUNK_PART_TILES"), *env_pipe = getenv("GAVISUNK_PART_PIPE");  // tuning experiments
@@ -1670,6 +2122,45 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
         t->c_overflow = ov;
         t->cbuckets = reinterpret_cast<uint4 *>(d);
         n_generic = ov;
+        // LDS join: k = 20 makes a slice (partition x top 4 bucket bits) exactly a 32-bit item space
+        const char *env = getenv("GAVISUNK_TABLE");
+        t->join = t->compact == 1 && k == 20 && t->c_qb >= 5 && t->c_qb - 4 <= 13 && t->c_locbits <= 15 && env &&
+                  !strcmp(env, "compact-lds");
+        if (t->join) {
+            std::vector<uint32_t> list(ov);
+            if (ov) HIP_TRY(hipMemcpy(list.data(), dlist, ov * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            std::vector<std::pair<uint64_t, uint32_t>> codes(ov);
+            const int kbits = 2 * k - 4, sb = t->c_qb - 4;
+            for (uint64_t i = 0; i < ov; i++) {
+                const uint64_t c = keys[list[i]];
+                const BucketRem br = hmix2((c >> 4) & ((1ULL << kbits) - 1ULL), kbits, t->c_qb);
+                const uint64_t slice = ((uint64_t)part_of(c, k) << 4) | (br.bucket >> sb);
+                const uint64_t item = ((uint64_t)(br.bucket & ((1u << sb) - 1u)) << t->c_rembits) | br.rem;
+                codes[i] = {(slice << 32) | item, loc[list[i]]};
+            }
+            std::sort(codes.begin(), codes.end());
+            std::vector<uint64_t> hc(ov);
+            std::vector<uint32_t> hl(ov), hs(kJoinSlices + 1, 0);
+            for (uint64_t i = 0; i < ov; i++) {
+                hc[i] = codes[i].first;
+                hl[i] = codes[i].second;
+                hs[(codes[i].first >> 32) + 1]++;
+            }
+            for (int i = 0; i < kJoinSlices; i++) {
+                if (hs[i + 1] > (uint32_t)kJoinOvfMax) t->join = 0;  // a slice's overflow keys must fit its LDS side list
+                hs[i + 1] += hs[i];
+            }
+            if (t->join) {
+                if ((rc = dev_alloc(&t->j_ovf_code, ov)) || (rc = dev_alloc(&t->j_ovf_loc, ov)) ||
+                    (rc = dev_alloc(&t->j_ovf_start, kJoinSlices + 1)))
+                    return rc;
+                if (ov) {
+                    HIP_TRY(hipMemcpy(t->j_ovf_code, hc.data(), ov * sizeof(uint64_t), hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpy(t->j_ovf_loc, hl.data(), ov * sizeof(uint32_t), hipMemcpyHostToDevice));
+                }
+                HIP_TRY(hipMemcpy(t->j_ovf_start, hs.data(), hs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
+        }
     }
     int lg;
     t->cap = pow2_cap(2 * n_generic, lg);
@@ -1699,7 +2190,7 @@ const char *gs_table_layout(const gs_table *t) {
     if (!t) return "";
     if (t->compact)
         snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x %s (%d-bit remainder, %d-bit loc%s), %llu overflow keys in a generic 16 B-slot side table",
-                 t->compact == 1 ? "compact-l2" : "compact-hbm", t->c_qb, t->c_w64 ? "u64" : "u32", t->c_rembits, t->c_locbits,
+                 t->compact == 1 ? (t->join ? "compact-lds" : "compact-l2") : "compact-hbm", t->c_qb, t->c_w64 ? "u64" : "u32", t->c_rembits, t->c_locbits,
                  t->c_has_flag ? ", second-chance buckets" : "", (unsigned long long)t->c_overflow);
     else
         snprintf(buf, sizeof buf, "generic: open-addressed 16 B slots in HBM");
@@ -1713,6 +2204,9 @@ void gs_table_destroy(gs_table *t) {
     (void)hipFree(t->slots);
     (void)hipFree(t->cbuckets);
     (void)hipFree(t->cpayload);
+    (void)hipFree(t->j_ovf_code);
+    (void)hipFree(t->j_ovf_loc);
+    (void)hipFree(t->j_ovf_start);
     (void)hipFree(t->d_status);
     if (t->h_status) (void)hipHostFree(t->h_status);
     if (t->h_init) (void)hipHostFree(t->h_init);
@@ -1919,6 +2413,13 @@ void gs_reads_destroy(gs_reads *r) {
     (void)hipFree(r->hits);
     (void)hipFree(r->tile_desc);
     (void)hipFree(r->part_recs);
+    (void)hipFree(r->jq.item);
+    (void)hipFree(r->jq.woff);
+    (void)hipFree(r->jq.seg);
+    (void)hipFree(r->jq.segT);
+    (void)hipFree(r->jq.hits);
+    (void)hipFree(r->jq.hsub);
+    (void)hipFree(r->jq.gflag);
     (void)hipFree(r->complex_list);
     delete r;
 }

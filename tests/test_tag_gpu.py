@@ -12,10 +12,11 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "compact-hbm", "generic"], autouse=True)
+@pytest.fixture(params=["auto", "compact-lds", "compact-hbm", "generic"], autouse=True)
 def table_layout(request, monkeypatch):
-    """Every test runs three times: with the layout the library picks (small k<=20 tables get the exact compact
-    copy probed out of the XCD-partitioned L2), with the compact table treated as HBM-resident (the layout of
+    """Every test runs four times: with the layout the library picks (small k <= 20 tables get the exact compact
+    copy probed out of the XCD-partitioned L2), with the radix join that probes the compact table's slices from
+    LDS (k = 20 only; other k keep the L2 path), with the compact table treated as HBM-resident (the layout of
     tables too large for L2), and with the generic 16-byte-slot table forced."""
     monkeypatch.setenv("GAVISUNK_TABLE", request.param)
     return request.param
@@ -167,7 +168,13 @@ def test_empty_and_tiny_batches():
 def test_layout_selection(table_layout):
     keys, loc, _ = _random_case(3, 20)
     tab = engine.DeviceTable(20, keys, loc, np.arange(len(keys), dtype=np.uint32))
-    assert tab.layout.startswith({"auto": "compact-l2", "compact-hbm": "compact-hbm", "generic": "generic"}[table_layout])
+    assert tab.layout.startswith({"auto": "compact-l2", "compact-lds": "compact-lds", "compact-hbm": "compact-hbm",
+                                  "generic": "generic"}[table_layout])
+    tab.close()
+    keys, loc, _ = _random_case(3, 18)
+    tab = engine.DeviceTable(18, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    assert tab.layout.startswith({"auto": "compact-l2", "compact-lds": "compact-l2", "compact-hbm": "compact-hbm",
+                                  "generic": "generic"}[table_layout])
     tab.close()
     keys, loc, _ = _random_case(3, 25)
     tab = engine.DeviceTable(25, keys, loc, np.arange(len(keys), dtype=np.uint32))

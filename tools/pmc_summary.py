@@ -2,13 +2,13 @@
 """Summarise rocprofv3 --pmc counter_collection.csv files: mean counter value per kernel name."""
 import csv, glob, sys, collections
 for d in sys.argv[1:]:
-    for f in glob.glob(d + "/*/*counter_collection.csv"):
+    for f in glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in acc.items():
-            if not k.startswith(("k_probe", "k_merge")):
+            if not k.startswith(("k_probe", "k_merge", "k_join")):
                 continue
             dur = None
             print(k, " ".join(f"{c}={sum(v)/len(v):.5g}" for c, v in sorted(cs.items())), f"(n={len(next(iter(cs.values())))})")
