@@ -1069,7 +1069,8 @@ constexpr int kJoinSliceBuckets = 8192;              // LDS image of a slice: <=
 constexpr int kJoinOvfMax = 256;                     // overflow keys of a slice kept in LDS
 constexpr uint32_t kJoinChunk = 32768;               // batches per queue buffer
 constexpr uint32_t kJoinHitCap = 4096;               // hit records per (slice, 64 batches): the fast path cannot exceed it
-constexpr int kJoinMergeBatches = 8;                 // batches per k_join_merge workgroup
+constexpr int kJoinMergeBatches = 4;                 // batches per k_join_merge workgroup (64 KiB of LDS: two per CU)
+constexpr int kJoinSub = 64 / kJoinMergeBatches;     // such groups per hit stream
 
 struct JoinQ {
     uint32_t *item;   // [batches][kJoinWin]     hashed key (bucket in slice | remainder), grouped by slice
@@ -1077,21 +1078,23 @@ struct JoinQ {
     uint32_t *seg;    // [batches][kJoinSlices]  start | count << 16 of a slice's items inside the batch
     uint32_t *segT;   // [kJoinSlices][bpad]     the same, transposed (bpad = batches rounded up to 64)
     uint32_t *hits;   // [kJoinSlices][bpad / 64][kJoinHitCap]  item position (16 bits: batch & 7, index) | (loc + 1) << 16
-    uint32_t *hsub;   // [bpad / 8][kJoinSlices] start | count << 16 of an 8-batch group inside its hit stream
+    uint32_t *hsub;   // [bpad / kJoinMergeBatches][kJoinSlices] start | count << 16 of a merge group inside its hit stream
     uint32_t *gflag;  // [bpad / 64]             1 = degenerate group: its tiles go to the generic probe
     uint32_t bpad;
 };
 
 template <int KT>
-__global__ __launch_bounds__(1024) void k_join_bin(CompactView ct, const uint64_t *__restrict__ words,
-                                                    const TileDesc *__restrict__ tdesc, uint32_t n_tiles, uint32_t batch0,
-                                                    JoinQ jq) {
+__global__ __launch_bounds__(1024, 8) void k_join_bin(CompactView ct, const uint64_t *__restrict__ words,
+                                                       const TileDesc *__restrict__ tdesc, uint32_t n_tiles, uint32_t batch0,
+                                                       JoinQ jq) {
     __shared__ __align__(16) uint32_t dkey[kJoinWin];
     __shared__ __align__(16) uint16_t dwoff[kJoinWin];
     __shared__ __align__(16) uint32_t cnt[kJoinSlices];
     __shared__ __align__(16) uint32_t off[kJoinSlices];
     constexpr int k = KT;
     constexpr int kbits = 2 * k - 4;
+    static_assert(8 + KT - 1 <= 32, "the 8 windows of a thread must fit one 64-bit word");
+    constexpr uint64_t kmask = (1ULL << (2 * k)) - 1ULL, keymask = (1ULL << kbits) - 1ULL;
     const int tid = threadIdx.x;
     const uint32_t bl = blockIdx.x;
     if (tid < kJoinSlices) cnt[tid] = 0;
@@ -1108,8 +1111,6 @@ __global__ __launch_bounds__(1024) void k_join_bin(CompactView ct, const uint64_
     const int s = 16 * h;
     const uint64_t X = s ? ((a << s) | (b2 >> (64 - s))) : a;  // my 8 windows start at bases 0..7 of X (8 + k - 1 <= 32 bases)
     const uint64_t R = ~revpairs(X);                            // base i of X, complemented, at bits 2i+1:2i
-    static_assert(8 + KT - 1 <= 32, "the 8 windows of a thread must fit one 64-bit word");
-    constexpr uint64_t kmask = (1ULL << (2 * k)) - 1ULL, keymask = (1ULL << kbits) - 1ULL;
     const int sb = ct.qb - 4;  // bucket bits inside a slice; sb + rembits = 32
     uint32_t item[8], sr[8];
 #pragma unroll
@@ -1118,10 +1119,10 @@ __global__ __launch_bounds__(1024) void k_join_bin(CompactView ct, const uint64_
         const uint64_t r = (R >> (2 * j)) & kmask;
         const uint64_t c = f < r ? f : r;
         const BucketRem br = hmix2((c >> 4) & keymask, kbits, ct.qb);
-        const uint32_t slice = (part_of(c, k) << 4) | (br.bucket >> sb);
         item[j] = ((br.bucket & ((1u << sb) - 1u)) << ct.rembits) | (uint32_t)br.rem;
-        const uint32_t rank = (uint32_t)j < nvalid ? atomicAdd(&cnt[slice], 1u) : 0u;
-        sr[j] = slice | (rank << 8);
+        const uint32_t slice = (part_of(c, k) << 4) | (br.bucket >> sb);
+        // (an unconditional add to a dummy counter, so that the eight atomics overlap, measured slower)
+        sr[j] = slice | (((uint32_t)j < nvalid ? atomicAdd(&cnt[slice], 1u) : 0u) << 9);
     }
     __syncthreads();
     if (tid < 64) {  // exclusive prefix over the 256 counters, 4 per lane
@@ -1137,7 +1138,7 @@ __global__ __launch_bounds__(1024) void k_join_bin(CompactView ct, const uint64_
 #pragma unroll
     for (int j = 0; j < 8; j++)
         if ((uint32_t)j < nvalid) {
-            const uint32_t pos = off[sr[j] & 255u] + (sr[j] >> 8);
+            const uint32_t pos = off[sr[j] & 255u] + (sr[j] >> 9);
             dkey[pos] = item[j];
             dwoff[pos] = (uint16_t)(((uint32_t)q << 11) | (w0 + (uint32_t)j));
         }
@@ -1164,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_join_segT(JoinQ jq, uint32_t nb) {
     for (int i = ty; i < 64; i += 4) jq.segT[(uint64_t)(s0 + i) * jq.bpad + b0 + tx] = tl[tx][i];
 }
 
-template <int KT, int PIPE>
+template <int KT, int PIPE, bool HASFLAG>
 __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, uint32_t nb, uint32_t reps,
                                                       const uint64_t *__restrict__ ovf_code,
                                                       const uint32_t *__restrict__ ovf_loc,
@@ -1174,6 +1175,7 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
     __shared__ uint32_t sBase[16][65];
     __shared__ unsigned long long sEnd[16][64];
     __shared__ uint32_t sPend[16][PCAP][2];
+    __shared__ uint32_t sG[16][kJoinSub + 1];
     __shared__ uint32_t sOvfKey[kJoinOvfMax], sOvfLoc[kJoinOvfMax];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t s = blockIdx.x % (uint32_t)kJoinSlices, rep = blockIdx.x / (uint32_t)kJoinSlices;
@@ -1191,7 +1193,7 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
     const int rembits = ct.rembits, locbits = ct.locbits;
     const uint32_t remmask = (1u << rembits) - 1u;
     const uint32_t locmask = (1u << locbits) - 1u;
-    const uint32_t slot0mask = ct.has_flag ? 0x3FFFFFFFu : 0xFFFFFFFFu;
+    constexpr uint32_t slot0mask = HASFLAG ? 0x3FFFFFFFu : 0xFFFFFFFFu;
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     const uint32_t ng64 = jq.bpad / 64u;
 
@@ -1223,15 +1225,19 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
     };
 
     const uint32_t ngroups = (nb + 63u) / 64u;
-    for (uint32_t g = rep * 16u + (uint32_t)wave; g < ngroups; g += reps * 16u) {
+    const uint32_t gfirst = rep * 16u + (uint32_t)wave, gstep = reps * 16u;
+    uint32_t sg_next = gfirst < ngroups ? jq.segT[(uint64_t)s * jq.bpad + gfirst * 64u + (uint32_t)lane] : 0u;
+    for (uint32_t g = gfirst; g < ngroups; g += gstep) {
         const uint32_t b = g * 64u + (uint32_t)lane;
-        const uint32_t sg = jq.segT[(uint64_t)s * jq.bpad + b];  // batches past nb are empty
+        const uint32_t sg = sg_next;  // batches past nb are empty
+        // the next group's start/count table is on its way while this group is probed
+        if (g + gstep < ngroups) sg_next = jq.segT[(uint64_t)s * jq.bpad + (g + gstep) * 64u + (uint32_t)lane];
         const uint32_t cnt = sg >> 16, start = sg & 0xFFFFu;
         uint32_t T;
         const uint32_t ex = wave_excl_scan(cnt, lane, T);
-        uint32_t *hsub = jq.hsub + (uint64_t)g * 8u * kJoinSlices + s;  // [8 groups of 8 batches][slices]
+        uint32_t *hsub = jq.hsub + (uint64_t)g * kJoinSub * kJoinSlices + s;  // [merge groups of the 64 batches][slices]
         if (T == 0 || T > kJoinHitCap) {
-            if (lane < 8) hsub[(uint32_t)lane * kJoinSlices] = 0u;
+            if (lane < kJoinSub) hsub[(uint32_t)lane * kJoinSlices] = 0u;
             if (T && lane == 0) jq.gflag[g] = 1u;
             continue;
         }
@@ -1254,114 +1260,130 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
         const uint32_t nsteps = (T + 63u) / 64u;
         uint32_t *hout = jq.hits + ((uint64_t)s * ng64 + g) * kJoinHitCap;
         uint32_t cursor = 0;  // hits written so far (wave-uniform)
-        // hit-stream position where each 8-batch group starts: noted when the item stream crosses its first item
+        // hit-stream position where each merge group starts: noted when the item stream crosses its first item
         int jn = 0;         // next group whose start is not noted yet
-        uint32_t jpos = 0;  // its first item position (= ex of batch 8 jn)
-        uint32_t gstart[9];
-#pragma unroll
-        for (int j = 0; j < 9; j++) gstart[j] = 0;
-        for (uint32_t t0 = 0; t0 < nsteps; t0 += PIPE) {
-            uint32_t idx[PIPE], key[PIPE], res[PIPE];
-            int pslot[PIPE];
+        uint32_t jpos = 0;  // its first item position (= ex of its first batch)
+
+        uint32_t idx_n[PIPE], key_n[PIPE];  // the next window's items, loaded while this window is probed
+        auto fetch = [&](uint32_t t0) {
 #pragma unroll
             for (int u = 0; u < PIPE; u++) {
                 const uint32_t t = (t0 + (uint32_t)u) & 63u, p = (t0 + (uint32_t)u) * 64u + (uint32_t)lane;
                 const uint32_t sl = lane_value(wlo, (int)t), sh = lane_value(whi, (int)t), sbv = lane_value(before, (int)t);
                 // lanes past T may name one segment past the last: sBase has a spare entry
                 const uint32_t ci = __builtin_amdgcn_mbcnt_hi(sh, __builtin_amdgcn_mbcnt_lo(sl, sbv));
-                idx[u] = sBase[wave][ci] + p;
-                key[u] = p < T ? jq.item[idx[u]] : 0xFFFFFFFFu;
+                idx_n[u] = sBase[wave][ci] + p;
+                key_n[u] = jq.item[p < T ? idx_n[u] : 0u];  // no branch: lanes past T read a valid word and are masked below
             }
+        };
+        uint4 bk_n[PIPE];                   // and their home buckets
+        fetch(0);
+#pragma unroll
+        for (int u = 0; u < PIPE; u++) bk_n[u] = sT[(key_n[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1)];
+        for (uint32_t t0 = 0; t0 < nsteps; t0 += PIPE) {
+            uint32_t idx[PIPE], key[PIPE], res[PIPE];
+            uint4 bk[PIPE];
+            int pslot[PIPE];
+#pragma unroll
+            for (int u = 0; u < PIPE; u++) {
+                idx[u] = idx_n[u];
+                key[u] = key_n[u];
+                bk[u] = bk_n[u];
+            }
+            const bool more = t0 + PIPE < nsteps;  // wave-uniform
+            if (more) fetch(t0 + PIPE);
             // home buckets; lookups that need a second bucket or the overflow list are parked and resolved together
-            uint32_t npend = 0;  // wave-uniform
-            auto resolve = [&](int upto) {
+            uint32_t pfl[PIPE];  // 0, or what a parked lookup still has to try: bit 0 second-chance bucket, bit 1 overflow list
+            uint32_t anyp = 0;
+#pragma unroll
+            for (int u = 0; u < PIPE; u++) {
+                const bool live = (t0 + (uint32_t)u) * 64u + (uint32_t)lane < T;
+                const uint32_t ws = (key[u] & remmask) << locbits;
+                const uint32_t e0 = (bk[u].x ^ ws) & slot0mask, e1 = bk[u].y ^ ws, e2 = bk[u].z ^ ws, e3 = bk[u].w ^ ws;
+                const uint32_t m = min(min(e0, e1), min(e2, e3));
+                // a matching slot leaves its loc (< locmask: the all-ones loc is never stored); an empty slot leaves at least locmask
+                const bool hit = live && m < locmask;
+                res[u] = hit ? m + 1u : 0u;
+                // bits 31:30 of slot 0: a key of this bucket lives in its second-chance bucket / in the overflow list only
+                // (set on full buckets only; an empty slot 0 has them set too, hence the test on slot 3: slots fill in order)
+                const uint32_t pf = HASFLAG ? (bk[u].x >> 30) : 1u;
+                const bool pend = live && !hit && bk[u].w != kEmptySlot32;
+                pfl[u] = pend ? (HASFLAG ? (pf >> 1) | ((pf & 1u) << 1) : 2u) : 0u;
+                anyp |= pfl[u];
+                pslot[u] = -1;
+            }
+            if (more) {  // the next window's bucket reads are in flight while this window is finished
+#pragma unroll
+                for (int u = 0; u < PIPE; u++) bk_n[u] = sT[(key_n[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1)];
+            }
+            while (__ballot(anyp != 0)) {  // wave-uniform; one round unless more than PCAP lookups of the window are parked
+                uint32_t npend = 0;
+#pragma unroll
+                for (int u = 0; u < PIPE; u++) {
+                    const unsigned long long pb = __ballot(pfl[u] != 0);
+                    const uint32_t np = __popcll(pb);
+                    if (pb && npend + np <= (uint32_t)PCAP) {
+                        if (pfl[u]) {
+                            pslot[u] = (int)(npend + (uint32_t)__popcll(pb & lt));
+                            sPend[wave][pslot[u]][0] = key[u];
+                            sPend[wave][pslot[u]][1] = pfl[u];
+                        }
+                        npend += np;
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if ((uint32_t)lane < npend) sPend[wave][lane][0] = second(sPend[wave][lane][0], sPend[wave][lane][1]);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                anyp = 0;
 #pragma unroll
-                for (int v = 0; v < PIPE; v++)
-                    if (v <= upto && pslot[v] >= 0) {
-                        res[v] = sPend[wave][pslot[v]][0];
-                        pslot[v] = -1;
+                for (int u = 0; u < PIPE; u++) {
+                    if (pslot[u] >= 0) {
+                        res[u] = sPend[wave][pslot[u]][0];
+                        pfl[u] = 0;
+                        pslot[u] = -1;
                     }
-                npend = 0;
+                    anyp |= pfl[u];
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-            };
-#pragma unroll
-            for (int u = 0; u < PIPE; u++) {
-                const bool live = (t0 + (uint32_t)u) * 64u + (uint32_t)lane < T;
-                const uint32_t bucket = (key[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1), rem = key[u] & remmask;
-                const uint4 bk = sT[bucket];
-                const uint32_t ws = rem << locbits;
-                const uint32_t e0 = (bk.x ^ ws) & slot0mask, e1 = bk.y ^ ws, e2 = bk.z ^ ws, e3 = bk.w ^ ws;
-                const uint32_t m = min(min(e0, e1), min(e2, e3));
-                // a matching slot leaves its loc (< locmask: the all-ones loc is never stored); an empty slot leaves at least locmask
-                const bool hit = live && m < locmask;
-                res[u] = hit ? m + 1u : 0u;
-                const bool full = bk.w != kEmptySlot32;  // slots fill in order
-                const uint32_t again = ct.has_flag ? (bk.x >> 31) : 0u;
-                const uint32_t generic = ct.has_flag ? ((bk.x >> 30) & 1u) : 1u;
-                const bool pend = live && !hit && full && (again | generic) != 0u;
-                pslot[u] = -1;
-                const unsigned long long pb = __ballot(pend);
-                if (pb) {
-                    const uint32_t np = __popcll(pb);
-                    if (npend + np > (uint32_t)PCAP) resolve(u - 1);
-                    if (pend) {
-                        pslot[u] = (int)(npend + (uint32_t)__popcll(pb & lt));
-                        sPend[wave][pslot[u]][0] = key[u];
-                        sPend[wave][pslot[u]][1] = again | (generic << 1);
-                    }
-                    npend += np;
-                }
             }
-            if (npend) resolve(PIPE - 1);
 #pragma unroll
             for (int u = 0; u < PIPE; u++) {
                 const unsigned long long hb = __ballot(res[u] != 0);
                 const uint32_t p0 = (t0 + (uint32_t)u) * 64u;
                 // 8-batch groups that start inside [p0, p0 + 64): their hits start after the hits of the lanes before
-                while (jn < 8 && jpos < p0 + 64u) {  // wave-uniform
+                while (jn < kJoinSub && jpos < p0 + 64u) {  // wave-uniform
                     const uint32_t d = jpos > p0 ? jpos - p0 : 0u;
                     const uint32_t v = cursor + (uint32_t)__popcll(hb & (d ? (~0ULL >> (64 - d)) : 0ULL));
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (j == jn) gstart[j] = v;
+                    if (lane == 0) sG[wave][jn] = v;
                     jn++;
-                    jpos = jn < 8 ? lane_value(ex, jn * 8) : 0xFFFFFFFFu;
+                    jpos = jn < kJoinSub ? lane_value(ex, jn * kJoinMergeBatches) : 0xFFFFFFFFu;
                 }
                 if (res[u]) hout[cursor + (uint32_t)__popcll(hb & lt)] = (idx[u] & 0xFFFFu) | (res[u] << 16);
                 cursor += (uint32_t)__popcll(hb);
             }
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (j >= jn) gstart[j] = cursor;  // groups without items
-        gstart[8] = cursor;
-        if (lane < 8) {
-            uint32_t st = 0, en = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (j == lane) {
-                    st = gstart[j];
-                    en = gstart[j + 1];
-                }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < kJoinSub) {
+            // groups whose first item was never reached have no items: they start (and end) at the end of the stream
+            const uint32_t st = lane < jn ? sG[wave][lane] : cursor;
+            const uint32_t en = lane + 1 < jn ? sG[wave][lane + 1] : cursor;
             hsub[(uint32_t)lane * kJoinSlices] = st | ((en - st) << 16);
         }
     }
 }
 
-// One workgroup per 8 batches (32 tiles).  loc + 1 per window in LDS, 16 bits each; lane l of the wave that owns a tile
-// reads its 32 windows as one 64-byte row, the 16-byte pieces of a row rotated by l to spread the banks.
-__global__ __launch_bounds__(1024) void k_join_merge(JoinQ jq, uint32_t batch0, uint32_t nb, uint32_t n_tiles, TileArrays ta,
+// One workgroup per 4 batches (16 tiles, one per wave).  loc + 1 per window in LDS, 16 bits each; lane l of the wave that owns a
+// tile reads its 32 windows as one 64-byte row, the 16-byte pieces of a row rotated by l to spread the banks.
+__global__ __launch_bounds__(1024, 8) void k_join_merge(JoinQ jq, uint32_t batch0, uint32_t nb, uint32_t n_tiles, TileArrays ta,
                                                      uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
                                                      uint32_t *complex_list, uint32_t *complex_n) {
-    __shared__ __align__(16) uint16_t locat[kJoinMergeBatches * kJoinWin];  // 128 KiB
+    __shared__ __align__(16) uint16_t locat[kJoinMergeBatches * kJoinWin];  // 64 KiB
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t g8 = blockIdx.x, g64 = g8 >> 3;
+    const uint32_t g8 = blockIdx.x, g64 = g8 / (uint32_t)kJoinSub;  // g8: merge group
     const uint32_t tile_lo = (batch0 + g8 * kJoinMergeBatches) * kJoinTiles;
     if (jq.gflag[g64]) {  // degenerate group: exact generic probe for these tiles
         if (tid < kJoinMergeBatches * kJoinTiles && tile_lo + tid < n_tiles) complex_list[atomicAdd(complex_n, 1u)] = tile_lo + tid;
@@ -1373,9 +1395,9 @@ __global__ __launch_bounds__(1024) void k_join_merge(JoinQ jq, uint32_t batch0, 
     for (int i = 0; i < (int)(sizeof(locat) / 16 / 1024); i++) reinterpret_cast<uint4 *>(locat)[tid + 1024 * i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t ng64 = jq.bpad / 64u;
-    const uint16_t *woff = jq.woff + (uint64_t)g8 * kJoinMergeBatches * kJoinWin;
+    const uint16_t *woff = jq.woff + (uint64_t)(g8 * kJoinMergeBatches / 8u) * 8u * kJoinWin;  // records name batch & 7
     auto put = [&](uint32_t rec, uint32_t wo) {
-        const uint32_t w = (((rec & 0xFFFFu) >> 13) << 13) | wo;  // window inside the 8 batches
+        const uint32_t w = ((((rec & 0xFFFFu) >> 13) & (uint32_t)(kJoinMergeBatches - 1)) << 13) | wo;  // window inside the group
         locat[(w & ~31u) | ((((w >> 3) + (w >> 5)) & 3u) << 3) | (w & 7u)] = (uint16_t)(rec >> 16);
     };
     constexpr int MU = 4;  // streams in flight per wave
@@ -1403,10 +1425,10 @@ __global__ __launch_bounds__(1024) void k_join_merge(JoinQ jq, uint32_t batch0, 
             }
     }
     __syncthreads();
-    for (int i = 0; i < 2; i++) {
-        const uint32_t tl = (uint32_t)wave * 2u + (uint32_t)i;  // tile inside the group
+    {
+        const uint32_t tl = (uint32_t)wave;  // tile inside the group
         const uint32_t tile = tile_lo + tl;
-        if (tile >= n_tiles) break;
+        if (tile >= n_tiles) return;
         uint32_t raw = 0, chg = 0, first_loc = GS_NONE, prev = GS_NONE;
         const uint4 *row = reinterpret_cast<const uint4 *>(locat + tl * kTileWindows + lane * 32);
 #pragma unroll
@@ -1834,7 +1856,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
         if ((rc = dev_alloc(&r->jq.item, nb * kJoinWin)) || (rc = dev_alloc(&r->jq.woff, bpad * kJoinWin)) ||
             (rc = dev_alloc(&r->jq.seg, nb * kJoinSlices)) || (rc = dev_alloc(&r->jq.segT, bpad * kJoinSlices)) ||
             (rc = dev_alloc(&r->jq.hits, bpad / 64 * kJoinSlices * kJoinHitCap)) ||
-            (rc = dev_alloc(&r->jq.hsub, bpad / 8 * kJoinSlices)) || (rc = dev_alloc(&r->jq.gflag, bpad / 64)) ||
+            (rc = dev_alloc(&r->jq.hsub, bpad / kJoinMergeBatches * kJoinSlices)) || (rc = dev_alloc(&r->jq.gflag, bpad / 64)) ||
             (rc = dev_alloc(&r->complex_list, r->n_tiles)))
             return rc;
     }
@@ -1857,22 +1879,22 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             const char *env_reps = getenv("GAVISUNK_JOIN_REPS");  // tuning: workgroups per table slice
             const uint32_t reps = env_reps ? std::max(1, atoi(env_reps)) : 1u;
             const char *env_jp = getenv("GAVISUNK_JOIN_PIPE");  // tuning: item loads in flight per lane
-            const int jpipe = env_jp ? atoi(env_jp) : 4;
+            const int jpipe = env_jp ? atoi(env_jp) : 8;
             for (uint32_t b0 = 0; b0 < n_batches; b0 += kJoinChunk) {
                 const uint32_t nb = std::min(kJoinChunk, n_batches - b0);
                 const uint32_t ng64 = (nb + 63) / 64;
                 hipLaunchKernelGGL((k_join_bin<20>), dim3(nb), dim3(1024), 0, t->stream, cv, (const uint64_t *)r->words,
                                    (const TileDesc *)r->tile_desc, r->n_tiles, b0, r->jq);
                 hipLaunchKernelGGL(k_join_segT, dim3(ng64, kJoinSlices / 64), dim3(256), 0, t->stream, r->jq, nb);
-#define GS_LAUNCH_JOIN_PROBE(PIPE)                                                                                        \
-    hipLaunchKernelGGL((k_join_probe<20, PIPE>), dim3(kJoinSlices * reps), dim3(1024), 0, t->stream, cv, r->jq, nb, reps, \
+#define GS_LAUNCH_JOIN_PROBE(PIPE, HF)                                                                                        \
+    hipLaunchKernelGGL((k_join_probe<20, PIPE, HF>), dim3(kJoinSlices * reps), dim3(1024), 0, t->stream, cv, r->jq, nb, reps, \
                        (const uint64_t *)t->j_ovf_code, (const uint32_t *)t->j_ovf_loc, (const uint32_t *)t->j_ovf_start)
-                if (jpipe == 16)
-                    GS_LAUNCH_JOIN_PROBE(16);
-                else if (jpipe == 8)
-                    GS_LAUNCH_JOIN_PROBE(8);
+                if (!t->c_has_flag)
+                    GS_LAUNCH_JOIN_PROBE(8, false);
+                else if (jpipe == 4)
+                    GS_LAUNCH_JOIN_PROBE(4, true);
                 else
-                    GS_LAUNCH_JOIN_PROBE(4);
+                    GS_LAUNCH_JOIN_PROBE(8, true);
 #undef GS_LAUNCH_JOIN_PROBE
                 hipLaunchKernelGGL(k_join_merge, dim3((nb + kJoinMergeBatches - 1) / kJoinMergeBatches), dim3(1024), 0, t->stream,
                                    r->jq, b0, nb, r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list,
