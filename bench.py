@@ -230,8 +230,8 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-            if table.layout.startswith("compact") and a.reads == 10000 and a.seed == 20 and world == 1:
-                traffic = tj["k_probe_part"]["hbm_bytes_per_launch"]
+            if a.reads == 10000 and a.seed == 20 and world == 1:
+                traffic = tj[table.layout.split(":")[0]]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -254,7 +254,8 @@ def main():
                        "h_raw": round(h_raw, 5), "h_emit": round(h_emit, 7), "tiles": c["tiles"],
                        "table_MiB": round(table.nbytes / 2**20, 1), "table_layout": table.layout,
                        "parallelism": f"read-sharded x{world}, table replicated"},
-            "roofline": {"bound": "hbm", "kernel": "k_probe_part+k_merge_part+k_probe" if table.layout.startswith("compact") else "k_probe", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": {"compact-lds": "k_join_bin+k_join_segT+k_join_probe+k_join_merge",
+                                    "compact-l2": "k_probe_part+k_merge_part+k_probe"}.get(table.layout.split(":")[0], "k_probe"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": "HBM bytes per launch from profiles/r01/traffic.json (PMC run, gfx950-corrected)" if traffic else None,
                          "alg_bytes_per_launch": int(n_bases * bpb),

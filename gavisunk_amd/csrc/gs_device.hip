@@ -1067,7 +1067,7 @@ constexpr int kJoinWin = kJoinTiles * kTileWindows;  // windows per batch
 constexpr int kJoinSlices = 256;                     // kNPart x 16
 constexpr int kJoinSliceBuckets = 8192;              // LDS image of a slice: <= 128 KiB
 constexpr int kJoinOvfMax = 256;                     // overflow keys of a slice kept in LDS
-constexpr uint32_t kJoinChunk = 32768;               // batches per queue buffer
+constexpr uint32_t kJoinChunkMax = 32768;            // batches per queue buffer (item indices stay below 2^28)
 constexpr uint32_t kJoinHitCap = 4096;               // hit records per (slice, 64 batches): the fast path cannot exceed it
 constexpr int kJoinMergeBatches = 4;                 // batches per k_join_merge workgroup (64 KiB of LDS: two per CU)
 constexpr int kJoinSub = 64 / kJoinMergeBatches;     // such groups per hit stream
@@ -1246,6 +1246,7 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
         sEnd[wave][lane] = 0ULL;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (lane == 0) sBase[wave][__popcll(nz)] = 0u - T;  // positions past T (last step) name this entry: item[0..63]
         if (cnt) {
             sBase[wave][__popcll(nz & lt)] = b * (uint32_t)kJoinWin + start - ex;
             const uint32_t e = ex + cnt - 1u;
@@ -1273,7 +1274,7 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
                 // lanes past T may name one segment past the last: sBase has a spare entry
                 const uint32_t ci = __builtin_amdgcn_mbcnt_hi(sh, __builtin_amdgcn_mbcnt_lo(sl, sbv));
                 idx_n[u] = sBase[wave][ci] + p;
-                key_n[u] = jq.item[p < T ? idx_n[u] : 0u];  // no branch: lanes past T read a valid word and are masked below
+                key_n[u] = jq.item[idx_n[u]];  // lanes past T read some valid word (sBase's spare entry) and are masked below
             }
         };
         uint4 bk_n[PIPE];                   // and their home buckets
@@ -1846,11 +1847,18 @@ int ensure_out_buffers(gs_reads *r, uint32_t cand_cap) {
     return GS_OK;
 }
 
+// batches per pass of the join kernels over one set of queues (test knob: small chunks exercise the chunk loop)
+uint32_t join_chunk() {
+    const char *e = getenv("GAVISUNK_JOIN_CHUNK");
+    const long v = e ? atol(e) : 0;
+    return v >= 64 && v <= (long)kJoinChunkMax ? (uint32_t)v / 64u * 64u : kJoinChunkMax;
+}
+
 int launch_phase1(gs_table *t, gs_reads *r) {
     HIP_TRY(hipSetDevice(t->device));
     if (t->compact == 1 && t->join && r->n_tiles && !r->jq.item) {
         int rc;
-        const uint64_t nb = std::min<uint64_t>(kJoinChunk, (r->n_tiles + kJoinTiles - 1) / kJoinTiles);
+        const uint64_t nb = std::min<uint64_t>(join_chunk(), (r->n_tiles + kJoinTiles - 1) / kJoinTiles);
         const uint64_t bpad = (nb + 63) / 64 * 64;
         r->jq.bpad = (uint32_t)bpad;
         if ((rc = dev_alloc(&r->jq.item, nb * kJoinWin)) || (rc = dev_alloc(&r->jq.woff, bpad * kJoinWin)) ||
@@ -1880,8 +1888,9 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             const uint32_t reps = env_reps ? std::max(1, atoi(env_reps)) : 1u;
             const char *env_jp = getenv("GAVISUNK_JOIN_PIPE");  // tuning: item loads in flight per lane
             const int jpipe = env_jp ? atoi(env_jp) : 8;
-            for (uint32_t b0 = 0; b0 < n_batches; b0 += kJoinChunk) {
-                const uint32_t nb = std::min(kJoinChunk, n_batches - b0);
+            const uint32_t chunk = std::min<uint32_t>(join_chunk(), r->jq.bpad);  // what the queues were sized for
+            for (uint32_t b0 = 0; b0 < n_batches; b0 += chunk) {
+                const uint32_t nb = std::min(chunk, n_batches - b0);
                 const uint32_t ng64 = (nb + 63) / 64;
                 hipLaunchKernelGGL((k_join_bin<20>), dim3(nb), dim3(1024), 0, t->stream, cv, (const uint64_t *)r->words,
                                    (const TileDesc *)r->tile_desc, r->n_tiles, b0, r->jq);
@@ -1893,6 +1902,8 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                     GS_LAUNCH_JOIN_PROBE(8, false);
                 else if (jpipe == 4)
                     GS_LAUNCH_JOIN_PROBE(4, true);
+                else if (jpipe == 6)
+                    GS_LAUNCH_JOIN_PROBE(6, true);
                 else
                     GS_LAUNCH_JOIN_PROBE(8, true);
 #undef GS_LAUNCH_JOIN_PROBE
@@ -2146,8 +2157,8 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
         n_generic = ov;
         // LDS join: k = 20 makes a slice (partition x top 4 bucket bits) exactly a 32-bit item space
         const char *env = getenv("GAVISUNK_TABLE");
-        t->join = t->compact == 1 && k == 20 && t->c_qb >= 5 && t->c_qb - 4 <= 13 && t->c_locbits <= 15 && env &&
-                  !strcmp(env, "compact-lds");
+        t->join = t->compact == 1 && k == 20 && t->c_qb >= 5 && t->c_qb - 4 <= 13 && t->c_locbits <= 15 &&
+                  !(env && !strcmp(env, "compact-l2"));
         if (t->join) {
             std::vector<uint32_t> list(ov);
             if (ov) HIP_TRY(hipMemcpy(list.data(), dlist, ov * sizeof(uint32_t), hipMemcpyDeviceToHost));

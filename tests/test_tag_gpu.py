@@ -12,12 +12,12 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "compact-lds", "compact-hbm", "generic"], autouse=True)
+@pytest.fixture(params=["auto", "compact-l2", "compact-hbm", "generic"], autouse=True)
 def table_layout(request, monkeypatch):
     """Every test runs four times: with the layout the library picks (small k <= 20 tables get the exact compact
-    copy probed out of the XCD-partitioned L2), with the radix join that probes the compact table's slices from
-    LDS (k = 20 only; other k keep the L2 path), with the compact table treated as HBM-resident (the layout of
-    tables too large for L2), and with the generic 16-byte-slot table forced."""
+    copy: at k = 20 the radix join probes its slices from LDS, at other k it is probed out of the XCD-partitioned
+    L2), with the L2 path forced, with the compact table treated as HBM-resident (the layout of tables too large
+    for L2), and with the generic 16-byte-slot table forced."""
     monkeypatch.setenv("GAVISUNK_TABLE", request.param)
     return request.param
 
@@ -168,12 +168,12 @@ def test_empty_and_tiny_batches():
 def test_layout_selection(table_layout):
     keys, loc, _ = _random_case(3, 20)
     tab = engine.DeviceTable(20, keys, loc, np.arange(len(keys), dtype=np.uint32))
-    assert tab.layout.startswith({"auto": "compact-l2", "compact-lds": "compact-lds", "compact-hbm": "compact-hbm",
+    assert tab.layout.startswith({"auto": "compact-lds", "compact-l2": "compact-l2", "compact-hbm": "compact-hbm",
                                   "generic": "generic"}[table_layout])
     tab.close()
     keys, loc, _ = _random_case(3, 18)
     tab = engine.DeviceTable(18, keys, loc, np.arange(len(keys), dtype=np.uint32))
-    assert tab.layout.startswith({"auto": "compact-l2", "compact-lds": "compact-l2", "compact-hbm": "compact-hbm",
+    assert tab.layout.startswith({"auto": "compact-l2", "compact-l2": "compact-l2", "compact-hbm": "compact-hbm",
                                   "generic": "generic"}[table_layout])
     tab.close()
     keys, loc, _ = _random_case(3, 25)
@@ -247,6 +247,36 @@ def test_undersized_compact_table_uses_every_overflow_path(qb, monkeypatch, tabl
     assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] and len(gh) == len(oh) > 100
     assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"])
     assert np.array_equal(gh["payload"], oh["row"])
+
+
+def test_many_batches_in_small_chunks(monkeypatch):
+    """A few hundred 8192-window batches: several 64-batch groups per table slice, and (compact-lds) the queue
+    buffers reused chunk after chunk."""
+    monkeypatch.setenv("GAVISUNK_JOIN_CHUNK", "128")
+    k = 20
+    keys, loc, seqs = _random_case(77, k, n_reads=500, glen=200000, median=6000, n_groups_div=400)
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert st == 0 and ctr["windows"] == octr["windows"] > 2_000_000 and ctr["raw_hits"] == octr["raw_hits"]
+    assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"])
+    assert np.array_equal(gh["payload"], oh["row"]) and carry == (loc[oprev] if oprev != oracle.NONE else _lib.GS_NONE)
+
+
+def test_homopolymer_reads_take_the_exact_fallback():
+    """Long poly-A / poly-T reads put nearly every window of many batches into one table slice: more than a
+    slice's stream holds.  Those tiles go to the generic exact probe; ordinary reads around them do not."""
+    k = 20
+    keys, loc, seqs = _random_case(78, k, n_reads=60, glen=60000, median=3000)
+    keys = np.concatenate([keys, np.zeros(1, np.uint64)])  # the poly-A k-mer (canonical of poly-T too) is a SUNK here
+    loc = np.concatenate([loc, np.array([int(loc.max()) + 1], np.uint32)])
+    order = np.argsort(keys, kind="stable")
+    keys, loc = keys[order], loc[order]
+    seqs = seqs[:20] + [b"A" * 700000, b"T" * 3000 + seqs[20] + b"A" * 50] + seqs[21:40] + [b"T" * 300000] + seqs[40:]
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] > 1_000_000 and len(gh) == len(oh) > 100
+    assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"])
+    assert np.array_equal(gh["payload"], oh["row"]) and carry == (loc[oprev] if oprev != oracle.NONE else _lib.GS_NONE)
 
 
 def test_table_without_keys():
