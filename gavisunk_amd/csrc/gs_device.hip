@@ -1053,7 +1053,9 @@ __global__ __launch_bounds__(256) void k_merge_part(const PartRec *recs, uint32_
 //   k_join_probe  one workgroup per slice stages its 2^(qb-4) buckets (<= 128 KiB) in LDS and streams the
 //                 slice's items of all batches: one ds_read_b128 per window instead of an L2 request.  A
 //                 wave takes 64 batches at a time and appends its hits {item position, loc + 1} to one
-//                 contiguous stream per (slice, 64 batches), with the start of every 8-batch group noted.
+//                 contiguous stream per (slice, 64 batches), with the start of every merge group noted.  Lookups
+//                 that need the second-chance bucket or the overflow list are parked and resolved a wave-full at
+//                 a time; their hits go to a short unordered side list.
 //   k_join_merge  a workgroup per 8 batches (32 tiles) scatters the hits of the 256 streams into window
 //                 order (LDS, 16 bits per window) and writes the same per-tile summary as probe_tile:
 //                 nothing downstream changes.
@@ -1069,6 +1071,7 @@ constexpr int kJoinSliceBuckets = 8192;              // LDS image of a slice: <=
 constexpr int kJoinOvfMax = 256;                     // overflow keys of a slice kept in LDS
 constexpr uint32_t kJoinChunkMax = 32768;            // batches per queue buffer (item indices stay below 2^28)
 constexpr uint32_t kJoinHitCap = 4096;               // hit records per (slice, 64 batches): the fast path cannot exceed it
+constexpr uint32_t kJoinLateCap = 256;                // late hit records per (slice, 64 batches); more = degenerate group
 constexpr int kJoinMergeBatches = 4;                 // batches per k_join_merge workgroup (64 KiB of LDS: two per CU)
 constexpr int kJoinSub = 64 / kJoinMergeBatches;     // such groups per hit stream
 
@@ -1080,6 +1083,9 @@ struct JoinQ {
     uint32_t *hits;   // [kJoinSlices][bpad / 64][kJoinHitCap]  item position (16 bits: batch & 7, index) | (loc + 1) << 16
     uint32_t *hsub;   // [bpad / kJoinMergeBatches][kJoinSlices] start | count << 16 of a merge group inside its hit stream
     uint32_t *gflag;  // [bpad / 64]             1 = degenerate group: its tiles go to the generic probe
+    uint2 *late;      // [kJoinSlices][bpad / 64][kJoinLateCap]  hits found in a second-chance bucket or the overflow list, in no
+                      //                          order: {item position (19 bits: batch & 63, index), loc + 1}
+    uint32_t *nlate;  // [bpad / 64][kJoinSlices]
     uint32_t bpad;
 };
 
@@ -1165,12 +1171,12 @@ __global__ __launch_bounds__(256) void k_join_segT(JoinQ jq, uint32_t nb) {
     for (int i = ty; i < 64; i += 4) jq.segT[(uint64_t)(s0 + i) * jq.bpad + b0 + tx] = tl[tx][i];
 }
 
-template <int KT, int PIPE, bool HASFLAG>
+template <int KT, int PIPE, bool HASFLAG, int DBG>
 __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, uint32_t nb, uint32_t reps,
                                                       const uint64_t *__restrict__ ovf_code,
                                                       const uint32_t *__restrict__ ovf_loc,
                                                       const uint32_t *__restrict__ ovf_start) {
-    constexpr int PCAP = 64;  // deferred (second-chance / overflow) lookups resolved together
+    constexpr int PCAP = 96;  // parked (second-chance / overflow) lookups; resolved 64 at a time
     __shared__ uint4 sT[kJoinSliceBuckets];
     __shared__ uint32_t sBase[16][65];
     __shared__ unsigned long long sEnd[16][64];
@@ -1238,6 +1244,7 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
         uint32_t *hsub = jq.hsub + (uint64_t)g * kJoinSub * kJoinSlices + s;  // [merge groups of the 64 batches][slices]
         if (T == 0 || T > kJoinHitCap) {
             if (lane < kJoinSub) hsub[(uint32_t)lane * kJoinSlices] = 0u;
+            if (lane == 0) jq.nlate[(uint64_t)g * kJoinSlices + s] = 0u;
             if (T && lane == 0) jq.gflag[g] = 1u;
             continue;
         }
@@ -1269,6 +1276,7 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
         auto fetch = [&](uint32_t t0) {
 #pragma unroll
             for (int u = 0; u < PIPE; u++) {
+                if (t0 + (uint32_t)u >= nsteps) break;  // wave-uniform: the last window of a group is usually short
                 const uint32_t t = (t0 + (uint32_t)u) & 63u, p = (t0 + (uint32_t)u) * 64u + (uint32_t)lane;
                 const uint32_t sl = lane_value(wlo, (int)t), sh = lane_value(whi, (int)t), sbv = lane_value(before, (int)t);
                 // lanes past T may name one segment past the last: sBase has a spare entry
@@ -1278,13 +1286,40 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
             }
         };
         uint4 bk_n[PIPE];                   // and their home buckets
+#pragma unroll
+        for (int u = 0; u < PIPE; u++) key_n[u] = 0u;  // steps a short window does not have still name a valid bucket
         fetch(0);
 #pragma unroll
         for (int u = 0; u < PIPE; u++) bk_n[u] = sT[(key_n[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1)];
-        for (uint32_t t0 = 0; t0 < nsteps; t0 += PIPE) {
-            uint32_t idx[PIPE], key[PIPE], res[PIPE];
+        uint2 *lout = jq.late + ((uint64_t)s * ng64 + g) * kJoinLateCap;
+        uint32_t npend = 0, nlate = 0;  // wave-uniform: parked lookups, late hits written
+        // resolve the parked lookups (at most one per lane); their hits go to the side list, in no particular order
+        auto flush_parked = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j0 = 0; j0 < npend; j0 += 64u) {
+                uint32_t res = 0, where = 0;
+                if (j0 + (uint32_t)lane < npend) {
+                    where = sPend[wave][j0 + lane][1];
+                    res = second(sPend[wave][j0 + lane][0], where >> 19);
+                }
+                const unsigned long long hb = __ballot(res != 0);
+                const uint32_t nh = __popcll(hb);
+                if (nlate + nh > kJoinLateCap) {
+                    if (lane == 0) jq.gflag[g] = 1u;  // more late hits than the list holds: exact generic probe for this group
+                } else if (res) {
+                    lout[nlate + (uint32_t)__popcll(hb & lt)] = make_uint2(where & 0x7FFFFu, res);
+                }
+                nlate = min(nlate + nh, kJoinLateCap);
+            }
+            npend = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto window = [&](uint32_t t0, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;  // all PIPE steps exist: no guards
+            uint32_t idx[PIPE], key[PIPE], rp[PIPE];  // rp: loc + 1 of a hit in the home bucket, or 0
             uint4 bk[PIPE];
-            int pslot[PIPE];
 #pragma unroll
             for (int u = 0; u < PIPE; u++) {
                 idx[u] = idx_n[u];
@@ -1293,85 +1328,81 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
             }
             const bool more = t0 + PIPE < nsteps;  // wave-uniform
             if (more) fetch(t0 + PIPE);
-            // home buckets; lookups that need a second bucket or the overflow list are parked and resolved together
-            uint32_t pfl[PIPE];  // 0, or what a parked lookup still has to try: bit 0 second-chance bucket, bit 1 overflow list
-            uint32_t anyp = 0;
+            if (npend > (uint32_t)PCAP - 64u) flush_parked();  // the one place inside a group: room for 64 more lookups
 #pragma unroll
             for (int u = 0; u < PIPE; u++) {
+                if (!FULL && t0 + (uint32_t)u >= nsteps) {  // wave-uniform
+                    rp[u] = 0u;
+                    continue;
+                }
                 const bool live = (t0 + (uint32_t)u) * 64u + (uint32_t)lane < T;
                 const uint32_t ws = (key[u] & remmask) << locbits;
                 const uint32_t e0 = (bk[u].x ^ ws) & slot0mask, e1 = bk[u].y ^ ws, e2 = bk[u].z ^ ws, e3 = bk[u].w ^ ws;
                 const uint32_t m = min(min(e0, e1), min(e2, e3));
                 // a matching slot leaves its loc (< locmask: the all-ones loc is never stored); an empty slot leaves at least locmask
-                const bool hit = live && m < locmask;
-                res[u] = hit ? m + 1u : 0u;
+                const bool hit = m < locmask;
+                rp[u] = live && hit ? m + 1u : 0u;
                 // bits 31:30 of slot 0: a key of this bucket lives in its second-chance bucket / in the overflow list only
-                // (set on full buckets only; an empty slot 0 has them set too, hence the test on slot 3: slots fill in order)
-                const uint32_t pf = HASFLAG ? (bk[u].x >> 30) : 1u;
-                const bool pend = live && !hit && bk[u].w != kEmptySlot32;
-                pfl[u] = pend ? (HASFLAG ? (pf >> 1) | ((pf & 1u) << 1) : 2u) : 0u;
-                anyp |= pfl[u];
-                pslot[u] = -1;
+                // (set on full buckets only; an empty slot 0 has them set too, hence the test on slot 3: slots fill in order).
+                // Such lookups are parked: bit 0 try the second-chance bucket, bit 1 try the overflow list.
+                const uint32_t pf = HASFLAG ? ((bk[u].x >> 31) | ((bk[u].x >> 29) & 2u)) : 2u;
+                const bool pend = DBG != 2 && live && !hit && bk[u].w != kEmptySlot32 && pf != 0u;
+                const unsigned long long pb = __ballot(pend);
+                if (pb) {  // wave-uniform
+                    const uint32_t np = __popcll(pb);
+                    if (npend + np > (uint32_t)PCAP) {  // no room (a table with very many displaced keys): exact generic probe
+                        if (lane == 0) jq.gflag[g] = 1u;
+                        continue;
+                    }
+                    if (pend) {
+                        const uint32_t slot = npend + (uint32_t)__popcll(pb & lt);
+                        sPend[wave][slot][0] = key[u];
+                        sPend[wave][slot][1] = (pf << 19) | (idx[u] & 0x7FFFFu);  // batch & 63, index inside the batch
+                    }
+                    npend += np;
+                }
             }
             if (more) {  // the next window's bucket reads are in flight while this window is finished
 #pragma unroll
-                for (int u = 0; u < PIPE; u++) bk_n[u] = sT[(key_n[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1)];
-            }
-            while (__ballot(anyp != 0)) {  // wave-uniform; one round unless more than PCAP lookups of the window are parked
-                uint32_t npend = 0;
-#pragma unroll
-                for (int u = 0; u < PIPE; u++) {
-                    const unsigned long long pb = __ballot(pfl[u] != 0);
-                    const uint32_t np = __popcll(pb);
-                    if (pb && npend + np <= (uint32_t)PCAP) {
-                        if (pfl[u]) {
-                            pslot[u] = (int)(npend + (uint32_t)__popcll(pb & lt));
-                            sPend[wave][pslot[u]][0] = key[u];
-                            sPend[wave][pslot[u]][1] = pfl[u];
-                        }
-                        npend += np;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if ((uint32_t)lane < npend) sPend[wave][lane][0] = second(sPend[wave][lane][0], sPend[wave][lane][1]);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                anyp = 0;
-#pragma unroll
-                for (int u = 0; u < PIPE; u++) {
-                    if (pslot[u] >= 0) {
-                        res[u] = sPend[wave][pslot[u]][0];
-                        pfl[u] = 0;
-                        pslot[u] = -1;
-                    }
-                    anyp |= pfl[u];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                for (int u = 0; u < PIPE; u++)
+                    bk_n[u] = DBG == 3 ? make_uint4(key_n[u], ~0u, ~0u, ~0u) : sT[(key_n[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1)];
             }
 #pragma unroll
             for (int u = 0; u < PIPE; u++) {
-                const unsigned long long hb = __ballot(res[u] != 0);
+                if (!FULL && t0 + (uint32_t)u >= nsteps) break;  // wave-uniform
+                const unsigned long long hb = __ballot(rp[u] != 0);
                 const uint32_t p0 = (t0 + (uint32_t)u) * 64u;
-                // 8-batch groups that start inside [p0, p0 + 64): their hits start after the hits of the lanes before
+                // merge groups that start inside [p0, p0 + 64): their hits start after the hits of the lanes before
                 while (jn < kJoinSub && jpos < p0 + 64u) {  // wave-uniform
                     const uint32_t d = jpos > p0 ? jpos - p0 : 0u;
-                    const uint32_t v = cursor + (uint32_t)__popcll(hb & (d ? (~0ULL >> (64 - d)) : 0ULL));
+                    const uint32_t v = DBG ? 0u : cursor + (uint32_t)__popcll(hb & (d ? (~0ULL >> (64 - d)) : 0ULL));
                     if (lane == 0) sG[wave][jn] = v;
                     jn++;
                     jpos = jn < kJoinSub ? lane_value(ex, jn * kJoinMergeBatches) : 0xFFFFFFFFu;
                 }
-                if (res[u]) hout[cursor + (uint32_t)__popcll(hb & lt)] = (idx[u] & 0xFFFFu) | (res[u] << 16);
+                if (DBG) {  // timing experiments: an empty hit stream keeps everything downstream well-defined
+                    if (DBG == 1 ? rp[u] == 0x12345u : (rp[u] != 0 && cursor == 0xFFFFFFF0u)) hout[(uint32_t)__popcll(hb & lt)] = idx[u];
+                    if (DBG == 1) continue;
+                    cursor += (uint32_t)__popcll(hb);
+                    continue;
+                }
+                if (rp[u]) hout[cursor + (uint32_t)__popcll(hb & lt)] = (idx[u] & 0xFFFFu) | (rp[u] << 16);
                 cursor += (uint32_t)__popcll(hb);
             }
+        };
+        {
+            uint32_t t0 = 0;
+            for (; t0 + PIPE <= nsteps; t0 += PIPE) window(t0, std::true_type{});
+            if (t0 < nsteps) window(t0, std::false_type{});
         }
+        if (npend) flush_parked();
+        if (lane == 0) jq.nlate[(uint64_t)g * kJoinSlices + s] = DBG ? 0u : nlate;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane < kJoinSub) {
             // groups whose first item was never reached have no items: they start (and end) at the end of the stream
-            const uint32_t st = lane < jn ? sG[wave][lane] : cursor;
-            const uint32_t en = lane + 1 < jn ? sG[wave][lane + 1] : cursor;
+            const uint32_t st = DBG ? 0u : (lane < jn ? sG[wave][lane] : cursor);
+            const uint32_t en = DBG ? 0u : (lane + 1 < jn ? sG[wave][lane + 1] : cursor);
             hsub[(uint32_t)lane * kJoinSlices] = st | ((en - st) << 16);
         }
     }
@@ -1392,10 +1423,21 @@ __global__ __launch_bounds__(1024, 8) void k_join_merge(JoinQ jq, uint32_t batch
     }
     // the 16 hit streams this wave scatters (slices wave, wave + 16, ...): start/count first, so that the loads overlap the clear
     const uint32_t hs_mine = lane < 16 ? jq.hsub[(uint64_t)g8 * kJoinSlices + (uint32_t)wave + 16u * (uint32_t)lane] : 0u;
+    const uint32_t ng64 = jq.bpad / 64u;
+    // side lists of the 64-batch group (hits found in second-chance buckets / the overflow list, a few per slice, unordered):
+    // 4 threads per slice
+    const uint32_t late_n = jq.nlate[(uint64_t)g64 * kJoinSlices + ((uint32_t)tid >> 2)];
+    const uint2 *late_l = jq.late + ((uint64_t)((uint32_t)tid >> 2) * ng64 + g64) * kJoinLateCap;
+    const uint32_t late_mine = g8 % (uint32_t)kJoinSub;  // (batch & 63) / kJoinMergeBatches of my batches
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(locat) / 16 / 1024); i++) reinterpret_cast<uint4 *>(locat)[tid + 1024 * i] = make_uint4(0, 0, 0, 0);
+    uint2 lrec[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t j = ((uint32_t)tid & 3u) + 4u * (uint32_t)i;
+        lrec[i] = j < late_n ? late_l[j] : make_uint2(0u, 0u);  // loc + 1 is never 0
+    }
     __syncthreads();
-    const uint32_t ng64 = jq.bpad / 64u;
     const uint16_t *woff = jq.woff + (uint64_t)(g8 * kJoinMergeBatches / 8u) * 8u * kJoinWin;  // records name batch & 7
     auto put = [&](uint32_t rec, uint32_t wo) {
         const uint32_t w = ((((rec & 0xFFFFu) >> 13) & (uint32_t)(kJoinMergeBatches - 1)) << 13) | wo;  // window inside the group
@@ -1424,6 +1466,16 @@ __global__ __launch_bounds__(1024, 8) void k_join_merge(JoinQ jq, uint32_t batch
                 const uint32_t r2 = h[u][j];
                 put(r2, woff[r2 & 0xFFFFu]);
             }
+    }
+    {  // the side lists: this merge group's records are taken (the first 16 of each list were loaded up front)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (lrec[i].y && (lrec[i].x >> 13) / (uint32_t)kJoinMergeBatches == late_mine)
+                put((lrec[i].x & 0xFFFFu) | (lrec[i].y << 16), woff[lrec[i].x & 0xFFFFu]);
+        for (uint32_t j = 16u + ((uint32_t)tid & 3u); j < late_n; j += 4u) {
+            const uint2 r = late_l[j];
+            if ((r.x >> 13) / (uint32_t)kJoinMergeBatches == late_mine) put((r.x & 0xFFFFu) | (r.y << 16), woff[r.x & 0xFFFFu]);
+        }
     }
     __syncthreads();
     {
@@ -1865,6 +1917,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             (rc = dev_alloc(&r->jq.seg, nb * kJoinSlices)) || (rc = dev_alloc(&r->jq.segT, bpad * kJoinSlices)) ||
             (rc = dev_alloc(&r->jq.hits, bpad / 64 * kJoinSlices * kJoinHitCap)) ||
             (rc = dev_alloc(&r->jq.hsub, bpad / kJoinMergeBatches * kJoinSlices)) || (rc = dev_alloc(&r->jq.gflag, bpad / 64)) ||
+            (rc = dev_alloc(&r->jq.late, bpad / 64 * kJoinSlices * kJoinLateCap)) || (rc = dev_alloc(&r->jq.nlate, bpad / 64 * kJoinSlices)) ||
             (rc = dev_alloc(&r->complex_list, r->n_tiles)))
             return rc;
     }
@@ -1895,11 +1948,20 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                 hipLaunchKernelGGL((k_join_bin<20>), dim3(nb), dim3(1024), 0, t->stream, cv, (const uint64_t *)r->words,
                                    (const TileDesc *)r->tile_desc, r->n_tiles, b0, r->jq);
                 hipLaunchKernelGGL(k_join_segT, dim3(ng64, kJoinSlices / 64), dim3(256), 0, t->stream, r->jq, nb);
-#define GS_LAUNCH_JOIN_PROBE(PIPE, HF)                                                                                        \
-    hipLaunchKernelGGL((k_join_probe<20, PIPE, HF>), dim3(kJoinSlices * reps), dim3(1024), 0, t->stream, cv, r->jq, nb, reps, \
+#define GS_LAUNCH_JOIN_PROBE(PIPE, HF) GS_LAUNCH_JOIN_PROBE_DBG(PIPE, HF, 0)
+#define GS_LAUNCH_JOIN_PROBE_DBG(PIPE, HF, DBG)                                                                                \
+    hipLaunchKernelGGL((k_join_probe<20, PIPE, HF, DBG>), dim3(kJoinSlices * reps), dim3(1024), 0, t->stream, cv, r->jq, nb, reps, \
                        (const uint64_t *)t->j_ovf_code, (const uint32_t *)t->j_ovf_loc, (const uint32_t *)t->j_ovf_start)
+                const char *jdbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
+                const int jmode = jdbg ? atoi(jdbg) : 0;
                 if (!t->c_has_flag)
                     GS_LAUNCH_JOIN_PROBE(8, false);
+                else if (jmode == 11)
+                    GS_LAUNCH_JOIN_PROBE_DBG(8, true, 1);
+                else if (jmode == 12)
+                    GS_LAUNCH_JOIN_PROBE_DBG(8, true, 2);
+                else if (jmode == 13)
+                    GS_LAUNCH_JOIN_PROBE_DBG(8, true, 3);
                 else if (jpipe == 4)
                     GS_LAUNCH_JOIN_PROBE(4, true);
                 else if (jpipe == 6)
@@ -1907,6 +1969,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                 else
                     GS_LAUNCH_JOIN_PROBE(8, true);
 #undef GS_LAUNCH_JOIN_PROBE
+#undef GS_LAUNCH_JOIN_PROBE_DBG
                 hipLaunchKernelGGL(k_join_merge, dim3((nb + kJoinMergeBatches - 1) / kJoinMergeBatches), dim3(1024), 0, t->stream,
                                    r->jq, b0, nb, r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list,
                                    t->d_complex_n);
@@ -2453,6 +2516,8 @@ void gs_reads_destroy(gs_reads *r) {
     (void)hipFree(r->jq.hits);
     (void)hipFree(r->jq.hsub);
     (void)hipFree(r->jq.gflag);
+    (void)hipFree(r->jq.late);
+    (void)hipFree(r->jq.nlate);
     (void)hipFree(r->complex_list);
     delete r;
 }
