@@ -30,6 +30,26 @@ __global__ void calib_write48_scattered_48MB(uint4 *p, uint64_t nrec) {  // 48-b
     const int lane = threadIdx.x & 63;
     if (w < nrec && lane < 3) p[w * 3 + lane] = make_uint4(1, 2, 3, 4);
 }
+__global__ void calib_read4_1GiB(const uint32_t *p, uint64_t n, uint64_t *out) {  // 4 B per lane, coalesced
+    uint64_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) acc += p[i];
+    if (acc == 0x1234) out[0] = acc;
+}
+// the join probe's shape: a wave reads 64 consecutive dwords that start at an arbitrary dword (not line-aligned),
+// two runs of 32 per wave-load taken from places 32 KiB apart; 1/4 of the buffer is read (every 4th 128-byte run)
+__global__ void calib_read4_segments_256MiB(const uint32_t *p, uint64_t nseg, uint64_t *out) {
+    uint64_t acc = 0;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w * 2 < nseg; w += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
+        const uint64_t seg = w * 2 + (lane >> 5);                // 32-dword segment
+        const uint64_t base = seg * 128 + ((seg * 7) & 31);      // in a 128-dword (512 B) cell, at an odd offset
+        acc += p[base + (lane & 31)];
+    }
+    if (acc == 0x1234) out[0] = acc;
+}
+__global__ void calib_write4_compact_256MiB(uint32_t *p, uint64_t n) {  // 4 B per lane, coalesced stores (hit streams)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
+}
 int main() {
     const uint64_t bytes = 1ull << 30;
     void *buf; uint64_t *out;
@@ -39,6 +59,9 @@ int main() {
     hipLaunchKernelGGL(calib_rand16_64Mprobes, dim3(4096), dim3(256), 0, 0, (const uint4 *)buf, bytes / 16 - 1, 64, out);
     hipLaunchKernelGGL(calib_write16_1GiB, dim3(4096), dim3(256), 0, 0, (uint4 *)buf, bytes / 16);
     hipLaunchKernelGGL(calib_write48_scattered_48MB, dim3(1 << 20 >> 2), dim3(256), 0, 0, (uint4 *)buf, (uint64_t)1 << 20);
+    hipLaunchKernelGGL(calib_read4_1GiB, dim3(4096), dim3(256), 0, 0, (const uint32_t *)buf, bytes / 4, out);
+    hipLaunchKernelGGL(calib_read4_segments_256MiB, dim3(4096), dim3(256), 0, 0, (const uint32_t *)buf, bytes / 512 - 1, out);
+    hipLaunchKernelGGL(calib_write4_compact_256MiB, dim3(4096), dim3(256), 0, 0, (uint32_t *)buf, bytes / 16);
     CK(hipDeviceSynchronize());
     printf("done\n");
     return 0;
