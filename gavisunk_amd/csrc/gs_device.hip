@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_merge_part(const PartRec *recs, uint32_
 //                 contiguous stream per (slice, 64 batches), with the start of every merge group noted.  Lookups
 //                 that need the second-chance bucket or the overflow list are parked and resolved a wave-full at
 //                 a time; their hits go to a short unordered side list.
-//   k_join_merge  a workgroup per 8 batches (32 tiles) scatters the hits of the 256 streams into window
+//   k_join_merge  a workgroup per 4 batches (16 tiles) scatters the hits of the 256 streams into window
 //                 order (LDS, 16 bits per window) and writes the same per-tile summary as probe_tile:
 //                 nothing downstream changes.
 //
@@ -1080,11 +1080,11 @@ struct JoinQ {
     uint16_t *woff;   // [batches][kJoinWin]     window of the item inside its batch
     uint32_t *seg;    // [batches][kJoinSlices]  start | count << 16 of a slice's items inside the batch
     uint32_t *segT;   // [kJoinSlices][bpad]     the same, transposed (bpad = batches rounded up to 64)
-    uint32_t *hits;   // [kJoinSlices][bpad / 64][kJoinHitCap]  item position (16 bits: batch & 7, index) | (loc + 1) << 16
+    uint32_t *hits;   // [kJoinSlices][bpad / 64][kJoinHitCap]  window in its merge group (15 bits: batch & 3, window) | (loc + 1) << 16
     uint32_t *hsub;   // [bpad / kJoinMergeBatches][kJoinSlices] start | count << 16 of a merge group inside its hit stream
     uint32_t *gflag;  // [bpad / 64]             1 = degenerate group: its tiles go to the generic probe
     uint2 *late;      // [kJoinSlices][bpad / 64][kJoinLateCap]  hits found in a second-chance bucket or the overflow list, in no
-                      //                          order: {item position (19 bits: batch & 63, index), loc + 1}
+                      //                          order: {batch & 63, window in the batch (19 bits), loc + 1}
     uint32_t *nlate;  // [bpad / 64][kJoinSlices]
     uint32_t bpad;
 };
@@ -1281,8 +1281,10 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
                 const uint32_t sl = lane_value(wlo, (int)t), sh = lane_value(whi, (int)t), sbv = lane_value(before, (int)t);
                 // lanes past T may name one segment past the last: sBase has a spare entry
                 const uint32_t ci = __builtin_amdgcn_mbcnt_hi(sh, __builtin_amdgcn_mbcnt_lo(sl, sbv));
-                idx_n[u] = sBase[wave][ci] + p;
-                key_n[u] = jq.item[idx_n[u]];  // lanes past T read some valid word (sBase's spare entry) and are masked below
+                const uint32_t ix = sBase[wave][ci] + p;
+                key_n[u] = jq.item[ix];  // lanes past T read some valid word (sBase's spare entry) and are masked below
+                // where a hit of this item is: batch & 63 | window inside the batch
+                idx_n[u] = (ix & 0x7E000u) | (uint32_t)jq.woff[ix];
             }
         };
         uint4 bk_n[PIPE];                   // and their home buckets
@@ -1307,7 +1309,7 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
                 const uint32_t nh = __popcll(hb);
                 if (nlate + nh > kJoinLateCap) {
                     if (lane == 0) jq.gflag[g] = 1u;  // more late hits than the list holds: exact generic probe for this group
-                } else if (res) {
+                } else if (res) {  // {batch & 63, window inside the batch}, loc + 1
                     lout[nlate + (uint32_t)__popcll(hb & lt)] = make_uint2(where & 0x7FFFFu, res);
                 }
                 nlate = min(nlate + nh, kJoinLateCap);
@@ -1386,7 +1388,8 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
                     cursor += (uint32_t)__popcll(hb);
                     continue;
                 }
-                if (rp[u]) hout[cursor + (uint32_t)__popcll(hb & lt)] = (idx[u] & 0xFFFFu) | (rp[u] << 16);
+                // a hit record names its window inside the 4-batch merge group: (batch & 3) << 13 | window in the batch
+                if (rp[u]) hout[cursor + (uint32_t)__popcll(hb & lt)] = (idx[u] & 0x7FFFu) | (rp[u] << 16);
                 cursor += (uint32_t)__popcll(hb);
             }
         };
@@ -1438,14 +1441,13 @@ __global__ __launch_bounds__(1024, 8) void k_join_merge(JoinQ jq, uint32_t batch
         lrec[i] = j < late_n ? late_l[j] : make_uint2(0u, 0u);  // loc + 1 is never 0
     }
     __syncthreads();
-    const uint16_t *woff = jq.woff + (uint64_t)(g8 * kJoinMergeBatches / 8u) * 8u * kJoinWin;  // records name batch & 7
-    auto put = [&](uint32_t rec, uint32_t wo) {
-        const uint32_t w = ((((rec & 0xFFFFu) >> 13) & (uint32_t)(kJoinMergeBatches - 1)) << 13) | wo;  // window inside the group
+    auto put = [&](uint32_t rec) {
+        const uint32_t w = rec & 0x7FFFu;  // window inside the group
         locat[(w & ~31u) | ((((w >> 3) + (w >> 5)) & 3u) << 3) | (w & 7u)] = (uint16_t)(rec >> 16);
     };
     constexpr int MU = 4;  // streams in flight per wave
     for (int i0 = 0; i0 < 16; i0 += MU) {
-        uint32_t rec[MU], wo[MU], cnt[MU];
+        uint32_t rec[MU], cnt[MU];
         const uint32_t *h[MU];
 #pragma unroll
         for (int u = 0; u < MU; u++) {
@@ -1456,25 +1458,19 @@ __global__ __launch_bounds__(1024, 8) void k_join_merge(JoinQ jq, uint32_t batch
             rec[u] = (uint32_t)lane < cnt[u] ? h[u][lane] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < MU; u++) wo[u] = rec[u] ? woff[rec[u] & 0xFFFFu] : 0u;
+        for (int u = 0; u < MU; u++)
+            if (rec[u]) put(rec[u]);
 #pragma unroll
         for (int u = 0; u < MU; u++)
-            if (rec[u]) put(rec[u], wo[u]);
-#pragma unroll
-        for (int u = 0; u < MU; u++)
-            for (uint32_t j = 64u + (uint32_t)lane; j < cnt[u]; j += 64u) {  // long streams (rare)
-                const uint32_t r2 = h[u][j];
-                put(r2, woff[r2 & 0xFFFFu]);
-            }
+            for (uint32_t j = 64u + (uint32_t)lane; j < cnt[u]; j += 64u) put(h[u][j]);  // long streams (rare)
     }
     {  // the side lists: this merge group's records are taken (the first 16 of each list were loaded up front)
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            if (lrec[i].y && (lrec[i].x >> 13) / (uint32_t)kJoinMergeBatches == late_mine)
-                put((lrec[i].x & 0xFFFFu) | (lrec[i].y << 16), woff[lrec[i].x & 0xFFFFu]);
+            if (lrec[i].y && (lrec[i].x >> 13) / (uint32_t)kJoinMergeBatches == late_mine) put((lrec[i].x & 0x7FFFu) | (lrec[i].y << 16));
         for (uint32_t j = 16u + ((uint32_t)tid & 3u); j < late_n; j += 4u) {
             const uint2 r = late_l[j];
-            if ((r.x >> 13) / (uint32_t)kJoinMergeBatches == late_mine) put((r.x & 0xFFFFu) | (r.y << 16), woff[r.x & 0xFFFFu]);
+            if ((r.x >> 13) / (uint32_t)kJoinMergeBatches == late_mine) put((r.x & 0x7FFFu) | (r.y << 16));
         }
     }
     __syncthreads();
