@@ -1090,45 +1090,49 @@ struct JoinQ {
 };
 
 template <int KT>
-__global__ __launch_bounds__(1024, 8) void k_join_bin(CompactView ct, const uint64_t *__restrict__ words,
-                                                       const TileDesc *__restrict__ tdesc, uint32_t n_tiles, uint32_t batch0,
-                                                       JoinQ jq) {
+__global__ __launch_bounds__(512, 6) void k_join_bin(CompactView ct, const uint64_t *__restrict__ words,
+                                                      const TileDesc *__restrict__ tdesc, uint32_t n_tiles, uint32_t batch0,
+                                                      JoinQ jq) {
     __shared__ __align__(16) uint32_t dkey[kJoinWin];
     __shared__ __align__(16) uint16_t dwoff[kJoinWin];
     __shared__ __align__(16) uint32_t cnt[kJoinSlices];
     __shared__ __align__(16) uint32_t off[kJoinSlices];
     constexpr int k = KT;
     constexpr int kbits = 2 * k - 4;
-    static_assert(8 + KT - 1 <= 32, "the 8 windows of a thread must fit one 64-bit word");
+    static_assert(8 + KT - 1 <= 32, "8 consecutive windows must fit one 64-bit word");
     constexpr uint64_t kmask = (1ULL << (2 * k)) - 1ULL, keymask = (1ULL << kbits) - 1ULL;
     const int tid = threadIdx.x;
     const uint32_t bl = blockIdx.x;
     if (tid < kJoinSlices) cnt[tid] = 0;
-    // thread = 8 consecutive windows: word (tid >> 2) of the batch's 256 words, quarter (tid & 3) of it
-    const int q = tid >> 8, l = (tid >> 2) & 63, h = tid & 3;
+    // thread = 16 consecutive windows: word (tid >> 1) of the batch's 256 words, half (tid & 1) of it; three workgroups per CU
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 7), l = (tid >> 1) & 63, h = tid & 1;  // q is the same for a whole wave
     const uint32_t tile = (batch0 + bl) * kJoinTiles + q;
-    TileDesc td = tdesc[min(tile, n_tiles - 1)];
+    TileDesc td = tdesc[min(tile, n_tiles - 1)];  // scalar load
     if (tile >= n_tiles) td.nwin_left = 0;
     const uint64_t a = __builtin_nontemporal_load(words + td.wbase + l);
     const uint64_t b2 = __builtin_nontemporal_load(words + td.wbase + l + 1);
     __syncthreads();
-    const uint32_t w0 = (uint32_t)l * 32u + (uint32_t)h * 8u;
-    const uint32_t nvalid = td.nwin_left > w0 ? min(td.nwin_left - w0, 8u) : 0u;
-    const int s = 16 * h;
-    const uint64_t X = s ? ((a << s) | (b2 >> (64 - s))) : a;  // my 8 windows start at bases 0..7 of X (8 + k - 1 <= 32 bases)
-    const uint64_t R = ~revpairs(X);                            // base i of X, complemented, at bits 2i+1:2i
+    const uint32_t w0 = (uint32_t)l * 32u + (uint32_t)h * 16u;
+    const uint32_t nvalid = td.nwin_left > w0 ? min(td.nwin_left - w0, 16u) : 0u;
     const int sb = ct.qb - 4;  // bucket bits inside a slice; sb + rembits = 32
-    uint32_t item[8], sr[8];
+    uint32_t item[16], sr[16];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint64_t f = (X << (2 * j)) >> (64 - 2 * k);
-        const uint64_t r = (R >> (2 * j)) & kmask;
-        const uint64_t c = f < r ? f : r;
-        const BucketRem br = hmix2((c >> 4) & keymask, kbits, ct.qb);
-        item[j] = ((br.bucket & ((1u << sb) - 1u)) << ct.rembits) | (uint32_t)br.rem;
-        const uint32_t slice = (part_of(c, k) << 4) | (br.bucket >> sb);
-        // (an unconditional add to a dummy counter, so that the eight atomics overlap, measured slower)
-        sr[j] = slice | (((uint32_t)j < nvalid ? atomicAdd(&cnt[slice], 1u) : 0u) << 9);
+    for (int half = 0; half < 2; half++) {
+        const int s = 32 * h + 16 * half;
+        const uint64_t X = s ? ((a << s) | (b2 >> (64 - s))) : a;  // 8 windows start at bases 0..7 of X (8 + k - 1 <= 32 bases)
+        const uint64_t R = ~revpairs(X);                            // base i of X, complemented, at bits 2i+1:2i
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+            const int j = half * 8 + jj;
+            const uint64_t f = (X << (2 * jj)) >> (64 - 2 * k);
+            const uint64_t r = (R >> (2 * jj)) & kmask;
+            const uint64_t c = f < r ? f : r;
+            const BucketRem br = hmix2((c >> 4) & keymask, kbits, ct.qb);
+            item[j] = ((br.bucket & ((1u << sb) - 1u)) << ct.rembits) | (uint32_t)br.rem;
+            const uint32_t slice = (part_of(c, k) << 4) | (br.bucket >> sb);
+            // (an unconditional add to a dummy counter, so that the atomics overlap, measured slower)
+            sr[j] = slice | (((uint32_t)j < nvalid ? atomicAdd(&cnt[slice], 1u) : 0u) << 9);
+        }
     }
     __syncthreads();
     if (tid < 64) {  // exclusive prefix over the 256 counters, 4 per lane
@@ -1142,7 +1146,7 @@ __global__ __launch_bounds__(1024, 8) void k_join_bin(CompactView ct, const uint
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; j++)
+    for (int j = 0; j < 16; j++)
         if ((uint32_t)j < nvalid) {
             const uint32_t pos = off[sr[j] & 255u] + (sr[j] >> 9);
             dkey[pos] = item[j];
@@ -1153,11 +1157,15 @@ __global__ __launch_bounds__(1024, 8) void k_join_bin(CompactView ct, const uint
     uint4 *gk = reinterpret_cast<uint4 *>(jq.item + (uint64_t)bl * kJoinWin);
     uint4 *gw = reinterpret_cast<uint4 *>(jq.woff + (uint64_t)bl * kJoinWin);
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const uint32_t e4 = (uint32_t)tid + 1024u * (uint32_t)i;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t e4 = (uint32_t)tid + 512u * (uint32_t)i;
         if (e4 * 4u < total) gk[e4] = reinterpret_cast<const uint4 *>(dkey)[e4];
     }
-    if ((uint32_t)tid * 8u < total) gw[tid] = reinterpret_cast<const uint4 *>(dwoff)[tid];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t e8 = (uint32_t)tid + 512u * (uint32_t)i;
+        if (e8 * 8u < total) gw[e8] = reinterpret_cast<const uint4 *>(dwoff)[e8];
+    }
 }
 
 // seg [nb][256] -> segT [256][bpad] in 64 x 64 pieces (batches past nb read as empty); also clears the group flags
@@ -1272,8 +1280,10 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
         int jn = 0;         // next group whose start is not noted yet
         uint32_t jpos = 0;  // its first item position (= ex of its first batch)
 
-        uint32_t idx_n[PIPE], key_n[PIPE];  // the next window's items, loaded while this window is probed
-        auto fetch = [&](uint32_t t0) {
+        // two sets of window buffers {where a hit would be, item, home bucket}: one is probed while the other is loaded
+        uint32_t idx_a[PIPE], key_a[PIPE], idx_b[PIPE], key_b[PIPE];
+        uint4 bk_a[PIPE], bk_b[PIPE];
+        auto fetch = [&](uint32_t t0, uint32_t (&idx_n)[PIPE], uint32_t (&key_n)[PIPE]) {
 #pragma unroll
             for (int u = 0; u < PIPE; u++) {
                 if (t0 + (uint32_t)u >= nsteps) break;  // wave-uniform: the last window of a group is usually short
@@ -1287,12 +1297,11 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
                 idx_n[u] = (ix & 0x7E000u) | (uint32_t)jq.woff[ix];
             }
         };
-        uint4 bk_n[PIPE];                   // and their home buckets
 #pragma unroll
-        for (int u = 0; u < PIPE; u++) key_n[u] = 0u;  // steps a short window does not have still name a valid bucket
-        fetch(0);
+        for (int u = 0; u < PIPE; u++) key_a[u] = key_b[u] = 0u;  // steps a short window does not have still name a valid bucket
+        fetch(0, idx_a, key_a);
 #pragma unroll
-        for (int u = 0; u < PIPE; u++) bk_n[u] = sT[(key_n[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1)];
+        for (int u = 0; u < PIPE; u++) bk_a[u] = sT[(key_a[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1)];
         uint2 *lout = jq.late + ((uint64_t)s * ng64 + g) * kJoinLateCap;
         uint32_t npend = 0, nlate = 0;  // wave-uniform: parked lookups, late hits written
         // resolve the parked lookups (at most one per lane); their hits go to the side list, in no particular order
@@ -1318,18 +1327,12 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
-        auto window = [&](uint32_t t0, auto full_tag) {
+        auto window = [&](uint32_t t0, auto full_tag, uint32_t (&idx)[PIPE], uint32_t (&key)[PIPE], uint4 (&bk)[PIPE],
+                          uint32_t (&idx_n)[PIPE], uint32_t (&key_n)[PIPE], uint4 (&bk_n)[PIPE]) {
             constexpr bool FULL = decltype(full_tag)::value;  // all PIPE steps exist: no guards
-            uint32_t idx[PIPE], key[PIPE], rp[PIPE];  // rp: loc + 1 of a hit in the home bucket, or 0
-            uint4 bk[PIPE];
-#pragma unroll
-            for (int u = 0; u < PIPE; u++) {
-                idx[u] = idx_n[u];
-                key[u] = key_n[u];
-                bk[u] = bk_n[u];
-            }
+            uint32_t rp[PIPE];  // loc + 1 of a hit in the home bucket, or 0
             const bool more = t0 + PIPE < nsteps;  // wave-uniform
-            if (more) fetch(t0 + PIPE);
+            if (more) fetch(t0 + PIPE, idx_n, key_n);
             if (npend > (uint32_t)PCAP - 64u) flush_parked();  // the one place inside a group: room for 64 more lookups
 #pragma unroll
             for (int u = 0; u < PIPE; u++) {
@@ -1395,8 +1398,20 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
         };
         {
             uint32_t t0 = 0;
-            for (; t0 + PIPE <= nsteps; t0 += PIPE) window(t0, std::true_type{});
-            if (t0 < nsteps) window(t0, std::false_type{});
+            bool in_a = true;  // wave-uniform: which set holds the window at t0
+            for (; t0 + 2 * PIPE <= nsteps; t0 += 2 * PIPE) {
+                window(t0, std::true_type{}, idx_a, key_a, bk_a, idx_b, key_b, bk_b);
+                window(t0 + PIPE, std::true_type{}, idx_b, key_b, bk_b, idx_a, key_a, bk_a);
+            }
+            if (t0 + PIPE <= nsteps) {
+                window(t0, std::true_type{}, idx_a, key_a, bk_a, idx_b, key_b, bk_b);
+                t0 += PIPE;
+                in_a = false;
+            }
+            if (t0 < nsteps) {
+                if (in_a) window(t0, std::false_type{}, idx_a, key_a, bk_a, idx_b, key_b, bk_b);
+                else window(t0, std::false_type{}, idx_b, key_b, bk_b, idx_a, key_a, bk_a);
+            }
         }
         if (npend) flush_parked();
         if (lane == 0) jq.nlate[(uint64_t)g * kJoinSlices + s] = DBG ? 0u : nlate;
@@ -1936,12 +1951,12 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             const char *env_reps = getenv("GAVISUNK_JOIN_REPS");  // tuning: workgroups per table slice
             const uint32_t reps = env_reps ? std::max(1, atoi(env_reps)) : 1u;
             const char *env_jp = getenv("GAVISUNK_JOIN_PIPE");  // tuning: item loads in flight per lane
-            const int jpipe = env_jp ? atoi(env_jp) : 8;
+            const int jpipe = env_jp ? atoi(env_jp) : 4;
             const uint32_t chunk = std::min<uint32_t>(join_chunk(), r->jq.bpad);  // what the queues were sized for
             for (uint32_t b0 = 0; b0 < n_batches; b0 += chunk) {
                 const uint32_t nb = std::min(chunk, n_batches - b0);
                 const uint32_t ng64 = (nb + 63) / 64;
-                hipLaunchKernelGGL((k_join_bin<20>), dim3(nb), dim3(1024), 0, t->stream, cv, (const uint64_t *)r->words,
+                hipLaunchKernelGGL((k_join_bin<20>), dim3(nb), dim3(512), 0, t->stream, cv, (const uint64_t *)r->words,
                                    (const TileDesc *)r->tile_desc, r->n_tiles, b0, r->jq);
                 hipLaunchKernelGGL(k_join_segT, dim3(ng64, kJoinSlices / 64), dim3(256), 0, t->stream, r->jq, nb);
 #define GS_LAUNCH_JOIN_PROBE(PIPE, HF) GS_LAUNCH_JOIN_PROBE_DBG(PIPE, HF, 0)
@@ -1951,19 +1966,19 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                 const char *jdbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
                 const int jmode = jdbg ? atoi(jdbg) : 0;
                 if (!t->c_has_flag)
-                    GS_LAUNCH_JOIN_PROBE(8, false);
+                    GS_LAUNCH_JOIN_PROBE(4, false);
                 else if (jmode == 11)
-                    GS_LAUNCH_JOIN_PROBE_DBG(8, true, 1);
+                    GS_LAUNCH_JOIN_PROBE_DBG(4, true, 1);
                 else if (jmode == 12)
-                    GS_LAUNCH_JOIN_PROBE_DBG(8, true, 2);
+                    GS_LAUNCH_JOIN_PROBE_DBG(4, true, 2);
                 else if (jmode == 13)
-                    GS_LAUNCH_JOIN_PROBE_DBG(8, true, 3);
-                else if (jpipe == 4)
-                    GS_LAUNCH_JOIN_PROBE(4, true);
-                else if (jpipe == 6)
-                    GS_LAUNCH_JOIN_PROBE(6, true);
+                    GS_LAUNCH_JOIN_PROBE_DBG(4, true, 3);
+                else if (jpipe == 3)
+                    GS_LAUNCH_JOIN_PROBE(3, true);
+                else if (jpipe == 5)
+                    GS_LAUNCH_JOIN_PROBE(5, true);
                 else
-                    GS_LAUNCH_JOIN_PROBE(8, true);
+                    GS_LAUNCH_JOIN_PROBE(4, true);  // 4 steps per window, two windows in flight: measured best (118 VGPRs, no spills)
 #undef GS_LAUNCH_JOIN_PROBE
 #undef GS_LAUNCH_JOIN_PROBE_DBG
                 hipLaunchKernelGGL(k_join_merge, dim3((nb + kJoinMergeBatches - 1) / kJoinMergeBatches), dim3(1024), 0, t->stream,
