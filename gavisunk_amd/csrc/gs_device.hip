@@ -17,6 +17,8 @@
 //     k_probe<true>    compact table out in HBM: one 16-byte bucket load (one 64-byte line) per window
 //     k_probe_part + k_merge_part (+ k_probe<true> on the few tiles that cannot be merged)
 //                      compact table resident in the XCD-partitioned L2s
+//     k_join_bin + k_join_segT + k_join_probe + k_join_merge (k = 20, the default for small tables)
+//                      windows routed to the CU that holds their 1/256 slice of the compact table in LDS
 //   -> per tile {n_raw, first loc, last loc} and the ordered candidates (hits whose loc differs from the
 //      previous raw hit of the tile; the tile's first raw hit is always a candidate)
 //   scan A     over tiles: raw-hit prefix and the loc carried into each tile (`prevLoc` of
@@ -1068,7 +1070,7 @@ constexpr int kJoinTiles = 4;
 constexpr int kJoinWin = kJoinTiles * kTileWindows;  // windows per batch
 constexpr int kJoinSlices = 256;                     // kNPart x 16
 constexpr int kJoinSliceBuckets = 8192;              // LDS image of a slice: <= 128 KiB
-constexpr int kJoinOvfMax = 256;                     // overflow keys of a slice kept in LDS
+constexpr int kJoinOvfMax = 512;                     // overflow keys of a slice kept in LDS
 constexpr uint32_t kJoinChunkMax = 32768;            // batches per queue buffer (item indices stay below 2^28)
 constexpr uint32_t kJoinHitCap = 4096;               // hit records per (slice, 64 batches): the fast path cannot exceed it
 constexpr uint32_t kJoinLateCap = 256;                // late hit records per (slice, 64 batches); more = degenerate group
