@@ -106,15 +106,19 @@ __device__ __forceinline__ Slot load_slot(const Slot *p) {
     return s;
 }
 
+// Exclusive prefix sum over the 64 lanes with DPP adds (6 VALU instructions: shifts inside the rows of 16 lanes, then the
+// two row broadcasts of gfx9); `total` comes back wave-uniform.  All 64 lanes must be active.
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t &total) {
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    total = __shfl(x, 63);
-    return x - v;
+    (void)lane;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    total = (uint32_t)__builtin_amdgcn_readlane(x, 63);
+    return (uint32_t)x - v;
 }
 
 #ifndef GS_PART_WAVES
@@ -1930,14 +1934,14 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             (rc = dev_alloc(&r->jq.seg, nb * kJoinSlices)) || (rc = dev_alloc(&r->jq.segT, bpad * kJoinSlices)) ||
             (rc = dev_alloc(&r->jq.hits, bpad / 64 * kJoinSlices * kJoinHitCap)) ||
             (rc = dev_alloc(&r->jq.hsub, bpad / kJoinMergeBatches * kJoinSlices)) || (rc = dev_alloc(&r->jq.gflag, bpad / 64)) ||
-            (rc = dev_alloc(&r->jq.late, bpad / 64 * kJoinSlices * kJoinLateCap)) || (rc = dev_alloc(&r->jq.nlate, bpad / 64 * kJoinSlices)) ||
-            (rc = dev_alloc(&r->complex_list, r->n_tiles)))
+            (rc = dev_alloc(&r->jq.late, bpad / 64 * kJoinSlices * kJoinLateCap)) || (rc = dev_alloc(&r->jq.nlate, bpad / 64 * kJoinSlices)))
             return rc;
+        if (!r->complex_list && (rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
     }
     if (t->compact == 1 && !t->join && r->n_tiles && !r->part_recs) {
         int rc;
         if ((rc = dev_alloc(&r->part_recs, (uint64_t)r->n_tiles * kNPart))) return rc;
-        if ((rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
+        if (!r->complex_list && (rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
     }
     memset(t->h_init, 0, sizeof(PassStatus));
     t->h_init->err_pos = ~0ULL;
