@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
     const uint32_t n_ovf = ovf_start[s + 1] - ovf_start[s];
     {
         const uint4 *src = ct.buckets + ((uint64_t)(s >> 4) << ct.qb) + ((uint64_t)(s & 15u) << sb);
-        for (uint32_t i = tid; i < (1u << sb); i += 1024u) sT[i] = src[i];
+        for (uint32_t i = tid; i < (1u << sb); i += blockDim.x) sT[i] = src[i];
         if ((uint32_t)tid < n_ovf) {
             sOvfKey[tid] = (uint32_t)ovf_code[ovf_start[s] + tid];  // the item part; the slice part is s
             sOvfLoc[tid] = ovf_loc[ovf_start[s] + tid];
@@ -1245,7 +1245,8 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
     };
 
     const uint32_t ngroups = (nb + 63u) / 64u;
-    const uint32_t gfirst = rep * 16u + (uint32_t)wave, gstep = reps * 16u;
+    const uint32_t nwaves = blockDim.x >> 6;  // 16; fewer only in occupancy experiments
+    const uint32_t gfirst = rep * nwaves + (uint32_t)wave, gstep = reps * nwaves;
     uint32_t sg_next = gfirst < ngroups ? jq.segT[(uint64_t)s * jq.bpad + gfirst * 64u + (uint32_t)lane] : 0u;
     for (uint32_t g = gfirst; g < ngroups; g += gstep) {
         const uint32_t b = g * 64u + (uint32_t)lane;
@@ -1956,6 +1957,8 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             const uint32_t n_batches = (r->n_tiles + kJoinTiles - 1) / kJoinTiles;
             const char *env_reps = getenv("GAVISUNK_JOIN_REPS");  // tuning: workgroups per table slice
             const uint32_t reps = env_reps ? std::max(1, atoi(env_reps)) : 1u;
+            const char *env_jt = getenv("GAVISUNK_JOIN_THREADS");  // occupancy experiment: probe workgroup size (multiple of 64)
+            const uint32_t jthreads = env_jt ? std::min(1024, std::max(64, atoi(env_jt) / 64 * 64)) : 1024u;
             const char *env_jp = getenv("GAVISUNK_JOIN_PIPE");  // tuning: item loads in flight per lane
             const int jpipe = env_jp ? atoi(env_jp) : 4;
             const uint32_t chunk = std::min<uint32_t>(join_chunk(), r->jq.bpad);  // what the queues were sized for
@@ -1967,7 +1970,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                 hipLaunchKernelGGL(k_join_segT, dim3(ng64, kJoinSlices / 64), dim3(256), 0, t->stream, r->jq, nb);
 #define GS_LAUNCH_JOIN_PROBE(PIPE, HF) GS_LAUNCH_JOIN_PROBE_DBG(PIPE, HF, 0)
 #define GS_LAUNCH_JOIN_PROBE_DBG(PIPE, HF, DBG)                                                                                \
-    hipLaunchKernelGGL((k_join_probe<20, PIPE, HF, DBG>), dim3(kJoinSlices * reps), dim3(1024), 0, t->stream, cv, r->jq, nb, reps, \
+    hipLaunchKernelGGL((k_join_probe<20, PIPE, HF, DBG>), dim3(kJoinSlices * reps), dim3(jthreads), 0, t->stream, cv, r->jq, nb, reps, \
                        (const uint64_t *)t->j_ovf_code, (const uint32_t *)t->j_ovf_loc, (const uint32_t *)t->j_ovf_start)
                 const char *jdbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
                 const int jmode = jdbg ? atoi(jdbg) : 0;

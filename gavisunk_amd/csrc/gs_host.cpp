@@ -6,9 +6,12 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 
 #include "gs_common.h"
@@ -167,41 +170,61 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
     *out = nullptr;
     auto *d = new gs_sunkdb();
     std::string line;
-    CodeMap keymap;  // db code -> key index
-    {
+    auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = tnow();
+    // The two files are independent until the join at the end: the k-mer list is read by a second thread while this one
+    // reads the location table (both are dominated by their hash-map inserts).
+    int db_rc = GS_OK;
+    bool db_open = true;
+    std::thread db_thread([&]() {
+        CodeMap keymap;  // db code -> key index
+        std::string l;
+        std::vector<uint64_t> keys;  // local while growing: the two threads must not share cache lines of *d
+        int k = 0;
         LineReader r(db_path);
         if (!r.ok()) {
-            set_error("cannot open the file %s", db_path);
-            delete d;
-            return GS_E_IO;
+            db_open = false;
+            db_rc = GS_E_IO;
+            return;
         }
         bool first = true;
-        while (r.next(line)) {
+        while (r.next(l)) {
             if (first) {  // k = len(first line), kmerpos_annot3.nim:28-38
-                d->k = (int)line.size();
+                k = (int)l.size();
                 first = false;
             }
-            const uint64_t code = encode_kmer(line.data(), line.size());
+            const uint64_t code = encode_kmer(l.data(), l.size());
             bool fresh;
             uint32_t &slot = keymap.at(code, fresh);
             if (fresh) {
-                slot = (uint32_t)d->keys.size();
-                d->keys.push_back(code);
+                slot = (uint32_t)keys.size();
+                keys.push_back(code);
             }
         }
-        if (d->k < 1 || d->k > 32) {
-            set_error("%s: k = %d is outside 1..32 (2 bits per base in a uint64)", db_path, d->k);
-            delete d;
-            return GS_E_ARG;
+        d->k = k;
+        d->keys = std::move(keys);
+        if (k < 1 || k > 32) db_rc = GS_E_ARG;
+    });
+    struct Joiner {  // the thread is joined on every way out
+        std::thread &t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
         }
-    }
+    } joiner{db_thread};
+    // the reference reads the k-mer list first: its errors win over errors in the location table
+    auto db_error = [&]() {
+        if (!db_open) set_error("cannot open the file %s", db_path);
+        else set_error("%s: k = %d is outside 1..32 (2 bits per base in a uint64)", db_path, d->k);
+        return db_rc;
+    };
     CodeMap rowmap;  // loc code -> last row with that code
     {
         LineReader r(loc_path);
         if (!r.ok()) {
-            set_error("cannot open the file %s", loc_path);
+            db_thread.join();
+            const int rc = db_rc != GS_OK ? db_error() : (set_error("cannot open the file %s", loc_path), GS_E_IO);
             delete d;
-            return GS_E_IO;
+            return rc;
         }
         std::unordered_map<std::string, uint32_t> contig_id;
         struct PairHash {
@@ -236,9 +259,13 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
             }
             int64_t start, group;
             if (nf < 4 || !parse_i64(f[1], fe[1], start) || !parse_i64(f[3], fe[3], group)) {
-                set_error("%s:%llu: expected `chrom<TAB>start<TAB>kmer<TAB>group`", loc_path, (unsigned long long)lineno);
+                db_thread.join();
+                const int rc = db_rc != GS_OK ? db_error()
+                                              : (set_error("%s:%llu: expected `chrom<TAB>start<TAB>kmer<TAB>group`", loc_path,
+                                                           (unsigned long long)lineno),
+                                                 GS_E_IO);
                 delete d;
-                return GS_E_IO;
+                return rc;
             }
             // consecutive rows nearly always share the contig and very often the group: skip the hash lookups then
             uint32_t cid;
@@ -282,18 +309,36 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
             rowmap.at(encode_kmer(f[2], fe[2] - f[2]), fresh) = row;  // later row overwrites (:68)
         }
     }
+    const double t_loc = tnow();
+    db_thread.join();
+    const double t_db = tnow();
+    if (db_rc != GS_OK) {
+        const int rc = db_error();
+        delete d;
+        return rc;
+    }
     d->key_row.resize(d->keys.size());
     d->key_loc.resize(d->keys.size());
-    for (size_t i = 0; i < d->keys.size(); i++) {
-        uint32_t row;
-        if (rowmap.get(d->keys[i], row)) {
-            d->key_row[i] = row;
-            d->key_loc[i] = d->row_loc[row];
-        } else {
-            d->key_row[i] = GS_MISSING;
-            d->key_loc[i] = GS_MISSING;
+    auto join_range = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            uint32_t row;
+            if (rowmap.get(d->keys[i], row)) {
+                d->key_row[i] = row;
+                d->key_loc[i] = d->row_loc[row];
+            } else {
+                d->key_row[i] = GS_MISSING;
+                d->key_loc[i] = GS_MISSING;
+            }
         }
-    }
+    };
+    const size_t nk = d->keys.size();
+    const unsigned nthr = nk < (1u << 16) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthr; t++) pool.emplace_back(join_range, nk * t / nthr, nk * (t + 1) / nthr);
+    join_range(0, nk / nthr);
+    for (auto &t : pool) t.join();
+    if (getenv("GAVISUNK_TIMING"))
+        fprintf(stderr, "[sunkdb] loc %.3f s, +db wait %.3f s, join %.3f s (%u threads)\n", t_loc - t_start, t_db - t_loc, tnow() - t_db, nthr);
     *out = d;
     return GS_OK;
 }

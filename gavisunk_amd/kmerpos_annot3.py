@@ -11,15 +11,70 @@ batch, default 2^31).
 from __future__ import annotations
 
 import os
+import queue
 import sys
+import threading
 
 from . import _lib, engine
 
 
+class _Prefetch:
+    """Read batches parsed and 2-bit packed by a second thread (the native parser runs without the GIL), one batch ahead:
+    the first batch is ready when the k-mer list and the location table are, later ones while the GPU tags their
+    predecessors.  Errors of the reads file surface where the reference meets them: when the batch is asked for."""
+
+    def __init__(self, path: str, max_bases: int):
+        self._q: queue.Queue = queue.Queue(maxsize=1)
+        self._stop = threading.Event()
+        self._t = threading.Thread(target=self._work, args=(path, max_bases), daemon=True)
+        self._t.start()
+
+    def _put(self, item) -> bool:
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def _work(self, path, max_bases):
+        try:
+            for b in engine.read_batches(path, max_bases=max_bases):
+                if not self._put(b):
+                    b.close()
+                    return
+            self._put(None)
+        except BaseException as e:  # handed to the consumer
+            self._put(e)
+
+    def __iter__(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def close(self):
+        self._stop.set()
+        while True:  # drop what was parsed ahead
+            try:
+                item = self._q.get_nowait()
+            except queue.Empty:
+                break
+            if item is not None and not isinstance(item, BaseException):
+                item.close()
+        self._t.join(timeout=5)
+
+
 def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_bases: int = 1 << 31) -> int:
+    batches = _Prefetch(reads, batch_bases)
     try:
         db = engine.SunkDB(kmers, locs)
     except _lib.GsError as e:
+        batches.close()
         sys.stderr.write(e.msg + "\n")
         return 1
     sys.stderr.write("FINISHED READING KMERS\n")
@@ -28,7 +83,7 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
     carry = _lib.GS_NONE
     rc = 0
     with open(ofile, "w") as out:
-        for batch in engine.read_batches(reads, max_bases=batch_bases):
+        for batch in batches:
             dev = engine.DeviceReads(batch, db.k, device)
             st, hits, carry, _ = engine.tag(table, dev, carry)
             out.write(engine.format_sunkpos(hits, batch.names, db))
@@ -38,6 +93,7 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
                 sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
                 rc = 1
                 break
+    batches.close()
     table.close()
     db.close()
     return rc
