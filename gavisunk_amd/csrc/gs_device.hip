@@ -164,6 +164,9 @@ __host__ __device__ __forceinline__ uint32_t part_of(uint64_t c, int k) {
     return ((x0 ^ xl) << 2) | (x1 ^ xl2);
 }
 
+// n low bits set; n may be 32 (a 31-bit remainder with its alt bit position, in tables whose slots have no spare bit)
+__host__ __device__ __forceinline__ uint32_t low_bits32(int n) { return n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u; }
+
 // slot = [ flags(2, slot 0 only) | alt(1) | rem | loc ];  flags: bit 31 = a key of this bucket lives in its
 // second-chance bucket, bit 30 = a key of this bucket lives in the generic table only
 struct CompactView {
@@ -222,7 +225,7 @@ __device__ __forceinline__ bool compact_lookup(const CompactView &ct, const Tabl
         }
         return false;
     }
-    const uint32_t locmask = (1u << ct.locbits) - 1u, tagmask = (1u << (ct.rembits + 1)) - 1u;
+    const uint32_t locmask = (1u << ct.locbits) - 1u, tagmask = low_bits32(ct.rembits + 1);
     const uint4 *pb = ct.buckets + ((uint64_t)part_of(c, k) << ct.qb);
     const uint4 b = pb[br.bucket];
     const uint32_t sl[4] = {b.x, b.y, b.z, b.w};
@@ -395,7 +398,7 @@ __device__ __forceinline__ void probe_tile(const TableView &tab, const CompactVi
         // compact table out in HBM: one 16-byte bucket load per window (one 64-byte line from the fabric), 8 in flight
         const int kbits = 2 * k - 4;
         const uint64_t keymask = (1ULL << kbits) - 1ULL;
-        const uint32_t locmask = (1u << ct.locbits) - 1u, tagmask = (1u << (ct.rembits + 1)) - 1u;
+        const uint32_t locmask = (1u << ct.locbits) - 1u, tagmask = low_bits32(ct.rembits + 1);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             uint64_t c[8];
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView c
     const int kbits = 2 * k - 4;
     const uint64_t keymask = (1ULL << kbits) - 1ULL;
     const uint32_t locmask = (1u << ct.locbits) - 1u;
-    const uint32_t tagmask = (1u << (ct.rembits + 1)) - 1u;  // remainder + alt bit
+    const uint32_t tagmask = low_bits32(ct.rembits + 1);  // remainder + alt bit
     const uint4 *part_buckets = ct.buckets + ((uint64_t)p << ct.qb);
     uint32_t (*runs)[3] = sRun[wave];
     PartState st;

@@ -279,6 +279,23 @@ def test_homopolymer_reads_take_the_exact_fallback():
     assert np.array_equal(gh["payload"], oh["row"]) and carry == (loc[oprev] if oprev != oracle.NONE else _lib.GS_NONE)
 
 
+@pytest.mark.parametrize("k,qb", [(20, "5"), (22, None)])
+def test_slots_without_a_spare_bit(k, qb, monkeypatch, table_layout):
+    """A single location group and a 31-bit remainder fill a 32-bit slot completely (k = 22 gets there by itself,
+    k = 20 with the smallest bucket count): the tag mask is then all 32 bits (found by tools/fuzz_tag.py)."""
+    if qb:
+        monkeypatch.setenv("GAVISUNK_COMPACT_QB", qb)
+    keys, loc, seqs = _random_case(91, k, n_reads=60, glen=8000, median=2000)
+    loc = np.zeros_like(loc)
+    if table_layout != "generic":
+        tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+        assert "31-bit remainder, 1-bit loc" in tab.layout
+        tab.close()
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] > 10000 and len(gh) == len(oh) == 1
+
+
 def test_table_without_keys():
     st, h, carry, ctr = _engine_hits(20, np.zeros(0, np.uint64), np.zeros(0, np.uint32), [b"ACGT" * 100, b""])
     assert st == 0 and len(h) == 0 and carry == _lib.GS_NONE and ctr["raw_hits"] == 0
