@@ -1663,7 +1663,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(TileArrays ta, uint
 // k_emit: one thread per tile
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, int compact, ReadsView rd, TileArrays ta,
-                                              const uint32_t *cand, uint32_t cand_cap, gs_hit *hits, uint64_t hit_cap) {
+                                              const uint32_t *cand, uint32_t cand_cap, gs_hit *hits, gs_hit *hits_host,
+                                              uint64_t hit_cap) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= rd.n_tiles) return;
     const uint32_t nc = ta.n_cand[tile];
@@ -1709,6 +1710,7 @@ __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, int
         hrec.pos = (uint32_t)(w - suppressed_before);
         hrec.payload = payload;
         hits[o] = hrec;
+        hits_host[o] = hrec;  // the few emitted rows also go straight to pinned host memory
     }
 }
 
@@ -1892,6 +1894,7 @@ struct gs_reads {
     uint32_t *cand = nullptr;
     uint32_t cand_cap = 0;
     gs_hit *hits = nullptr;
+    gs_hit *hits_host = nullptr;       // pinned mirror written by k_emit itself: no device-to-host copy after the pass
     uint64_t hit_cap = 0;
     TileDesc *tile_desc = nullptr;     // [n_tiles]
     PartRec *part_recs = nullptr;      // [n_tiles * kNPart], fast path only
@@ -1910,11 +1913,14 @@ int ensure_out_buffers(gs_reads *r, uint32_t cand_cap) {
     if (r->cand && r->cand_cap >= cand_cap) return GS_OK;
     if (r->cand) (void)hipFree(r->cand);
     if (r->hits) (void)hipFree(r->hits);
+    if (r->hits_host) (void)hipHostFree(r->hits_host);
     r->cand = nullptr;
     r->hits = nullptr;
+    r->hits_host = nullptr;
     int rc;
     if ((rc = dev_alloc(&r->cand, cand_cap))) return rc;
     if ((rc = dev_alloc(&r->hits, cand_cap))) return rc;
+    HIP_TRY(hipHostMalloc((void **)&r->hits_host, (size_t)cand_cap * sizeof(gs_hit), hipHostMallocDefault));
     r->cand_cap = cand_cap;
     r->hit_cap = cand_cap;
     return GS_OK;
@@ -2085,7 +2091,7 @@ int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
     if (r->n_tiles) {
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
         hipLaunchKernelGGL(k_emit, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, view(t), cv, t->compact, view(r), r->ta,
-                           r->cand, r->cand_cap, r->hits, r->hit_cap);
+                           r->cand, r->cand_cap, r->hits, r->hits_host, r->hit_cap);
     }
     HIP_TRY(hipEventRecord(t->ev[2], t->stream));
     HIP_TRY(hipMemcpyAsync(t->h_status, t->d_status, sizeof(PassStatus), hipMemcpyDeviceToHost, t->stream));
@@ -2530,6 +2536,7 @@ void gs_reads_destroy(gs_reads *r) {
     (void)hipFree(r->block_agg);
     (void)hipFree(r->cand);
     (void)hipFree(r->hits);
+    if (r->hits_host) (void)hipHostFree(r->hits_host);
     (void)hipFree(r->tile_desc);
     (void)hipFree(r->part_recs);
     (void)hipFree(r->jq.item);
@@ -2657,7 +2664,10 @@ static int copy_hits(gs_table *t, gs_reads *r, void *out, uint64_t cap, uint64_t
             set_error("%llu hits do not fit in cap = %llu", (unsigned long long)t->res_n, (unsigned long long)cap);
             return GS_E_CAPACITY;
         }
-        if (t->res_n) HIP_TRY(hipMemcpy(out, r->hits, t->res_n * sizeof(gs_hit), kind));
+        if (t->res_n) {
+            if (kind == hipMemcpyDeviceToHost) memcpy(out, r->hits_host, t->res_n * sizeof(gs_hit));  // k_emit wrote them there too
+            else HIP_TRY(hipMemcpy(out, r->hits, t->res_n * sizeof(gs_hit), kind));
+        }
     }
     if (t->res_keyerr) {
         set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
