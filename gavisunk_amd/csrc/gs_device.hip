@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <type_traits>
@@ -2575,6 +2576,8 @@ int gs_tag_launch(gs_table *t, gs_reads *r, uint32_t carry_in) {
     return launch_phase2(t, r, carry_in);
 }
 
+static hipError_t wait_stream(hipStream_t st);
+
 int gs_tag_phase1(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_loc) {
     int rc;
     if ((rc = check_pair(t, r, "gs_tag_phase1"))) return rc;
@@ -2585,7 +2588,7 @@ int gs_tag_phase1(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_lo
     if ((rc = launch_scan(t, r, 0))) return rc;
     Agg tot;
     HIP_TRY(hipMemcpyAsync(&tot, t->d_totals, sizeof tot, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipStreamSynchronize(t->stream));
+    HIP_TRY(wait_stream(t->stream));
     if (has_raw) *has_raw = tot.has;
     if (last_loc) *last_loc = tot.has ? tot.loc : GS_NONE;
     return GS_OK;
@@ -2595,6 +2598,16 @@ int gs_tag_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
     int rc;
     if ((rc = check_pair(t, r, "gs_tag_phase2"))) return rc;
     return launch_phase2(t, r, carry_in);
+}
+
+// A pass over a batch is a millisecond or two: poll first (the wake-up of a blocking wait can cost a third of that),
+// block only when the pass turns out to be long.
+static hipError_t wait_stream(hipStream_t st) {
+    hipError_t q = hipErrorNotReady;
+    const auto t_poll = std::chrono::steady_clock::now();
+    while ((q = hipStreamQuery(st)) == hipErrorNotReady)
+        if (std::chrono::steady_clock::now() - t_poll > std::chrono::milliseconds(20)) break;
+    return q == hipErrorNotReady ? hipStreamSynchronize(st) : q;
 }
 
 // Waits for the pass and caches its outcome in the table handle (idempotent until the next launch).
@@ -2607,7 +2620,7 @@ static int settle(gs_table *t, gs_reads *r) {
     }
     HIP_TRY(hipSetDevice(t->device));
     for (int attempt = 0; attempt < 8; attempt++) {
-        HIP_TRY(hipStreamSynchronize(t->stream));
+        HIP_TRY(wait_stream(t->stream));
         const uint32_t ncand = t->h_status->cand_count;
         const unsigned long long err = t->h_status->err_pos;
         const Agg tot[2] = {t->h_status->totals[0], t->h_status->totals[1]};
