@@ -106,6 +106,27 @@ def test_missing_file_is_an_io_error(tmp_path):
     with pytest.raises(_lib.GsError) as e:
         engine.SunkDB(str(tmp_path / "nope.db"), str(tmp_path / "nope.loc"))
     assert e.value.status == _lib.GS_E_IO
+    assert "nope.db" in e.value.msg  # the k-mer list is read first (kmerpos_annot3.nim:20-40): its error wins
+
+
+def test_loader_errors_name_the_right_file(tmp_path):
+    """The two files are parsed by two threads; errors still come out as if the k-mer list had been read first."""
+    db, loc = tmp_path / "k.db", tmp_path / "k.loc"
+    db.write_text("ACGTACGTACGTACGTACGT\n")
+    with pytest.raises(_lib.GsError) as e:
+        engine.SunkDB(str(db), str(tmp_path / "nope.loc"))
+    assert e.value.status == _lib.GS_E_IO and "nope.loc" in e.value.msg
+    loc.write_text("ctg\t12\tACGTACGTACGTACGTACGT\t12\nctg\tnot-a-number\tACGTACGTACGTACGTACGA\t12\n")
+    with pytest.raises(_lib.GsError) as e:
+        engine.SunkDB(str(db), str(loc))
+    assert e.value.status == _lib.GS_E_IO and "k.loc:2" in e.value.msg
+    with pytest.raises(_lib.GsError) as e:
+        engine.SunkDB(str(tmp_path / "nope.db"), str(loc))
+    assert "nope.db" in e.value.msg
+    loc.write_text("ctg\t12\tACGTACGTACGTACGTACGT\t12\n")
+    d = engine.SunkDB(str(db), str(loc))
+    assert d.k == 20 and len(d.keys) == 1 and d.key_row.tolist() == [0] and d.contigs == ["ctg"]
+    d.close()
 
 
 @pytest.mark.skipif(_lib.lib().gs_device_count() > 0, reason="only meaningful on a box without a GPU")
