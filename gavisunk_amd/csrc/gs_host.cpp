@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -30,16 +32,27 @@ void set_error(const char *fmt, ...) {
 }
 
 // ---------------------------------------------------------------------------------- line reader
+// Lines of a plain or gzip-compressed file.  A second thread inflates / reads one 1 MiB block ahead while the caller
+// splits the previous block into lines (for .gz inputs inflating is the larger half of the work).
 class LineReader {
    public:
     explicit LineReader(const char *path) {
         f_ = gzopen(path, "rb");  // transparently reads plain files too
         if (f_) gzbuffer(f_, 1 << 20);
-        buf_.resize(1 << 20);
     }
     ~LineReader() {
+        if (th_.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                stop_ = true;
+            }
+            cv_.notify_all();
+            th_.join();
+        }
         if (f_) gzclose(f_);
     }
+    LineReader(const LineReader &) = delete;
+    LineReader &operator=(const LineReader &) = delete;
     bool ok() const { return f_ != nullptr; }
     // Next line without its '\n' (and without a trailing '\r'); false at EOF.
     bool next(std::string &line) {
@@ -47,20 +60,17 @@ class LineReader {
         bool any = false;
         for (;;) {
             if (pos_ == end_) {
-                int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
-                if (n <= 0) {
+                if (!refill()) {
                     if (any && !line.empty() && line.back() == '\r') line.pop_back();
                     return any;
                 }
-                pos_ = 0;
-                end_ = (size_t)n;
             }
-            const char *p = buf_.data() + pos_;
+            const char *p = cur_ + pos_;
             const char *nl = (const char *)memchr(p, '\n', end_ - pos_);
             any = true;
             if (nl) {
                 line.append(p, nl - p);
-                pos_ = (size_t)(nl - buf_.data()) + 1;
+                pos_ = (size_t)(nl - cur_) + 1;
                 if (!line.empty() && line.back() == '\r') line.pop_back();
                 return true;
             }
@@ -70,8 +80,61 @@ class LineReader {
     }
 
    private:
+    struct Block {
+        std::vector<char> data;
+        size_t n = 0;
+        bool full = false;
+    };
+    void produce() {  // blocks are filled and consumed in the same alternating order
+        for (int i = 0;; i ^= 1) {
+            Block &b = blk_[i];
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return !b.full || stop_; });
+                if (stop_) return;
+            }
+            if (b.data.empty()) b.data.resize(1 << 20);
+            const int n = gzread(f_, b.data.data(), (unsigned)b.data.size());
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (n <= 0) {
+                    eof_ = true;
+                } else {
+                    b.n = (size_t)n;
+                    b.full = true;
+                }
+            }
+            cv_.notify_all();
+            if (n <= 0) return;
+        }
+    }
+    bool refill() {
+        if (!f_) return false;
+        if (!th_.joinable() && !eof_) th_ = std::thread([this] { produce(); });
+        std::unique_lock<std::mutex> lk(m_);
+        if (have_) {  // hand the block just consumed back
+            blk_[cons_].full = false;
+            cons_ ^= 1;
+            have_ = false;
+            cv_.notify_all();
+        }
+        cv_.wait(lk, [&] { return blk_[cons_].full || eof_; });
+        if (!blk_[cons_].full) return false;
+        cur_ = blk_[cons_].data.data();
+        pos_ = 0;
+        end_ = blk_[cons_].n;
+        have_ = true;
+        return true;
+    }
+
     gzFile f_ = nullptr;
-    std::vector<char> buf_;
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    Block blk_[2];
+    int cons_ = 0;
+    bool have_ = false, eof_ = false, stop_ = false;
+    const char *cur_ = nullptr;
     size_t pos_ = 0, end_ = 0;
 };
 
