@@ -240,9 +240,8 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
     int db_rc = GS_OK;
     bool db_open = true;
     std::thread db_thread([&]() {
-        CodeMap keymap;  // db code -> key index
         std::string l;
-        std::vector<uint64_t> keys;  // local while growing: the two threads must not share cache lines of *d
+        std::vector<uint64_t> codes;  // local while growing: the two threads must not share cache lines of *d
         int k = 0;
         LineReader r(db_path);
         if (!r.ok()) {
@@ -256,16 +255,36 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
                 k = (int)l.size();
                 first = false;
             }
-            const uint64_t code = encode_kmer(l.data(), l.size());
-            bool fresh;
-            uint32_t &slot = keymap.at(code, fresh);
-            if (fresh) {
-                slot = (uint32_t)keys.size();
-                keys.push_back(code);
-            }
+            codes.push_back(encode_kmer(l.data(), l.size()));
         }
+        // a k-mer listed twice is one key (the reference's HashSet): keep first occurrences, in file order.  The hashing
+        // is split over threads by hash class, like the row map below.
+        const size_t n = codes.size();
+        std::vector<uint8_t> is_first(n, 0);
+        auto mark = [&](unsigned part) {
+            CodeMap seen;
+            seen.reserve(n / 8 + n / 32 + 16);
+            for (size_t i = 0; i < n; i++)
+                if ((unsigned)((codes[i] * 0xD6E8FEB86659FD93ULL) >> 61) == part) {
+                    bool fresh;
+                    seen.at(codes[i], fresh);
+                    is_first[i] = fresh;
+                }
+        };
+        if (n < (1u << 16)) {
+            for (unsigned p2 = 0; p2 < 8; p2++) mark(p2);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned p2 = 1; p2 < 8; p2++) pool.emplace_back(mark, p2);
+            mark(0);
+            for (auto &t : pool) t.join();
+        }
+        size_t nk = 0;
+        for (size_t i = 0; i < n; i++)
+            if (is_first[i]) codes[nk++] = codes[i];
+        codes.resize(nk);
         d->k = k;
-        d->keys = std::move(keys);
+        d->keys = std::move(codes);
         if (k < 1 || k > 32) db_rc = GS_E_ARG;
     });
     struct Joiner {  // the thread is joined on every way out
@@ -280,7 +299,12 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
         else set_error("%s: k = %d is outside 1..32 (2 bits per base in a uint64)", db_path, d->k);
         return db_rc;
     };
-    CodeMap rowmap;  // loc code -> last row with that code
+    // loc code -> last row with that code.  The codes are collected while the text is parsed and hashed afterwards by
+    // several threads, each owning the codes of one hash class (rows stay in file order inside a class: last row wins).
+    constexpr unsigned kMapParts = 8;
+    CodeMap rowmap[kMapParts];
+    auto map_part = [](uint64_t code) { return (unsigned)((code * 0xD6E8FEB86659FD93ULL) >> 61); };
+    std::vector<uint64_t> row_code;
     {
         LineReader r(loc_path);
         if (!r.ok()) {
@@ -368,8 +392,28 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
             last_group = group;
             last_lid = lid;
             d->row_loc.push_back(lid);
-            bool fresh;
-            rowmap.at(encode_kmer(f[2], fe[2] - f[2]), fresh) = row;  // later row overwrites (:68)
+            (void)row;
+            row_code.push_back(encode_kmer(f[2], fe[2] - f[2]));
+        }
+    }
+    {
+        const size_t nrows = row_code.size();
+        auto build = [&](unsigned part) {
+            CodeMap &m = rowmap[part];
+            m.reserve(nrows / kMapParts + nrows / (4 * kMapParts) + 16);
+            for (size_t i = 0; i < nrows; i++)
+                if (map_part(row_code[i]) == part) {
+                    bool fresh;
+                    m.at(row_code[i], fresh) = (uint32_t)i;  // later row overwrites (kmerpos_annot3.nim:68)
+                }
+        };
+        if (nrows < (1u << 16)) {
+            for (unsigned p2 = 0; p2 < kMapParts; p2++) build(p2);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned p2 = 1; p2 < kMapParts; p2++) pool.emplace_back(build, p2);
+            build(0);
+            for (auto &t : pool) t.join();
         }
     }
     const double t_loc = tnow();
@@ -385,7 +429,7 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
     auto join_range = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; i++) {
             uint32_t row;
-            if (rowmap.get(d->keys[i], row)) {
+            if (rowmap[map_part(d->keys[i])].get(d->keys[i], row)) {
                 d->key_row[i] = row;
                 d->key_loc[i] = d->row_loc[row];
             } else {
