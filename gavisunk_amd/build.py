@@ -33,7 +33,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread"]
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

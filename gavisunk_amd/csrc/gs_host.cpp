@@ -2,6 +2,7 @@
 //   SUNK list + loc table loader  <- kmerpos_annot3.nim:20-69
 //   FASTA/FASTQ(.gz) reader + 2-bit packer  <- `readfq(reads)`, kmerpos_annot3.nim:85, rlen.nim:13
 // Native C++ because the reference's counterpart is native (Nim); no GPU involved here.
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -34,9 +35,84 @@ void set_error(const char *fmt, ...) {
 // ---------------------------------------------------------------------------------- line reader
 // Lines of a plain or gzip-compressed file.  A second thread inflates / reads one 1 MiB block ahead while the caller
 // splits the previous block into lines (for .gz inputs inflating is the larger half of the work).
+// Whole-buffer gzip decompression with libdeflate when the system has it (2-3x zlib's inflate); resolved at run time,
+// so the library neither needs its header nor fails without it.
+struct Deflate {
+    void *(*alloc)() = nullptr;
+    int (*gunzip)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    Deflate() {
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        gunzip = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(h, "libdeflate_gzip_decompress_ex");
+        release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        if (!alloc || !gunzip || !release) alloc = nullptr;
+    }
+    bool ok() const { return alloc != nullptr; }
+};
+static const Deflate &deflate_lib() {
+    static const Deflate d;
+    return d;
+}
+
+// A .gz file of moderate size, inflated in one go: members one after the other (a plain `gzip` file has one, bgzip
+// files many), the output buffer sized from the trailer of the last member and grown when that guess is short.
+// Returns false (and leaves `out` unspecified) whenever anything is unusual: the caller then streams with zlib.
+static bool inflate_whole_file(const char *path, std::vector<char> &out) {
+    const Deflate &lib = deflate_lib();
+    if (!lib.ok() || getenv("GAVISUNK_NO_LIBDEFLATE")) return false;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return false;
+    std::vector<unsigned char> in;
+    bool good = false;
+    if (fseek(fp, 0, SEEK_END) == 0) {
+        const long sz = ftell(fp);
+        if (sz >= 18 && sz <= (1L << 30) && fseek(fp, 0, SEEK_SET) == 0) {
+            in.resize((size_t)sz);
+            good = fread(in.data(), 1, in.size(), fp) == in.size() && in[0] == 0x1f && in[1] == 0x8b;
+        }
+    }
+    fclose(fp);
+    if (!good) return false;
+    const size_t n = in.size();
+    const size_t isize = (size_t)in[n - 4] | ((size_t)in[n - 3] << 8) | ((size_t)in[n - 2] << 16) | ((size_t)in[n - 1] << 24);
+    size_t cap = std::max<size_t>(isize, n) + 4096;  // exact for a single member below 4 GiB; a first guess otherwise
+    if (cap > (3ull << 30)) return false;
+    void *d = lib.alloc();
+    if (!d) return false;
+    out.resize(cap);
+    size_t ipos = 0, opos = 0;
+    good = true;
+    while (ipos < n && good) {
+        size_t used_in = 0, used_out = 0;
+        const int rc = lib.gunzip(d, in.data() + ipos, n - ipos, out.data() + opos, out.size() - opos, &used_in, &used_out);
+        if (rc == 0 && used_in > 0) {
+            ipos += used_in;
+            opos += used_out;
+        } else if (rc == 3 && out.size() < (3ull << 30)) {  // LIBDEFLATE_INSUFFICIENT_SPACE: grow, redo this member
+            out.resize(std::min<size_t>(out.size() * 2, 3ull << 30));
+        } else {
+            good = false;
+        }
+    }
+    lib.release(d);
+    if (!good) return false;
+    out.resize(opos);
+    return true;
+}
+
 class LineReader {
    public:
     explicit LineReader(const char *path) {
+        const size_t len = strlen(path);
+        if (len > 3 && !strcmp(path + len - 3, ".gz") && inflate_whole_file(path, whole_)) {
+            in_memory_ = true;
+            cur_ = whole_.data();
+            end_ = whole_.size();
+            return;
+        }
         f_ = gzopen(path, "rb");  // transparently reads plain files too
         if (f_) gzbuffer(f_, 1 << 20);
     }
@@ -53,7 +129,7 @@ class LineReader {
     }
     LineReader(const LineReader &) = delete;
     LineReader &operator=(const LineReader &) = delete;
-    bool ok() const { return f_ != nullptr; }
+    bool ok() const { return f_ != nullptr || in_memory_; }
     // Next line without its '\n' (and without a trailing '\r'); false at EOF.
     bool next(std::string &line) {
         line.clear();
@@ -109,7 +185,7 @@ class LineReader {
         }
     }
     bool refill() {
-        if (!f_) return false;
+        if (!f_) return false;  // also the end of an in-memory file
         if (!th_.joinable() && !eof_) th_ = std::thread([this] { produce(); });
         std::unique_lock<std::mutex> lk(m_);
         if (have_) {  // hand the block just consumed back
@@ -128,6 +204,8 @@ class LineReader {
     }
 
     gzFile f_ = nullptr;
+    std::vector<char> whole_;  // the inflated file, when it was inflated in one go
+    bool in_memory_ = false;
     std::thread th_;
     std::mutex m_;
     std::condition_variable cv_;

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, TAG_CASES
-from gavisunk_amd import _lib, engine, rlen
+from gavisunk_amd import _lib, engine, rlen, synth
 from oracle import oracle
 
 
@@ -127,6 +127,44 @@ def test_loader_errors_name_the_right_file(tmp_path):
     d = engine.SunkDB(str(db), str(loc))
     assert d.k == 20 and len(d.keys) == 1 and d.key_row.tolist() == [0] and d.contigs == ["ctg"]
     d.close()
+
+
+def test_gzip_inputs_whole_file_and_streamed(tmp_path, monkeypatch):
+    """.gz inputs are inflated in one go by libdeflate when the system has it (one member or many), streamed through zlib
+    otherwise: the parsed batch must not depend on the route."""
+    import gzip
+    rng = np.random.default_rng(5)
+    reads = [rng.integers(0, 4, int(n), dtype=np.uint8) for n in rng.integers(0, 30000, 200)]
+    names = [f"r{i} extra words" for i in range(len(reads))]
+    plain = tmp_path / "r.fq"
+    synth.write_fasta(str(plain), names, reads, fastq=True)
+    raw = plain.read_bytes()
+    one = tmp_path / "one.fq.gz"
+    one.write_bytes(gzip.compress(raw, 1))
+    many = tmp_path / "many.fq.gz"  # members cut at arbitrary bytes, like bgzip blocks
+    cuts = [0, 1, 70000, 70001, len(raw) // 2, len(raw)]
+    many.write_bytes(b"".join(gzip.compress(raw[a:b], 6) for a, b in zip(cuts, cuts[1:])) + gzip.compress(b""))
+    empty = tmp_path / "empty.fq.gz"
+    empty.write_bytes(gzip.compress(b""))
+
+    def parse(path):
+        out = []
+        for b in engine.read_batches(str(path), max_bases=1 << 20):
+            out.append((b.names, b.len.copy(), b.words.copy(), b.word_off.copy()))
+            b.close()
+        return out
+
+    want = parse(plain)
+    assert sum(len(x[0]) for x in want) == len(reads)
+    for route in ("libdeflate", "zlib"):
+        if route == "zlib":
+            monkeypatch.setenv("GAVISUNK_NO_LIBDEFLATE", "1")
+        for path in (one, many):
+            got = parse(path)
+            assert len(got) == len(want)
+            for g, w in zip(got, want):
+                assert g[0] == w[0] and all(np.array_equal(a, b) for a, b in zip(g[1:], w[1:]))
+        assert parse(empty) == []
 
 
 @pytest.mark.skipif(_lib.lib().gs_device_count() > 0, reason="only meaningful on a box without a GPU")
