@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -60,7 +61,19 @@ static const Deflate &deflate_lib() {
 // A .gz file of moderate size, inflated in one go: members one after the other (a plain `gzip` file has one, bgzip
 // files many), the output buffer sized from the trailer of the last member and grown when that guess is short.
 // Returns false (and leaves `out` unspecified) whenever anything is unusual: the caller then streams with zlib.
-static bool inflate_whole_file(const char *path, std::vector<char> &out) {
+struct RawBuf {  // uninitialised storage (a 230 MB std::vector would be zeroed first)
+    std::unique_ptr<char[]> p;
+    size_t cap = 0, n = 0;
+    void reserve_keep(size_t want) {
+        if (want <= cap) return;
+        std::unique_ptr<char[]> q(new char[want]);
+        if (n) memcpy(q.get(), p.get(), n);
+        p = std::move(q);
+        cap = want;
+    }
+};
+
+static bool inflate_whole_file(const char *path, RawBuf &out) {
     const Deflate &lib = deflate_lib();
     if (!lib.ok() || getenv("GAVISUNK_NO_LIBDEFLATE")) return false;
     FILE *fp = fopen(path, "rb");
@@ -82,25 +95,23 @@ static bool inflate_whole_file(const char *path, std::vector<char> &out) {
     if (cap > (3ull << 30)) return false;
     void *d = lib.alloc();
     if (!d) return false;
-    out.resize(cap);
-    size_t ipos = 0, opos = 0;
+    out.reserve_keep(cap);
+    size_t ipos = 0;
     good = true;
     while (ipos < n && good) {
         size_t used_in = 0, used_out = 0;
-        const int rc = lib.gunzip(d, in.data() + ipos, n - ipos, out.data() + opos, out.size() - opos, &used_in, &used_out);
+        const int rc = lib.gunzip(d, in.data() + ipos, n - ipos, out.p.get() + out.n, out.cap - out.n, &used_in, &used_out);
         if (rc == 0 && used_in > 0) {
             ipos += used_in;
-            opos += used_out;
-        } else if (rc == 3 && out.size() < (3ull << 30)) {  // LIBDEFLATE_INSUFFICIENT_SPACE: grow, redo this member
-            out.resize(std::min<size_t>(out.size() * 2, 3ull << 30));
+            out.n += used_out;
+        } else if (rc == 3 && out.cap < (3ull << 30)) {  // LIBDEFLATE_INSUFFICIENT_SPACE: grow, redo this member
+            out.reserve_keep(std::min<size_t>(out.cap * 2, 3ull << 30));
         } else {
             good = false;
         }
     }
     lib.release(d);
-    if (!good) return false;
-    out.resize(opos);
-    return true;
+    return good;
 }
 
 class LineReader {
@@ -109,8 +120,8 @@ class LineReader {
         const size_t len = strlen(path);
         if (len > 3 && !strcmp(path + len - 3, ".gz") && inflate_whole_file(path, whole_)) {
             in_memory_ = true;
-            cur_ = whole_.data();
-            end_ = whole_.size();
+            cur_ = whole_.p.get();
+            end_ = whole_.n;
             return;
         }
         f_ = gzopen(path, "rb");  // transparently reads plain files too
@@ -204,7 +215,7 @@ class LineReader {
     }
 
     gzFile f_ = nullptr;
-    std::vector<char> whole_;  // the inflated file, when it was inflated in one go
+    RawBuf whole_;  // the inflated file, when it was inflated in one go
     bool in_memory_ = false;
     std::thread th_;
     std::mutex m_;
