@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the small per-read GPU kernels against the Python oracle (run on the GPU box; not part of
-the test suite): diag_filter_v3 + diag_filter_step2 and process-by-contig (pair / component / regions).
+the test suite): diag_filter_v3 + diag_filter_step2, process-by-contig (pair / component / regions), the bad-SUNK caller,
+and the GPU SUNK definition against its NumPy restatement.
 usage: fuzz_filters.py [seconds] [first seed]
 """
 import io
@@ -12,7 +13,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gavisunk_amd import diag_filter_step2, diag_filter_v3, process_by_contig  # noqa: E402
+from gavisunk_amd import badsunks, diag_filter_step2, diag_filter_v3, engine, process_by_contig, synth  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 
@@ -99,13 +100,65 @@ def fuzz_pair(seed, tmp):
     return None
 
 
+def fuzz_sunkdef(seed, tmp):
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([16, 20, 20, 21, 25, 31, 32]))
+    fam = rng.integers(0, 4, int(rng.integers(30, 900)), dtype=np.uint8)
+    contigs = []
+    for i in range(int(rng.integers(1, 9))):
+        n = int(rng.choice([0, 1, k - 1, k, k + 1, 500, 12000, 60000]))
+        c = rng.integers(0, 4, n, dtype=np.uint8)
+        for _ in range(int(rng.integers(0, 1 + n // 4000))):
+            q = int(rng.integers(0, max(n - len(fam), 1)))
+            c[q:q + len(fam)] = fam[: len(c[q:q + len(fam)])]
+        a = bytearray(synth.codes_to_ascii(c))
+        for q in rng.integers(0, max(n, 1), n // int(rng.choice([500, 3000, 10**9]))):
+            a[int(q)] = ord("N")
+        if rng.random() < 0.3:
+            a = bytearray(bytes(a).lower())
+        contigs.append((f"c{i}", bytes(a)))
+    if contigs[0][1] and rng.random() < 0.5:  # a reverse-complement copy: those k-mers stop being unique
+        src = synth.ascii_to_codes(contigs[0][1][:4000].upper().replace(b"N", b"A"))
+        contigs.append(("rc0", synth.codes_to_ascii(synth.revcomp_codes(src))))
+    exp = synth.define_sunks(contigs, k)
+    got = engine.define_sunks(contigs, k)
+    same = (len(got) == len(exp) and np.array_equal(got.contig_id, exp.contig_id) and np.array_equal(got.start, exp.start)
+            and np.array_equal(got.code, exp.code) and np.array_equal(got.group, exp.group))
+    return None if same else f"define_sunks differs at k {k} ({len(got)} / {len(exp)} SUNKs)"
+
+
+def fuzz_badsunks(seed, tmp):
+    rng = np.random.default_rng(seed)
+    h1 = [f"h1_{i}" for i in range(int(rng.integers(1, 5)))]
+    h2 = [f"h2_{i}" for i in range(int(rng.integers(1, 5)))]
+
+    def sp(own, other):
+        rows = []
+        for r in range(int(rng.integers(1, 500))):
+            for _ in range(int(rng.integers(1, 30))):
+                c = own[int(rng.integers(0, len(own)))] if rng.random() < 0.8 else other[int(rng.integers(0, len(other)))]
+                g = int(rng.zipf(1.4)) % 400 * 1000
+                rows.append(f"r{r}\t{int(rng.integers(0, 50000))}\t{c}\t{g + 5}\t{g}\n")
+        return "".join(rows)
+
+    fai1 = "".join(f"{c}\t10\n" for c in h1)
+    fai2 = "".join(f"{c}\t10\n" for c in h2)
+    sp1, sp2 = sp(h1, h2), sp(h2, h1)
+    paths = {n: os.path.join(tmp, n) for n in ("f1", "f2", "s1", "s2", "out")}
+    for n, t in (("f1", fai1), ("f2", fai2), ("s1", sp1), ("s2", sp2)):
+        open(paths[n], "w").write(t)
+    assert badsunks.main([paths["f1"], paths["f2"], paths["s1"], paths["s2"], paths["out"]]) == 0
+    got = set(open(paths["out"]).read().split())
+    return None if got == oracle.badsunks(fai1, fai2, sp1, sp2) else "badsunks differs"
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0, rounds = time.time(), 0
     with tempfile.TemporaryDirectory() as tmp:
         while time.time() - t0 < budget:
-            for name, fn in (("diag", fuzz_diag), ("pair", fuzz_pair)):
+            for name, fn in (("diag", fuzz_diag), ("pair", fuzz_pair), ("sunkdef", fuzz_sunkdef), ("badsunks", fuzz_badsunks)):
                 err = fn(seed, tmp)
                 if err:
                     print(f"MISMATCH {name} seed {seed}: {err}", flush=True)
