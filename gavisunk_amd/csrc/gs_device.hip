@@ -1131,6 +1131,9 @@ __global__ __launch_bounds__(512, 6) void k_join_bin(CompactView ct, const uint6
         const int s = 32 * h + 16 * half;
         const uint64_t X = s ? ((a << s) | (b2 >> (64 - s))) : a;  // 8 windows start at bases 0..7 of X (8 + k - 1 <= 32 bases)
         const uint64_t R = ~revpairs(X);                            // base i of X, complemented, at bits 2i+1:2i
+        // the partition of every window at once (it is the same for a k-mer and its reverse complement, so the forward
+        // strand will do): field b of W1 = x_b ^ x_{b+k-1}, field b+1 of W2 = x_{b+1} ^ x_{b+k-2}; fields 0..8 sit in the high word
+        const uint32_t w1 = (uint32_t)((X ^ (X << (2 * (k - 1)))) >> 32), w2 = (uint32_t)((X ^ (X << (2 * (k - 3)))) >> 32);
 #pragma unroll
         for (int jj = 0; jj < 8; jj++) {
             const int j = half * 8 + jj;
@@ -1139,7 +1142,8 @@ __global__ __launch_bounds__(512, 6) void k_join_bin(CompactView ct, const uint6
             const uint64_t c = f < r ? f : r;
             const BucketRem br = hmix2((c >> 4) & keymask, kbits, ct.qb);
             item[j] = ((br.bucket & ((1u << sb) - 1u)) << ct.rembits) | (uint32_t)br.rem;
-            const uint32_t slice = (part_of(c, k) << 4) | (br.bucket >> sb);
+            const uint32_t part = (((w1 >> (30 - 2 * jj)) & 3u) << 2) | ((w2 >> (28 - 2 * jj)) & 3u);
+            const uint32_t slice = (part << 4) | (br.bucket >> sb);
             // (an unconditional add to a dummy counter, so that the atomics overlap, measured slower)
             sr[j] = slice | (((uint32_t)j < nvalid ? atomicAdd(&cnt[slice], 1u) : 0u) << 9);
         }
