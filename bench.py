@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-groups", type=int, default=0,
+                    help="experiment, not the headline workload: cut location groups every N bases (more, smaller groups)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +135,8 @@ def main():
     genome, rng = synth.genome_config2(a.seed)
     if rank == 0:
         sunks = synth.define_sunks([("ctg5M", synth.codes_to_ascii(genome))], k)
-        _, loc = np.unique(sunks.group, return_inverse=True)
+        group_key = sunks.group if not a.split_groups else sunks.group * (1 << 24) + (sunks.start - sunks.group) // a.split_groups
+        _, loc = np.unique(group_key, return_inverse=True)
         keys, loc, payload, group = sunks.code, loc.astype(np.uint32), np.arange(len(sunks), dtype=np.uint32), sunks.group
     else:
         keys = loc = payload = group = None
@@ -230,7 +233,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-            if a.reads == 10000 and a.seed == 20 and world == 1:
+            if a.reads == 10000 and a.seed == 20 and world == 1 and not a.split_groups:
                 traffic = tj[table.layout.split(":")[0]]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass

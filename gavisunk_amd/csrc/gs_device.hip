@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
     {
         const uint4 *src = ct.buckets + ((uint64_t)(s >> 4) << ct.qb) + ((uint64_t)(s & 15u) << sb);
         for (uint32_t i = tid; i < (1u << sb); i += blockDim.x) sT[i] = src[i];
-        if ((uint32_t)tid < n_ovf) {
+        if ((uint32_t)tid < n_ovf && n_ovf <= (uint32_t)kJoinOvfMax) {
             sOvfKey[tid] = (uint32_t)ovf_code[ovf_start[s] + tid];  // the item part; the slice part is s
             sOvfLoc[tid] = ovf_loc[ovf_start[s] + tid];
         }
@@ -1241,13 +1241,25 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
             }
         }
         if (!res && (flags & 2u)) {  // rare: the key overflowed both buckets at build time
-            uint32_t lo = 0, hi = n_ovf;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (sOvfKey[mid] < key) lo = mid + 1;
-                else hi = mid;
+            if (n_ovf <= (uint32_t)kJoinOvfMax) {
+                uint32_t lo = 0, hi = n_ovf;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sOvfKey[mid] < key) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo < n_ovf && sOvfKey[lo] == key) res = sOvfLoc[lo] + 1u;
+            } else {  // more overflow keys than the LDS list holds (tables without second-chance buckets): search them in HBM
+                const uint64_t code = ((uint64_t)s << 32) | key;
+                uint32_t lo = ovf_start[s], hi = ovf_start[s + 1];
+                const uint32_t end = hi;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (ovf_code[mid] < code) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo < end && ovf_code[lo] == code) res = ovf_loc[lo] + 1u;
             }
-            if (lo < n_ovf && sOvfKey[lo] == key) res = sOvfLoc[lo] + 1u;
         }
         return res;
     };
@@ -2276,10 +2288,7 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
                 hl[i] = codes[i].second;
                 hs[(codes[i].first >> 32) + 1]++;
             }
-            for (int i = 0; i < kJoinSlices; i++) {
-                if (hs[i + 1] > (uint32_t)kJoinOvfMax) t->join = 0;  // a slice's overflow keys must fit its LDS side list
-                hs[i + 1] += hs[i];
-            }
+            for (int i = 0; i < kJoinSlices; i++) hs[i + 1] += hs[i];  // (a slice with more than kJoinOvfMax keys searches them in HBM)
             if (t->join) {
                 if ((rc = dev_alloc(&t->j_ovf_code, ov)) || (rc = dev_alloc(&t->j_ovf_loc, ov)) ||
                     (rc = dev_alloc(&t->j_ovf_start, kJoinSlices + 1)))
