@@ -1,6 +1,9 @@
 """BASELINE.json configs[1] at full size (5 Mb contig, 10 000 synthetic ONT reads, 242 Mbase, k = 20).
 
-The oracle cannot walk 242 Mbase in a test, so the full-size run is checked through properties that do not depend on size:
+The whole emitted list (all 10 000 reads, 37 280 rows) is compared with what the reference's own `kmerpos_annot3` binary
+printed on the same inputs (tests/golden/config2_full/c2.sunkpos.gz, made by tests/golden/make_golden_config2.py in the
+build container; tests/test_oracle_golden.py holds the oracle to the same file on the CPU).  On top of that, properties
+that do not depend on size:
 
 * the three independent probe paths (LDS join, L2-partitioned table, HBM-resident compact table) return the same array, bit for bit;
 * splitting the read set into device batches with `prevLoc` threaded through them changes nothing;
@@ -19,6 +22,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 K = 20
+CONFIG2_ROWS = {}
 
 
 @pytest.fixture(scope="module")
@@ -29,6 +33,7 @@ def config2():
     loc = loc.astype(np.uint32)
     order = np.argsort(keys, kind="stable")
     seqs = [synth.codes_to_ascii(r) for r in reads]
+    CONFIG2_ROWS["start"], CONFIG2_ROWS["group"] = sunks.start[order].tolist(), sunks.group[order].tolist()
     return keys[order], loc[order], seqs
 
 
@@ -64,6 +69,17 @@ def test_config2_full_size_properties(config2, monkeypatch):
     nwin = np.array([max(len(s) - K + 1, 1) for s in seqs], dtype=np.int64)
     assert c["windows"] == int(nwin.sum()) > 240_000_000 and len(whole) == c["emitted"] <= c["raw_hits"]
     assert 0.2 < c["raw_hits"] / c["windows"] < 0.3 and len(whole) > 30_000
+
+    # every row equals the reference binary's output on these inputs
+    import gzip
+    import os
+
+    from conftest import GOLDEN
+    want = gzip.open(os.path.join(GOLDEN, "config2_full", "c2.sunkpos.gz"), "rb").read().split(b"\n")[:-1]
+    start, group = CONFIG2_ROWS["start"], CONFIG2_ROWS["group"]
+    got = [b"r%d\t%d\tctg5M\t%d\t%d" % (a, b, start[p], group[p])
+           for a, b, p in zip(whole["read"].tolist(), whole["pos"].tolist(), whole["payload"].tolist())]
+    assert got == want
 
     # stream order, positions inside the read (pos is deflated, so it is below the window count all the more)
     key = whole["read"].astype(np.int64) << 32 | whole["pos"].astype(np.int64)

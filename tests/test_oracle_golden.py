@@ -47,3 +47,31 @@ def test_murmur_known_values():
     assert oracle.murmur3_32(b"a") == 0x3C2569B2
     assert oracle.murmur3_32(b"abc") == 0xB3DD93FA
     assert oracle.murmur3_32(b"Hello, world!") == 0xC0363E43
+
+
+def test_oracle_config2_full_size_against_reference_binary():
+    """BASELINE.json configs[1] at full size: the oracle over ALL 10 000 reads (252 Mbase) equals, row for row, what the
+    reference's own `kmerpos_annot3` binary printed on the same inputs (tests/golden/config2_full, made by
+    tests/golden/make_golden_config2.py; tagONT.smk:36)."""
+    import gzip
+    import json
+    import os
+
+    import numpy as np
+
+    from conftest import GOLDEN
+    from gavisunk_amd import synth
+
+    d = os.path.join(GOLDEN, "config2_full")
+    meta = json.load(open(os.path.join(d, "case.json")))
+    seq, sunks, names, reads = synth.config2(seed=20, n_reads=10000, k=20)
+    assert len(sunks) == meta["sunks"] and sum(len(r) for r in reads) == meta["bases"]
+    t = oracle.Table(20, sunks.code, sunks.code, sunks.contig_id, sunks.group)
+    buf, off = oracle.concat_reads([synth.codes_to_ascii(r) for r in reads])
+    rc, hits, _, ctr = t.tag(buf, off, cap=1 << 22)
+    assert rc == 0 and len(hits) == meta["rows"]["c2.sunkpos"]
+    want = gzip.open(os.path.join(d, "c2.sunkpos.gz"), "rb").read().split(b"\n")[:-1]
+    rd, pos, row = hits["read"], hits["pos"], hits["row"]
+    st, gr = sunks.start[row], sunks.group[row]
+    got = [b"r%d\t%d\tctg5M\t%d\t%d" % (a, b, c, e) for a, b, c, e in zip(rd.tolist(), pos.tolist(), st.tolist(), gr.tolist())]
+    assert got == want
