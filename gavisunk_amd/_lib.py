@@ -38,6 +38,7 @@ SIGNATURES = {
     "gs_last_error": (C.c_char_p, []),
     "gs_version": (C.c_char_p, []),
     "gs_device_count": (I, []),
+    "gs_device_synchronize": (I, [I]),
     "gs_sunkdb_load": (I, [C.c_char_p, C.c_char_p, C.POINTER(P)]),
     "gs_sunkdb_free": (None, [P]),
     "gs_sunkdb_k": (I, [P]),
@@ -65,11 +66,13 @@ SIGNATURES = {
     "gs_batch_name": (C.c_char_p, [P, U32]),
     "gs_batch_from_ascii": (I, [P, P, U32, C.POINTER(P)]),
     "gs_table_create": (I, [I, I, U64, P, P, P, C.POINTER(P)]),
+    "gs_table_create_device": (I, [I, I, U64, P, P, P, C.POINTER(P)]),
     "gs_table_destroy": (None, [P]),
     "gs_table_bytes": (U64, [P]),
     "gs_table_layout": (C.c_char_p, [P]),
     "gs_reads_upload": (I, [I, P, U64, P, P, U32, I, C.POINTER(P)]),
     "gs_reads_upload_ascii": (I, [I, P, P, U32, I, C.POINTER(P)]),
+    "gs_reads_from_device_ascii": (I, [I, P, P, U32, I, C.POINTER(P)]),
     "gs_reads_destroy": (None, [P]),
     "gs_reads_n_bases": (U64, [P]),
     "gs_reads_n_windows": (U64, [P]),
@@ -99,6 +102,15 @@ SIGNATURES = {
     "gs_key_histogram": (I, [I, U64, P, U32, P, P, P, U32]),
     "gs_union_regions": (I, [I, U64, P, P, U32, P, P, P, P]),
     "gs_sunks_define": (I, [I, I, U32, P, P, C.POINTER(P)]),
+    "gs_sunks_define_device": (I, [I, I, U32, P, P, C.POINTER(P)]),
+    "gs_sunkset_dev_free": (None, [P]),
+    "gs_sunkset_dev_n": (U64, [P]),
+    "gs_sunkset_dev_n_groups": (U64, [P]),
+    "gs_sunkset_dev_code": (P, [P]),
+    "gs_sunkset_dev_pos": (P, [P]),
+    "gs_sunkset_dev_group": (P, [P]),
+    "gs_sunkset_dev_loc": (P, [P]),
+    "gs_copy_to_host": (I, [I, P, P, U64]),
     "gs_sunkset_free": (None, [P]),
     "gs_sunkset_n": (U64, [P]),
     "gs_sunkset_code": (P, [P]),

@@ -10,7 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgavisunk.so")
+LIB_TUNING = os.path.join(HERE, "libgavisunk_tuning.so")  # -DGS_TUNING: experiment switches for tools/ (never shipped, never loaded by default)
 SOURCES = ["gs_device.hip", "gs_filter.hip", "gs_pair.hip", "gs_sunkdef.hip", "gs_host.cpp"]
+LIB_SYNTH = os.path.join(HERE, "libgssynth.so")  # bench / test support: synthetic inputs generated on the GPU (gs_synth.hip)
 
 
 def hipcc() -> str:
@@ -20,25 +22,40 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: libgavisunk.so cannot be built (there is no CPU fallback)")
 
 
-def stale() -> bool:
-    if not os.path.exists(LIB):
+def stale(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "gavisunk.h")]
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.startswith("gs_synth")] + [os.path.join(ROOT, "include", "gavisunk.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not stale():
-        return LIB
+def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+    """tuning=True builds libgavisunk_tuning.so with -DGS_TUNING: the phase-off / pipeline-depth switches the timing
+    experiments under tools/ use (GAVISUNK_LIB=.../libgavisunk_tuning.so selects it).  The product library has none."""
+    lib = LIB_TUNING if tuning else LIB
+    if not force and not stale(lib):
+        return lib
     cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread", "-ldl"]
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC] + (["-DGS_TUNING"] if tuning else []) + [
+           "-o", lib] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
+
+
+def build_synth(force: bool = False, verbose: bool = False) -> str:
+    src = os.path.join(CSRC, "gs_synth.hip")
+    if not force and os.path.exists(LIB_SYNTH) and os.path.getmtime(LIB_SYNTH) >= max(os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "gs_synth.h"))):
+        return LIB_SYNTH
+    cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-I", CSRC, "-o", LIB_SYNTH, src]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB_SYNTH
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    build_synth(force="--force" in sys.argv, verbose=True)
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))

@@ -32,6 +32,11 @@ inline uint64_t encode_kmer(const char *s, size_t n) {
     return c;
 }
 
+// device-wide radix sort of (u64 key, u32 value) pairs by the low `end_bit` key bits (rocPRIM; gs_sunkdef.hip).
+// All pointers are device memory; `stream` is a hipStream_t.
+int sort_pairs_u64_u32(const uint64_t *k_in, uint64_t *k_out, const uint32_t *v_in, uint32_t *v_out, uint64_t n, int end_bit,
+                       void *stream);
+
 constexpr int kTileWindows = 2048;  // windows per tile = 64 lanes x 32 windows (one 64-bit word per lane)
 constexpr int kTileWords = 64;
 

@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <type_traits>
@@ -1212,10 +1213,11 @@ __global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, u
     {
         const uint4 *src = ct.buckets + ((uint64_t)(s >> 4) << ct.qb) + ((uint64_t)(s & 15u) << sb);
         for (uint32_t i = tid; i < (1u << sb); i += blockDim.x) sT[i] = src[i];
-        if ((uint32_t)tid < n_ovf && n_ovf <= (uint32_t)kJoinOvfMax) {
-            sOvfKey[tid] = (uint32_t)ovf_code[ovf_start[s] + tid];  // the item part; the slice part is s
-            sOvfLoc[tid] = ovf_loc[ovf_start[s] + tid];
-        }
+        if (n_ovf <= (uint32_t)kJoinOvfMax)
+            for (uint32_t i = tid; i < n_ovf; i += blockDim.x) {
+                sOvfKey[i] = (uint32_t)ovf_code[ovf_start[s] + i];  // the item part; the slice part is s
+                sOvfLoc[i] = ovf_loc[ovf_start[s] + i];
+            }
     }
     __syncthreads();
     const int rembits = ct.rembits, locbits = ct.locbits;
@@ -1543,6 +1545,8 @@ __global__ __launch_bounds__(1024, 8) void k_join_merge(JoinQ jq, uint32_t batch
     }
 }
 
+#include "gs_mz.h"
+
 // ------------------------------------------------------------------------------------------
 // tile scans (3 launches each): exclusive scan of {sum, last non-empty loc}
 // ------------------------------------------------------------------------------------------
@@ -1679,7 +1683,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(TileArrays ta, uint
 // ------------------------------------------------------------------------------------------
 // k_emit: one thread per tile
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, int compact, ReadsView rd, TileArrays ta,
+__global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, MzView mz, int compact, ReadsView rd, TileArrays ta,
                                               const uint32_t *cand, uint32_t cand_cap, gs_hit *hits, gs_hit *hits_host,
                                               uint64_t hit_cap) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1711,7 +1715,9 @@ __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, int
         const uint64_t a = rd.words[wi], b2 = rd.words[wi + 1];
         const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(w & 31u), k, kmask);
         uint32_t payload = 0, loc_unused = 0;
-        if (compact) {
+        if (compact == 4) {
+            payload = mz_payload(mz, c);
+        } else if (compact) {
             compact_lookup(ct, tab, c, k, loc_unused, &payload);
         } else {
             uint64_t hh = slot_of(c, tab.shift);
@@ -1871,7 +1877,16 @@ struct gs_table {
     uint64_t c_overflow = 0;
     // LDS join (k = 20): the compact table's slices are probed from LDS; keys that overflowed both buckets, in
     // hashed form (slice << 32 | item), sorted
+    // minimiser-addressed table (gs_mz.h): large tables
+    int mz = 0;
+    uint4 *mz_regions = nullptr;
+    uint32_t mz_n_regions = 0;
+    int mz_m = 0, mz_locbits = 0;
+    uint64_t *mz_skeys = nullptr;
+    uint32_t *mz_spayload = nullptr;
+    uint64_t mz_overflow = 0;
     int join = 0;
+    uint32_t join_chunk = kJoinChunkMax;
     uint64_t *j_ovf_code = nullptr;
     uint32_t *j_ovf_loc = nullptr;
     uint32_t *j_ovf_start = nullptr;  // [kJoinSlices + 1] first overflow key of every slice
@@ -1922,6 +1937,9 @@ struct gs_reads {
 namespace {
 
 TableView view(const gs_table *t) { return TableView{t->slots, t->cap - 1, t->shift, t->k}; }
+MzView mz_view(const gs_table *t) {
+    return MzView{t->mz_regions, t->mz_n_regions, t->k, t->mz_m, t->mz_locbits, t->mz_skeys, t->mz_spayload, t->n};
+}
 ReadsView view(const gs_reads *r) {
     return ReadsView{r->words, r->read_word_off, r->read_nwin, r->read_tile0, r->tile_read, r->n_tiles};
 }
@@ -1943,8 +1961,9 @@ int ensure_out_buffers(gs_reads *r, uint32_t cand_cap) {
     return GS_OK;
 }
 
-// batches per pass of the join kernels over one set of queues (test knob: small chunks exercise the chunk loop)
-uint32_t join_chunk() {
+// batches per pass of the join kernels over one set of queues (GAVISUNK_JOIN_CHUNK, a test knob read once when the
+// table is created: small chunks exercise the chunk loop)
+uint32_t join_chunk_from_env() {
     const char *e = getenv("GAVISUNK_JOIN_CHUNK");
     const long v = e ? atol(e) : 0;
     return v >= 64 && v <= (long)kJoinChunkMax ? (uint32_t)v / 64u * 64u : kJoinChunkMax;
@@ -1954,7 +1973,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
     HIP_TRY(hipSetDevice(t->device));
     if (t->compact == 1 && t->join && r->n_tiles && !r->jq.item) {
         int rc;
-        const uint64_t nb = std::min<uint64_t>(join_chunk(), (r->n_tiles + kJoinTiles - 1) / kJoinTiles);
+        const uint64_t nb = std::min<uint64_t>(t->join_chunk, (r->n_tiles + kJoinTiles - 1) / kJoinTiles);
         const uint64_t bpad = (nb + 63) / 64 * 64;
         r->jq.bpad = (uint32_t)bpad;
         if ((rc = dev_alloc(&r->jq.item, nb * kJoinWin)) || (rc = dev_alloc(&r->jq.woff, bpad * kJoinWin)) ||
@@ -1979,15 +1998,22 @@ int launch_phase1(gs_table *t, gs_reads *r) {
     if (r->n_tiles) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
-        if (t->compact == 1 && t->join) {
+        if (t->mz) {
+            hipLaunchKernelGGL(k_probe_mz, dim3(blocks), dim3(256), 0, t->stream, mz_view(t), view(t), (const uint64_t *)r->words,
+                               (const TileDesc *)r->tile_desc, r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count);
+        } else if (t->compact == 1 && t->join) {
             const uint32_t n_batches = (r->n_tiles + kJoinTiles - 1) / kJoinTiles;
-            const char *env_reps = getenv("GAVISUNK_JOIN_REPS");  // tuning: workgroups per table slice
+#ifdef GS_TUNING  // experiments only (tools/, libgavisunk_tuning.so): the shipped library has no such switches
+            const char *env_reps = getenv("GAVISUNK_JOIN_REPS");  // workgroups per table slice
             const uint32_t reps = env_reps ? std::max(1, atoi(env_reps)) : 1u;
             const char *env_jt = getenv("GAVISUNK_JOIN_THREADS");  // occupancy experiment: probe workgroup size (multiple of 64)
-            const uint32_t jthreads = env_jt ? std::min(1024, std::max(64, atoi(env_jt) / 64 * 64)) : 1024u;
-            const char *env_jp = getenv("GAVISUNK_JOIN_PIPE");  // tuning: item loads in flight per lane
+            const uint32_t jthreads = env_jt ? std::min(1024, std::max(512, atoi(env_jt) / 64 * 64)) : 1024u;
+            const char *env_jp = getenv("GAVISUNK_JOIN_PIPE");  // item loads in flight per lane
             const int jpipe = env_jp ? atoi(env_jp) : 4;
-            const uint32_t chunk = std::min<uint32_t>(join_chunk(), r->jq.bpad);  // what the queues were sized for
+#else
+            const uint32_t reps = 1u, jthreads = 1024u;
+#endif
+            const uint32_t chunk = std::min<uint32_t>(t->join_chunk, r->jq.bpad);  // what the queues were sized for
             for (uint32_t b0 = 0; b0 < n_batches; b0 += chunk) {
                 const uint32_t nb = std::min(chunk, n_batches - b0);
                 const uint32_t ng64 = (nb + 63) / 64;
@@ -1998,22 +2024,26 @@ int launch_phase1(gs_table *t, gs_reads *r) {
 #define GS_LAUNCH_JOIN_PROBE_DBG(PIPE, HF, DBG)                                                                                \
     hipLaunchKernelGGL((k_join_probe<20, PIPE, HF, DBG>), dim3(kJoinSlices * reps), dim3(jthreads), 0, t->stream, cv, r->jq, nb, reps, \
                        (const uint64_t *)t->j_ovf_code, (const uint32_t *)t->j_ovf_loc, (const uint32_t *)t->j_ovf_start)
-                const char *jdbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
-                const int jmode = jdbg ? atoi(jdbg) : 0;
-                if (!t->c_has_flag)
+                if (!t->c_has_flag) {
                     GS_LAUNCH_JOIN_PROBE(4, false);
-                else if (jmode == 11)
-                    GS_LAUNCH_JOIN_PROBE_DBG(4, true, 1);
-                else if (jmode == 12)
-                    GS_LAUNCH_JOIN_PROBE_DBG(4, true, 2);
-                else if (jmode == 13)
-                    GS_LAUNCH_JOIN_PROBE_DBG(4, true, 3);
-                else if (jpipe == 3)
-                    GS_LAUNCH_JOIN_PROBE(3, true);
-                else if (jpipe == 5)
-                    GS_LAUNCH_JOIN_PROBE(5, true);
-                else
-                    GS_LAUNCH_JOIN_PROBE(4, true);  // 4 steps per window, two windows in flight: measured best (118 VGPRs, no spills)
+                } else {
+#ifdef GS_TUNING
+                    const char *jdbg = getenv("GAVISUNK_DEBUG_MODE");  // phases switched off for timing: RESULTS ARE WRONG
+                    const int jmode = jdbg ? atoi(jdbg) : 0;
+                    if (jmode == 11)
+                        GS_LAUNCH_JOIN_PROBE_DBG(4, true, 1);
+                    else if (jmode == 12)
+                        GS_LAUNCH_JOIN_PROBE_DBG(4, true, 2);
+                    else if (jmode == 13)
+                        GS_LAUNCH_JOIN_PROBE_DBG(4, true, 3);
+                    else if (jpipe == 3)
+                        GS_LAUNCH_JOIN_PROBE(3, true);
+                    else if (jpipe == 5)
+                        GS_LAUNCH_JOIN_PROBE(5, true);
+                    else
+#endif
+                        GS_LAUNCH_JOIN_PROBE(4, true);  // 4 steps per window, two windows in flight: measured best (118 VGPRs, no spills)
+                }
 #undef GS_LAUNCH_JOIN_PROBE
 #undef GS_LAUNCH_JOIN_PROBE_DBG
                 hipLaunchKernelGGL(k_join_merge, dim3((nb + kJoinMergeBatches - 1) / kJoinMergeBatches), dim3(1024), 0, t->stream,
@@ -2025,38 +2055,39 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                                view(r), r->ta, r->cand, r->cand_cap, t->d_cand_count, t->d_err_pos,
                                (const uint32_t *)r->complex_list, (const uint32_t *)t->d_complex_n);
         } else if (t->compact == 1) {
-            const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // timing experiments only (results are wrong)
-            const int mode = dbg ? atoi(dbg) : 0;
-            const char *env_nt = getenv("GAVISUNK_PART_TILES"), *env_pipe = getenv("GAVISUNK_PART_PIPE");  // tuning experiments
-            const int nt = env_nt ? atoi(env_nt) : 4, pipe = env_pipe ? atoi(env_pipe) : 2;
+            constexpr int nt = 4;
             const uint32_t pblocks = ((r->n_tiles + nt - 1) / nt + 3) / 4 * kNPart;
 #define GS_LAUNCH_PART(KT, NT, PIPE, DBG)                                                                           \
     hipLaunchKernelGGL((k_probe_part<KT, NT, PIPE, DBG>), dim3(pblocks), dim3(256), 0, t->stream, cv, view(t),      \
                        (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->part_recs)
-            if (t->k != 20)
+            if (t->k != 20) {
                 GS_LAUNCH_PART(0, 4, 4, 0);
-            else if (mode == 1)
-                GS_LAUNCH_PART(20, 4, 4, 1);
-            else if (mode == 2)
-                GS_LAUNCH_PART(20, 4, 4, 2);
-            else if (mode == 3)
-                GS_LAUNCH_PART(20, 4, 2, 3);
-            else if (mode == 4)
-                GS_LAUNCH_PART(20, 4, 2, 4);
-            else if (mode == 5)
-                GS_LAUNCH_PART(20, 4, 2, 1);
-            else if (mode == 6)
-                GS_LAUNCH_PART(20, 4, 2, 6);
-            else if (nt == 2 && pipe == 4)
-                GS_LAUNCH_PART(20, 2, 4, 0);
-            else if (nt == 2 && pipe == 8)
-                GS_LAUNCH_PART(20, 2, 8, 0);
-            else if (nt == 4 && pipe == 8)
-                GS_LAUNCH_PART(20, 4, 8, 0);
-            else if (nt == 4 && pipe == 2)
-                GS_LAUNCH_PART(20, 4, 2, 0);
-            else
-                GS_LAUNCH_PART(20, 4, 4, 0);
+            } else {
+#ifdef GS_TUNING
+                const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // phases switched off for timing: RESULTS ARE WRONG
+                const int mode = dbg ? atoi(dbg) : 0;
+                const char *env_pipe = getenv("GAVISUNK_PART_PIPE");
+                const int pipe = env_pipe ? atoi(env_pipe) : 2;
+                if (mode == 1)
+                    GS_LAUNCH_PART(20, 4, 4, 1);
+                else if (mode == 2)
+                    GS_LAUNCH_PART(20, 4, 4, 2);
+                else if (mode == 3)
+                    GS_LAUNCH_PART(20, 4, 2, 3);
+                else if (mode == 4)
+                    GS_LAUNCH_PART(20, 4, 2, 4);
+                else if (mode == 5)
+                    GS_LAUNCH_PART(20, 4, 2, 1);
+                else if (mode == 6)
+                    GS_LAUNCH_PART(20, 4, 2, 6);
+                else if (pipe == 8)
+                    GS_LAUNCH_PART(20, 4, 8, 0);
+                else if (pipe == 2)
+                    GS_LAUNCH_PART(20, 4, 2, 0);
+                else
+#endif
+                    GS_LAUNCH_PART(20, 4, 4, 0);
+            }
 #undef GS_LAUNCH_PART
             hipLaunchKernelGGL(k_merge_part, dim3((r->n_tiles + 15) / 16), dim3(256), 0, t->stream, (const PartRec *)r->part_recs,
                                r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list, t->d_complex_n);
@@ -2107,7 +2138,7 @@ int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
     if ((rc = launch_scan(t, r, 1))) return rc;
     if (r->n_tiles) {
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
-        hipLaunchKernelGGL(k_emit, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, view(t), cv, t->compact, view(r), r->ta,
+        hipLaunchKernelGGL(k_emit, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, view(t), cv, mz_view(t), t->mz ? 4 : t->compact, view(r), r->ta,
                            r->cand, r->cand_cap, r->hits, r->hits_host, r->hit_cap);
     }
     HIP_TRY(hipEventRecord(t->ev[2], t->stream));
@@ -2136,16 +2167,10 @@ uint64_t revcomp_code(uint64_t c, int k) {
 //   2 = "compact-hbm": 32-bit slots, larger; one 16-byte bucket load per window                              -> k_probe<true>
 //   3 = "compact-hbm": 64-bit slots (remainder + loc do not fit 32 bits: long k, many groups, huge tables)    -> k_probe<true>
 //   0 = generic 16-byte slots only (k < 16, or a key without loc row)
-int choose_compact(int k, uint64_t n, uint64_t generic_bytes, const uint32_t *loc, int &qb, int &rembits, int &locbits,
-                   int &has_flag) {
-    const char *env = getenv("GAVISUNK_TABLE");
+int choose_compact(int k, uint64_t n, uint64_t generic_bytes, uint32_t maxloc, bool any_missing, const char *env, int &qb,
+                   int &rembits, int &locbits, int &has_flag) {
     if (env && !strcmp(env, "generic")) return 0;
-    if (k < 16 || n == 0) return 0;
-    uint32_t maxloc = 0;
-    for (uint64_t i = 0; i < n; i++) {
-        if (loc[i] >= GS_MISSING) return 0;
-        maxloc = std::max(maxloc, loc[i]);
-    }
+    if (k < 16 || n == 0 || any_missing) return 0;
     locbits = 1;
     while ((1ull << locbits) < (uint64_t)maxloc + 2) locbits++;  // the all-ones loc stays unused
     const int kbits = 2 * k - 4;
@@ -2175,31 +2200,80 @@ int choose_compact(int k, uint64_t n, uint64_t generic_bytes, const uint32_t *lo
     return 3;
 }
 
-}  // namespace
-
-extern "C" {
-
-int gs_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
+// Minimiser-addressed layout (gs_mz.h): applies when a slot [2k-3 tag bits | loc] fits 64 bits.  m from the key count: the
+// places of the assembly that own a minimiser (about n / (0.65 (w + 1) / 2)) should be few against the 4^m / 2 values.
+int mz_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, uint32_t &n_regions, int &locbits) {
+    if (k < 16 || n == 0 || any_missing) return 0;
+    locbits = 1;
+    while ((1ull << locbits) < (uint64_t)maxloc + 2) locbits++;
+    if (2 * k - 3 + locbits > 64) return 0;
+    const int m_hi = std::min(31, k - 1);
+    m = std::max(8, k - 7);  // w <= 8: the adjacent k-mers one minimiser owns fill at most half a 16-slot region
+    for (; m < m_hi; m++) {
+        const double w = k - m + 1, places = (double)n / (0.65 * (w + 1) / 2);
+        if (places <= 0.25 * std::pow(4.0, m)) break;
+    }
+    if (const char *e = getenv("GAVISUNK_MZ_M")) {  // tuning / test knob, read once per table
+        const int v = atoi(e);
+        if (v >= 4 && v <= m_hi) m = v;
+    }
+    double per_region = 4.0;  // keys per 16-slot region
+    bool forced_load = false;
+    if (const char *e = getenv("GAVISUNK_MZ_LOAD")) {  // test knob: an undersized table makes the walk and the overflow path busy
+        const double v = atof(e);
+        if (v >= 0.5 && v <= 16.0) {
+            per_region = v;
+            forced_load = true;
+        }
+    }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    uint64_t regions = std::max<uint64_t>((uint64_t)((double)n / per_region), 64);
+    regions = std::min<uint64_t>(regions, (uint64_t)(0.45 * (double)free_b) / 128);
+    regions = std::min<uint64_t>(regions, 0xFFFFFFF0ull);
+    if (regions < 64 || (!forced_load && (double)n / (double)regions > 10.0)) return 0;
+    n_regions = (uint32_t)regions;
+    return 1;
 }
 
-int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const uint32_t *loc, const uint32_t *payload,
-                    gs_table **out) {
-    if (!out || k < 1 || k > 32 || (n && (!keys || !loc || !payload))) {
-        set_error("gs_table_create: bad argument (k must be 1..32)");
-        return GS_E_ARG;
+__global__ void k_loc_stats(const uint32_t *loc, uint64_t n, uint32_t *out) {  // out[0] max loc below GS_MISSING, out[1] any >= GS_MISSING
+    uint32_t mx = 0, miss = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t l = loc[i];
+        if (l >= GS_MISSING) miss = 1;
+        else mx = max(mx, l);
     }
-    *out = nullptr;
-    if (gs_device_count() <= device || device < 0) {
-        set_error("gs_table_create: HIP device %d not available (%d devices) -- there is no CPU fallback", device,
-                  gs_device_count());
-        return GS_E_NODEVICE;
+    atomicMax(out, mx);
+    if (miss) atomicMax(out + 1, 1u);
+}
+
+__global__ void k_gather_list(const uint64_t *keys, const uint32_t *loc, const uint32_t *list, uint64_t n, uint64_t *ok, uint32_t *ol) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        ok[i] = keys[list[i]];
+        ol[i] = loc[list[i]];
     }
-    HIP_TRY(hipSetDevice(device));
-    auto *t = new gs_table();
-    std::unique_ptr<gs_table, void (*)(gs_table *)> guard(t, gs_table_destroy);  // frees everything on an early return
+}
+
+__global__ void k_iota(uint32_t *p, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (uint32_t)i;
+}
+
+struct DevBufs {  // temporary device buffers of a build, freed on every return path
+    std::vector<void *> p;
+    ~DevBufs() {
+        for (void *x : p) (void)hipFree(x);
+    }
+    template <typename T>
+    int get(T **d, uint64_t n) {
+        int rc = dev_alloc(d, n);
+        if (!rc) p.push_back(*d);
+        return rc;
+    }
+};
+
+int table_init(gs_table *t, int device, int k, uint64_t n) {
     t->device = device;
     t->k = k;
     t->n = n;
@@ -2214,14 +2288,23 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     t->d_cand_count = &t->d_status->cand_count;
     t->d_complex_n = &t->d_status->complex_n;
     t->d_carry_in = &t->d_status->carry_in;
-    uint64_t *dk = nullptr;
-    uint32_t *dl = nullptr, *dp = nullptr, *dlist = nullptr;
-    if ((rc = dev_alloc(&dk, n)) || (rc = dev_alloc(&dl, n)) || (rc = dev_alloc(&dp, n))) return rc;
-    if (n) {
-        HIP_TRY(hipMemcpyAsync(dk, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
-        HIP_TRY(hipMemcpyAsync(dl, loc, n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
-        HIP_TRY(hipMemcpyAsync(dp, payload, n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
-    }
+    return GS_OK;
+}
+
+// Builds the device tables from key / loc / payload arrays that already are in device memory (not owned).
+int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint32_t *dp, uint64_t n) {
+    const int k = t->k;
+    int rc;
+    DevBufs tmp;
+    uint32_t *dlist = nullptr, *dstat = nullptr;
+    uint32_t stat[2] = {0, 0};
+    if ((rc = tmp.get(&dstat, 2))) return rc;
+    HIP_TRY(hipMemsetAsync(dstat, 0, 2 * sizeof(uint32_t), t->stream));
+    if (n) hipLaunchKernelGGL(k_loc_stats, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, t->stream, dl, n, dstat);
+    HIP_TRY(hipMemcpyAsync(stat, dstat, sizeof stat, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const uint32_t maxloc = stat[0];
+    const bool any_missing = stat[1] != 0;
     auto pow2_cap = [](uint64_t want, int &lg) {
         uint64_t c = 1024;
         lg = 10;
@@ -2233,20 +2316,57 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     };
     int lg_full;
     const uint64_t cap_full = pow2_cap(2 * n, lg_full);
-    // The exact compact copy first (when it applies); the generic 16-byte-slot table then only has to hold the
-    // keys the compact one could not take.  Without a compact copy the generic table holds everything.
-    t->compact = choose_compact(k, n, cap_full * sizeof(Slot), loc, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
+    // Layout (GAVISUNK_TABLE forces one; read once per table).  Exact compact copy first, when it applies: small tables
+    // are probed from LDS / the L2s; tables that only fit HBM take the minimiser-addressed layout (the one-bucket-load
+    // "compact-hbm" layout stays available, forced).  The generic 16-byte-slot table holds what those could not take,
+    // or everything.
+    const char *env = getenv("GAVISUNK_TABLE");
+    const bool force_mz = env && !strcmp(env, "minimizer");
+    t->compact = force_mz ? 0 : choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, env, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
+    if (force_mz || ((t->compact == 2 || t->compact == 3) && !(env && !strcmp(env, "compact-hbm")))) {
+        if (mz_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_n_regions, t->mz_locbits)) {
+            t->mz = 1;
+            t->compact = 0;
+        } else if (force_mz) {
+            t->compact = choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, nullptr, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
+        }
+    }
     uint64_t n_generic = n;
-    if (t->compact) {
+    if (t->mz) {
+        const uint64_t nslots = (uint64_t)t->mz_n_regions * 2 * kMzPieces;
+        const uint64_t ocap = std::max<uint64_t>(getenv("GAVISUNK_MZ_M") || getenv("GAVISUNK_MZ_LOAD") ? n : n / 8, 1u << 16);
+        unsigned long long *dov = nullptr;
+        if ((rc = dev_alloc((unsigned long long **)&t->mz_regions, nslots)) || (rc = tmp.get(&dov, 1)) || (rc = tmp.get(&dlist, ocap)))
+            return rc;
+        HIP_TRY(hipMemsetAsync(t->mz_regions, 0xFF, nslots * sizeof(unsigned long long), t->stream));
+        HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
+        hipLaunchKernelGGL(k_mz_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream,
+                           reinterpret_cast<unsigned long long *>(t->mz_regions), t->mz_n_regions, k, t->mz_m, t->mz_locbits, dk, dl, n,
+                           dov, dlist, ocap);
+        unsigned long long ov = 0;
+        HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        HIP_TRY(hipGetLastError());
+        if (ov > ocap) {
+            set_error("gs_table_create: %llu of %llu keys do not fit their minimiser regions (m = %d); force another layout with GAVISUNK_TABLE",
+                      ov, (unsigned long long)n, t->mz_m);
+            return GS_E_NOMEM;
+        }
+        t->mz_overflow = ov;
+        n_generic = ov;
+        // sorted key list + payloads: what k_emit reports for an emitted row
+        if ((rc = dev_alloc(&t->mz_skeys, n)) || (rc = dev_alloc(&t->mz_spayload, n))) return rc;
+        if ((rc = sort_pairs_u64_u32(dk, t->mz_skeys, dp, t->mz_spayload, n, 2 * k, t->stream))) return rc;
+    } else if (t->compact) {
         t->c_w64 = t->compact == 3;
         if (t->compact == 3) t->compact = 2;  // same probe kernel; the view says which slot width
         const uint64_t nslots = (uint64_t)(4 * kNPart) << t->c_qb;
         const uint64_t slot_words = t->c_w64 ? 2 * nslots : nslots;  // in uint32 units
         uint32_t *d = nullptr;
         unsigned long long *dov = nullptr;
-        if ((rc = dev_alloc(&d, slot_words)) || (rc = dev_alloc(&t->cpayload, nslots)) || (rc = dev_alloc(&dov, 1)) ||
-            (rc = dev_alloc(&dlist, n)))
-            return rc;
+        if ((rc = dev_alloc(&d, slot_words))) return rc;
+        t->cbuckets = reinterpret_cast<uint4 *>(d);
+        if ((rc = dev_alloc(&t->cpayload, nslots)) || (rc = tmp.get(&dov, 1)) || (rc = tmp.get(&dlist, n))) return rc;
         HIP_TRY(hipMemsetAsync(d, 0xFF, slot_words * sizeof(uint32_t), t->stream));
         HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
         if (t->c_w64)
@@ -2254,31 +2374,39 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
                                reinterpret_cast<unsigned long long *>(d), t->cpayload, k, t->c_qb, t->c_rembits, t->c_locbits, dk,
                                dl, dp, n, dov, dlist);
         else
-        hipLaunchKernelGGL(k_compact_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, d, t->cpayload, k,
-                           t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, dk, dl, dp, n, dov, dlist);
+            hipLaunchKernelGGL(k_compact_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, d, t->cpayload, k,
+                               t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, dk, dl, dp, n, dov, dlist);
         unsigned long long ov = 0;
         HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         HIP_TRY(hipGetLastError());
-        (void)hipFree(dov);
         t->c_overflow = ov;
-        t->cbuckets = reinterpret_cast<uint4 *>(d);
         n_generic = ov;
         // LDS join: k = 20 makes a slice (partition x top 4 bucket bits) exactly a 32-bit item space
-        const char *env = getenv("GAVISUNK_TABLE");
         t->join = t->compact == 1 && k == 20 && t->c_qb >= 5 && t->c_qb - 4 <= 13 && t->c_locbits <= 15 &&
                   !(env && !strcmp(env, "compact-l2"));
         if (t->join) {
-            std::vector<uint32_t> list(ov);
-            if (ov) HIP_TRY(hipMemcpy(list.data(), dlist, ov * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            t->join_chunk = join_chunk_from_env();
+            // the overflow keys in hashed form (slice << 32 | item), sorted: the probe kernel searches them per slice
+            std::vector<uint64_t> ok(ov);
+            std::vector<uint32_t> ol(ov);
+            if (ov) {
+                uint64_t *d_ok = nullptr;
+                uint32_t *d_ol = nullptr;
+                if ((rc = tmp.get(&d_ok, ov)) || (rc = tmp.get(&d_ol, ov))) return rc;
+                hipLaunchKernelGGL(k_gather_list, dim3((unsigned)((ov + 255) / 256)), dim3(256), 0, t->stream, dk, dl, dlist, ov, d_ok, d_ol);
+                HIP_TRY(hipMemcpyAsync(ok.data(), d_ok, ov * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipMemcpyAsync(ol.data(), d_ol, ov * sizeof(uint32_t), hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));
+            }
             std::vector<std::pair<uint64_t, uint32_t>> codes(ov);
             const int kbits = 2 * k - 4, sb = t->c_qb - 4;
             for (uint64_t i = 0; i < ov; i++) {
-                const uint64_t c = keys[list[i]];
+                const uint64_t c = ok[i];
                 const BucketRem br = hmix2((c >> 4) & ((1ULL << kbits) - 1ULL), kbits, t->c_qb);
                 const uint64_t slice = ((uint64_t)part_of(c, k) << 4) | (br.bucket >> sb);
                 const uint64_t item = ((uint64_t)(br.bucket & ((1u << sb) - 1u)) << t->c_rembits) | br.rem;
-                codes[i] = {(slice << 32) | item, loc[list[i]]};
+                codes[i] = {(slice << 32) | item, ol[i]};
             }
             std::sort(codes.begin(), codes.end());
             std::vector<uint64_t> hc(ov);
@@ -2289,16 +2417,14 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
                 hs[(codes[i].first >> 32) + 1]++;
             }
             for (int i = 0; i < kJoinSlices; i++) hs[i + 1] += hs[i];  // (a slice with more than kJoinOvfMax keys searches them in HBM)
-            if (t->join) {
-                if ((rc = dev_alloc(&t->j_ovf_code, ov)) || (rc = dev_alloc(&t->j_ovf_loc, ov)) ||
-                    (rc = dev_alloc(&t->j_ovf_start, kJoinSlices + 1)))
-                    return rc;
-                if (ov) {
-                    HIP_TRY(hipMemcpy(t->j_ovf_code, hc.data(), ov * sizeof(uint64_t), hipMemcpyHostToDevice));
-                    HIP_TRY(hipMemcpy(t->j_ovf_loc, hl.data(), ov * sizeof(uint32_t), hipMemcpyHostToDevice));
-                }
-                HIP_TRY(hipMemcpy(t->j_ovf_start, hs.data(), hs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            if ((rc = dev_alloc(&t->j_ovf_code, ov)) || (rc = dev_alloc(&t->j_ovf_loc, ov)) ||
+                (rc = dev_alloc(&t->j_ovf_start, kJoinSlices + 1)))
+                return rc;
+            if (ov) {
+                HIP_TRY(hipMemcpy(t->j_ovf_code, hc.data(), ov * sizeof(uint64_t), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(t->j_ovf_loc, hl.data(), ov * sizeof(uint32_t), hipMemcpyHostToDevice));
             }
+            HIP_TRY(hipMemcpy(t->j_ovf_start, hs.data(), hs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
     }
     int lg;
@@ -2307,7 +2433,7 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     if ((rc = dev_alloc(&t->slots, t->cap))) return rc;
     hipLaunchKernelGGL(k_table_fill, dim3((unsigned)((t->cap + 255) / 256)), dim3(256), 0, t->stream, t->slots, t->cap);
     if (n_generic) {
-        if (t->compact)
+        if (t->compact || t->mz)
             hipLaunchKernelGGL(k_table_insert_list, dim3((unsigned)((n_generic + 255) / 256)), dim3(256), 0, t->stream,
                                t->slots, t->cap - 1, t->shift, dk, dl, dp, dlist, n_generic);
         else
@@ -2316,10 +2442,86 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
     }
     HIP_TRY(hipStreamSynchronize(t->stream));
     HIP_TRY(hipGetLastError());
-    (void)hipFree(dk);
-    (void)hipFree(dl);
-    (void)hipFree(dp);
-    (void)hipFree(dlist);
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gs_device_synchronize(int device) {
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_device_synchronize: HIP device %d not available", device);
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return GS_OK;
+}
+
+int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const uint32_t *loc, const uint32_t *payload,
+                    gs_table **out) {
+    if (!out || k < 1 || k > 32 || (n && (!keys || !loc || !payload)) || n > 0xFFFFFFF0ull) {
+        set_error("gs_table_create: bad argument (k must be 1..32, n below 2^32)");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_table_create: HIP device %d not available (%d devices) -- there is no CPU fallback", device,
+                  gs_device_count());
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    auto *t = new gs_table();
+    std::unique_ptr<gs_table, void (*)(gs_table *)> guard(t, gs_table_destroy);  // frees everything on an early return
+    int rc;
+    if ((rc = table_init(t, device, k, n))) return rc;
+    DevBufs in;
+    uint64_t *dk = nullptr;
+    uint32_t *dl = nullptr, *dp = nullptr;
+    if ((rc = in.get(&dk, n)) || (rc = in.get(&dl, n)) || (rc = in.get(&dp, n))) return rc;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(dk, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(dl, loc, n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(dp, payload, n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+    }
+    if ((rc = table_build(t, dk, dl, dp, n))) return rc;
+    *out = guard.release();
+    return GS_OK;
+}
+
+int gs_table_create_device(int device, int k, uint64_t n, const void *d_keys, const void *d_loc, const void *d_payload,
+                           gs_table **out) {
+    if (!out || k < 1 || k > 32 || (n && (!d_keys || !d_loc)) || n > 0xFFFFFFF0ull) {
+        set_error("gs_table_create_device: bad argument (k must be 1..32, n below 2^32)");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_table_create_device: HIP device %d not available -- there is no CPU fallback", device);
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());  // the arrays may have been written on another stream
+    auto *t = new gs_table();
+    std::unique_ptr<gs_table, void (*)(gs_table *)> guard(t, gs_table_destroy);
+    int rc;
+    if ((rc = table_init(t, device, k, n))) return rc;
+    DevBufs in;
+    const uint32_t *dp = static_cast<const uint32_t *>(d_payload);
+    if (!dp) {  // payload = index of the key
+        uint32_t *iota = nullptr;
+        if ((rc = in.get(&iota, n))) return rc;
+        if (n) hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, iota, n);
+        dp = iota;
+    }
+    if ((rc = table_build(t, static_cast<const uint64_t *>(d_keys), static_cast<const uint32_t *>(d_loc), dp, n))) return rc;
     *out = guard.release();
     return GS_OK;
 }
@@ -2327,7 +2529,10 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
 const char *gs_table_layout(const gs_table *t) {
     static thread_local char buf[160];
     if (!t) return "";
-    if (t->compact)
+    if (t->mz)
+        snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 128 B (8 pieces x 2 x u64 [%d-bit tag | %d-bit loc]), minimiser length %d (w = %d), %llu overflow keys in a generic 16 B-slot side table",
+                 t->mz_n_regions, 2 * t->k - 3, t->mz_locbits, t->mz_m, t->k - t->mz_m + 1, (unsigned long long)t->mz_overflow);
+    else if (t->compact)
         snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x %s (%d-bit remainder, %d-bit loc%s), %llu overflow keys in a generic 16 B-slot side table",
                  t->compact == 1 ? (t->join ? "compact-lds" : "compact-l2") : "compact-hbm", t->c_qb, t->c_w64 ? "u64" : "u32", t->c_rembits, t->c_locbits,
                  t->c_has_flag ? ", second-chance buckets" : "", (unsigned long long)t->c_overflow);
@@ -2343,6 +2548,9 @@ void gs_table_destroy(gs_table *t) {
     (void)hipFree(t->slots);
     (void)hipFree(t->cbuckets);
     (void)hipFree(t->cpayload);
+    (void)hipFree(t->mz_regions);
+    (void)hipFree(t->mz_skeys);
+    (void)hipFree(t->mz_spayload);
     (void)hipFree(t->j_ovf_code);
     (void)hipFree(t->j_ovf_loc);
     (void)hipFree(t->j_ovf_start);
@@ -2356,7 +2564,9 @@ void gs_table_destroy(gs_table *t) {
 }
 
 uint64_t gs_table_bytes(const gs_table *t) {
-    return t ? t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)((t->c_w64 ? 48 : 32) * kNPart) << t->c_qb) : 0) : 0;  // slots + payloads
+    if (!t) return 0;
+    if (t->mz) return t->cap * sizeof(Slot) + (uint64_t)t->mz_n_regions * 128 + t->n * 12;  // regions + sorted keys / payloads
+    return t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)((t->c_w64 ? 48 : 32) * kNPart) << t->c_qb) : 0);  // slots + payloads
 }
 
 // index building + allocations shared by the two upload entry points; the packed words are zeroed, not filled
@@ -2484,9 +2694,11 @@ __global__ void k_pack_reads(const uint8_t *seq, const uint64_t *byte_off, const
     words[w] = v;
 }
 
-int gs_reads_upload_ascii(int device, const uint8_t *seq, const uint64_t *off, uint32_t n_reads, int k, gs_reads **out) {
+// shared by the two ASCII entry points: index + allocations, then the packing kernel over a device copy of the bases
+static int reads_from_ascii(int device, const uint8_t *seq, bool seq_on_device, const uint64_t *off, uint32_t n_reads, int k,
+                            gs_reads **out, const char *who) {
     if (!out || (n_reads && (!off || (off[n_reads] && !seq)))) {
-        set_error("gs_reads_upload_ascii: bad argument");
+        set_error("%s: bad argument", who);
         return GS_E_ARG;
     }
     std::vector<uint64_t> word_off((size_t)n_reads + 1, 0);
@@ -2494,7 +2706,7 @@ int gs_reads_upload_ascii(int device, const uint8_t *seq, const uint64_t *off, u
     for (uint32_t i = 0; i < n_reads; i++) {
         const uint64_t l = off[i + 1] - off[i];
         if (l > 0xFFFFFFFFull) {
-            set_error("gs_reads_upload_ascii: read %u is longer than 2^32 bases", i);
+            set_error("%s: read %u is longer than 2^32 bases", who, i);
             return GS_E_ARG;
         }
         len[i] = (uint32_t)l;
@@ -2509,23 +2721,39 @@ int gs_reads_upload_ascii(int device, const uint8_t *seq, const uint64_t *off, u
     uint8_t *d_seq = nullptr;
     uint64_t *d_boff = nullptr;
     const uint64_t nbytes = off[n_reads];
-    if ((rc = dev_alloc(&d_seq, nbytes)) || (rc = dev_alloc(&d_boff, (uint64_t)n_reads + 1))) return rc;
+    if (!seq_on_device && (rc = dev_alloc(&d_seq, nbytes))) return rc;
+    if ((rc = dev_alloc(&d_boff, (uint64_t)n_reads + 1))) {
+        (void)hipFree(d_seq);
+        return rc;
+    }
     hipError_t e = hipSuccess;
-    if (nbytes) e = hipMemcpy(d_seq, seq, nbytes, hipMemcpyHostToDevice);
+    if (!seq_on_device && nbytes) e = hipMemcpy(d_seq, seq, nbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_boff, off, ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, 0, d_seq, d_boff,
+        hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, 0, seq_on_device ? seq : d_seq, d_boff,
                            guard->read_word_off, n_reads, n_words, guard->words);
         e = hipDeviceSynchronize();
     }
     (void)hipFree(d_seq);
     (void)hipFree(d_boff);
     if (e != hipSuccess) {
-        set_error("gs_reads_upload_ascii: %s", hipGetErrorString(e));
+        set_error("%s: %s", who, hipGetErrorString(e));
         return GS_E_NODEVICE;
     }
     *out = guard.release();
     return GS_OK;
+}
+
+int gs_reads_upload_ascii(int device, const uint8_t *seq, const uint64_t *off, uint32_t n_reads, int k, gs_reads **out) {
+    return reads_from_ascii(device, seq, false, off, n_reads, k, out, "gs_reads_upload_ascii");
+}
+
+int gs_reads_from_device_ascii(int device, const void *d_seq, const uint64_t *off, uint32_t n_reads, int k, gs_reads **out) {
+    if (gs_device_count() > device && device >= 0) {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipDeviceSynchronize());  // the bases may have been written on another stream
+    }
+    return reads_from_ascii(device, static_cast<const uint8_t *>(d_seq), true, off, n_reads, k, out, "gs_reads_from_device_ascii");
 }
 
 void gs_reads_destroy(gs_reads *r) {

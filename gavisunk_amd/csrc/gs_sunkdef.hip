@@ -8,11 +8,12 @@
 //   k_mark_unique    code differs from both neighbours
 //   select           -> the singly-unique ones
 //   radix sort       by (contig, pos)  = kmer.loc order
-//   k_group_heads / inclusive max-scan / k_group_ids   group = start of the run with gaps <= k
+//   k_group_flags / inclusive sum-scan / k_group_loc   group = start of the run with gaps <= k, loc = dense id of the run
 #include <hip/hip_runtime.h>
 
 #include <cstring>
 #include <algorithm>
+#include <memory>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -114,18 +115,6 @@ __global__ void k_mark_unique(const uint64_t *keys, uint64_t n, uint64_t invalid
     flag[i] = u ? 1 : 0;
 }
 
-__global__ void k_group_heads(const uint64_t *pos, uint64_t n, int k, uint64_t *head) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const bool is_new = i == 0 || (pos[i] >> 32) != (pos[i - 1] >> 32) || (pos[i] & 0xFFFFFFFFu) - (pos[i - 1] & 0xFFFFFFFFu) > (uint64_t)k;
-    head[i] = is_new ? i + 1 : 0;  // index + 1 of the run's head; max-scan carries it forward
-}
-
-__global__ void k_group_ids(const uint64_t *pos, const uint64_t *head, uint64_t n, int64_t *group) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) group[i] = (int64_t)(pos[head[i] - 1] & 0xFFFFFFFFu);
-}
-
 struct Bufs {
     std::vector<void *> p;
     ~Bufs() {
@@ -142,30 +131,68 @@ struct Bufs {
 
 }  // namespace
 
-extern "C" {
-
-int gs_sunks_define(int device, int k, uint32_t n_contigs, const uint8_t *seq, const uint64_t *off, gs_sunkset **out) {
-    if (!out || k < 1 || k > 32 || (n_contigs && (!seq || !off))) {
-        set_error("gs_sunks_define: bad argument (k must be 1..32)");
-        return GS_E_ARG;
-    }
-    *out = nullptr;
-    if (gs_device_count() <= device || device < 0) {
-        set_error("gs_sunks_define: HIP device %d not available -- there is no CPU fallback", device);
+int gs::sort_pairs_u64_u32(const uint64_t *k_in, uint64_t *k_out, const uint32_t *v_in, uint32_t *v_out, uint64_t n, int end_bit,
+                           void *stream) {
+    if (!n) return GS_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    size_t tb = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, k_in, k_out, v_in, v_out, n, 0u, (unsigned)end_bit, st));
+    void *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+    hipError_t e = rocprim::radix_sort_pairs(tmp, tb, k_in, k_out, v_in, v_out, n, 0u, (unsigned)end_bit, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) {
+        set_error("radix sort failed: %s", hipGetErrorString(e));
         return GS_E_NODEVICE;
     }
-    HIP_TRY(hipSetDevice(device));
-    auto *res = new gs_sunkset();
+    return GS_OK;
+}
+
+struct gs_sunkset_dev {
+    int device = 0, k = 0;
+    uint64_t n = 0, n_groups = 0;
+    uint64_t *code = nullptr;  // canonical code, kmer.loc order
+    uint64_t *pos = nullptr;   // contig << 32 | start
+    uint32_t *group = nullptr; // start of the merged interval
+    uint32_t *loc = nullptr;   // dense id of (contig, group)
+};
+
+namespace {
+
+__global__ void k_group_flags(const uint64_t *pos, uint64_t n, int k, uint32_t *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || (pos[i] >> 32) != (pos[i - 1] >> 32) || (pos[i] & 0xFFFFFFFFu) - (pos[i - 1] & 0xFFFFFFFFu) > (uint64_t)k) ? 1u : 0u;
+}
+// rank[i] = inclusive count of run heads up to i;  loc = rank - 1;  group = start of the run's head (looked up through
+// the head's row: head_row[rank - 1], filled by the heads themselves)
+__global__ void k_head_rows(const uint32_t *flag, const uint32_t *rank, const uint64_t *pos, uint64_t n, uint32_t *head_start) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) head_start[rank[i] - 1] = (uint32_t)(pos[i] & 0xFFFFFFFFu);
+}
+__global__ void k_group_loc(const uint32_t *rank, const uint32_t *head_start, uint64_t n, uint32_t *group, uint32_t *loc) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        loc[i] = rank[i] - 1;
+        group[i] = head_start[rank[i] - 1];
+    }
+}
+
+// The whole definition on device memory.  d_seq: ASCII bases of all contigs back to back (device), off: host offsets.
+// Results are freshly allocated device arrays owned by `res`.
+int sunks_define_core(int device, int k, uint32_t n_contigs, const uint8_t *d_seq, const uint64_t *off, gs_sunkset_dev *res) {
+    res->device = device;
     res->k = k;
     const uint64_t n = n_contigs ? off[n_contigs] : 0;
-    if (n == 0) {
-        *out = res;
-        return GS_OK;
+    if (n == 0) return GS_OK;
+    if (n > 0xFFFFFFF0ull) {
+        set_error("gs_sunks_define: more than 2^32 bases; split the assembly");
+        return GS_E_ARG;
     }
     for (uint32_t c = 0; c < n_contigs; c++)
         if (off[c + 1] - off[c] > 0xFFFFFFFFull) {
             set_error("gs_sunks_define: contig %u is longer than 2^32 bases", c);
-            delete res;
             return GS_E_ARG;
         }
     std::vector<uint64_t> chunk_off(n_contigs + 1, 0);
@@ -174,74 +201,185 @@ int gs_sunks_define(int device, int k, uint32_t n_contigs, const uint8_t *seq, c
         const uint64_t nwin = len >= (uint64_t)k ? len - k + 1 : 0;
         chunk_off[c + 1] = chunk_off[c] + (nwin + kChunk - 1) / kChunk;
     }
-    Bufs b;
-    int rc;
-    uint8_t *d_seq, *d_flag;
-    uint64_t *d_coff, *d_chunk, *d_k0, *d_v0, *d_k1, *d_v1, *d_cnt;
-    if ((rc = b.get(&d_seq, n + 64)) || (rc = b.get(&d_coff, (uint64_t)n_contigs + 1)) ||
-        (rc = b.get(&d_chunk, (uint64_t)n_contigs + 1)) || (rc = b.get(&d_k0, n)) || (rc = b.get(&d_v0, n)) ||
-        (rc = b.get(&d_k1, n)) || (rc = b.get(&d_v1, n)) || (rc = b.get(&d_flag, n)) || (rc = b.get(&d_cnt, 1))) {
-        delete res;
-        return rc;
-    }
-    HIP_TRY(hipMemcpy(d_seq, seq, n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_coff, off, ((uint64_t)n_contigs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_chunk, chunk_off.data(), chunk_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    const uint64_t invalid_key = k == 32 ? ~0ULL : (1ULL << (2 * k));  // sorts after every real code (k = 32: poly-T is never canonical)
-    const int end_bit = k == 32 ? 64 : 2 * k + 1;
-    hipLaunchKernelGGL(k_fill_invalid, dim3(n_contigs), dim3(64), 0, 0, d_k0, d_v0, d_coff, n_contigs, k, invalid_key);
-    if (chunk_off[n_contigs])
-        hipLaunchKernelGGL(k_window_codes, dim3((unsigned)((chunk_off[n_contigs] + 127) / 128)), dim3(128), 0, 0, d_seq, d_coff,
-                           d_chunk, n_contigs, k, invalid_key, d_k0, d_v0);
-    HIP_TRY(hipGetLastError());
-    // sort by code
-    size_t tmp_bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, n, 0u, (unsigned)end_bit));
-    size_t tb2 = 0, tb3 = 0, tb4 = 0;
-    HIP_TRY(rocprim::select(nullptr, tb2, d_v1, d_flag, d_v0, d_cnt, n));
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb3, d_v0, d_v1, d_k0, d_k1, n, 0u, 64u));
-    HIP_TRY(rocprim::inclusive_scan(nullptr, tb4, d_k0, d_k1, n, rocprim::maximum<uint64_t>()));
-    tmp_bytes = std::max(std::max(tmp_bytes, tb2), std::max(tb3, tb4));
-    void *d_tmp;
-    if ((rc = b.get((uint8_t **)&d_tmp, tmp_bytes))) {
-        delete res;
-        return rc;
-    }
-    size_t tbb = tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tbb, d_k0, d_k1, d_v0, d_v1, n, 0u, (unsigned)end_bit));
-    hipLaunchKernelGGL(k_mark_unique, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_k1, n, invalid_key, d_flag);
-    // singly-unique: positions -> v0, codes -> k0
-    tbb = tmp_bytes;
-    HIP_TRY(rocprim::select(d_tmp, tbb, d_v1, d_flag, d_v0, d_cnt, n));
-    tbb = tmp_bytes;
-    HIP_TRY(rocprim::select(d_tmp, tbb, d_k1, d_flag, d_k0, d_cnt, n));
     uint64_t m = 0;
-    HIP_TRY(hipMemcpy(&m, d_cnt, sizeof m, hipMemcpyDeviceToHost));
+    uint64_t *d_code = nullptr, *d_pos = nullptr;  // survivors of the first stage
+    {
+        Bufs b;  // stage 1: window codes, sort by code, keep the singly-unique ones
+        int rc;
+        uint8_t *d_flag;
+        uint64_t *d_coff, *d_chunk, *d_k0, *d_v0, *d_k1, *d_v1, *d_cnt;
+        if ((rc = b.get(&d_coff, (uint64_t)n_contigs + 1)) || (rc = b.get(&d_chunk, (uint64_t)n_contigs + 1)) ||
+            (rc = b.get(&d_k0, n)) || (rc = b.get(&d_v0, n)) || (rc = b.get(&d_k1, n)) || (rc = b.get(&d_v1, n)) ||
+            (rc = b.get(&d_flag, n)) || (rc = b.get(&d_cnt, 1)))
+            return rc;
+        HIP_TRY(hipMemcpy(d_coff, off, ((uint64_t)n_contigs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_chunk, chunk_off.data(), chunk_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        const uint64_t invalid_key = k == 32 ? ~0ULL : (1ULL << (2 * k));  // sorts after every real code (k = 32: poly-T is never canonical)
+        const int end_bit = k == 32 ? 64 : 2 * k + 1;
+        hipLaunchKernelGGL(k_fill_invalid, dim3(n_contigs), dim3(64), 0, 0, d_k0, d_v0, d_coff, n_contigs, k, invalid_key);
+        if (chunk_off[n_contigs])
+            hipLaunchKernelGGL(k_window_codes, dim3((unsigned)((chunk_off[n_contigs] + 127) / 128)), dim3(128), 0, 0, d_seq, d_coff,
+                               d_chunk, n_contigs, k, invalid_key, d_k0, d_v0);
+        HIP_TRY(hipGetLastError());
+        size_t tmp_bytes = 0, tb2 = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, n, 0u, (unsigned)end_bit));
+        HIP_TRY(rocprim::select(nullptr, tb2, d_v1, d_flag, d_v0, d_cnt, n));
+        tmp_bytes = std::max(tmp_bytes, tb2);
+        void *d_tmp;
+        if ((rc = b.get((uint8_t **)&d_tmp, tmp_bytes))) return rc;
+        size_t tbb = tmp_bytes;
+        HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tbb, d_k0, d_k1, d_v0, d_v1, n, 0u, (unsigned)end_bit));
+        hipLaunchKernelGGL(k_mark_unique, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_k1, n, invalid_key, d_flag);
+        // singly-unique: positions -> v0, codes -> k0
+        tbb = tmp_bytes;
+        HIP_TRY(rocprim::select(d_tmp, tbb, d_v1, d_flag, d_v0, d_cnt, n));
+        tbb = tmp_bytes;
+        HIP_TRY(rocprim::select(d_tmp, tbb, d_k1, d_flag, d_k0, d_cnt, n));
+        HIP_TRY(hipMemcpy(&m, d_cnt, sizeof m, hipMemcpyDeviceToHost));
+        if (m) {  // compact copies: the big buffers go away before the second stage
+            HIP_TRY(hipMalloc((void **)&d_code, m * sizeof(uint64_t)));
+            if (hipMalloc((void **)&d_pos, m * sizeof(uint64_t)) != hipSuccess) {
+                (void)hipFree(d_code);
+                set_error("gs_sunks_define: out of device memory");
+                return GS_E_NOMEM;
+            }
+            HIP_TRY(hipMemcpy(d_code, d_k0, m * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(d_pos, d_v0, m * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+        }
+    }
+    res->n = m;
+    if (!m) return GS_OK;
+    Bufs b;  // stage 2: kmer.loc order = by (contig, pos); groups
+    b.p.push_back(d_code);
+    b.p.push_back(d_pos);
+    int rc;
+    uint32_t *d_flag32, *d_rank, *d_head;
+    void *d_tmp;
+    HIP_TRY(hipMalloc((void **)&res->code, m * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&res->pos, m * sizeof(uint64_t)));
+    size_t t1 = 0, t2 = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, d_pos, res->pos, d_code, res->code, m, 0u, 64u));
+    HIP_TRY(rocprim::inclusive_scan(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr, m, rocprim::plus<uint32_t>()));
+    size_t tmp_bytes = std::max(t1, t2);
+    if ((rc = b.get((uint8_t **)&d_tmp, tmp_bytes))) return rc;
+    size_t tbb = tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tbb, d_pos, res->pos, d_code, res->code, m, 0u, 64u));
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(d_code);
+    (void)hipFree(d_pos);
+    b.p.erase(b.p.begin(), b.p.begin() + 2);
+    if ((rc = b.get(&d_flag32, m)) || (rc = b.get(&d_rank, m))) return rc;
+    HIP_TRY(hipMalloc((void **)&res->group, m * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&res->loc, m * sizeof(uint32_t)));
+    const unsigned gb = (unsigned)((m + 255) / 256);
+    hipLaunchKernelGGL(k_group_flags, dim3(gb), dim3(256), 0, 0, res->pos, m, k, d_flag32);
+    tbb = tmp_bytes;
+    HIP_TRY(rocprim::inclusive_scan(d_tmp, tbb, d_flag32, d_rank, m, rocprim::plus<uint32_t>()));
+    uint32_t ng = 0;
+    HIP_TRY(hipMemcpy(&ng, d_rank + (m - 1), sizeof ng, hipMemcpyDeviceToHost));
+    res->n_groups = ng;
+    if ((rc = b.get(&d_head, ng))) return rc;
+    hipLaunchKernelGGL(k_head_rows, dim3(gb), dim3(256), 0, 0, d_flag32, d_rank, res->pos, m, d_head);
+    hipLaunchKernelGGL(k_group_loc, dim3(gb), dim3(256), 0, 0, d_rank, d_head, m, res->group, res->loc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return GS_OK;
+}
+
+int check_define_args(const char *who, int device, int k, uint32_t n_contigs, const void *seq, const uint64_t *off, void *out) {
+    if (!out || k < 1 || k > 32 || (n_contigs && (!seq || !off))) {
+        set_error("%s: bad argument (k must be 1..32)", who);
+        return GS_E_ARG;
+    }
+    if (gs_device_count() <= device || device < 0) {
+        set_error("%s: HIP device %d not available -- there is no CPU fallback", who, device);
+        return GS_E_NODEVICE;
+    }
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void gs_sunkset_dev_free(gs_sunkset_dev *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipFree(s->code);
+    (void)hipFree(s->pos);
+    (void)hipFree(s->group);
+    (void)hipFree(s->loc);
+    delete s;
+}
+uint64_t gs_sunkset_dev_n(const gs_sunkset_dev *s) { return s ? s->n : 0; }
+uint64_t gs_sunkset_dev_n_groups(const gs_sunkset_dev *s) { return s ? s->n_groups : 0; }
+const void *gs_sunkset_dev_code(const gs_sunkset_dev *s) { return s ? s->code : nullptr; }
+const void *gs_sunkset_dev_pos(const gs_sunkset_dev *s) { return s ? s->pos : nullptr; }
+const void *gs_sunkset_dev_group(const gs_sunkset_dev *s) { return s ? s->group : nullptr; }
+const void *gs_sunkset_dev_loc(const gs_sunkset_dev *s) { return s ? s->loc : nullptr; }
+
+int gs_sunks_define_device(int device, int k, uint32_t n_contigs, const void *d_seq, const uint64_t *off, gs_sunkset_dev **out) {
+    int rc = check_define_args("gs_sunks_define_device", device, k, n_contigs, d_seq, off, out);
+    if (rc) return rc;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());  // the sequence may have been written on another stream
+    auto *res = new gs_sunkset_dev();
+    if ((rc = sunks_define_core(device, k, n_contigs, static_cast<const uint8_t *>(d_seq), off, res))) {
+        gs_sunkset_dev_free(res);
+        return rc;
+    }
+    *out = res;
+    return GS_OK;
+}
+
+int gs_copy_to_host(int device, void *dst, const void *d_src, uint64_t bytes) {
+    if (bytes && (!dst || !d_src)) {
+        set_error("gs_copy_to_host: bad argument");
+        return GS_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    if (bytes) HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
+int gs_sunks_define(int device, int k, uint32_t n_contigs, const uint8_t *seq, const uint64_t *off, gs_sunkset **out) {
+    int rc = check_define_args("gs_sunks_define", device, k, n_contigs, seq, off, out);
+    if (rc) return rc;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    auto res = std::make_unique<gs_sunkset>();
+    res->k = k;
+    const uint64_t n = n_contigs ? off[n_contigs] : 0;
+    if (n == 0) {
+        *out = res.release();
+        return GS_OK;
+    }
+    Bufs b;
+    uint8_t *d_seq;
+    if ((rc = b.get(&d_seq, n + 64))) return rc;
+    HIP_TRY(hipMemcpy(d_seq, seq, n, hipMemcpyHostToDevice));
+    gs_sunkset_dev *dv = new gs_sunkset_dev();
+    std::unique_ptr<gs_sunkset_dev, void (*)(gs_sunkset_dev *)> guard(dv, gs_sunkset_dev_free);
+    if ((rc = sunks_define_core(device, k, n_contigs, d_seq, off, dv))) return rc;
+    const uint64_t m = dv->n;
     res->code.resize(m);
     res->contig.resize(m);
     res->start.resize(m);
     res->group.resize(m);
     if (m) {
-        // kmer.loc order: by (contig, pos)
-        tbb = tmp_bytes;
-        HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tbb, d_v0, d_v1, d_k0, d_k1, m, 0u, 64u));
-        // groups: head index of each run (gap <= k merges: overlapping or book-ended intervals), carried by a max-scan
-        hipLaunchKernelGGL(k_group_heads, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, d_v1, m, k, d_k0);
-        tbb = tmp_bytes;
-        HIP_TRY(rocprim::inclusive_scan(d_tmp, tbb, d_k0, d_v0, m, rocprim::maximum<uint64_t>()));
-        int64_t *d_group = reinterpret_cast<int64_t *>(d_k0);
-        hipLaunchKernelGGL(k_group_ids, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, d_v1, d_v0, m, d_group);
-        HIP_TRY(hipGetLastError());
         std::vector<uint64_t> posv(m);
-        HIP_TRY(hipMemcpy(res->code.data(), d_k1, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(posv.data(), d_v1, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(res->group.data(), d_group, m * sizeof(int64_t), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> grp(m);
+        HIP_TRY(hipMemcpy(res->code.data(), dv->code, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(posv.data(), dv->pos, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(grp.data(), dv->group, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint64_t i = 0; i < m; i++) {
             res->contig[i] = (uint32_t)(posv[i] >> 32);
             res->start[i] = (int64_t)(posv[i] & 0xFFFFFFFFu);
+            res->group[i] = (int64_t)grp[i];
         }
     }
-    *out = res;
+    *out = res.release();
     return GS_OK;
 }
 

@@ -102,3 +102,92 @@ def broadcast_array(arr: Optional[np.ndarray], dtype, device=None, src: int = 0)
         t = torch.empty(nbytes, dtype=torch.uint8, device=device)
     dist.broadcast(t, src=src)
     return t.cpu().numpy().view(dtype)
+
+
+class Comm:
+    """One rank of a read-sharded run.  Control plane = torch.distributed over gloo (rendezvous, barrier, the 8-byte phase-1
+    summaries, scalars); data plane = RCCL behind the C-ABI (gs_comm_*: table broadcast, hit gather) when `rccl`.
+    torch never touches the GPU here: a torch wheel bundles its own HIP runtime, and two HIP runtimes cannot both hold the
+    device in one process, so all device work stays in libgavisunk.so."""
+
+    def __init__(self, device: int, rccl: bool = True):
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device
+        self.rccl = None
+        if rccl:
+            from . import rccl as _rccl
+
+            self.rccl = _rccl.RcclComm(self, device)
+
+    # ---- control plane -------------------------------------------------------------------------------------
+    def barrier(self):
+        self.dist.barrier()
+
+    def _all_gather_i64(self, vals):
+        import torch
+
+        mine = torch.tensor([int(v) for v in vals], dtype=torch.int64)
+        out = torch.empty((self.world, len(vals)), dtype=torch.int64)
+        self.dist.all_gather_into_tensor(out, mine.reshape(1, -1))
+        return out.tolist()
+
+    def exchange_summaries(self, has_raw: int, last_loc: int):
+        return [(int(h), int(l)) for h, l in self._all_gather_i64([has_raw, last_loc])]
+
+    def all_max(self, x: float) -> float:
+        import torch
+
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_sum(self, x: int) -> int:
+        return sum(r[0] for r in self._all_gather_i64([x]))
+
+    def broadcast_bytes(self, data, src: int = 0) -> bytes:
+        import torch
+
+        n = torch.tensor([len(data) if self.rank == src else 0], dtype=torch.int64)
+        self.dist.broadcast(n, src=src)
+        t = torch.frombuffer(bytearray(data), dtype=torch.uint8) if self.rank == src else torch.empty(int(n.item()), dtype=torch.uint8)
+        self.dist.broadcast(t, src=src)
+        return t.numpy().tobytes()
+
+    # ---- data plane ----------------------------------------------------------------------------------------
+    def gather_hits(self, table, reads, n_local: int, read_offset: int, dst: int = 0):
+        """Per-rank hit lists of the last pass concatenated on rank `dst` in shard order (numpy HIT_DTYPE), None elsewhere."""
+        from . import engine
+
+        counts = [r[0] for r in self._all_gather_i64([n_local])]
+        if self.rccl is not None:
+            return self.rccl.gather_hits(table, reads, counts, read_offset, dst)
+        import torch
+
+        from ._lib import check, lib
+
+        mine = np.zeros(max(n_local, 1), dtype=engine.HIT_DTYPE)
+        if n_local:
+            check(lib().gs_tag_hits_to_host(table._h, reads._h, mine.ctypes.data, n_local, None))
+            mine["read"][:n_local] += np.uint32(read_offset)
+        width = max(max(counts), 1)
+        padded = torch.zeros((width, 3), dtype=torch.int32)
+        padded[:n_local] = torch.from_numpy(mine[:n_local].view(np.int32).reshape(-1, 3))
+        if self.rank == dst:
+            bufs = [torch.empty_like(padded) for _ in range(self.world)]
+            self.dist.gather(padded, bufs, dst=dst)
+            cat = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).numpy()
+            return np.ascontiguousarray(cat).view(engine.HIT_DTYPE).reshape(-1)
+        self.dist.gather(padded, None, dst=dst)
+        return None
+
+    def close(self):
+        if self.rccl is not None:
+            self.rccl.close()
+            self.rccl = None
+        self.dist.barrier()
+        self.dist.destroy_process_group()

@@ -273,3 +273,67 @@ def define_sunks(contigs, k: int, device: int = 0):
                   _view(L.gs_sunkset_code(h), n, np.uint64).copy(), _view(L.gs_sunkset_group(h), n, np.int64).copy())
     L.gs_sunkset_free(h)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Device-resident inputs (genome-scale runs: nothing crosses PCIe between SUNK definition and tagging).
+# The caller holds device memory (e.g. torch tensors) and passes raw device pointers through the C-ABI.
+# ---------------------------------------------------------------------------------------------------
+class DeviceSunkSet:
+    """gs_sunks_define_device: the SUNKs of an assembly whose bases (ASCII) are in device memory; the result stays there."""
+
+    def __init__(self, d_seq_ptr: int, off: np.ndarray, k: int, device: int = 0):
+        off = np.ascontiguousarray(off, np.uint64)
+        h = C.c_void_p()
+        check(lib().gs_sunks_define_device(device, k, len(off) - 1, d_seq_ptr, off.ctypes.data, C.byref(h)))
+        self._h, self.k, self.device = h, k, device
+        L = lib()
+        self.n, self.n_groups = L.gs_sunkset_dev_n(h), L.gs_sunkset_dev_n_groups(h)
+
+    def _host(self, ptr: int, dtype, lo: int = 0, hi: int | None = None) -> np.ndarray:
+        hi = self.n if hi is None else hi
+        out = np.empty(max(hi - lo, 0), dtype=dtype)
+        if len(out):
+            check(lib().gs_copy_to_host(self.device, out.ctypes.data, ptr + lo * out.itemsize, out.nbytes))
+        return out
+
+    def code(self, lo=0, hi=None):
+        return self._host(lib().gs_sunkset_dev_code(self._h), np.uint64, lo, hi)
+
+    def pos(self, lo=0, hi=None):
+        return self._host(lib().gs_sunkset_dev_pos(self._h), np.uint64, lo, hi)
+
+    def group(self, lo=0, hi=None):
+        return self._host(lib().gs_sunkset_dev_group(self._h), np.uint32, lo, hi)
+
+    def loc(self, lo=0, hi=None):
+        return self._host(lib().gs_sunkset_dev_loc(self._h), np.uint32, lo, hi)
+
+    def table(self) -> "DeviceTable":
+        """The tagger's table straight from the device arrays (payload of a hit = its kmer.loc row)."""
+        L = lib()
+        h = C.c_void_p()
+        check(L.gs_table_create_device(self.device, self.k, self.n, L.gs_sunkset_dev_code(self._h),
+                                       L.gs_sunkset_dev_loc(self._h), None, C.byref(h)))
+        t = DeviceTable.__new__(DeviceTable)
+        t._h, t.k, t.device, t.n = h, self.k, self.device, self.n
+        return t
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_sunkset_dev_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def device_reads_from_device_ascii(d_seq_ptr: int, off: np.ndarray, k: int, device: int = 0) -> DeviceReads:
+    """gs_reads_from_device_ascii: reads whose bases (ASCII, back to back) are in device memory; packed on the GPU."""
+    off = np.ascontiguousarray(off, np.uint64)
+    h = C.c_void_p()
+    check(lib().gs_reads_from_device_ascii(device, d_seq_ptr, off.ctypes.data, len(off) - 1, k, C.byref(h)))
+    r = DeviceReads.__new__(DeviceReads)
+    r._h, r.k, r.device = h, k, device
+    r.n_reads, r.n_bases = len(off) - 1, int(off[-1])
+    r.n_windows = lib().gs_reads_n_windows(h)
+    return r

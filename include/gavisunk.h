@@ -43,6 +43,8 @@ typedef enum gs_status {
 const char *gs_last_error(void);
 const char *gs_version(void);
 int gs_device_count(void);
+/* hipDeviceSynchronize on `device`: everything the library (or RCCL through gs_comm_*) enqueued there has finished */
+int gs_device_synchronize(int device);
 
 /* ------------------------------------------------------------------------------------------
  * Host-side parsing (native, like the reference's Nim programs).  No GPU needed.
@@ -111,10 +113,17 @@ int gs_batch_from_ascii(const uint8_t *seq, const uint64_t *off, uint32_t n_read
 typedef struct gs_table gs_table;
 int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const uint32_t *loc,
                     const uint32_t *payload, gs_table **out);
+/* The same from arrays that already are in DEVICE memory of `device` (e.g. the result of gs_sunks_define_device: no
+ * text or host round trip between SUNK definition and tagging).  d_payload may be NULL:
+ * payload[i] = i.  The arrays are read during the call only; the caller keeps owning them. */
+int gs_table_create_device(int device, int k, uint64_t n, const void *d_keys, const void *d_loc, const void *d_payload,
+                           gs_table **out);
 void gs_table_destroy(gs_table *t);
 uint64_t gs_table_bytes(const gs_table *t);
-/* Human-readable description of the layout chosen for this table (small tables get an exact
- * compact copy that stays resident in the XCD-partitioned L2; GAVISUNK_TABLE=generic disables it). */
+/* Human-readable description of the layout chosen for this table: "compact-lds" / "compact-l2" (small tables: an exact
+ * compact copy probed from LDS / the XCD-partitioned L2s), "minimizer-hbm" (tables that only fit HBM: 128-byte regions
+ * addressed by the k-mer's minimiser, so that consecutive windows share one memory request), "compact-hbm", "generic".
+ * GAVISUNK_TABLE=generic|compact-l2|compact-hbm|minimizer (read once, when the table is created) forces one. */
 const char *gs_table_layout(const gs_table *t);
 
 /* Device-resident batch of packed reads (+ the per-tile index the kernels need). */
@@ -124,6 +133,9 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
 /* The same from unpacked reads: ASCII bases back to back, off[n_reads+1] in bytes; the 2-bit packing (with the
  * `encode` table above) runs on the GPU. */
 int gs_reads_upload_ascii(int device, const uint8_t *seq, const uint64_t *off, uint32_t n_reads, int k, gs_reads **out);
+/* The same from bases that already are in DEVICE memory of `device` (d_seq: ASCII back to back; off: host offsets).  The
+ * bases are read during the call only. */
+int gs_reads_from_device_ascii(int device, const void *d_seq, const uint64_t *off, uint32_t n_reads, int k, gs_reads **out);
 void gs_reads_destroy(gs_reads *r);
 uint64_t gs_reads_n_bases(const gs_reads *r);
 uint64_t gs_reads_n_windows(const gs_reads *r);
@@ -254,6 +266,23 @@ const uint64_t *gs_sunkset_code(const gs_sunkset *s);
 const uint32_t *gs_sunkset_contig(const gs_sunkset *s);
 const int64_t *gs_sunkset_start(const gs_sunkset *s);
 const int64_t *gs_sunkset_group(const gs_sunkset *s);
+
+
+/* The same with the assembly already in DEVICE memory and the result kept there: feed it to gs_table_create_device
+ * (keys = code, loc = loc, payload NULL: a hit's payload is then the kmer.loc row).  Arrays (device pointers, valid until
+ * gs_sunkset_dev_free), all in kmer.loc order:  code u64 | pos u64 = contig << 32 | start | group u32 = start of the merged
+ * interval | loc u32 = dense id of the (contig, group) pair. */
+typedef struct gs_sunkset_dev gs_sunkset_dev;
+int gs_sunks_define_device(int device, int k, uint32_t n_contigs, const void *d_seq, const uint64_t *off, gs_sunkset_dev **out);
+void gs_sunkset_dev_free(gs_sunkset_dev *s);
+uint64_t gs_sunkset_dev_n(const gs_sunkset_dev *s);
+uint64_t gs_sunkset_dev_n_groups(const gs_sunkset_dev *s);
+const void *gs_sunkset_dev_code(const gs_sunkset_dev *s);
+const void *gs_sunkset_dev_pos(const gs_sunkset_dev *s);
+const void *gs_sunkset_dev_group(const gs_sunkset_dev *s);
+const void *gs_sunkset_dev_loc(const gs_sunkset_dev *s);
+/* plain device-to-host copy for callers that hold such device pointers but no HIP binding of their own */
+int gs_copy_to_host(int device, void *dst, const void *d_src, uint64_t bytes);
 
 
 /* Contig-wide union of the reads' validated SUNK sets (process-by-contig_lowmem_AR.py:219-260; SURVEY.md

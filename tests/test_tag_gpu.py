@@ -12,12 +12,13 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "compact-l2", "compact-hbm", "generic"], autouse=True)
+@pytest.fixture(params=["auto", "compact-l2", "compact-hbm", "minimizer", "generic"], autouse=True)
 def table_layout(request, monkeypatch):
-    """Every test runs four times: with the layout the library picks (small k <= 20 tables get the exact compact
+    """Every test runs five times: with the layout the library picks (small k <= 20 tables get the exact compact
     copy: at k = 20 the radix join probes its slices from LDS, at other k it is probed out of the XCD-partitioned
-    L2), with the L2 path forced, with the compact table treated as HBM-resident (the layout of tables too large
-    for L2), and with the generic 16-byte-slot table forced."""
+    L2), with the L2 path forced, with the compact table treated as HBM-resident (one bucket load per window), with
+    the minimiser-addressed layout that genome-scale tables get (lane = window, k >= 16), and with the generic
+    16-byte-slot table forced."""
     monkeypatch.setenv("GAVISUNK_TABLE", request.param)
     return request.param
 
@@ -169,17 +170,27 @@ def test_layout_selection(table_layout):
     keys, loc, _ = _random_case(3, 20)
     tab = engine.DeviceTable(20, keys, loc, np.arange(len(keys), dtype=np.uint32))
     assert tab.layout.startswith({"auto": "compact-lds", "compact-l2": "compact-l2", "compact-hbm": "compact-hbm",
-                                  "generic": "generic"}[table_layout])
+                                  "minimizer": "minimizer-hbm", "generic": "generic"}[table_layout])
     tab.close()
     keys, loc, _ = _random_case(3, 18)
     tab = engine.DeviceTable(18, keys, loc, np.arange(len(keys), dtype=np.uint32))
     assert tab.layout.startswith({"auto": "compact-l2", "compact-l2": "compact-l2", "compact-hbm": "compact-hbm",
-                                  "generic": "generic"}[table_layout])
+                                  "minimizer": "minimizer-hbm", "generic": "generic"}[table_layout])
     tab.close()
     keys, loc, _ = _random_case(3, 25)
     tab = engine.DeviceTable(25, keys, loc, np.arange(len(keys), dtype=np.uint32))
-    # 46-bit keys do not fit 32-bit compact slots without blowing the table up: 64-bit slots take over
-    assert tab.layout.startswith("generic") if table_layout == "generic" else ("compact-hbm" in tab.layout and "x u64" in tab.layout)
+    # 46-bit keys do not fit 32-bit compact slots without blowing the table up: such tables live in HBM, where the
+    # minimiser-addressed layout is the default; forced, the one-bucket-load layout takes 64-bit slots
+    if table_layout == "generic":
+        assert tab.layout.startswith("generic")
+    elif table_layout in ("auto", "minimizer", "compact-l2"):
+        assert tab.layout.startswith("minimizer-hbm") and "47-bit tag" in tab.layout and "minimiser length 18 " in tab.layout
+    else:
+        assert "compact-hbm" in tab.layout and "x u64" in tab.layout
+    tab.close()
+    keys, loc, _ = _random_case(3, 11)  # k < 16: only the generic table applies
+    tab = engine.DeviceTable(11, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    assert tab.layout.startswith("generic")
     tab.close()
 
 
@@ -232,7 +243,7 @@ def test_low_complexity_reads_overflow_one_partition():
 def test_undersized_compact_table_uses_every_overflow_path(qb, monkeypatch, table_layout):
     """With far too few buckets most keys live in their second-chance bucket or only in the generic side table:
     deferred lookups, their flushes and the generic fallback carry the load, and the answer must not change."""
-    if table_layout == "generic":
+    if table_layout in ("generic", "minimizer"):
         pytest.skip("needs a compact layout")
     monkeypatch.setenv("GAVISUNK_COMPACT_QB", qb)
     k = 20
@@ -287,13 +298,57 @@ def test_slots_without_a_spare_bit(k, qb, monkeypatch, table_layout):
         monkeypatch.setenv("GAVISUNK_COMPACT_QB", qb)
     keys, loc, seqs = _random_case(91, k, n_reads=60, glen=8000, median=2000)
     loc = np.zeros_like(loc)
-    if table_layout != "generic":
+    if table_layout not in ("generic", "minimizer"):
         tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
         assert "31-bit remainder, 1-bit loc" in tab.layout
         tab.close()
     rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
     st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
     assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] > 10000 and len(gh) == len(oh) == 1
+
+
+@pytest.mark.parametrize("m,load", [("6", "4"), ("12", "16"), ("16", "12"), ("9", "1"), ("19", "4")])
+def test_minimizer_table_walks_and_overflows(m, load, monkeypatch, table_layout):
+    """The minimiser-addressed layout with the wrong geometry on purpose: a short minimiser piles hundreds of keys on one
+    128-byte region (most keys then live in the generic side table and lookups walk all 8 pieces first); 16 or 12 keys
+    per region fill the pieces, so keys sit further round their region; a sparse table is the easy case."""
+    if table_layout != "minimizer":
+        pytest.skip("minimiser-addressed layout only")
+    monkeypatch.setenv("GAVISUNK_MZ_M", m)
+    monkeypatch.setenv("GAVISUNK_MZ_LOAD", load)
+    k = 20
+    keys, loc, seqs = _random_case(56, k, n_reads=60, glen=60000, median=4000)
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    assert tab.layout.startswith("minimizer-hbm") and f"minimiser length {m} " in tab.layout
+    n_ovf = int(tab.layout.split("), ")[-1].split(" overflow")[0])
+    assert n_ovf > (10000 if m == "6" else 50 if load in ("16", "12") else -1)
+    tab.close()
+    seqs = seqs + [b"A" * 5000, b"ACGT" * 700, seqs[0][:19], b""]
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] and ctr["windows"] == octr["windows"] and len(gh) == len(oh) > 100
+    assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"])
+    assert np.array_equal(gh["payload"], oh["row"]) and carry == (loc[oprev] if oprev != oracle.NONE else _lib.GS_NONE)
+
+
+def test_join_overflow_lists_longer_than_lds_are_searched_in_hbm(monkeypatch, table_layout):
+    """32 buckets per partition for a quarter of a million keys: nearly every key overflows, ~900 per table slice -- more
+    than the 512 the LDS join keeps in LDS, so its probe kernel binary-searches the slice's sorted overflow list in HBM.
+    (A 31-bit remainder leaves one loc bit: one location group, so the raw-hit count is what is compared.)"""
+    if table_layout != "auto":
+        pytest.skip("LDS join only")
+    monkeypatch.setenv("GAVISUNK_COMPACT_QB", "5")
+    k = 20
+    keys, loc, seqs = _random_case(92, k, n_reads=80, glen=250000, median=4000)
+    loc = np.zeros_like(loc)
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    assert tab.layout.startswith("compact-lds") and "2^5 buckets" in tab.layout
+    assert int(tab.layout.split("), ")[1].split(" overflow")[0]) > 600 * 256
+    tab.close()
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] > 50000 and len(gh) == len(oh) == 1
+    assert gh["pos"][0] == oh["pos"][0] and gh["payload"][0] == oh["row"][0]
 
 
 def test_table_without_keys():
