@@ -397,7 +397,7 @@ def main():
                        "reads_per_gpu": a.reads, "bases_per_gpu": n_bases, "sunks": int(n_sunks), "sunk_groups": int(n_groups),
                        "windows": c["windows"], "raw_hits": c["raw_hits"], "emitted_rows": c["emitted"],
                        "h_raw": round(h_raw, 5), "h_emit": round(h_emit, 7), "tiles": c["tiles"],
-                       "table_GiB": round(table.nbytes / 2**30, 2), "table_layout": table.layout,
+                       "fallback_tiles": c["fallback_tiles"], "table_GiB": round(table.nbytes / 2**30, 2), "table_layout": table.layout,
                        "parallelism": f"read-sharded x{world}, table replicated",
                        "env_knobs": knobs},
             "roofline": {"bound": "hbm", "kernel": kernel_names(table.layout), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

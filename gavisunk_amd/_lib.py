@@ -26,7 +26,7 @@ class GsHit(C.Structure):
 
 class GsCounters(C.Structure):
     _fields_ = [("windows", C.c_uint64), ("raw_hits", C.c_uint64), ("emitted", C.c_uint64), ("tiles", C.c_uint64),
-                ("launches", C.c_uint64), ("probe_ms", C.c_double), ("total_ms", C.c_double)]
+                ("launches", C.c_uint64), ("probe_ms", C.c_double), ("total_ms", C.c_double), ("fallback_tiles", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

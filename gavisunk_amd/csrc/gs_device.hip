@@ -1998,9 +1998,19 @@ int launch_phase1(gs_table *t, gs_reads *r) {
     if (r->n_tiles) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
-        if (t->mz) {
-            hipLaunchKernelGGL(k_probe_mz, dim3(blocks), dim3(256), 0, t->stream, mz_view(t), view(t), (const uint64_t *)r->words,
+        if (t->mz == 2) {  // GAVISUNK_TABLE=minimizer-exact: every tile by the per-lane form (the fast form's fallback)
+            hipLaunchKernelGGL(k_probe_mz_exact, dim3(blocks), dim3(256), 0, t->stream, mz_view(t), view(t), (const uint64_t *)r->words,
                                (const TileDesc *)r->tile_desc, r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count);
+        } else if (t->mz) {
+#define GS_LAUNCH_MZ(KT, MT)                                                                                                  \
+    hipLaunchKernelGGL((k_probe_mz<KT, MT>), dim3((r->n_tiles + kMzWaves - 1) / kMzWaves), dim3(64 * kMzWaves), 0, t->stream,  \
+                       mz_view(t), view(t), (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->ta,     \
+                       r->cand, r->cand_cap, t->d_cand_count, t->d_complex_n)
+            if (t->k == 20 && t->mz_m == 16)
+                GS_LAUNCH_MZ(20, 16);  // GAVISUNK's default SUNK length and the minimiser length of its tables: constants
+            else
+                GS_LAUNCH_MZ(0, 0);
+#undef GS_LAUNCH_MZ
         } else if (t->compact == 1 && t->join) {
             const uint32_t n_batches = (r->n_tiles + kJoinTiles - 1) / kJoinTiles;
 #ifdef GS_TUNING  // experiments only (tools/, libgavisunk_tuning.so): the shipped library has no such switches
@@ -2208,7 +2218,8 @@ int mz_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, uint
     while ((1ull << locbits) < (uint64_t)maxloc + 2) locbits++;
     if (2 * k - 3 + locbits > 64) return 0;
     const int m_hi = std::min(31, k - 1);
-    m = std::max(8, k - 7);  // w <= 8: the adjacent k-mers one minimiser owns fill at most half a 16-slot region
+    m = std::max(8, k - 4);  // w <= 5: the adjacent k-mers one minimiser owns are a third of a region (measured: the probe
+                             // kernel is instruction-bound, so shorter runs cost nothing while crowded regions do)
     for (; m < m_hi; m++) {
         const double w = k - m + 1, places = (double)n / (0.65 * (w + 1) / 2);
         if (places <= 0.25 * std::pow(4.0, m)) break;
@@ -2217,7 +2228,7 @@ int mz_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, uint
         const int v = atoi(e);
         if (v >= 4 && v <= m_hi) m = v;
     }
-    double per_region = 4.0;  // keys per 16-slot region
+    double per_region = 3.0;  // keys per 14-slot region
     bool forced_load = false;
     if (const char *e = getenv("GAVISUNK_MZ_LOAD")) {  // test knob: an undersized table makes the walk and the overflow path busy
         const double v = atof(e);
@@ -2321,11 +2332,11 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
     // "compact-hbm" layout stays available, forced).  The generic 16-byte-slot table holds what those could not take,
     // or everything.
     const char *env = getenv("GAVISUNK_TABLE");
-    const bool force_mz = env && !strcmp(env, "minimizer");
+    const bool force_mz = env && (!strcmp(env, "minimizer") || !strcmp(env, "minimizer-exact"));
     t->compact = force_mz ? 0 : choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, env, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
     if (force_mz || ((t->compact == 2 || t->compact == 3) && !(env && !strcmp(env, "compact-hbm")))) {
         if (mz_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_n_regions, t->mz_locbits)) {
-            t->mz = 1;
+            t->mz = env && !strcmp(env, "minimizer-exact") ? 2 : 1;
             t->compact = 0;
         } else if (force_mz) {
             t->compact = choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, nullptr, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
@@ -2527,10 +2538,10 @@ int gs_table_create_device(int device, int k, uint64_t n, const void *d_keys, co
 }
 
 const char *gs_table_layout(const gs_table *t) {
-    static thread_local char buf[160];
+    static thread_local char buf[256];
     if (!t) return "";
     if (t->mz)
-        snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 128 B (8 pieces x 2 x u64 [%d-bit tag | %d-bit loc]), minimiser length %d (w = %d), %llu overflow keys in a generic 16 B-slot side table",
+        snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 128 B (16 fingerprint bytes + 14 x u64 [%d-bit tag | %d-bit loc]), minimiser length %d (w = %d), %llu overflow keys in a generic 16 B-slot side table",
                  t->mz_n_regions, 2 * t->k - 3, t->mz_locbits, t->mz_m, t->k - t->mz_m + 1, (unsigned long long)t->mz_overflow);
     else if (t->compact)
         snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x %s (%d-bit remainder, %d-bit loc%s), %llu overflow keys in a generic 16 B-slot side table",
@@ -2880,6 +2891,7 @@ static int settle(gs_table *t, gs_reads *r) {
         t->ctr.launches += 1;
         t->ctr.windows = r->n_windows;
         t->ctr.tiles = r->n_tiles;
+        t->ctr.fallback_tiles = t->h_status->complex_n;
         t->ctr.raw_hits = tot[0].sum;
         t->ctr.emitted = tot[1].sum;
         t->res_n = tot[1].sum;

@@ -3,29 +3,34 @@
 //
 // Why.  A random probe of a table that lives in HBM costs one fabric request whatever it fetches, and the chip moves
 // ~47 G such requests per second (profiles/r02/ubench_run_coalescing.txt: 64-byte and 128-byte regions alike) -- one
-// request per window is the 0.09-of-roofline wall of the direct layouts.  The texture path, though, coalesces the lanes
-// of ONE wave-load that fall into the same 128-byte line into one request: with runs of L adjacent lanes per line the
-// same microbenchmark reads 47 G lines/s x L windows (L = 3: 142, L = 4: 186, L = 6: 270 G windows/s).
+// request per window is the 0.09-of-roofline wall of the direct layouts.  Lanes of ONE wave-load that fall into the same
+// 128-byte line, though, are one request: with runs of L adjacent lanes per line the same microbenchmark reads
+// 47 G lines/s x L windows (L = 3: 142, L = 4: 186, L = 6: 270 G windows/s).
 //
 // So (1) a lane is a WINDOW (consecutive lanes = consecutive windows of a read), and (2) the 128-byte region a k-mer lives
 // in is chosen by its MINIMISER -- the smallest hash among the canonical m-mers inside it -- which consecutive windows
-// share ((w + 1) / 2 of them on average, w = k - m + 1).  Inside the region the k-mer's own hash picks one of 8 pieces
-// of 16 bytes = 2 slots, so a window still costs ONE 16-byte load.
+// share ((w + 1) / 2 of them on average, w = k - m + 1).  A region is fetched ONCE per run of windows, whole, into LDS.
 //
 //   H       = min over the w m-mers of the k-mer of mix_a(min(m-mer, its reverse complement))     strand-symmetric
 //   region  = mul_hi(mix_b(H), n_regions)                                                          128 bytes each
 //   l | hi  = mix_a(low 32 bits of the canonical code) ^ mix_b(high bits), high bits               a bijection
-//   piece   = l >> 29,   tag = (l & 0x1FFFFFFF) << (2k - 32) | hi                                  2k - 3 bits
-//   slot    = tag << locbits | loc                    64 bits, all ones = empty (the all-ones loc is never stored)
+//   fp      = min(l >> 24, 0xFE)                                                                    fingerprint byte
+//   tag     = (l & 0x1FFFFFFF) << (2k - 32) | hi                                                    2k - 3 bits
 //
-// (region, piece, tag) does not determine the key -- the region comes from the minimiser -- but (piece, tag) alone does,
-// so a matching slot is an exact hit.  A key goes to the first piece with a free slot, starting at its own piece and
-// walking round the region; a lookup walks the same way and stops at the first piece that is not full.  A key whose
-// region is full (16 keys) stays in the generic 16-byte-slot table; a lookup that found all 8 pieces full and no match
-// asks that table.  m >= k - 7 (a minimiser owns at most w = 8 adjacent k-mers of a place: half a region) and grows with
-// the key count (about log4 of it: each minimiser value should own <= ~1 place in the assembly): human-genome-scale
-// tables of 20-mers get m = 16, runs of ~3 windows; small ones m = 13, runs of ~4.5.  m-mers longer than 16 bases
-// (k > 23) are hashed down to 32 bits.
+//   region  = 16 bytes of fingerprints | 14 slots of 8 bytes
+//             byte 0      0xFF - (keys in the region): a region is full at 14
+//             byte 1      0xFF
+//             byte i      fingerprint of slot i (i = 2..15), 0xFF = empty
+//             slot i      tag << locbits | loc            (all ones = empty; the all-ones loc is never stored)
+//
+// (fp, tag) determine l and with it the key -- 0xFE stands for both 0xFE and 0xFF, which differ in bit 24 of l, and that
+// bit is in the tag too -- so a slot whose fingerprint and tag match is an exact hit, wherever the region came from.
+// A lookup reads the 16 fingerprint bytes, compares them all at once, and reads only the slots whose fingerprint matches
+// (one for a hit, none for 95 % of the misses).  Keys fill a region's slots in arrival order; a key whose region is full
+// stays in the generic 16-byte-slot table, and a lookup without a match in a FULL region asks that table.
+// m >= k - 7 (a minimiser owns at most w = 8 adjacent k-mers of one place) and grows with the key count (about log4 of
+// it: each minimiser value should own <= ~1 place of the assembly): human-genome-scale tables of 20-mers get m = 16, runs
+// of ~3 windows.  m-mers longer than 16 bases (k > 23) are hashed down to 32 bits.
 //
 // Payloads (the loc row a hit reports) are not in the slots: only the emitted rows (1e-4 of the windows) need one, and
 // k_emit finds it by binary search in the sorted key list kept beside the table.
@@ -41,7 +46,8 @@ struct MzView {
 };
 
 constexpr uint64_t kMzEmpty = ~0ULL;
-constexpr int kMzPieces = 8;       // 16-byte pieces per 128-byte region
+constexpr int kMzPieces = 8;       // 16-byte pieces per 128-byte region: piece 0 = fingerprints, pieces 1..7 = 14 slots
+constexpr int kMzSlots = 14;       // keys per region
 constexpr int kMzCandLds = 128;    // candidates of a tile kept in LDS; tiles with more are walked a second time
 constexpr int kMzU = 4;            // wave-steps (64 windows each) whose table loads are in flight together
 
@@ -51,21 +57,17 @@ __host__ __device__ __forceinline__ uint32_t mz_mix_a(uint32_t x) {
     x ^= x >> 15;
     x *= 0x85EBCA6Bu;
     x ^= x >> 13;
-    x *= 0xC2B2AE35u;
-    x ^= x >> 16;
     return x;
 }
-__host__ __device__ __forceinline__ uint32_t mz_mix_b(uint32_t x) {
+__host__ __device__ __forceinline__ uint32_t mz_mix_b(uint32_t x) {  // mz_mix_b(0) = 0
     x ^= x >> 16;
     x *= 0x7FEB352Du;
     x ^= x >> 15;
-    x *= 0x846CA68Bu;
-    x ^= x >> 16;
     return x;
 }
 
 struct MzKey {
-    uint32_t piece;
+    uint32_t fp;  // fingerprint byte, 0..0xFE
     uint64_t tag;
 };
 // k >= 16: the canonical code has 2k - 32 >= 0 bits above its low word
@@ -73,7 +75,7 @@ __host__ __device__ __forceinline__ MzKey mz_key(uint64_t c, int k) {
     const uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
     const uint32_t l = mz_mix_a(lo) ^ mz_mix_b(hi + 0x632BE5ABu);
     MzKey o;
-    o.piece = l >> 29;
+    o.fp = min(l >> 24, 0xFEu);
     o.tag = ((uint64_t)(l & 0x1FFFFFFFu) << (2 * k - 32)) | (uint64_t)hi;  // k = 16: hi = 0, no shift
     return o;
 }
@@ -100,7 +102,7 @@ __host__ __device__ __forceinline__ uint32_t mz_minimizer(uint64_t c, int k, int
 }
 
 // ------------------------------------------------------------------------------------------
-// build: one thread per key, first free slot on the walk round the region
+// build: one thread per key; the region's count byte hands out the slots in arrival order
 // ------------------------------------------------------------------------------------------
 __global__ void k_mz_insert(unsigned long long *slots, uint32_t n_regions, int k, int m, int locbits, const uint64_t *keys,
                             const uint32_t *loc, uint64_t n, unsigned long long *overflow, uint32_t *overflow_list,
@@ -110,15 +112,24 @@ __global__ void k_mz_insert(unsigned long long *slots, uint32_t n_regions, int k
     const uint64_t c = keys[i];
     const uint32_t reg = mz_region(mz_minimizer(c, k, m), n_regions);
     const MzKey key = mz_key(c, k);
-    const unsigned long long v = (key.tag << locbits) | (unsigned long long)loc[i];
-    unsigned long long *base = slots + (uint64_t)reg * (2 * kMzPieces);
-    for (int w = 0; w < kMzPieces; w++) {
-        unsigned long long *p = base + 2 * ((key.piece + (uint32_t)w) & (uint32_t)(kMzPieces - 1));
-        if (atomicCAS(p, kMzEmpty, v) == kMzEmpty) return;
-        if (atomicCAS(p + 1, kMzEmpty, v) == kMzEmpty) return;
+    unsigned long long *base = slots + (uint64_t)reg * 16;
+    uint32_t *fpw = reinterpret_cast<uint32_t *>(base);  // 4 words of fingerprint bytes
+    uint32_t old = fpw[0], cnt;
+    for (;;) {
+        cnt = 0xFFu - (old & 0xFFu);
+        if (cnt >= (uint32_t)kMzSlots) break;
+        const uint32_t seen = atomicCAS(fpw, old, old - 1u);
+        if (seen == old) break;
+        old = seen;
     }
-    const unsigned long long o = atomicAdd(overflow, 1ULL);
-    if (o < overflow_cap) overflow_list[o] = (uint32_t)i;  // goes to the generic table
+    if (cnt >= (uint32_t)kMzSlots) {  // the region is full: the key stays in the generic table
+        const unsigned long long o = atomicAdd(overflow, 1ULL);
+        if (o < overflow_cap) overflow_list[o] = (uint32_t)i;
+        return;
+    }
+    const uint32_t slot = 2u + cnt;
+    base[slot] = (key.tag << locbits) | (unsigned long long)loc[i];
+    atomicAnd(fpw + (slot >> 2), ~(0xFFu << (8u * (slot & 3u))) | (key.fp << (8u * (slot & 3u))));
 }
 
 // payload of a key that is known to be in the table (k_emit): binary search in the sorted key list
@@ -131,6 +142,37 @@ __device__ __forceinline__ uint32_t mz_payload(const MzView &mz, uint64_t c) {
     }
     return lo < mz.n_keys && mz.skeys[lo] == c ? mz.spayload[lo] : 0u;
 }
+
+// bit 7 of every byte of x that equals the byte replicated in T (exact: no borrow between bytes)
+__device__ __forceinline__ uint32_t mz_byte_eq(uint32_t x, uint32_t T) {
+    const uint32_t z = x ^ T;
+    return ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);
+}
+struct MzCand {  // fingerprint matches of a lookup: bit 7 of byte b of word j = slot 4 j + b
+    uint32_t m[4];
+    __device__ __forceinline__ bool any() const { return (m[0] | m[1] | m[2] | m[3]) != 0u; }
+    __device__ __forceinline__ uint32_t pop() {  // lowest matching slot, removed
+        const uint32_t j = m[0] ? 0u : m[1] ? 1u : m[2] ? 2u : 3u;
+        const uint32_t x = m[0] ? m[0] : m[1] ? m[1] : m[2] ? m[2] : m[3];
+        const uint32_t bit = (uint32_t)__ffs((int)x) - 1u;
+        const uint32_t clr = ~(1u << bit);
+        m[0] &= j == 0u ? clr : ~0u;
+        m[1] &= j == 1u ? clr : ~0u;
+        m[2] &= j == 2u ? clr : ~0u;
+        m[3] &= j == 3u ? clr : ~0u;
+        return j * 4u + (bit >> 3);
+    }
+};
+__device__ __forceinline__ MzCand mz_candidates(const uint4 F, uint32_t fp) {
+    const uint32_t T = __builtin_amdgcn_perm(0u, fp, 0u);  // byte 0 of fp in all four bytes
+    MzCand c;
+    c.m[0] = mz_byte_eq(F.x, T) & 0x80800000u;  // bytes 0 and 1 are not fingerprints
+    c.m[1] = mz_byte_eq(F.y, T);
+    c.m[2] = mz_byte_eq(F.z, T);
+    c.m[3] = mz_byte_eq(F.w, T);
+    return c;
+}
+__device__ __forceinline__ bool mz_region_full(const uint4 F) { return (F.x & 0xFFu) <= 0xFFu - (uint32_t)kMzSlots; }
 
 // ------------------------------------------------------------------------------------------
 // probe: one wavefront per tile, 32 steps of 64 consecutive windows (lane = window)
@@ -148,11 +190,8 @@ struct MzWin {
     uint64_t f, r;  // forward code and reverse-complement code of the window that starts at this lane's base
     uint32_t h;     // hash of the canonical m-mer that starts there
 };
-// step s (wave-uniform, 0..32) of a tile whose 66 words are held as W0 (word = lane) and W1 (word 64 + (lane & 1))
-__device__ __forceinline__ MzWin mz_window(uint64_t W0, uint64_t W1, int s, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
-    const uint64_t A = mz_word(W0, W1, 2 * s), B = mz_word(W0, W1, 2 * s + 1), C = mz_word(W0, W1, 2 * s + 2);
-    const bool hsel = lane >= 32;
-    const uint64_t a = hsel ? B : A, b = hsel ? C : B;
+// the window whose first base is base (lane & 31) of the 64-base string a:b
+__device__ __forceinline__ MzWin mz_win_of(uint64_t a, uint64_t b, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
     const int sh = 2 * (lane & 31);
     const uint64_t x = sh ? ((a << sh) | (b >> (64 - sh))) : a;  // 32 bases from the window's first one
     MzWin o;
@@ -166,6 +205,12 @@ __device__ __forceinline__ MzWin mz_window(uint64_t W0, uint64_t W1, int s, int 
         o.h = mz_mmer_hash(fm < rm ? fm : rm);
     }
     return o;
+}
+// step s (wave-uniform, 0..32) of a tile whose 66 words are held as W0 (word = lane) and W1 (word 64 + (lane & 1))
+__device__ __forceinline__ MzWin mz_window(uint64_t W0, uint64_t W1, int s, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
+    const uint64_t A = mz_word(W0, W1, 2 * s), B = mz_word(W0, W1, 2 * s + 1), C = mz_word(W0, W1, 2 * s + 2);
+    const bool hsel = lane >= 32;
+    return mz_win_of(hsel ? B : A, hsel ? C : B, lane, k, m, kmask, mmask);
 }
 
 // lane i <- lane i + 1, lane 63 <- fill (wave-uniform)
@@ -197,15 +242,17 @@ __device__ __forceinline__ MzTileOut mz_tile(const MzView &mz, const TableView &
     for (uint32_t s0 = 0; s0 < nsteps; s0 += kMzU) {
         const uint4 *addr[kMzU];
         uint64_t want[kMzU];
+        uint32_t fp[kMzU];
         uint4 bk[kMzU];
         bool valid[kMzU];
-        // phase A: minimiser, region, piece of kMzU steps; their loads leave together
+        // phase A: minimiser, region, fingerprint of kMzU steps; their fingerprint loads leave together
 #pragma unroll
         for (int u = 0; u < kMzU; u++) {
             const uint32_t s = s0 + (uint32_t)u;
             valid[u] = false;
             addr[u] = mz.regions;
             want[u] = 0;
+            fp[u] = 0;
             bk[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
             if (s >= nsteps) continue;  // wave-uniform
             const MzWin nxt = mz_window(W0, W1, (int)s + 1, lane, k, m, kmask, mmask);
@@ -216,59 +263,43 @@ __device__ __forceinline__ MzTileOut mz_tile(const MzView &mz, const TableView &
             }
             const uint64_t c = cur.f < cur.r ? cur.f : cur.r;
             const MzKey key = mz_key(c, k);
-            addr[u] = mz.regions + (uint64_t)mz_region(H, mz.n_regions) * kMzPieces + key.piece;
+            addr[u] = mz.regions + (uint64_t)mz_region(H, mz.n_regions) * kMzPieces;
             want[u] = key.tag << locbits;
+            fp[u] = key.fp;
             valid[u] = s * 64u + (uint32_t)lane < td.nwin_left;
             if (valid[u]) bk[u] = *addr[u];
             cur = nxt;
         }
-        // phase B: compare, walk on where a piece is full (rare), ordered bookkeeping
+        // phase B: the slots whose fingerprint matches (dependent loads), the generic table for full regions, bookkeeping
 #pragma unroll
         for (int u = 0; u < kMzU; u++) {
             const uint32_t s = s0 + (uint32_t)u;
             if (s >= nsteps) break;  // wave-uniform
-            uint64_t s_lo = (uint64_t)bk[u].x | ((uint64_t)bk[u].y << 32), s_hi = (uint64_t)bk[u].z | ((uint64_t)bk[u].w << 32);
-            uint64_t e0 = s_lo ^ want[u], e1 = s_hi ^ want[u];
-            uint64_t e = e0 < e1 ? e0 : e1;
-            bool hit = valid[u] && e < locmask;
-            bool more = valid[u] && !hit && s_hi != kMzEmpty;  // the piece is full: the key may sit further round the region
-            if (__ballot(more)) {
-                const uint4 *rbase = (const uint4 *)((uintptr_t)addr[u] & ~(uintptr_t)127);
-                const uint32_t p0 = (uint32_t)(((uintptr_t)addr[u] >> 4) & 7u);
-                uint32_t step = 1;
-                while (__ballot(more)) {
-                    if (more) {
-                        if (step == (uint32_t)kMzPieces) {  // 16 keys in the region: the key, if any, is in the generic table
-                            const MzWin ww = mz_window(W0, W1, (int)s, lane, k, m, kmask, mmask);
-                            const uint64_t c = ww.f < ww.r ? ww.f : ww.r;
-                            uint64_t hh = slot_of(c, tab.shift);
-                            Slot sl = load_slot(tab.slots + hh);
-                            while (sl.key != c && sl.key != kEmptyKey) {
-                                hh = (hh + 1) & tab.mask;
-                                sl = load_slot(tab.slots + hh);
-                            }
-                            if (sl.key == c) {
-                                hit = true;
-                                e = sl.loc;
-                            }
-                            more = false;
-                        } else {
-                            const uint4 b2 = rbase[(p0 + step) & 7u];
-                            s_lo = (uint64_t)b2.x | ((uint64_t)b2.y << 32);
-                            s_hi = (uint64_t)b2.z | ((uint64_t)b2.w << 32);
-                            e0 = s_lo ^ want[u];
-                            e1 = s_hi ^ want[u];
-                            const uint64_t e2 = e0 < e1 ? e0 : e1;
-                            if (e2 < locmask) {
-                                hit = true;
-                                e = e2;
-                                more = false;
-                            } else if (s_hi == kMzEmpty) {
-                                more = false;
-                            }
-                        }
+            MzCand cd = mz_candidates(bk[u], fp[u]);
+            bool hit = false;
+            uint64_t e = 0;
+            while (__ballot(valid[u] && !hit && cd.any())) {
+                if (valid[u] && !hit && cd.any()) {
+                    const uint64_t sv = reinterpret_cast<const uint64_t *>(addr[u])[cd.pop()];
+                    const uint64_t e2 = sv ^ want[u];
+                    if (e2 < locmask) {
+                        hit = true;
+                        e = e2;
                     }
-                    step++;
+                }
+            }
+            if (valid[u] && !hit && mz_region_full(bk[u])) {  // 14 keys in the region and none is it: the generic table
+                const MzWin ww = mz_window(W0, W1, (int)s, lane, k, m, kmask, mmask);
+                const uint64_t c = ww.f < ww.r ? ww.f : ww.r;
+                uint64_t hh = slot_of(c, tab.shift);
+                Slot sl = load_slot(tab.slots + hh);
+                while (sl.key != c && sl.key != kEmptyKey) {
+                    hh = (hh + 1) & tab.mask;
+                    sl = load_slot(tab.slots + hh);
+                }
+                if (sl.key == c) {
+                    hit = true;
+                    e = sl.loc;
                 }
             }
             const uint32_t loc = (uint32_t)e;
@@ -295,15 +326,13 @@ __device__ __forceinline__ MzTileOut mz_tile(const MzView &mz, const TableView &
     return MzTileOut{n_raw, n_cand, first_loc, carry};
 }
 
-__global__ __launch_bounds__(256) void k_probe_mz(MzView mz, TableView tab, const uint64_t *__restrict__ words,
-                                                  const TileDesc *__restrict__ tdesc, uint32_t n_tiles, TileArrays ta,
-                                                  uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count) {
-    __shared__ uint32_t s_cand[4][kMzCandLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t tile = blockIdx.x * 4u + (uint32_t)wave;
-    if (tile >= n_tiles) return;
-    const TileDesc td = tdesc[tile];
-    MzTileOut o = mz_tile<0>(mz, tab, words, td, s_cand[wave]);
+// The exact per-lane form of a tile (every table load its own request, walks and generic lookups inline): the fallback of
+// k_probe_mz for tiles that do not fit its LDS budgets, and the reference the fast form is tested against.
+__device__ __forceinline__ void mz_tile_exact(const MzView &mz, const TableView &tab, const uint64_t *__restrict__ words,
+                                              const TileDesc td, uint32_t tile, uint32_t n_tiles, const TileArrays &ta, uint32_t *cand,
+                                              uint32_t cand_cap, uint32_t *g_cand_count, uint32_t *s_cand) {
+    const int lane = threadIdx.x & 63;
+    MzTileOut o = mz_tile<0>(mz, tab, words, td, s_cand);
     // up to kDirectCand candidates go to the tile's own slots; longer lists are allocated with one atomic
     uint32_t off = tile * (uint32_t)kDirectCand;
     if (o.n_cand > (uint32_t)kDirectCand) {
@@ -314,10 +343,311 @@ __global__ __launch_bounds__(256) void k_probe_mz(MzView mz, TableView tab, cons
         if (o.n_cand <= (uint32_t)kMzCandLds) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = lane; i < o.n_cand; i += 64u) cand[off + i] = s_cand[wave][i];
+            for (uint32_t i = lane; i < o.n_cand; i += 64u) cand[off + i] = s_cand[i];
         } else {
             mz_tile<1>(mz, tab, words, td, cand + off);  // (rare) walk the tile again, candidates straight to their place
         }
+    }
+    if (lane == 0) {
+        ta.n_raw[tile] = o.n_raw;
+        ta.n_cand[tile] = o.n_cand;
+        ta.cand_off[tile] = off;
+        if (o.n_raw) {
+            ta.first_loc[tile] = o.first_loc;
+            ta.last_loc[tile] = o.last_loc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab, const uint64_t *__restrict__ words,
+                                                        const TileDesc *__restrict__ tdesc, uint32_t n_tiles, TileArrays ta,
+                                                        uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count) {
+    __shared__ uint32_t s_cand[4][kMzCandLds];
+    const int wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * 4u + (uint32_t)wave;
+    if (tile >= n_tiles) return;
+    mz_tile_exact(mz, tab, words, tdesc[tile], tile, n_tiles, ta, cand, cand_cap, g_cand_count, s_cand[wave]);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_probe_mz: the fast form.  One wavefront per tile, lane = window, and per step of 64 windows:
+//
+//   stage    minimiser -> region of every window; a RUN = adjacent lanes with the same region (its first lane is the
+//            leader).  The whole 128-byte region of every run is fetched ONCE, straight into LDS: 8 lanes x 16 bytes per
+//            run by LDS-DMA (global_load_lds_dwordx4), kMzDma wave-instructions per step whatever the run count (runs
+//            past the last one repeat it: same line, no new request).  One request per run is what the fabric sees.
+//   consume  (kMzStages - 1 steps later, behind a counted vmcnt) a window reads its region's 16 fingerprint bytes from LDS,
+//            then the slots whose fingerprint matches.  Outcome: hit (loc), miss, or -- 14 keys in the region and none is
+//            it -- "ask the generic table", which is deferred: such a window takes a place in the tile's hit list like a
+//            hit does.  A step with more than kMzRunCap runs (rare) is consumed in two halves, the second fetched on the spot.
+//   after the last step: the deferred lookups of the tile go to the generic table 64 at a time (their latencies overlap),
+//            then one ordered pass over the hit list does the tile's bookkeeping exactly as mz_tile does.
+//
+// A tile with more maybe-hits than the list holds (kMzListCap) or more deferred lookups than their queue (kMzDeferCap) is
+// done over by mz_tile_exact: exactness never depends on the budgets.
+// ------------------------------------------------------------------------------------------
+constexpr int kMzRunCap = 32;                  // runs of a step whose regions fit the LDS cache slot (4 KiB)
+constexpr int kMzDma = kMzRunCap * 8 / 64;     // LDS-DMA wave-instructions per step
+constexpr int kMzStages = 2;                   // steps whose region fetches are in flight together
+constexpr int kMzListCap = 960;                // maybe-hits of a tile
+constexpr int kMzDeferCap = 256;               // deferred generic-table lookups of a tile
+constexpr int kMzWaves = 2;                    // waves per workgroup
+constexpr uint32_t kMzPending = 0xFFFFFFFFu;
+
+struct MzWaveLds {
+    uint4 cache[kMzStages][kMzRunCap * 8];  // after the last step: the tile's candidates (2048 x u32: a whole tile's worth)
+    uint32_t list[kMzListCap];
+    uint32_t defer[kMzDeferCap];
+    uint64_t words[kTileWords + 2];         // the tile's packed bases
+};
+static_assert(sizeof(uint4) * kMzStages * kMzRunCap * 8 >= sizeof(uint32_t) * kTileWindows, "candidate overlay");
+
+// LDS accesses of the main loop are written as asm: while an LDS-DMA is in flight hipcc puts `s_waitcnt vmcnt(0)` in
+// front of every LDS access it knows of (it cannot tell which bytes the DMA writes), which would serialise the steps.
+// The counted vmcnt waits in the loop are what orders these reads behind the DMA that fills them.
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ uint4 lds_read_b128(uint32_t addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint64_t lds_read_b64(uint32_t addr) {
+    uint64_t v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_write_b32(uint32_t addr, uint32_t v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// the window that starts at this lane's base in step s, from the tile's 66 words staged in LDS (two 8-byte reads, one
+// instruction; lanes 0..31 share one address pair, lanes 32..63 the next)
+__device__ __forceinline__ MzWin mz_window_lds(uint32_t words_a, uint32_t s, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
+    uint4 v;
+    const uint32_t addr = words_a + (2u * s + (uint32_t)(lane >> 5)) * 8u;
+    asm volatile("ds_read2_b64 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return mz_win_of((uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32), lane, k, m, kmask, mmask);
+}
+
+// lane i <- lane i - 1, lane 0 <- fill
+__device__ __forceinline__ uint32_t mz_shift_up(uint32_t x, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+
+// KT / MT: k and m as compile-time constants (0 = take them from the table)
+template <int KT, int MT>
+__global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView tab, const uint64_t *__restrict__ words,
+                                                           const TileDesc *__restrict__ tdesc, uint32_t n_tiles, TileArrays ta,
+                                                           uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
+                                                           uint32_t *g_fallback_tiles) {
+    __shared__ MzWaveLds s_lds[kMzWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t tile = blockIdx.x * (uint32_t)kMzWaves + (uint32_t)wave;
+    if (tile >= n_tiles) return;
+    MzWaveLds &L = s_lds[wave];
+    const TileDesc td = tdesc[tile];
+    const int k = KT ? KT : mz.k, m = MT ? MT : mz.m, w = k - m + 1, locbits = mz.locbits;
+    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+    const uint64_t mmask = (1ULL << (2 * m)) - 1ULL;
+    const uint64_t locmask = (1ULL << locbits) - 1ULL;
+    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    // the tile's 64 words + the two after them (the buffer carries that much slack after the last read), staged in LDS
+    L.words[lane] = __builtin_nontemporal_load(words + td.wbase + lane);
+    if (lane < 2) L.words[64 + lane] = __builtin_nontemporal_load(words + td.wbase + 64 + lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nsteps = min((td.nwin_left + 63u) / 64u, 32u);
+    const uint32_t list_a = lds_addr(&L.list[0]), defer_a = lds_addr(&L.defer[0]), words_a = lds_addr(&L.words[0]);
+
+    // per in-flight step (slot = step % kMzStages): fingerprint | run << 8 | valid << 14, the tag to look for, lane r = region
+    // of run r, and the run count
+    uint32_t meta[kMzStages], runreg[kMzStages], nruns[kMzStages];
+    uint64_t want[kMzStages];
+    MzWin cur = mz_window_lds(words_a, 0, lane, k, m, kmask, mmask);
+    bool redo = false;  // wave-uniform: a budget was exceeded, the exact form does the tile over
+
+    // LDS-DMA wave-instructions that fetch the regions of (the first kMzRunCap of) R runs: 8 runs each
+    auto dma_count = [](uint32_t R) { return min((R + 7u) / 8u, (uint32_t)kMzDma); };
+    // the regions of runs [r0, r0 + kMzRunCap) of a step into cache slot `slot`
+    auto fetch = [&](int slot, uint32_t rr_lane, uint32_t R, uint32_t r0) {
+        const uint32_t ni = dma_count(R - r0);
+#pragma unroll
+        for (int it = 0; it < kMzDma; it++) {
+            if ((uint32_t)it >= ni) break;  // wave-uniform
+            const uint32_t q = min(r0 + (uint32_t)(it * 8 + (lane >> 3)), R - 1u);
+            const uint32_t rr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q * 4u), (int)rr_lane);
+            const uint4 *src = mz.regions + (uint64_t)rr * kMzPieces + (lane & 7);
+            __builtin_amdgcn_global_load_lds(src, &L.cache[slot][it * 64], 16, 0, 0);
+        }
+    };
+    auto stage = [&](uint32_t s, int slot) {
+        const MzWin nxt = mz_window_lds(words_a, s + 1u, lane, k, m, kmask, mmask);
+        uint32_t H = cur.h, x = cur.h;
+        if constexpr (MT != 0) {
+#pragma unroll
+            for (int j = 1; j < KT - MT + 1; j++) {
+                x = mz_shift_down(x, lane_value(nxt.h, j - 1));
+                H = min(H, x);
+            }
+        } else {
+            for (int j = 1; j < w; j++) {
+                x = mz_shift_down(x, lane_value(nxt.h, j - 1));
+                H = min(H, x);
+            }
+        }
+        const uint64_t c = cur.f < cur.r ? cur.f : cur.r;
+        cur = nxt;
+        const MzKey key = mz_key(c, k);
+        const uint32_t reg = mz_region(H, mz.n_regions);
+        const bool valid = s * 64u + (uint32_t)lane < td.nwin_left;
+        const bool leader = valid && (lane == 0 || reg != mz_shift_up(reg, ~reg));
+        const unsigned long long lb = __ballot(leader);
+        const uint32_t R = (uint32_t)__popcll(lb);  // >= 1: lane 0 of an existing step is valid
+        const uint32_t myrun = (uint32_t)__popcll(lb & (lt | (1ULL << lane))) - 1u;
+        meta[slot] = key.fp | (myrun << 8) | ((valid ? 1u : 0u) << 14);
+        want[slot] = key.tag << locbits;
+        nruns[slot] = R;
+        // lane r <- region of run r (leaders push; the others push to lane 63, which holds a run only when all 64 lanes lead)
+        runreg[slot] = (uint32_t)__builtin_amdgcn_ds_permute((int)((leader ? myrun : 63u) * 4u), (int)reg);
+        fetch(slot, runreg[slot], R, 0u);
+    };
+
+    uint32_t maybe = 0;                  // bit s: this lane's window of step s has a place in the hit list
+    uint32_t lcount = 0, dcount = 0;     // wave-uniform: entries of the list / of the deferred queue
+    // the windows of step s whose run is in [r0, r0 + kMzRunCap): their regions are in cache slot u
+    auto lookups = [&](uint32_t s, int u, uint32_t r0) {
+        const uint32_t fp = meta[u] & 0xFFu, myrun = (meta[u] >> 8) & 63u;
+        const bool mine = ((meta[u] >> 14) & 1u) && myrun >= r0 && myrun < r0 + (uint32_t)kMzRunCap;
+        const uint32_t reg_a = lds_addr(&L.cache[u][0]) + (myrun - r0) * 128u;
+        uint4 F = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (mine) F = lds_read_b128(reg_a);
+        MzCand cd = mz_candidates(F, fp);
+        bool hit = false;
+        uint64_t e = 0;
+        while (__ballot(mine && !hit && cd.any())) {  // one round for a hit; a second one only after a fingerprint collision
+            if (mine && !hit && cd.any()) {
+                const uint64_t e2 = lds_read_b64(reg_a + cd.pop() * 8u) ^ want[u];
+                if (e2 < locmask) {
+                    hit = true;
+                    e = e2;
+                }
+            }
+        }
+        const bool defer = mine && !hit && mz_region_full(F);  // generic table, after the last step
+        const bool mb_mine = hit || defer;
+        const unsigned long long mb = __ballot(mb_mine), db = __ballot(defer);
+        if (mb) {
+            // (a big step calls this twice, lower lanes first: its entries still land in lane order)
+            const uint32_t idx = lcount + (uint32_t)__popcll(mb & lt);
+            if (mb_mine && idx < (uint32_t)kMzListCap) lds_write_b32(list_a + idx * 4u, hit ? (uint32_t)e + 1u : kMzPending);
+            if (defer) {
+                const uint32_t qi = dcount + (uint32_t)__popcll(db & lt);
+                if (qi < (uint32_t)kMzDeferCap) lds_write_b32(defer_a + qi * 4u, (s * 64u + (uint32_t)lane) | (idx << 16));
+            }
+            lcount += (uint32_t)__popcll(mb);
+            dcount += (uint32_t)__popcll(db);
+            if (lcount > (uint32_t)kMzListCap || dcount > (uint32_t)kMzDeferCap) redo = true;
+            maybe |= (mb_mine ? 1u : 0u) << s;
+        }
+    };
+
+    static_assert(kMzStages == 2, "the prologue below stages steps 0 and 1 by hand (slot indices must be compile-time)");
+    stage(0, 0);
+    if (nsteps > 1) stage(1, 1);
+    for (uint32_t s0 = 0; s0 < nsteps && !redo; s0 += kMzStages) {
+#pragma unroll
+        for (int u = 0; u < kMzStages; u++) {
+            const uint32_t s = s0 + (uint32_t)u;
+            if (s >= nsteps || redo) break;  // wave-uniform
+            // the fetches of step s have landed once at most those of the next step (1 to kMzDma instructions) are outstanding
+            switch (s + 1 < nsteps ? dma_count(nruns[u ^ 1]) : 0u) {  // wave-uniform
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            }
+            if (nruns[u] <= (uint32_t)kMzRunCap) {
+                lookups(s, u, 0u);
+            } else {
+                // a big step: its windows in lane order are runs 0..31 then 32..63, and a hit list entry is written at its
+                // rank among the step's maybe-hits -- so the first half is looked up first, and the ranks line up
+                lookups(s, u, 0u);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                fetch(u, runreg[u], nruns[u], (uint32_t)kMzRunCap);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lookups(s, u, (uint32_t)kMzRunCap);
+            }
+            if (s + kMzStages < nsteps && !redo) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of this slot are done before it is refilled
+                stage(s + kMzStages, u);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (redo) {
+        if (lane == 0) atomicAdd(g_fallback_tiles, 1u);
+        mz_tile_exact(mz, tab, words, td, tile, n_tiles, ta, cand, cand_cap, g_cand_count, reinterpret_cast<uint32_t *>(&L.cache[0][0]));
+        return;
+    }
+    // the deferred lookups, 64 at a time
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j0 = 0; j0 < dcount; j0 += 64u) {
+        if (j0 + (uint32_t)lane < dcount) {
+            const uint32_t ent = L.defer[j0 + lane];
+            const uint32_t wi = ent & 0xFFFFu;
+            const uint64_t a = L.words[wi >> 5], b2 = L.words[(wi >> 5) + 1];
+            const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(wi & 31u), k, kmask);
+            uint64_t hh = slot_of(c, tab.shift);
+            Slot sl = load_slot(tab.slots + hh);
+            while (sl.key != c && sl.key != kEmptyKey) {
+                hh = (hh + 1) & tab.mask;
+                sl = load_slot(tab.slots + hh);
+            }
+            L.list[ent >> 16] = sl.key == c ? sl.loc + 1u : 0u;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ordered pass over the hit list: the same bookkeeping as mz_tile; the candidates go to LDS (the cache slots are free
+    // now and hold a whole tile's worth), then to their place
+    uint32_t *cbuf = reinterpret_cast<uint32_t *>(&L.cache[0][0]);
+    uint32_t n_raw = 0, n_cand = 0, first_loc = GS_NONE, carry = GS_NONE, run = 0;
+    for (uint32_t s = 0; s < nsteps; s++) {
+        const bool mine = (maybe >> s) & 1u;
+        const unsigned long long mb = __ballot(mine);
+        if (!mb) continue;
+        const uint32_t v = mine ? L.list[run + (uint32_t)__popcll(mb & lt)] : 0u;
+        run += (uint32_t)__popcll(mb);
+        const bool hit = v != 0u;
+        const uint32_t loc = v - 1u;
+        const unsigned long long hb = __ballot(hit);
+        if (!hb) continue;
+        const unsigned long long below = hb & lt;
+        const int src = below ? 63 - __clzll((long long)below) : 0;
+        const uint32_t pl = __shfl(loc, src);
+        const uint32_t prev = below ? pl : carry;
+        const bool chg = hit && loc != prev;
+        const unsigned long long cb = __ballot(chg);
+        if (chg) cbuf[n_cand + (uint32_t)__popcll(cb & lt)] = ((n_raw + (uint32_t)__popcll(below)) << 16) | (s * 64u + (uint32_t)lane);
+        n_cand += (uint32_t)__popcll(cb);
+        if (first_loc == GS_NONE) first_loc = lane_value(loc, __ffsll((unsigned long long)hb) - 1);
+        carry = lane_value(loc, 63 - __clzll((long long)hb));
+        n_raw += (uint32_t)__popcll(hb);
+    }
+    const MzTileOut o{n_raw, n_cand, first_loc, carry};
+    uint32_t off = tile * (uint32_t)kDirectCand;
+    if (o.n_cand > (uint32_t)kDirectCand) {
+        if (lane == 0) off = n_tiles * (uint32_t)kDirectCand + atomicAdd(g_cand_count, o.n_cand);
+        off = __shfl(off, 0);
+    }
+    if (o.n_cand && (uint64_t)off + o.n_cand <= cand_cap) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < o.n_cand; i += 64u) cand[off + i] = cbuf[i];
     }
     if (lane == 0) {
         ta.n_raw[tile] = o.n_raw;

@@ -158,6 +158,7 @@ typedef struct gs_counters {
     uint64_t launches;     /* tag passes accumulated in the two times below */
     double probe_ms;       /* HIP-event time of the probe kernel, summed over `launches` */
     double total_ms;       /* HIP-event time of the whole pass (all kernels), summed */
+    uint64_t fallback_tiles; /* tiles of the last pass that the fast probe path handed to its exact fallback */
 } gs_counters;
 
 /* The tagger's main loop (kmerpos_annot3.nim:82-96) over a resident batch.

@@ -12,13 +12,13 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "compact-l2", "compact-hbm", "minimizer", "generic"], autouse=True)
+@pytest.fixture(params=["auto", "compact-l2", "compact-hbm", "minimizer", "minimizer-exact", "generic"], autouse=True)
 def table_layout(request, monkeypatch):
     """Every test runs five times: with the layout the library picks (small k <= 20 tables get the exact compact
     copy: at k = 20 the radix join probes its slices from LDS, at other k it is probed out of the XCD-partitioned
     L2), with the L2 path forced, with the compact table treated as HBM-resident (one bucket load per window), with
-    the minimiser-addressed layout that genome-scale tables get (lane = window, k >= 16), and with the generic
-    16-byte-slot table forced."""
+    the minimiser-addressed layout that genome-scale tables get (lane = window, k >= 16; "minimizer-exact" runs every
+    tile through the per-lane form that is the fast kernel's fallback), and with the generic 16-byte-slot table forced."""
     monkeypatch.setenv("GAVISUNK_TABLE", request.param)
     return request.param
 
@@ -170,12 +170,12 @@ def test_layout_selection(table_layout):
     keys, loc, _ = _random_case(3, 20)
     tab = engine.DeviceTable(20, keys, loc, np.arange(len(keys), dtype=np.uint32))
     assert tab.layout.startswith({"auto": "compact-lds", "compact-l2": "compact-l2", "compact-hbm": "compact-hbm",
-                                  "minimizer": "minimizer-hbm", "generic": "generic"}[table_layout])
+                                  "minimizer": "minimizer-hbm", "minimizer-exact": "minimizer-hbm", "generic": "generic"}[table_layout])
     tab.close()
     keys, loc, _ = _random_case(3, 18)
     tab = engine.DeviceTable(18, keys, loc, np.arange(len(keys), dtype=np.uint32))
     assert tab.layout.startswith({"auto": "compact-l2", "compact-l2": "compact-l2", "compact-hbm": "compact-hbm",
-                                  "minimizer": "minimizer-hbm", "generic": "generic"}[table_layout])
+                                  "minimizer": "minimizer-hbm", "minimizer-exact": "minimizer-hbm", "generic": "generic"}[table_layout])
     tab.close()
     keys, loc, _ = _random_case(3, 25)
     tab = engine.DeviceTable(25, keys, loc, np.arange(len(keys), dtype=np.uint32))
@@ -183,8 +183,8 @@ def test_layout_selection(table_layout):
     # minimiser-addressed layout is the default; forced, the one-bucket-load layout takes 64-bit slots
     if table_layout == "generic":
         assert tab.layout.startswith("generic")
-    elif table_layout in ("auto", "minimizer", "compact-l2"):
-        assert tab.layout.startswith("minimizer-hbm") and "47-bit tag" in tab.layout and "minimiser length 18 " in tab.layout
+    elif table_layout in ("auto", "minimizer", "minimizer-exact", "compact-l2"):
+        assert tab.layout.startswith("minimizer-hbm") and "47-bit tag" in tab.layout and "minimiser length 21 " in tab.layout
     else:
         assert "compact-hbm" in tab.layout and "x u64" in tab.layout
     tab.close()
@@ -243,7 +243,7 @@ def test_low_complexity_reads_overflow_one_partition():
 def test_undersized_compact_table_uses_every_overflow_path(qb, monkeypatch, table_layout):
     """With far too few buckets most keys live in their second-chance bucket or only in the generic side table:
     deferred lookups, their flushes and the generic fallback carry the load, and the answer must not change."""
-    if table_layout in ("generic", "minimizer"):
+    if table_layout in ("generic", "minimizer", "minimizer-exact"):
         pytest.skip("needs a compact layout")
     monkeypatch.setenv("GAVISUNK_COMPACT_QB", qb)
     k = 20
@@ -298,7 +298,7 @@ def test_slots_without_a_spare_bit(k, qb, monkeypatch, table_layout):
         monkeypatch.setenv("GAVISUNK_COMPACT_QB", qb)
     keys, loc, seqs = _random_case(91, k, n_reads=60, glen=8000, median=2000)
     loc = np.zeros_like(loc)
-    if table_layout not in ("generic", "minimizer"):
+    if table_layout not in ("generic", "minimizer", "minimizer-exact"):
         tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
         assert "31-bit remainder, 1-bit loc" in tab.layout
         tab.close()
@@ -312,7 +312,7 @@ def test_minimizer_table_walks_and_overflows(m, load, monkeypatch, table_layout)
     """The minimiser-addressed layout with the wrong geometry on purpose: a short minimiser piles hundreds of keys on one
     128-byte region (most keys then live in the generic side table and lookups walk all 8 pieces first); 16 or 12 keys
     per region fill the pieces, so keys sit further round their region; a sparse table is the easy case."""
-    if table_layout != "minimizer":
+    if table_layout not in ("minimizer", "minimizer-exact"):
         pytest.skip("minimiser-addressed layout only")
     monkeypatch.setenv("GAVISUNK_MZ_M", m)
     monkeypatch.setenv("GAVISUNK_MZ_LOAD", load)

@@ -60,6 +60,62 @@ __global__ __launch_bounds__(256) void k_run(const uint4 *__restrict__ tab, uint
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// mode 5: the shape of k_probe_mz -- per step of 64 windows the R = 64 / L distinct regions are fetched whole (8 lanes x 16 B
+// each) by LDS-DMA, NI wave-instructions per step (runs past R repeat the last one), two steps in flight behind a counted vmcnt,
+// then every lane reads one 16-byte piece of its run's region from LDS.  LDSB bytes of LDS per wave set the occupancy.
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
+template <int NI, int LDSB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_dma(const uint4 *__restrict__ tab, uint64_t n_lines, int L, int rounds, uint32_t *out) {
+    __shared__ uint4 cache[WAVES][LDSB / 16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t gw = (uint64_t)blockIdx.x * WAVES + wave;
+    const uint32_t R = (64 + L - 1) / L;
+    uint32_t acc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define STAGE(r, slot)                                                                                                         \
+    _Pragma("unroll") for (int it = 0; it < NI; it++) {                                                                        \
+        const uint32_t q = min((uint32_t)(it * 8 + (lane >> 3)), R - 1u);                                                      \
+        const uint64_t reg = mix((gw * rounds + (r)) * 64 + q + 1) % n_lines;                                                  \
+        __builtin_amdgcn_global_load_lds(tab + reg * 8 + (lane & 7), &cache[wave][(slot) * NI * 64 + it * 64], 16, 0, 0);     \
+    }
+#else
+#define STAGE(r, slot)
+#endif
+    STAGE(0, 0);
+    STAGE(1, 1);
+    for (int r = 0; r < rounds; r += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+            const uint32_t myrun = (uint32_t)lane / (uint32_t)L;
+            const uint32_t a = lds_addr(&cache[wave][u * NI * 64]) + myrun * 128u + ((uint32_t)mix(gw * 77 + r * 64 + lane) & 7u) * 16u;
+            uint4 v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+            acc += v.x ^ v.w;
+            STAGE(r + u + 2, u);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int NI, int LDSB, int WAVES>
+int run_dma(const uint4 *tab, uint64_t n_lines, int L, uint32_t *out, int waves_per_cu) {
+    const int rounds = 256, blocks = 256 * waves_per_cu / WAVES * 4;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((k_dma<NI, LDSB, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, tab, n_lines, L, rounds, out);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+    }
+    const double win = (double)blocks * WAVES * 64 * rounds;
+    printf("LDS-DMA whole regions: NI=%d, %5.1f KiB LDS/wave (%2d waves/CU)  L=%2d : %7.1f G windows/s  %6.1f G lines/s  (%.3f ms)\n", NI, LDSB / 1024.0,
+           waves_per_cu, L, win / ms / 1e6, win / L / ms / 1e6, ms);
+    fflush(stdout);
+    return 0;
+}
+
 template <int MODE, int U>
 int run(const uint4 *tab, uint64_t n_lines, int L, uint32_t *out, const char *what) {
     const int rounds = 64, blocks = 256 * 8;
@@ -83,6 +139,13 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&tab, bytes)); CK(hipMalloc(&out, 4)); CK(hipMemset(tab, 1, bytes));
     const uint64_t n_lines = bytes / 128;
     printf("table %zu GiB, lane = window, runs of L adjacent lanes share a region\n", gib);
+    if (argc > 2) {  // only the LDS-DMA form
+        for (int L : {2, 3, 4, 6, 8}) if (run_dma<4, 13312, 2>(tab, n_lines, L, out, 12)) return 1;
+        for (int L : {3, 4}) if (run_dma<4, 8192, 2>(tab, n_lines, L, out, 18)) return 1;
+        for (int L : {3, 4, 8}) if (run_dma<2, 4096, 4>(tab, n_lines, L, out, 32)) return 1;
+        for (int L : {3, 4}) if (run_dma<3, 13312, 2>(tab, n_lines, L, out, 12)) return 1;
+        return 0;
+    }
     const int Ls[] = {1, 2, 3, 4, 6, 8, 16};
     for (int L : Ls) if (run<0, 4>(tab, n_lines, L, out, "16 B/window, 128-B regions")) return 1;
     for (int L : Ls) if (run<0, 8>(tab, n_lines, L, out, "16 B/window, 128-B regions")) return 1;
