@@ -326,13 +326,12 @@ def main():
     def step():
         nonlocal host_hits
         if world == 1:
+            # the emit kernel writes the rows to pinned host memory itself: the pass ends with the hit list on the host
             _lib.check(L.gs_tag_launch(table._h, dev_reads._h, _lib.GS_NONE))
-            st = L.gs_tag_finish(table._h, dev_reads._h, host_hits.ctypes.data, len(host_hits), C.byref(n_hits),
-                                 C.byref(carry), C.byref(ctr))
-            if st == _lib.GS_E_CAPACITY:  # first pass: size the host buffer from the count, fetch again
-                host_hits = np.zeros(int(n_hits.value * 1.25) + 1024, dtype=engine.HIT_DTYPE)
-                st = L.gs_tag_hits_to_host(table._h, dev_reads._h, host_hits.ctypes.data, len(host_hits), None)
-            _lib.check(st)
+            _lib.check(L.gs_tag_finish(table._h, dev_reads._h, None, 0, C.byref(n_hits), C.byref(carry), C.byref(ctr)))
+            vp = C.c_void_p()
+            _lib.check(L.gs_tag_hits_view(table._h, dev_reads._h, C.byref(vp), None))
+            host_hits = engine._view(vp.value, n_hits.value, engine.HIT_DTYPE)
             return None
         has, last = C.c_uint32(0), C.c_uint32(0)
         _lib.check(L.gs_tag_phase1(table._h, dev_reads._h, C.byref(has), C.byref(last)))

@@ -83,6 +83,7 @@ SIGNATURES = {
     "gs_tag_phase2": (I, [P, P, U32]),
     "gs_tag_hits_to_host": (I, [P, P, P, U64, C.POINTER(U64)]),
     "gs_tag_hits_to_device": (I, [P, P, P, U64, C.POINTER(U64)]),
+    "gs_tag_hits_view": (I, [P, P, C.POINTER(P), C.POINTER(U64)]),
     "gs_counters_reset": (None, [P]),
     "gs_sunkpos_load": (I, [C.c_char_p, C.POINTER(P)]),
     "gs_sunkpos_free": (None, [P]),

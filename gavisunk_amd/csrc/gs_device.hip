@@ -61,6 +61,7 @@ struct __align__(16) Slot {
 constexpr uint64_t kEmptyKey = ~0ULL;  // never a canonical code (k < 32: too wide; k = 32: poly-T is not canonical)
 constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ULL;
 constexpr int kDirectCand = 4;  // candidate slots every tile owns in the candidate buffer
+constexpr uint64_t kMirrorRows = 1u << 20;  // hit lists up to this long are written to the pinned host mirror by k_emit itself
 
 struct TableView {
     const Slot *slots;
@@ -1685,7 +1686,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(TileArrays ta, uint
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, MzView mz, int compact, ReadsView rd, TileArrays ta,
                                               const uint32_t *cand, uint32_t cand_cap, gs_hit *hits, gs_hit *hits_host,
-                                              uint64_t hit_cap) {
+                                              uint64_t hit_cap, const Agg *emit_total) {
+    // short lists (<= kMirrorRows) also go straight to pinned host memory, row by row: no copy after the pass; long ones
+    // are fetched in one bulk copy instead (scattered 12-byte writes across PCIe are slow)
+    const bool mirror = emit_total->sum <= kMirrorRows;
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= rd.n_tiles) return;
     const uint32_t nc = ta.n_cand[tile];
@@ -1716,7 +1720,7 @@ __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, MzV
         const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(w & 31u), k, kmask);
         uint32_t payload = 0, loc_unused = 0;
         if (compact == 4) {
-            payload = mz_payload(mz, c);
+            payload = mz_payload(mz, tab, c);
         } else if (compact) {
             compact_lookup(ct, tab, c, k, loc_unused, &payload);
         } else {
@@ -1733,7 +1737,7 @@ __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, MzV
         hrec.pos = (uint32_t)(w - suppressed_before);
         hrec.payload = payload;
         hits[o] = hrec;
-        hits_host[o] = hrec;  // the few emitted rows also go straight to pinned host memory
+        if (mirror) hits_host[o] = hrec;
     }
 }
 
@@ -1882,8 +1886,7 @@ struct gs_table {
     uint4 *mz_regions = nullptr;
     uint32_t mz_n_regions = 0;
     int mz_m = 0, mz_locbits = 0;
-    uint64_t *mz_skeys = nullptr;
-    uint32_t *mz_spayload = nullptr;
+    uint32_t *mz_pay = nullptr;  // payload per slot
     uint64_t mz_overflow = 0;
     int join = 0;
     uint32_t join_chunk = kJoinChunkMax;
@@ -1938,7 +1941,7 @@ namespace {
 
 TableView view(const gs_table *t) { return TableView{t->slots, t->cap - 1, t->shift, t->k}; }
 MzView mz_view(const gs_table *t) {
-    return MzView{t->mz_regions, t->mz_n_regions, t->k, t->mz_m, t->mz_locbits, t->mz_skeys, t->mz_spayload, t->n};
+    return MzView{t->mz_regions, t->mz_n_regions, t->k, t->mz_m, t->mz_locbits, t->mz_pay};
 }
 ReadsView view(const gs_reads *r) {
     return ReadsView{r->words, r->read_word_off, r->read_nwin, r->read_tile0, r->tile_read, r->n_tiles};
@@ -2149,7 +2152,7 @@ int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
     if (r->n_tiles) {
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
         hipLaunchKernelGGL(k_emit, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, view(t), cv, mz_view(t), t->mz ? 4 : t->compact, view(r), r->ta,
-                           r->cand, r->cand_cap, r->hits, r->hits_host, r->hit_cap);
+                           r->cand, r->cand_cap, r->hits, r->hits_host, r->hit_cap, (const Agg *)(t->d_totals + 1));
     }
     HIP_TRY(hipEventRecord(t->ev[2], t->stream));
     HIP_TRY(hipMemcpyAsync(t->h_status, t->d_status, sizeof(PassStatus), hipMemcpyDeviceToHost, t->stream));
@@ -2347,13 +2350,14 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
         const uint64_t nslots = (uint64_t)t->mz_n_regions * 2 * kMzPieces;
         const uint64_t ocap = std::max<uint64_t>(getenv("GAVISUNK_MZ_M") || getenv("GAVISUNK_MZ_LOAD") ? n : n / 8, 1u << 16);
         unsigned long long *dov = nullptr;
-        if ((rc = dev_alloc((unsigned long long **)&t->mz_regions, nslots)) || (rc = tmp.get(&dov, 1)) || (rc = tmp.get(&dlist, ocap)))
+        if ((rc = dev_alloc((unsigned long long **)&t->mz_regions, nslots)) || (rc = dev_alloc(&t->mz_pay, nslots)) ||
+            (rc = tmp.get(&dov, 1)) || (rc = tmp.get(&dlist, ocap)))
             return rc;
         HIP_TRY(hipMemsetAsync(t->mz_regions, 0xFF, nslots * sizeof(unsigned long long), t->stream));
         HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
         hipLaunchKernelGGL(k_mz_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream,
-                           reinterpret_cast<unsigned long long *>(t->mz_regions), t->mz_n_regions, k, t->mz_m, t->mz_locbits, dk, dl, n,
-                           dov, dlist, ocap);
+                           reinterpret_cast<unsigned long long *>(t->mz_regions), t->mz_pay, t->mz_n_regions, k, t->mz_m, t->mz_locbits,
+                           dk, dl, dp, n, dov, dlist, ocap);
         unsigned long long ov = 0;
         HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
@@ -2365,9 +2369,6 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
         }
         t->mz_overflow = ov;
         n_generic = ov;
-        // sorted key list + payloads: what k_emit reports for an emitted row
-        if ((rc = dev_alloc(&t->mz_skeys, n)) || (rc = dev_alloc(&t->mz_spayload, n))) return rc;
-        if ((rc = sort_pairs_u64_u32(dk, t->mz_skeys, dp, t->mz_spayload, n, 2 * k, t->stream))) return rc;
     } else if (t->compact) {
         t->c_w64 = t->compact == 3;
         if (t->compact == 3) t->compact = 2;  // same probe kernel; the view says which slot width
@@ -2560,8 +2561,7 @@ void gs_table_destroy(gs_table *t) {
     (void)hipFree(t->cbuckets);
     (void)hipFree(t->cpayload);
     (void)hipFree(t->mz_regions);
-    (void)hipFree(t->mz_skeys);
-    (void)hipFree(t->mz_spayload);
+    (void)hipFree(t->mz_pay);
     (void)hipFree(t->j_ovf_code);
     (void)hipFree(t->j_ovf_loc);
     (void)hipFree(t->j_ovf_start);
@@ -2576,7 +2576,7 @@ void gs_table_destroy(gs_table *t) {
 
 uint64_t gs_table_bytes(const gs_table *t) {
     if (!t) return 0;
-    if (t->mz) return t->cap * sizeof(Slot) + (uint64_t)t->mz_n_regions * 128 + t->n * 12;  // regions + sorted keys / payloads
+    if (t->mz) return t->cap * sizeof(Slot) + (uint64_t)t->mz_n_regions * (128 + 64);  // regions + payload words
     return t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)((t->c_w64 ? 48 : 32) * kNPart) << t->c_qb) : 0);  // slots + payloads
 }
 
@@ -2913,6 +2913,8 @@ static int settle(gs_table *t, gs_reads *r) {
                 if ((cv[j] & 0xFFFFu) < woff) before++;
             t->res_n = ep + before;
         }
+        if (t->res_n > kMirrorRows)  // long list: one bulk copy into the pinned mirror
+            HIP_TRY(hipMemcpy(r->hits_host, r->hits, std::min<uint64_t>(t->res_n, r->hit_cap) * sizeof(gs_hit), hipMemcpyDeviceToHost));
         t->pass_pending = false;
         t->settled_reads = r;
         return GS_OK;
@@ -2963,6 +2965,19 @@ int gs_tag_hits_to_host(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uin
     int rc;
     if ((rc = check_pair(t, r, "gs_tag_hits_to_host"))) return rc;
     return copy_hits(t, r, out, cap, n_out, hipMemcpyDeviceToHost);
+}
+
+int gs_tag_hits_view(gs_table *t, gs_reads *r, const gs_hit **out, uint64_t *n_out) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_hits_view"))) return rc;
+    if ((rc = settle(t, r))) return rc;
+    if (out) *out = r->hits_host;
+    if (n_out) *n_out = t->res_n;
+    if (t->res_keyerr) {
+        set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
+        return GS_E_KEYERROR;
+    }
+    return GS_OK;
 }
 
 int gs_tag_hits_to_device(gs_table *t, gs_reads *r, void *dst, uint64_t cap, uint64_t *n_out) {

@@ -32,17 +32,15 @@
 // it: each minimiser value should own <= ~1 place of the assembly): human-genome-scale tables of 20-mers get m = 16, runs
 // of ~3 windows.  m-mers longer than 16 bases (k > 23) are hashed down to 32 bits.
 //
-// Payloads (the loc row a hit reports) are not in the slots: only the emitted rows (1e-4 of the windows) need one, and
-// k_emit finds it by binary search in the sorted key list kept beside the table.
+// Payloads (the loc row a hit reports) are not in the slots: only the emitted rows (1e-4 .. 1e-3 of the windows) need one.
+// They sit in a parallel array, one 32-bit word per slot, that only k_emit reads.
 #pragma once
 
 struct MzView {
     const uint4 *regions;  // [n_regions][8] pieces of two 64-bit slots
     uint32_t n_regions;
     int k, m, locbits;
-    const uint64_t *skeys;     // keys sorted ascending
-    const uint32_t *spayload;  // payload of skeys[i]
-    uint64_t n_keys;
+    const uint32_t *pay;  // [n_regions][16]: payload of the key in slot i (words 0 and 1 of a region are unused)
 };
 
 constexpr uint64_t kMzEmpty = ~0ULL;
@@ -104,9 +102,9 @@ __host__ __device__ __forceinline__ uint32_t mz_minimizer(uint64_t c, int k, int
 // ------------------------------------------------------------------------------------------
 // build: one thread per key; the region's count byte hands out the slots in arrival order
 // ------------------------------------------------------------------------------------------
-__global__ void k_mz_insert(unsigned long long *slots, uint32_t n_regions, int k, int m, int locbits, const uint64_t *keys,
-                            const uint32_t *loc, uint64_t n, unsigned long long *overflow, uint32_t *overflow_list,
-                            uint64_t overflow_cap) {
+__global__ void k_mz_insert(unsigned long long *slots, uint32_t *pay, uint32_t n_regions, int k, int m, int locbits,
+                            const uint64_t *keys, const uint32_t *loc, const uint32_t *payload, uint64_t n,
+                            unsigned long long *overflow, uint32_t *overflow_list, uint64_t overflow_cap) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t c = keys[i];
@@ -129,18 +127,8 @@ __global__ void k_mz_insert(unsigned long long *slots, uint32_t n_regions, int k
     }
     const uint32_t slot = 2u + cnt;
     base[slot] = (key.tag << locbits) | (unsigned long long)loc[i];
+    pay[(uint64_t)reg * 16 + slot] = payload[i];
     atomicAnd(fpw + (slot >> 2), ~(0xFFu << (8u * (slot & 3u))) | (key.fp << (8u * (slot & 3u))));
-}
-
-// payload of a key that is known to be in the table (k_emit): binary search in the sorted key list
-__device__ __forceinline__ uint32_t mz_payload(const MzView &mz, uint64_t c) {
-    uint64_t lo = 0, hi = mz.n_keys;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (mz.skeys[mid] < c) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo < mz.n_keys && mz.skeys[lo] == c ? mz.spayload[lo] : 0u;
 }
 
 // bit 7 of every byte of x that equals the byte replicated in T (exact: no borrow between bytes)
@@ -173,6 +161,26 @@ __device__ __forceinline__ MzCand mz_candidates(const uint4 F, uint32_t fp) {
     return c;
 }
 __device__ __forceinline__ bool mz_region_full(const uint4 F) { return (F.x & 0xFFu) <= 0xFFu - (uint32_t)kMzSlots; }
+
+// payload of a key that is known to be in the table (k_emit, one emitted row at a time)
+__device__ __forceinline__ uint32_t mz_payload(const MzView &mz, const TableView &tab, uint64_t c) {
+    const uint32_t reg = mz_region(mz_minimizer(c, mz.k, mz.m), mz.n_regions);
+    const MzKey key = mz_key(c, mz.k);
+    const uint64_t want = key.tag << mz.locbits, locmask = (1ULL << mz.locbits) - 1ULL;
+    const uint4 *rp = mz.regions + (uint64_t)reg * kMzPieces;
+    MzCand cd = mz_candidates(*rp, key.fp);
+    while (cd.any()) {
+        const uint32_t slot = cd.pop();
+        if ((reinterpret_cast<const uint64_t *>(rp)[slot] ^ want) < locmask) return mz.pay[(uint64_t)reg * 16 + slot];
+    }
+    uint64_t hh = slot_of(c, tab.shift);  // a key of a full region lives in the generic table
+    Slot sl = load_slot(tab.slots + hh);
+    while (sl.key != c && sl.key != kEmptyKey) {
+        hh = (hh + 1) & tab.mask;
+        sl = load_slot(tab.slots + hh);
+    }
+    return sl.payload;
+}
 
 // ------------------------------------------------------------------------------------------
 // probe: one wavefront per tile, 32 steps of 64 consecutive windows (lane = window)

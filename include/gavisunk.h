@@ -181,6 +181,9 @@ int gs_tag_phase2(gs_table *t, gs_reads *r, uint32_t carry_in);
 /* Copy the emitted hits of the last pass again, to host memory or into caller-provided DEVICE
  * memory (for a collective); n_out as in gs_tag_finish. */
 int gs_tag_hits_to_host(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uint64_t *n_out);
+/* The same without a copy: the emit kernel writes every row to pinned HOST memory as well as to the device list; *out points
+ * at those *n_out rows.  Valid until the next pass over `r` or its destruction. */
+int gs_tag_hits_view(gs_table *t, gs_reads *r, const gs_hit **out, uint64_t *n_out);
 int gs_tag_hits_to_device(gs_table *t, gs_reads *r, void *dst_device, uint64_t cap, uint64_t *n_out);
 void gs_counters_reset(gs_table *t);
 
