@@ -125,18 +125,27 @@ def same_hits(gh, oh, rows_of_oracle=None):
 # ------------------------------------------------------------------------------------------------------------------
 # config 3: everything on the device
 # ------------------------------------------------------------------------------------------------------------------
-def config3(a, device, rank):
+def config3(a, device, rank, comm):
+    """-> table, packed reads, read lengths, SUNK count, group count, oracle sample, the read set (device ASCII).
+    With an RCCL communicator only rank 0 defines the SUNKs and builds the table; the others receive the built table."""
     from gavisunk_amd import engine, synth_gpu
 
     t0 = time.perf_counter()
     gen = synth_gpu.Genome(int(a.genome_mb * 1e6), n_contigs=24, seed=a.seed, device=device)
     log(f"assembly surrogate: {gen.n_bases} bases in 24 contigs ({time.perf_counter() - t0:.1f} s)")
-    t0 = time.perf_counter()
-    sunks = engine.DeviceSunkSet(gen.ptr, gen.off, K, device)
-    log(f"exact SUNK set: {sunks.n} keys in {sunks.n_groups} groups ({time.perf_counter() - t0:.1f} s, gs_sunks_define_device)")
-    t0 = time.perf_counter()
-    table = sunks.table()
-    log(f"table: {table.layout} | {table.nbytes / 2**30:.1f} GiB ({time.perf_counter() - t0:.1f} s)")
+    replicate = comm is not None and comm.rccl is not None
+    sunks = table = None
+    if rank == 0 or not replicate:
+        t0 = time.perf_counter()
+        sunks = engine.DeviceSunkSet(gen.ptr, gen.off, K, device)
+        log(f"exact SUNK set: {sunks.n} keys in {sunks.n_groups} groups ({time.perf_counter() - t0:.1f} s, gs_sunks_define_device)")
+        t0 = time.perf_counter()
+        table = sunks.table()
+        log(f"table: {table.layout} | {table.nbytes / 2**30:.1f} GiB ({time.perf_counter() - t0:.1f} s)")
+    if replicate:
+        t0 = time.perf_counter()
+        table = comm.rccl.broadcast_table(table, root=0)
+        log(f"table replicated over RCCL ({time.perf_counter() - t0:.1f} s, gs_table_broadcast)")
     t0 = time.perf_counter()
     rng = np.random.default_rng([a.seed, rank])
     lens = synth_gpu.lognormal_lengths(rng, a.reads, median=32000.0)
@@ -165,10 +174,10 @@ def config3(a, device, rank):
                "group": synth_gpu.gather(device, L.gs_sunkset_dev_group(sunks._h), np.uint32, rows)}
         sample = {"seqs": seqs, "sub": sub}
         log(f"oracle sample: {ns} reads, {len(q)} distinct windows, {len(rows)} SUNKs among them ({time.perf_counter() - t0:.1f} s)")
-    n_sunks, n_groups = sunks.n, sunks.n_groups
-    sunks.close()
-    rs.close()
-    return table, dev_reads, rlen, n_sunks, n_groups, sample
+    n_sunks, n_groups = (sunks.n, sunks.n_groups) if sunks is not None else (0, 0)
+    if sunks is not None:
+        sunks.close()
+    return table, dev_reads, rlen, n_sunks, n_groups, sample, rs
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -302,14 +311,33 @@ def main():
     device = local_rank % L.gs_device_count()
 
     comm = None
+    data_plane = "single GPU"
     if world > 1:
         from gavisunk_amd import dist as gdist
 
         # control plane: torch.distributed over gloo (rendezvous, barrier, 8-byte summaries); data plane: RCCL behind the
         # C-ABI (gs_comm_*).  torch never touches the GPU in this process: its wheel bundles a second HIP runtime.
-        comm = gdist.Comm(device, rccl=os.environ.get("GAVISUNK_BENCH_BACKEND", "nccl") == "nccl")
+        want_rccl = os.environ.get("GAVISUNK_BENCH_BACKEND", "nccl") == "nccl"
+        comm = gdist.Comm(device, rccl=False)
+        data_plane = "gloo, host-staged (GAVISUNK_BENCH_BACKEND=gloo: rehearsal)"
+        if want_rccl:
+            from gavisunk_amd import rccl as grccl
 
-    table, dev_reads, rlen, n_sunks, n_groups, sample = config3(a, device, rank)
+            err = ""
+            try:
+                comm.rccl = grccl.RcclComm(comm, device)
+            except Exception as e:  # the run still measures the path; the line says which transport carried it
+                err = str(e)
+            ok = comm.all_sum(1 if comm.rccl is not None else 0) == world
+            if not ok:
+                if comm.rccl is not None:
+                    comm.rccl.close()
+                comm.rccl = None
+                data_plane = f"gloo, host-staged (RCCL did not start on every rank: {err or 'another rank failed'})"
+            else:
+                data_plane = "RCCL over xGMI (gs_table_broadcast, gs_gather_hits)"
+
+    table, dev_reads, rlen, n_sunks, n_groups, sample, rs = config3(a, device, rank, comm)
     n_bases = int(rlen.sum())
     from gavisunk_amd import synth_gpu
 
@@ -322,6 +350,7 @@ def main():
     ctr = _lib.GsCounters()
     host_hits = np.zeros(1, dtype=engine.HIT_DTYPE)
     read_lo = rank * a.reads
+    full_reads = dev_reads
 
     def step():
         nonlocal host_hits
@@ -364,9 +393,30 @@ def main():
     else:
         total_bases = n_bases
     log(f"{a.steps} steps: {total_bases * a.steps / dt / 1e9:.1f} Gbase/s")
+    c_main = ctr.as_dict()  # counters of the timed passes (the strong-scaling leg below runs more)
+    # strong scaling beside the weak headline (N > 1): the SAME total read count as one GPU tags, cut over the ranks
+    strong = None
+    if world > 1:
+        per = max(a.reads // world, 1)
+        dev_reads = engine.device_reads_from_device_ascii(rs.ptr, rs.off[: per + 1], K, device)
+        read_lo = rank * per
+        step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step()
+        sync()
+        sdt = comm.all_max(time.perf_counter() - t1)
+        sbases = int(comm.all_sum(int(rs.off[per])))
+        strong = {"total_reads": per * world, "total_bases": sbases, "steps": 3, "ms_per_step": sdt / 3 * 1e3, "value": sbases * 3 / sdt,
+                  "unit": "bases/s", "note": "fixed total work (the one-GPU read count) cut over the ranks; the headline above is weak scaling"}
+        dev_reads.close()
+        dev_reads = full_reads
+        read_lo = rank * a.reads
+    rs.close()
 
     if rank == 0:
-        c = ctr.as_dict()
+        c = c_main
         h_raw = c["raw_hits"] / max(c["windows"], 1)
         h_emit = c["emitted"] / max(c["windows"], 1)
         probe_s = c["probe_ms"] / max(c["launches"], 1) / 1e3
@@ -387,6 +437,7 @@ def main():
             "ms_per_step_spread": {"min": min(step_s) * 1e3, "median": float(np.median(step_s)) * 1e3, "max": max(step_s) * 1e3},
             "higher_is_better": True,
             "scaling": "weak",
+            "strong_scaling": strong,
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
@@ -397,7 +448,7 @@ def main():
                        "windows": c["windows"], "raw_hits": c["raw_hits"], "emitted_rows": c["emitted"],
                        "h_raw": round(h_raw, 5), "h_emit": round(h_emit, 7), "tiles": c["tiles"],
                        "fallback_tiles": c["fallback_tiles"], "table_GiB": round(table.nbytes / 2**30, 2), "table_layout": table.layout,
-                       "parallelism": f"read-sharded x{world}, table replicated",
+                       "parallelism": f"read-sharded x{world}, table replicated", "data_plane": data_plane,
                        "env_knobs": knobs},
             "roofline": {"bound": "hbm", "kernel": kernel_names(table.layout), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": tnote,

@@ -85,6 +85,12 @@ SIGNATURES = {
     "gs_tag_hits_to_device": (I, [P, P, P, U64, C.POINTER(U64)]),
     "gs_tag_hits_view": (I, [P, P, C.POINTER(P), C.POINTER(U64)]),
     "gs_counters_reset": (None, [P]),
+    "gs_comm_unique_id": (I, [P]),
+    "gs_comm_init": (I, [I, I, I, P, C.POINTER(P)]),
+    "gs_comm_destroy": (None, [P]),
+    "gs_table_broadcast": (I, [P, I, P, C.POINTER(P)]),
+    "gs_gather_hits": (I, [P, I, P, P, U32, P, U64, C.POINTER(U64)]),
+    "gs_gather_view": (I, [P, C.POINTER(P), C.POINTER(U64)]),
     "gs_sunkpos_load": (I, [C.c_char_p, C.POINTER(P)]),
     "gs_sunkpos_free": (None, [P]),
     "gs_sunkpos_n_rows": (U64, [P]),

@@ -2991,3 +2991,5 @@ void gs_counters_reset(gs_table *t) {
 }
 
 }  // extern "C"
+
+#include "gs_comm.h"

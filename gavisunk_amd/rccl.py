@@ -1,0 +1,53 @@
+"""RCCL data plane of a read-sharded run, through the C-ABI (gs_comm_*): table broadcast and hit gather.
+The unique id travels over the caller's control plane (dist.Comm: torch.distributed / gloo)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import engine
+from ._lib import check, lib
+
+ID_BYTES = 128
+
+
+class RcclComm:
+    def __init__(self, ctrl, device: int):
+        """ctrl: an object with rank, world and broadcast_bytes(bytes, src) (dist.Comm)."""
+        L = lib()
+        buf = C.create_string_buffer(ID_BYTES)
+        if ctrl.rank == 0:
+            check(L.gs_comm_unique_id(buf))
+        idb = ctrl.broadcast_bytes(buf.raw, src=0)
+        h = C.c_void_p()
+        check(L.gs_comm_init(device, ctrl.world, ctrl.rank, idb, C.byref(h)))
+        self._h, self.rank, self.world, self.device = h, ctrl.rank, ctrl.world, device
+
+    def broadcast_table(self, table, root: int = 0):
+        """The root's built table on every rank (device-to-device over xGMI); returns this rank's table."""
+        out = C.c_void_p()
+        check(lib().gs_table_broadcast(self._h, root, table._h if table is not None else None, C.byref(out)))
+        if self.rank == root:
+            return table
+        t = engine.DeviceTable.__new__(engine.DeviceTable)
+        t._h, t.device = out, self.device
+        t.k = t.n = None
+        return t
+
+    def gather_hits(self, table, reads, counts, read_offset: int, dst: int = 0):
+        """All ranks' hit lists of the last pass on rank dst (numpy HIT_DTYPE), None elsewhere."""
+        n = C.c_uint64(0)
+        check(lib().gs_gather_hits(self._h, dst, table._h, reads._h, read_offset, None, 0, C.byref(n)))
+        if self.rank != dst:
+            return None
+        vp = C.c_void_p()
+        check(lib().gs_gather_view(self._h, C.byref(vp), None))  # pinned host memory of the library: no further copy
+        return engine._view(vp.value, n.value, engine.HIT_DTYPE)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close

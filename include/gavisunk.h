@@ -189,6 +189,34 @@ void gs_counters_reset(gs_table *t);
 
 
 /* ------------------------------------------------------------------------------------------
+ * Multi-GPU: read-sharded tagging, the SUNK table replicated.  One process per GPU; the data plane is
+ * RCCL over xGMI, inside the library.  The reference has no counterpart (its parallelism is Snakemake's per-chunk scatter,
+ * workflow/Snakefile:23-24, tagONT.smk:19-37); the exchange exists because `prevLoc` is never reset between reads
+ * (kmerpos_annot3.nim:82-84):
+ *   every rank   gs_tag_phase1 -> {has a raw hit, loc of the last one}                       (8 bytes per rank: the caller's
+ *                control plane all-gathers them; carry-in = last loc of the nearest earlier shard with a raw hit)
+ *                gs_tag_phase2(carry-in), gs_tag_finish
+ *   all ranks    gs_gather_hits: the per-rank hit lists back to back on the root, read indices shifted to the whole input
+ * ---------------------------------------------------------------------------------------- */
+#define GS_COMM_ID_BYTES 128
+typedef struct gs_comm gs_comm;
+/* rank 0 creates the id (ncclGetUniqueId) and hands its GS_COMM_ID_BYTES bytes to the other ranks out of band */
+int gs_comm_unique_id(void *id_out);
+/* collective over all ranks (ncclCommInitRank); `device` is this rank's GPU */
+int gs_comm_init(int device, int nranks, int rank, const void *unique_id, gs_comm **out);
+void gs_comm_destroy(gs_comm *c);
+/* The root's BUILT table, device array by device array, to every other rank (ncclBroadcast): nobody else parses or builds.
+ * The root passes its table and gets it back in *out; the others pass NULL and own the table they receive. */
+int gs_table_broadcast(gs_comm *c, int root, gs_table *mine, gs_table **out);
+/* After a finished pass on every rank: all ranks' emitted hits on the root, in rank order, `read` shifted by the rank's
+ * read_offset.  Counts and offsets travel by ncclAllGather, the rows by grouped ncclSend / ncclRecv of exactly their size.
+ * Root: `out` (host, `cap` rows; may be NULL to count) and *n_out = total rows; other ranks pass out = NULL. */
+int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read_offset, gs_hit *out, uint64_t cap, uint64_t *n_out);
+/* Root, after gs_gather_hits: the gathered rows where the library left them -- pinned host memory, valid until the next gather. */
+int gs_gather_view(gs_comm *c, const gs_hit **out, uint64_t *n_out);
+
+
+/* ------------------------------------------------------------------------------------------
  * Diagonal filter (workflow/src/diag_filter_v3.nim + diag_filter_step2.nim).
  * ---------------------------------------------------------------------------------------- */
 

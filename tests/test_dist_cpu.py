@@ -106,3 +106,26 @@ def test_resolve_carry():
     assert gdist.resolve_carry(s, 1) == GS_NONE
     assert gdist.resolve_carry(s, 2) == 5
     assert gdist.resolve_carry(s, 3) == 5
+
+
+def _ctrl_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = gdist.Comm(device=0, rccl=False)  # control plane only: no GPU here
+    summ = comm.exchange_summaries(rank % 2, 100 + rank)
+    mx = comm.all_max(1.5 * (rank + 1))
+    tot = comm.all_sum(10 ** 12 + rank)
+    blob = comm.broadcast_bytes(bytes(range(128)) if rank == 0 else b"", src=0)
+    comm.barrier()
+    if rank == world - 1:
+        np.save(out_path, np.array([summ == [(r % 2, 100 + r) for r in range(world)], mx == 1.5 * world,
+                                    tot == world * 10 ** 12 + sum(range(world)), blob == bytes(range(128))]))
+    comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_comm_control_plane(world, tmp_path):
+    """dist.Comm: what travels over gloo in a multi-GPU run (phase-1 summaries, scalars, the RCCL unique id's 128 bytes)."""
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_ctrl_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert np.load(out).all()

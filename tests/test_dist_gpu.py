@@ -78,3 +78,93 @@ def test_sharded_gpu_run_equals_single_pass(world, tmp_path):
     assert np.array_equal(got[:, 0], whole["read"].astype(np.int32))
     assert np.array_equal(got[:, 1], whole["pos"].astype(np.int32))
     assert np.array_equal(got[:, 2], whole["payload"].astype(np.int32))
+
+
+def _comm_worker(rank, world, port, out_path, use_rccl):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gavisunk_amd import _lib, engine
+    from gavisunk_amd import dist as gdist
+
+    L = _lib.lib()
+    device = rank % L.gs_device_count() if use_rccl else 0
+    comm = gdist.Comm(device, rccl=use_rccl)
+    k, keys, loc, reads = _case()
+    tab = None
+    if rank == 0 or not use_rccl:
+        tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32), device)
+    if use_rccl:
+        tab = comm.rccl.broadcast_table(tab, root=0)  # the built table, device to device
+    lo, hi = gdist.shard_bounds(len(reads), world, rank)
+    dev = engine.DeviceReads(engine.ReadBatch.from_ascii(reads[lo:hi]), k, device)
+    has, last = C.c_uint32(0), C.c_uint32(0)
+    _lib.check(L.gs_tag_phase1(tab._h, dev._h, C.byref(has), C.byref(last)))
+    summ = comm.exchange_summaries(has.value, last.value)
+    _lib.check(L.gs_tag_phase2(tab._h, dev._h, gdist.resolve_carry(summ, rank)))
+    n = C.c_uint64(0)
+    _lib.check(L.gs_tag_finish(tab._h, dev._h, None, 0, C.byref(n), None, None))
+    allhits = comm.gather_hits(tab, dev, n.value, lo)
+    if rank == 0:
+        np.save(out_path, allhits)
+    dev.close()
+    tab.close()
+    comm.close()
+
+
+def _check_against_single_pass(out):
+    from gavisunk_amd import engine
+
+    got = np.load(out)
+    k, keys, loc, reads = _case()
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    st, whole, _, _ = engine.tag(tab, engine.DeviceReads(engine.ReadBatch.from_ascii(reads), k))
+    assert st == 0 and len(whole) > 50 and np.array_equal(got, whole)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_comm_gloo_data_plane_on_one_gpu(world, tmp_path):
+    """dist.Comm with the host-staged gather (what a run falls back to when RCCL cannot start): real kernels, shared GPU."""
+    out = str(tmp_path / "hits.npy")
+    mp.spawn(_comm_worker, args=(world, _free_port(), out, False), nprocs=world, join=True)
+    _check_against_single_pass(out)
+
+
+def test_comm_rccl_data_plane():
+    """The RCCL data plane (table broadcast + hit gather through the C-ABI) on as many GPUs as the box has, at most 4;
+    skipped on a one-GPU box (RCCL refuses two ranks on one device)."""
+    import tempfile
+
+    from gavisunk_amd import _lib
+
+    ndev = _lib.lib().gs_device_count()
+    if ndev < 2:
+        pytest.skip("needs >= 2 GPUs")
+    world = min(ndev, 4)
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "hits.npy")
+        mp.spawn(_comm_worker, args=(world, _free_port(), out, True), nprocs=world, join=True)
+        _check_against_single_pass(out)
+
+
+def test_rccl_single_rank_through_the_c_abi():
+    """gs_comm_* with one rank (all a one-GPU box can run): communicator, table broadcast (the root gets its own table back),
+    gather = the rank's own list with the read offset applied."""
+    from gavisunk_amd import _lib, engine, rccl
+
+    class Solo:
+        rank, world = 0, 1
+
+        @staticmethod
+        def broadcast_bytes(b, src=0):
+            return bytes(b)
+
+    k, keys, loc, reads = _case()
+    comm = rccl.RcclComm(Solo, 0)
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    assert comm.broadcast_table(tab) is tab
+    dev = engine.DeviceReads(engine.ReadBatch.from_ascii(reads), k)
+    st, whole, _, _ = engine.tag(tab, dev)
+    got = comm.gather_hits(tab, dev, [len(whole)], 1000)
+    assert len(got) == len(whole) > 50 and np.array_equal(got["read"], whole["read"] + 1000)
+    assert np.array_equal(got["pos"], whole["pos"]) and np.array_equal(got["payload"], whole["payload"])
+    comm.close()
