@@ -23,7 +23,9 @@ def bad_of_hap(fai: str, sunkpos: str, device: int = 0):
     pairs = np.stack([sp.row_contig.astype(np.int64), sp.row_group], axis=1)
     uniq, inv = np.unique(pairs, axis=0, return_inverse=True)
     inv = np.ascontiguousarray(inv.reshape(-1), np.uint32)
-    sel = np.array([1 if sp.contigs[c] in contigs else 0 for c in uniq[:, 0].tolist()] + [0], dtype=np.uint8)
+    # `ID2.str.split(":", 1)` (badsunks_AR.py:29): the "contig" that is looked up in the fai is the text before the FIRST
+    # colon of `chrom:ID`, so a contig called chr1:1-5000 is looked up as chr1
+    sel = np.array([1 if sp.contigs[c].split(":", 1)[0] in contigs else 0 for c in uniq[:, 0].tolist()] + [0], dtype=np.uint8)
     n_keys = len(uniq)
     counts = np.zeros(max(n_keys, 1), np.uint32)
     hist_len = 1 << 16

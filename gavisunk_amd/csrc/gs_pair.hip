@@ -8,9 +8,9 @@
 //                  NaN stays, :140-147), majority orientation among kept pairs (tie -> 0, :150-152),
 //                  and the number of surviving pairs per row i (:153).
 //   k_pair_edges   writes the surviving pairs in (i, j) order = the order of `sub2`'s rows (:157-158).
-//   k_pair_graph   one thread per read: multi-position clean-up (:160-181), union-find over the IDs in
+//   k_pair_graph   one workgroup per read: multi-position clean-up (:160-181), lock-free union-find over the IDs in
 //                  first-appearance order, largest component with the lowest label on ties, its IDs in
-//                  vertex order (:189-198).  Serial per read, parallel over reads: the edge lists are small.
+//                  vertex order (:189-198).  O(n^2 + E) work per read, spread over 256 threads.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -89,62 +89,83 @@ __global__ __launch_bounds__(kPairThreads) void k_pair_edges(const uint64_t *rea
     }
 }
 
-__device__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
-    while (parent[x] != x) {
-        parent[x] = parent[parent[x]];
-        x = parent[x];
-    }
+// lock-free union-find over vertex indices: the root of a set is its smallest index (= its earliest vertex)
+__device__ __forceinline__ uint32_t uf_root(const uint32_t *parent, uint32_t x) {
+    uint32_t p;
+    while ((p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != x) x = p;
     return x;
 }
+__device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = uf_root(parent, a);
+        b = uf_root(parent, b);
+        if (a == b) return;
+        const uint32_t hi = max(a, b), lo = min(a, b);
+        if (atomicCAS(parent + hi, hi, lo) == hi) return;
+    }
+}
 
-// scratch per row (all uint32): deg, rank, vert, parent, size
-__global__ void k_pair_graph(uint32_t n_reads, const uint64_t *read_off, const int64_t *pos, const int64_t *id,
-                             const uint8_t *any_kept, const uint64_t *row_edge_off, const uint32_t *edge_i,
-                             const uint32_t *edge_j, uint8_t *edge_bad, uint32_t *deg, uint32_t *rank, uint32_t *vert,
-                             uint32_t *parent, uint32_t *csize, int64_t *out_ids, uint32_t *out_n) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
+// One workgroup per read; scratch per row (all uint32): deg, rank, vert, parent, size, plus app / vidx / flag below.
+// n hits of a read give up to n (n - 1) / 2 edges (n ~ 10^2 .. 10^3 on diploid assemblies): every phase is spread over
+// the workgroup, O(n^2 + E) work per read.
+//   deg[i]   occurrences of row i in mergedf = [first endpoints in edge order] ++ [second endpoints] (:160-163)
+//   rank[i]  where it first occurs there
+//   multi-position clean-up (:167-181), then the graph over ID values with vertices numbered by first appearance
+//   (source, then target, edge by edge), its largest component (lowest label on ties), its IDs in vertex order (:189-198)
+constexpr int kGraphThreads = 256;
+__global__ __launch_bounds__(kGraphThreads) void k_pair_graph(uint32_t n_reads, const uint64_t *read_off, const int64_t *pos,
+                                                              const int64_t *id, const uint8_t *any_kept,
+                                                              const uint64_t *row_edge_off, const uint32_t *edge_i,
+                                                              const uint32_t *edge_j, uint8_t *edge_bad, uint32_t *deg,
+                                                              uint32_t *rank, uint32_t *vert, uint32_t *parent, uint32_t *csize,
+                                                              uint32_t *app, int64_t *goodpos_of, int64_t *out_ids,
+                                                              uint32_t *out_n) {
+    __shared__ uint32_t s_nv, s_best_root, s_m;
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
     const uint64_t lo = read_off[r];
     const int n = (int)(read_off[r + 1] - lo);
-    out_n[r] = 0;
+    if (tid == 0) out_n[r] = 0;
     if (n < 2 || !any_kept[r]) return;  // `if sum(mask) < 1: continue` (:148)
     const uint64_t e0 = row_edge_off[lo], e1 = row_edge_off[lo + n];
     const uint64_t E = e1 - e0;
     const int64_t *P = pos + lo, *ID = id + lo;
-    uint32_t *dg = deg + lo, *rk = rank + lo, *vt = vert + lo, *pa = parent + lo, *cs = csize + lo;
-    // mergedf = [first endpoints in edge order] ++ [second endpoints in edge order] (:160-163):
-    // per row: how often it occurs (deg) and where it first occurs (rank)
-    for (int i = 0; i < n; i++) {
+    uint32_t *dg = deg + lo, *rk = rank + lo, *vt = vert + lo, *pa = parent + lo, *cs = csize + lo, *ap = app + lo;
+    int64_t *gp = goodpos_of + lo;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    for (int i = tid; i < n; i += kGraphThreads) {
         dg[i] = 0;
-        rk[i] = 0xFFFFFFFFu;
+        rk[i] = kNone;
+        ap[i] = kNone;
+        cs[i] = 0;
     }
-    for (uint64_t e = 0; e < E; e++) {
+    __syncthreads();
+    for (uint64_t e = tid; e < E; e += kGraphThreads) {
         const uint32_t a = edge_i[e0 + e], b = edge_j[e0 + e];
-        dg[a]++;
-        dg[b]++;
-        rk[a] = min(rk[a], (uint32_t)e);
-        rk[b] = min(rk[b], (uint32_t)(E + e));
+        atomicAdd(dg + a, 1u);
+        atomicAdd(dg + b, 1u);
+        atomicMin(rk + a, (uint32_t)e);
+        atomicMin(rk + b, (uint32_t)(E + e));
         edge_bad[e0 + e] = 0;
     }
-    // IDs seen with more than one pos keep their most frequent pos (value_counts().index[0]; ties: the pos that
-    // appears first in mergedf), and lose the pairs that start at that ID and touch the good pos on neither side
-    for (int a = 0; a < n; a++) {
+    __syncthreads();
+    // IDs seen with more than one pos keep their most frequent pos (value_counts().index[0]; ties: the pos that appears
+    // first in mergedf); gp[row] = that pos for rows of such an ID, else "no constraint" (vt[row] = 0 / 1 marks which)
+    for (int a = tid; a < n; a += kGraphThreads) {
+        vt[a] = 0;
         if (!dg[a]) continue;
-        bool first_of_id = true, multi = false;
-        for (int b = 0; b < n; b++) {
-            if (b == a || !dg[b] || ID[b] != ID[a]) continue;
-            if (b < a) first_of_id = false;
-            if (P[b] != P[a]) multi = true;
-        }
-        if (!first_of_id || !multi) continue;
+        bool multi = false;
+        for (int b = 0; b < n; b++)
+            if (dg[b] && ID[b] == ID[a] && P[b] != P[a]) multi = true;
+        if (!multi) continue;
         int64_t goodpos = 0;
         uint64_t best_cnt = 0;
-        uint32_t best_rank = 0xFFFFFFFFu;
+        uint32_t best_rank = kNone;
         for (int b = 0; b < n; b++) {
             if (!dg[b] || ID[b] != ID[a]) continue;
             bool first_of_pos = true;
             uint64_t cnt = 0;
-            uint32_t rnk = 0xFFFFFFFFu;
+            uint32_t rnk = kNone;
             for (int c = 0; c < n; c++) {
                 if (!dg[c] || ID[c] != ID[a] || P[c] != P[b]) continue;
                 if (c < b) first_of_pos = false;
@@ -158,40 +179,81 @@ __global__ void k_pair_graph(uint32_t n_reads, const uint64_t *read_off, const i
                 goodpos = P[b];
             }
         }
-        for (uint64_t e = 0; e < E; e++) {
-            const uint32_t x = edge_i[e0 + e], y = edge_j[e0 + e];
-            if (ID[x] == ID[a] && !(P[x] == goodpos || P[y] == goodpos)) edge_bad[e0 + e] = 1;  // :175-176
+        gp[a] = goodpos;
+        vt[a] = 1;
+    }
+    __syncthreads();
+    // ... and lose the pairs that start at that ID and touch the good pos on neither side (:175-176); the first appearance of
+    // every row among the surviving pairs (source of pair e: 2 e, target: 2 e + 1)
+    for (uint64_t e = tid; e < E; e += kGraphThreads) {
+        const uint32_t x = edge_i[e0 + e], y = edge_j[e0 + e];
+        const bool bad = vt[x] && !(P[x] == gp[x] || P[y] == gp[x]);
+        edge_bad[e0 + e] = bad ? 1 : 0;
+        if (!bad) {
+            atomicMin(ap + x, (uint32_t)(2 * e));
+            atomicMin(ap + y, (uint32_t)(2 * e + 1));
         }
     }
-    // graph over ID values, vertices numbered by first appearance (source, then target, edge by edge)
-    uint32_t nv = 0;
-    auto vertex_of = [&](uint32_t row) -> uint32_t {
-        for (uint32_t v = 0; v < nv; v++)
-            if (ID[vt[v]] == ID[row]) return v;
-        vt[nv] = row;
-        pa[nv] = nv;
-        return nv++;
-    };
-    for (uint64_t e = 0; e < E; e++) {
-        if (edge_bad[e0 + e]) continue;
-        const uint32_t va = vertex_of(edge_i[e0 + e]);
-        const uint32_t vb = vertex_of(edge_j[e0 + e]);
-        const uint32_t ra = uf_find(pa, va), rb = uf_find(pa, vb);
-        if (ra != rb) pa[max(ra, rb)] = min(ra, rb);  // the root is the component's lowest vertex = its label order
+    __syncthreads();
+    // a vertex = an ID value; its first appearance = the earliest of its rows'; its leader = the row that holds it
+    for (int a = tid; a < n; a += kGraphThreads) {
+        uint32_t mine = ap[a];
+        bool leader = mine != kNone;
+        for (int b = 0; b < n && leader; b++)
+            if (b != a && ID[b] == ID[a] && (ap[b] < mine || (ap[b] == mine && b < a))) leader = false;
+        rk[a] = leader ? 1u : 0u;  // (rank is free now)
     }
+    __syncthreads();
+    if (tid == 0) s_nv = 0;
+    __syncthreads();
+    // vertex index = number of leaders that appear earlier; vt[v] = leader row of vertex v; dg[row] = vertex of the row's ID
+    for (int a = tid; a < n; a += kGraphThreads) {
+        if (!rk[a]) continue;
+        uint32_t v = 0;
+        for (int b = 0; b < n; b++)
+            if (rk[b] && ap[b] < ap[a]) v++;
+        cs[a] = v;  // stash
+        atomicAdd(&s_nv, 1u);
+    }
+    __syncthreads();
+    const uint32_t nv = s_nv;
     if (!nv) return;
-    for (uint32_t v = 0; v < nv; v++) cs[v] = 0;
-    for (uint32_t v = 0; v < nv; v++) cs[uf_find(pa, v)]++;
-    uint32_t best_root = 0, best = 0;
-    for (uint32_t v = 0; v < nv; v++)
-        if (pa[v] == v && cs[v] > best) {  // strict: the first (lowest-label) maximum wins
-            best = cs[v];
-            best_root = v;
+    for (int a = tid; a < n; a += kGraphThreads) vt[a] = 0;
+    __syncthreads();
+    for (int a = tid; a < n; a += kGraphThreads)
+        if (rk[a]) {
+            vt[cs[a]] = (uint32_t)a;
+            pa[cs[a]] = cs[a];
         }
-    uint32_t m = 0;
-    for (uint32_t v = 0; v < nv; v++)
-        if (uf_find(pa, v) == best_root) out_ids[lo + m++] = ID[vt[v]];
-    out_n[r] = m;
+    __syncthreads();
+    for (int a = tid; a < n; a += kGraphThreads) {  // vertex of every row that appears in a surviving pair
+        dg[a] = kNone;
+        if (ap[a] == kNone) continue;
+        for (uint32_t v = 0; v < nv; v++)
+            if (ID[vt[v]] == ID[a]) {
+                dg[a] = v;
+                break;
+            }
+    }
+    __syncthreads();
+    for (int a = tid; a < n; a += kGraphThreads) cs[a] = 0;
+    for (uint64_t e = tid; e < E; e += kGraphThreads)
+        if (!edge_bad[e0 + e]) uf_union(pa, dg[edge_i[e0 + e]], dg[edge_j[e0 + e]]);
+    __syncthreads();
+    for (uint32_t v = tid; v < nv; v += kGraphThreads) atomicAdd(cs + uf_root(pa, v), 1u);
+    __syncthreads();
+    if (tid == 0) {  // the first (lowest-label) maximum wins
+        uint32_t best_root = 0, best = 0;
+        for (uint32_t v = 0; v < nv; v++)
+            if (pa[v] == v && cs[v] > best) {
+                best = cs[v];
+                best_root = v;
+            }
+        uint32_t m = 0;
+        for (uint32_t v = 0; v < nv; v++)
+            if (uf_root(pa, v) == best_root) out_ids[lo + m++] = ID[vt[v]];
+        out_n[r] = m;
+    }
 }
 
 struct DevBuf {
@@ -228,7 +290,8 @@ extern "C" int gs_pair_component(int device, uint32_t n_reads, const uint64_t *r
     int rc;
     uint64_t *d_off, *d_reoff;
     int64_t *d_pos, *d_start, *d_id, *d_out;
-    uint32_t *d_rowe, *d_outn, *d_deg, *d_rank, *d_vert, *d_parent, *d_size;
+    uint32_t *d_rowe, *d_outn, *d_deg, *d_rank, *d_vert, *d_parent, *d_size, *d_app;
+    int64_t *d_gp;
     uint8_t *d_orient, *d_any;
     if ((rc = db.put(&d_off, read_off, (uint64_t)n_reads + 1)) || (rc = db.put(&d_pos, pos, n_rows)) ||
         (rc = db.put(&d_start, start, n_rows)) || (rc = db.put(&d_id, id, n_rows)) ||
@@ -248,12 +311,13 @@ extern "C" int gs_pair_component(int device, uint32_t n_reads, const uint64_t *r
         (rc = db.put(&d_ej, (const uint32_t *)nullptr, n_edges)) || (rc = db.put(&d_bad, (const uint8_t *)nullptr, n_edges)) ||
         (rc = db.put(&d_deg, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_rank, (const uint32_t *)nullptr, n_rows)) ||
         (rc = db.put(&d_vert, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_parent, (const uint32_t *)nullptr, n_rows)) ||
-        (rc = db.put(&d_size, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_out, (const int64_t *)nullptr, n_rows)) ||
+        (rc = db.put(&d_size, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_app, (const uint32_t *)nullptr, n_rows)) ||
+        (rc = db.put(&d_gp, (const int64_t *)nullptr, n_rows)) || (rc = db.put(&d_out, (const int64_t *)nullptr, n_rows)) ||
         (rc = db.put(&d_outn, (const uint32_t *)nullptr, n_reads)))
         return rc;
     hipLaunchKernelGGL(k_pair_edges, dim3(n_reads), dim3(kPairThreads), 0, 0, d_off, d_pos, d_start, d_orient, d_reoff, d_ei, d_ej);
-    hipLaunchKernelGGL(k_pair_graph, dim3((n_reads + 63) / 64), dim3(64), 0, 0, n_reads, d_off, d_pos, d_id, d_any, d_reoff,
-                       d_ei, d_ej, d_bad, d_deg, d_rank, d_vert, d_parent, d_size, d_out, d_outn);
+    hipLaunchKernelGGL(k_pair_graph, dim3(n_reads), dim3(kGraphThreads), 0, 0, n_reads, d_off, d_pos, d_id, d_any, d_reoff,
+                       d_ei, d_ej, d_bad, d_deg, d_rank, d_vert, d_parent, d_size, d_app, d_gp, d_out, d_outn);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out_n, d_outn, n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -466,9 +466,9 @@ def pair_component_read(ids: Sequence[int], pos: Sequence[int], start: Sequence[
     return [verts[i] for i in range(len(verts)) if roots[i] == best_root]
 
 
-def process_by_contig(sunkpos_text: str, rlen_text: str, bad_text: str) -> Tuple[str, str]:
-    """process-by-contig_lowmem_AR.py:50-260 on the contents of its input files -> (tsv, bed).
-    Plain-Python restatement (dicts and lists instead of pandas); PARITY UNPINNED, see module header."""
+def per_read_inputs(sunkpos_text: str, rlen_text: str, bad_text: str):
+    """The file-level filtering of process-by-contig_lowmem_AR.py:50-108 -> (contig, {rname: rows}) with a read's rows sorted
+    by `start` (stable) and de-duplicated; None when nothing survives (:92-94)."""
     rows = parse_sunkpos(sunkpos_text)                                   # :60
     contig = rows[0][2]                                                  # :62
     bad = set(bad_text.splitlines())                                     # :67-68
@@ -478,7 +478,7 @@ def process_by_contig(sunkpos_text: str, rlen_text: str, bad_text: str) -> Tuple
         ids_of.setdefault(r[0], set()).add(r[4])
     multi = {n for n, s in ids_of.items() if len(s) > 1}                 # :91
     if not multi:
-        return f"{contig}\n", ""                                         # :92-94
+        return contig, None                                              # :92-94
     rows = [r for r in rows if r[0] in multi]
     rows.sort(key=lambda r: (r[0], r[3]))                                # :100 (stable)
     seen, ded = set(), []
@@ -495,6 +495,15 @@ def process_by_contig(sunkpos_text: str, rlen_text: str, bad_text: str) -> Tuple
     groups: Dict[str, list] = {}
     for r in sub:
         groups.setdefault(r[0], []).append(r)
+    return contig, groups
+
+
+def process_by_contig(sunkpos_text: str, rlen_text: str, bad_text: str) -> Tuple[str, str]:
+    """process-by-contig_lowmem_AR.py:50-260 on the contents of its input files -> (tsv, bed).
+    Plain-Python restatement (dicts and lists instead of pandas); PARITY UNPINNED, see module header."""
+    contig, groups = per_read_inputs(sunkpos_text, rlen_text, bad_text)
+    if groups is None:
+        return f"{contig}\n", ""                                         # :92-94
     outputs = []
     for rname in sorted(groups):                                         # :135 groupby -> sorted keys
         g = groups[rname]
@@ -541,8 +550,8 @@ def badsunks(fai1_text: str, fai2_text: str, sunkpos1_text: str, sunkpos2_text: 
     def one(fai_text, sp_text):
         contigs = {ln.split("\t")[0] for ln in fai_text.splitlines() if ln.strip()}
         cnt = Counter(f"{r[2]}:{r[4]}" for r in parse_sunkpos(sp_text))       # :22-24
-        own = {k: v for k, v in cnt.items() if k.rsplit(":", 1)[0] in contigs}    # :29-34 (split on the first ':' there;
-        other = {k: v for k, v in cnt.items() if k not in own}                    #  contig names carry no ':')
+        own = {k: v for k, v in cnt.items() if k.split(":", 1)[0] in contigs}     # :29-34 `str.split(":", 1)`: the text
+        other = {k: v for k, v in cnt.items() if k not in own}                    #  before the FIRST colon is looked up
         hist = Counter(own.values())
         top = max(hist.values())
         meancov = min(c for c, n in hist.items() if n == top)                     # :43 mode().values[0]

@@ -82,6 +82,40 @@ def synth_case(out_name, seed, n_reads):
     open(os.path.join(out, "expected.rlen"), "w").write("\n".join(rlen) + "\n")
 
 
+def synth_long_case(out_name, seed):
+    """Reads with 10^2 .. 10^3 hits (long reads on a diploid assembly), TIE-FREE by construction
+    (tests/golden/tie_census.py proves it on the result): every hit is its own SUNK group (ID = start) except planted
+    re-sightings of an ID at a far-away read position, which are consistent with almost no other hit and so lose the
+    `value_counts` vote by a wide margin; spurious locations stay isolated, so one component dominates."""
+    import numpy as np
+
+    out = os.path.join(HERE, out_name)
+    os.makedirs(out, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    rows, rlen = [], []
+    for r, n in enumerate((100, 150, 220, 300, 420, 560, 700, 850, 1000, 130, 90, 12)):
+        rlen.append(f"long{r:02d}\t{500000 if n > 20 else 9000}")
+        base = int(rng.integers(10**6, 10**7))
+        orient = 1 if r % 2 == 0 else -1
+        p = np.sort(rng.choice(np.arange(1, 450000), size=n, replace=False))
+        for i, pi in enumerate(p.tolist()):
+            u = rng.random()
+            if u < 0.06:
+                s = int(rng.integers(0, 3 * 10**7))                       # spurious location
+            else:
+                s = base + orient * pi + int(rng.integers(-25, 25)) + (2 * 10**7 if orient < 0 else 0)
+            rows.append((f"long{r:02d}", pi, "ctgL", s, s))
+            if u > 0.95 and i > 10:                                       # the same SUNK "seen" again, somewhere wrong
+                rows.append((f"long{r:02d}", int(p[i - 10]) + 7, "ctgL", s + 1, s))
+    rows.sort(key=lambda t: (t[0], t[1]))
+    open(os.path.join(out, "expected.diag2"), "w").write("".join("\t".join(map(str, t)) + "\n" for t in rows))
+    open(os.path.join(out, "expected.rlen"), "w").write("\n".join(rlen) + "\n")
+
+
+ALL_CASES = (("amy", "pair_amy", False, 7), ("multi_k20", "pair_multi_k20", True, 0), ("multi_k25", "pair_multi_k25", True, 5),
+             ("pair_synth_src", "pair_synth", False, 11), ("pair_long_src", "pair_long", False, 37))
+
+
 if __name__ == "__main__":
     if not os.path.exists(REF_SCRIPT):
         sys.exit("reference tree not present")
@@ -97,9 +131,9 @@ if __name__ == "__main__":
             shutil.copytree(os.path.join(keep, "_shim"), os.path.join(t, "_shim"))
             HERE = t
             synth_case("pair_synth_src", 9, 150)
+            synth_long_case("pair_long_src", 26)
             bad = []
-            for args in (("amy", "pair_amy", False, 7), ("multi_k20", "pair_multi_k20", True, 0),
-                         ("multi_k25", "pair_multi_k25", True, 5), ("pair_synth_src", "pair_synth", False, 11)):
+            for args in ALL_CASES:
                 run_case(*args)
                 for f in os.listdir(os.path.join(t, args[1])):
                     if f != "case.json" and not filecmp.cmp(os.path.join(t, args[1], f), os.path.join(keep, args[1], f), shallow=False):
@@ -107,7 +141,7 @@ if __name__ == "__main__":
         print("pair goldens reproduce" if not bad else f"MISMATCH: {bad}")
         sys.exit(1 if bad else 0)
     synth_case("pair_synth_src", 9, 150)
-    for args in (("amy", "pair_amy", False, 7), ("multi_k20", "pair_multi_k20", True, 0), ("multi_k25", "pair_multi_k25", True, 5),
-                 ("pair_synth_src", "pair_synth", False, 11)):
+    synth_long_case("pair_long_src", 26)
+    for args in ALL_CASES:
         m = run_case(*args)
         print(args[1], [(c["tag"], c["rc"], c["has_bed"]) for c in m["contigs"]])

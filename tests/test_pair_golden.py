@@ -9,7 +9,7 @@ import pytest
 from conftest import GOLDEN
 from oracle import oracle
 
-CASES = ["pair_amy", "pair_multi_k20", "pair_multi_k25", "pair_synth"]
+CASES = ["pair_amy", "pair_multi_k20", "pair_multi_k25", "pair_synth", "pair_long"]
 
 
 def _items(case):
@@ -29,7 +29,26 @@ def test_oracle_matches_reference_script(case):
         assert tsv == open(f"{d}/{t}.expected.tsv").read()
         assert bed == (open(f"{d}/{t}.expected.bed").read() if c["has_bed"] else "")
         n += tsv.count("\n")
-    assert n > (500 if case == "pair_synth" else 5)
+    assert n > (500 if case in ("pair_synth", "pair_long") else 5)
+
+
+def test_tie_census_of_the_goldens():
+    """Which goldens can contain a decision of the graph_tool stand-in / of pandas 2.x (tests/golden/tie_census.py): the AMY
+    locus, the two multi-contig cases and the long-read case (10^2 .. 10^3 hits per read, ~200 multi-position IDs) have no
+    `value_counts` tie and no largest-component tie -- whatever rule the pinned pandas 1.3.4 / graph-tool 2.43 apply, it
+    never had to choose there.  pair_synth does exercise `value_counts` ties (first-seen order, pandas 2.x): it pins the
+    clean-up code path only under that rule."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("tie_census", os.path.join(GOLDEN, "tie_census.py"))
+    tc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tc)
+    res = {c: tc.census_case(c) for c in CASES}
+    for c in ("pair_amy", "pair_multi_k20", "pair_multi_k25", "pair_long"):
+        assert res[c]["value_count_ties"] == 0 and res[c]["largest_ties"] == 0, (c, res[c])
+    assert res["pair_long"]["max_hits"] >= 1000 and res["pair_long"]["multipos_ids"] > 100
+    assert res["pair_synth"]["largest_ties"] == 0 and res["pair_synth"]["value_count_ties"] > 0
 
 
 @pytest.mark.gpu

@@ -88,3 +88,39 @@ def test_nothing_survives_writes_the_contig_line(tmp_path):
     tsv, bed = tmp_path / "o.tsv", tmp_path / "o.bed"
     assert process_by_contig.main(["unused.loc", str(sp), str(rlp), str(bd), str(tsv), str(bed)]) == 0
     assert tsv.read_text() == "ctgQ\n" and not bed.exists()
+
+
+def test_reads_with_hundreds_of_hits(tmp_path):
+    """n = 150 .. 900 hits per read (what long reads on diploid assemblies give): up to 4e5 pairs
+    per read.  The component kernel is a workgroup per read, O(n^2 + E); the whole call has to stay interactive.  The inputs
+    are tie-free by construction (distinct pos per ID except a few planted repeats with a clear majority; one dominant
+    component), so no stand-in decision of the provisional goldens can matter (tests/golden/tie_census.py)."""
+    import time
+
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(123)
+    offs, pos, start, ident = [0], [], [], []
+    expect = []
+    for n in (150, 300, 600, 900):
+        base = int(rng.integers(10**6, 10**7))
+        p = np.sort(rng.choice(np.arange(1, 400_000), size=n, replace=False))
+        s = base + p + rng.integers(-30, 30, n)
+        jump = rng.random(n) < 0.08
+        s[jump] = rng.integers(0, 2 * 10**7, int(jump.sum()))          # spurious locations
+        order = np.argsort(s, kind="stable")
+        p, s = p[order], s[order]
+        g = (s // 2000) * 2000
+        pos += p.tolist()
+        start += s.tolist()
+        ident += g.tolist()
+        offs.append(len(pos))
+        expect.append(orc.pair_component_read(g.tolist(), p.tolist(), s.tolist()))
+    read_off = np.array(offs, dtype=np.uint64)
+    t0 = time.perf_counter()
+    out_n, out_ids = process_by_contig.pair_component(read_off, np.array(pos, np.int64), np.array(start, np.int64), np.array(ident, np.int64))
+    dt = time.perf_counter() - t0
+    for r, exp in enumerate(expect):
+        lo = offs[r]
+        assert len(exp) > 20 and out_ids[lo:lo + out_n[r]].tolist() == exp
+    assert dt < 5.0, f"gs_pair_component took {dt:.1f} s"
