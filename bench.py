@@ -284,6 +284,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (config 3: 1 000 000)")
     ap.add_argument("--genome-mb", type=float, default=3100.0, help="assembly size in Mb (config 3: 3100)")
     ap.add_argument("--seed", type=int, default=30)
+    ap.add_argument("--k", type=int, default=20, help="SUNK length (headline: 20; 21 / 25 = BASELINE.json configs[4] rehearsals)")
     ap.add_argument("--check-reads", type=int, default=1000, help="reads of the stream the oracle walks for the parity leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity + CPU baseline)")
@@ -291,6 +292,8 @@ def main():
     ap.add_argument("--cli", action="store_true", help="config-2 leg: also time the command-line drop-in (.fa -> .sunkpos)")
     a = ap.parse_args()
 
+    global K
+    K = a.k
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -423,11 +426,11 @@ def main():
         pass_s = c["total_ms"] / max(c["launches"], 1) / 1e3
         bpb = alg_bytes_per_base(h_raw, h_emit)
         achieved = n_bases * bpb / probe_s / 1e9
-        full = a.genome_mb == 3100.0 and a.reads == 1_000_000
+        full = a.genome_mb == 3100.0 and a.reads == 1_000_000 and K == 20
         wkey = f"config3:{a.genome_mb:g}Mb:{a.reads}reads:seed{a.seed}"
         traffic, tnote = traffic_for(wkey) if world == 1 else (None, None)
         out = {
-            "metric": "ONT bases/sec SUNK-tagged (k=20), bit-exact hit list",
+            "metric": f"ONT bases/sec SUNK-tagged (k={K}), bit-exact hit list",
             "value": total_bases * a.steps / dt,
             "unit": "bases/s",
             "n_gpus": world,
@@ -443,7 +446,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("config 3 (BASELINE.json configs[2]): CHM13-scale haplotype surrogate, " if full else
                                     "REDUCED rehearsal of config 3 (not the headline workload): ") +
-                                   f"{a.genome_mb:g} Mb in 24 contigs, exact SUNK set, {a.reads} synthetic ONT reads per GPU, N50 {n50}, k=20",
+                                   f"{a.genome_mb:g} Mb in 24 contigs, exact SUNK set, {a.reads} synthetic ONT reads per GPU, N50 {n50}, k={K}",
                        "reads_per_gpu": a.reads, "bases_per_gpu": n_bases, "sunks": int(n_sunks), "sunk_groups": int(n_groups),
                        "windows": c["windows"], "raw_hits": c["raw_hits"], "emitted_rows": c["emitted"],
                        "h_raw": round(h_raw, 5), "h_emit": round(h_emit, 7), "tiles": c["tiles"],
@@ -498,7 +501,7 @@ def main():
             batch.close()
             out["engine_bases_per_s"] = int(off[-1]) / t_engine
             out["engine_note"] = f"{nchk} reads ({int(off[-1])} bases): gs_reads_upload of host-packed words + gs_tag + hits on host, one call each, first use of this batch"
-        if not a.no_config2 and world == 1:
+        if not a.no_config2 and world == 1 and K == 20:
             dev_reads.close()
             table.close()
             out["config2"] = config2_leg(a, device)
