@@ -233,7 +233,7 @@ int gs_table_broadcast(gs_comm *c, int root, gs_table *mine, gs_table **out) {
     // the arrays, one broadcast each
     if ((rc = bcast_array(R, c, root, &t->slots, hm.cap))) return rc;
     if (hm.mz) {
-        const uint64_t nslots = (uint64_t)hm.mz_n_regions * 16;
+        const uint64_t nslots = (uint64_t)hm.mz_n_regions * kMzWords;
         if ((rc = bcast_array(R, c, root, reinterpret_cast<unsigned long long **>(&t->mz_regions), nslots)) ||
             (rc = bcast_array(R, c, root, &t->mz_pay, nslots)))
             return rc;

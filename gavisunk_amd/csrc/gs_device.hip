@@ -2010,7 +2010,11 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                        mz_view(t), view(t), (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->ta,     \
                        r->cand, r->cand_cap, t->d_cand_count, t->d_complex_n)
             if (t->k == 20 && t->mz_m == 16)
-                GS_LAUNCH_MZ(20, 16);  // GAVISUNK's default SUNK length and the minimiser length of its tables: constants
+                GS_LAUNCH_MZ(20, 16);  // GAVISUNK's default SUNK length and the minimiser lengths its tables get: constants
+            else if (t->k == 20 && t->mz_m == 17)
+                GS_LAUNCH_MZ(20, 17);
+            else if (t->k == 20 && t->mz_m == 18)
+                GS_LAUNCH_MZ(20, 18);
             else
                 GS_LAUNCH_MZ(0, 0);
 #undef GS_LAUNCH_MZ
@@ -2225,17 +2229,17 @@ int mz_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, uint
                              // kernel is instruction-bound, so shorter runs cost nothing while crowded regions do)
     for (; m < m_hi; m++) {
         const double w = k - m + 1, places = (double)n / (0.65 * (w + 1) / 2);
-        if (places <= 0.25 * std::pow(4.0, m)) break;
+        if (places <= 0.06 * std::pow(4.0, m)) break;  // (0.25 left 13 % of a 1.5e9-key table's keys in full regions)
     }
     if (const char *e = getenv("GAVISUNK_MZ_M")) {  // tuning / test knob, read once per table
         const int v = atoi(e);
         if (v >= 4 && v <= m_hi) m = v;
     }
-    double per_region = 3.0;  // keys per 14-slot region
+    double per_region = 1.25;  // keys per 7-slot region (measured on the 100 Mb rehearsal: 1.0-1.25 tag at 133 Gbase/s, 1.5 at 124, 2 at 98)
     bool forced_load = false;
     if (const char *e = getenv("GAVISUNK_MZ_LOAD")) {  // test knob: an undersized table makes the walk and the overflow path busy
         const double v = atof(e);
-        if (v >= 0.5 && v <= 16.0) {
+        if (v >= 0.25 && v <= 16.0) {
             per_region = v;
             forced_load = true;
         }
@@ -2243,9 +2247,9 @@ int mz_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, uint
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
     uint64_t regions = std::max<uint64_t>((uint64_t)((double)n / per_region), 64);
-    regions = std::min<uint64_t>(regions, (uint64_t)(0.45 * (double)free_b) / 128);
+    regions = std::min<uint64_t>(regions, (uint64_t)(0.5 * (double)free_b) / (kMzWords * 12));
     regions = std::min<uint64_t>(regions, 0xFFFFFFF0ull);
-    if (regions < 64 || (!forced_load && (double)n / (double)regions > 10.0)) return 0;
+    if (regions < 64 || (!forced_load && (double)n / (double)regions > 5.0)) return 0;
     n_regions = (uint32_t)regions;
     return 1;
 }
@@ -2347,7 +2351,7 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
     }
     uint64_t n_generic = n;
     if (t->mz) {
-        const uint64_t nslots = (uint64_t)t->mz_n_regions * 2 * kMzPieces;
+        const uint64_t nslots = (uint64_t)t->mz_n_regions * kMzWords;
         const uint64_t ocap = std::max<uint64_t>(getenv("GAVISUNK_MZ_M") || getenv("GAVISUNK_MZ_LOAD") ? n : n / 8, 1u << 16);
         unsigned long long *dov = nullptr;
         if ((rc = dev_alloc((unsigned long long **)&t->mz_regions, nslots)) || (rc = dev_alloc(&t->mz_pay, nslots)) ||
@@ -2542,7 +2546,7 @@ const char *gs_table_layout(const gs_table *t) {
     static thread_local char buf[256];
     if (!t) return "";
     if (t->mz)
-        snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 128 B (16 fingerprint bytes + 14 x u64 [%d-bit tag | %d-bit loc]), minimiser length %d (w = %d), %llu overflow keys in a generic 16 B-slot side table",
+        snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 64 B (8 fingerprint bytes + 7 x u64 [%d-bit tag | %d-bit loc]), minimiser length %d (w = %d), %llu overflow keys in a generic 16 B-slot side table",
                  t->mz_n_regions, 2 * t->k - 3, t->mz_locbits, t->mz_m, t->k - t->mz_m + 1, (unsigned long long)t->mz_overflow);
     else if (t->compact)
         snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x %s (%d-bit remainder, %d-bit loc%s), %llu overflow keys in a generic 16 B-slot side table",
@@ -2576,7 +2580,7 @@ void gs_table_destroy(gs_table *t) {
 
 uint64_t gs_table_bytes(const gs_table *t) {
     if (!t) return 0;
-    if (t->mz) return t->cap * sizeof(Slot) + (uint64_t)t->mz_n_regions * (128 + 64);  // regions + payload words
+    if (t->mz) return t->cap * sizeof(Slot) + (uint64_t)t->mz_n_regions * kMzWords * 12;  // regions + payload words
     return t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)((t->c_w64 ? 48 : 32) * kNPart) << t->c_qb) : 0);  // slots + payloads
 }
 

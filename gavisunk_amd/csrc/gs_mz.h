@@ -4,8 +4,9 @@
 // Why.  A random probe of a table that lives in HBM costs one fabric request whatever it fetches, and the chip moves
 // ~47 G such requests per second (profiles/r02/ubench_run_coalescing.txt: 64-byte and 128-byte regions alike) -- one
 // request per window is the 0.09-of-roofline wall of the direct layouts.  Lanes of ONE wave-load that fall into the same
-// 128-byte line, though, are one request: with runs of L adjacent lanes per line the same microbenchmark reads
-// 47 G lines/s x L windows (L = 3: 142, L = 4: 186, L = 6: 270 G windows/s).
+// line, though, are one request: with runs of L adjacent lanes per line the same microbenchmark reads
+// 47 G lines/s x L windows (L = 3: 142, L = 4: 186, L = 6: 270 G windows/s).  Since requests, not bytes, are what is
+// scarce first, a region is 64 bytes: half a line, half the HBM traffic and half the LDS of a 128-byte one.
 //
 // So (1) a lane is a WINDOW (consecutive lanes = consecutive windows of a read), and (2) the 128-byte region a k-mer lives
 // in is chosen by its MINIMISER -- the smallest hash among the canonical m-mers inside it -- which consecutive windows
@@ -17,16 +18,15 @@
 //   fp      = min(l >> 24, 0xFE)                                                                    fingerprint byte
 //   tag     = (l & 0x1FFFFFFF) << (2k - 32) | hi                                                    2k - 3 bits
 //
-//   region  = 16 bytes of fingerprints | 14 slots of 8 bytes
-//             byte 0      0xFF - (keys in the region): a region is full at 14
-//             byte 1      0xFF
-//             byte i      fingerprint of slot i (i = 2..15), 0xFF = empty
-//             slot i      tag << locbits | loc            (all ones = empty; the all-ones loc is never stored)
+//   region  = 64 bytes = 8 words of 64 bits: word 0 = 8 fingerprint bytes, words 1..7 = slots
+//             byte 0      0xFF - (keys in the region): a region is full at 7
+//             byte i      fingerprint of slot i (i = 1..7), 0xFF = empty
+//             word i      tag << locbits | loc            (all ones = empty; the all-ones loc is never stored)
 //
 // (fp, tag) determine l and with it the key -- 0xFE stands for both 0xFE and 0xFF, which differ in bit 24 of l, and that
 // bit is in the tag too -- so a slot whose fingerprint and tag match is an exact hit, wherever the region came from.
-// A lookup reads the 16 fingerprint bytes, compares them all at once, and reads only the slots whose fingerprint matches
-// (one for a hit, none for 95 % of the misses).  Keys fill a region's slots in arrival order; a key whose region is full
+// A lookup reads the fingerprint word, compares its bytes all at once, and reads only the slots whose fingerprint matches
+// (one for a hit, none for 97 % of the misses).  Keys fill a region's slots in arrival order; a key whose region is full
 // stays in the generic 16-byte-slot table, and a lookup without a match in a FULL region asks that table.
 // m >= k - 7 (a minimiser owns at most w = 8 adjacent k-mers of one place) and grows with the key count (about log4 of
 // it: each minimiser value should own <= ~1 place of the assembly): human-genome-scale tables of 20-mers get m = 16, runs
@@ -44,8 +44,9 @@ struct MzView {
 };
 
 constexpr uint64_t kMzEmpty = ~0ULL;
-constexpr int kMzPieces = 8;       // 16-byte pieces per 128-byte region: piece 0 = fingerprints, pieces 1..7 = 14 slots
-constexpr int kMzSlots = 14;       // keys per region
+constexpr int kMzWords = 8;        // 64-bit words per region (64 bytes): word 0 = fingerprint bytes, words 1..7 = slots
+constexpr int kMzPieces = kMzWords / 2;  // 16-byte pieces per region (what one lane fetches)
+constexpr int kMzSlots = kMzWords - 1;   // keys per region
 constexpr int kMzCandLds = 128;    // candidates of a tile kept in LDS; tiles with more are walked a second time
 constexpr int kMzU = 4;            // wave-steps (64 windows each) whose table loads are in flight together
 
@@ -110,8 +111,8 @@ __global__ void k_mz_insert(unsigned long long *slots, uint32_t *pay, uint32_t n
     const uint64_t c = keys[i];
     const uint32_t reg = mz_region(mz_minimizer(c, k, m), n_regions);
     const MzKey key = mz_key(c, k);
-    unsigned long long *base = slots + (uint64_t)reg * 16;
-    uint32_t *fpw = reinterpret_cast<uint32_t *>(base);  // 4 words of fingerprint bytes
+    unsigned long long *base = slots + (uint64_t)reg * kMzWords;
+    uint32_t *fpw = reinterpret_cast<uint32_t *>(base);  // the two 32-bit halves of the fingerprint word
     uint32_t old = fpw[0], cnt;
     for (;;) {
         cnt = 0xFFu - (old & 0xFFu);
@@ -125,9 +126,9 @@ __global__ void k_mz_insert(unsigned long long *slots, uint32_t *pay, uint32_t n
         if (o < overflow_cap) overflow_list[o] = (uint32_t)i;
         return;
     }
-    const uint32_t slot = 2u + cnt;
+    const uint32_t slot = 1u + cnt;
     base[slot] = (key.tag << locbits) | (unsigned long long)loc[i];
-    pay[(uint64_t)reg * 16 + slot] = payload[i];
+    pay[(uint64_t)reg * kMzWords + slot] = payload[i];
     atomicAnd(fpw + (slot >> 2), ~(0xFFu << (8u * (slot & 3u))) | (key.fp << (8u * (slot & 3u))));
 }
 
@@ -136,42 +137,39 @@ __device__ __forceinline__ uint32_t mz_byte_eq(uint32_t x, uint32_t T) {
     const uint32_t z = x ^ T;
     return ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);
 }
-struct MzCand {  // fingerprint matches of a lookup: bit 7 of byte b of word j = slot 4 j + b
-    uint32_t m[4];
-    __device__ __forceinline__ bool any() const { return (m[0] | m[1] | m[2] | m[3]) != 0u; }
+struct MzCand {  // fingerprint matches of a lookup: bit 7 of byte b of half j = slot 4 j + b
+    uint32_t m0, m1;
+    __device__ __forceinline__ bool any() const { return (m0 | m1) != 0u; }
     __device__ __forceinline__ uint32_t pop() {  // lowest matching slot, removed
-        const uint32_t j = m[0] ? 0u : m[1] ? 1u : m[2] ? 2u : 3u;
-        const uint32_t x = m[0] ? m[0] : m[1] ? m[1] : m[2] ? m[2] : m[3];
+        const bool lo = m0 != 0u;
+        const uint32_t x = lo ? m0 : m1;
         const uint32_t bit = (uint32_t)__ffs((int)x) - 1u;
-        const uint32_t clr = ~(1u << bit);
-        m[0] &= j == 0u ? clr : ~0u;
-        m[1] &= j == 1u ? clr : ~0u;
-        m[2] &= j == 2u ? clr : ~0u;
-        m[3] &= j == 3u ? clr : ~0u;
-        return j * 4u + (bit >> 3);
+        const uint32_t y = x & (x - 1u);
+        m0 = lo ? y : m0;
+        m1 = lo ? m1 : y;
+        return (lo ? 0u : 4u) + (bit >> 3);
     }
 };
-__device__ __forceinline__ MzCand mz_candidates(const uint4 F, uint32_t fp) {
+// F = the region's fingerprint word (byte 0: 0xFF - keys stored, byte i: fingerprint of slot i or 0xFF)
+__device__ __forceinline__ MzCand mz_candidates(uint64_t F, uint32_t fp) {
     const uint32_t T = __builtin_amdgcn_perm(0u, fp, 0u);  // byte 0 of fp in all four bytes
     MzCand c;
-    c.m[0] = mz_byte_eq(F.x, T) & 0x80800000u;  // bytes 0 and 1 are not fingerprints
-    c.m[1] = mz_byte_eq(F.y, T);
-    c.m[2] = mz_byte_eq(F.z, T);
-    c.m[3] = mz_byte_eq(F.w, T);
+    c.m0 = mz_byte_eq((uint32_t)F, T) & 0x80808000u;  // byte 0 is the count
+    c.m1 = mz_byte_eq((uint32_t)(F >> 32), T);
     return c;
 }
-__device__ __forceinline__ bool mz_region_full(const uint4 F) { return (F.x & 0xFFu) <= 0xFFu - (uint32_t)kMzSlots; }
+__device__ __forceinline__ bool mz_region_full(uint64_t F) { return ((uint32_t)F & 0xFFu) <= 0xFFu - (uint32_t)kMzSlots; }
 
 // payload of a key that is known to be in the table (k_emit, one emitted row at a time)
 __device__ __forceinline__ uint32_t mz_payload(const MzView &mz, const TableView &tab, uint64_t c) {
     const uint32_t reg = mz_region(mz_minimizer(c, mz.k, mz.m), mz.n_regions);
     const MzKey key = mz_key(c, mz.k);
     const uint64_t want = key.tag << mz.locbits, locmask = (1ULL << mz.locbits) - 1ULL;
-    const uint4 *rp = mz.regions + (uint64_t)reg * kMzPieces;
-    MzCand cd = mz_candidates(*rp, key.fp);
+    const uint64_t *rp = reinterpret_cast<const uint64_t *>(mz.regions) + (uint64_t)reg * kMzWords;
+    MzCand cd = mz_candidates(rp[0], key.fp);
     while (cd.any()) {
         const uint32_t slot = cd.pop();
-        if ((reinterpret_cast<const uint64_t *>(rp)[slot] ^ want) < locmask) return mz.pay[(uint64_t)reg * 16 + slot];
+        if ((rp[slot] ^ want) < locmask) return mz.pay[(uint64_t)reg * kMzWords + slot];
     }
     uint64_t hh = slot_of(c, tab.shift);  // a key of a full region lives in the generic table
     Slot sl = load_slot(tab.slots + hh);
@@ -283,7 +281,8 @@ __device__ __forceinline__ MzTileOut mz_tile(const MzView &mz, const TableView &
         for (int u = 0; u < kMzU; u++) {
             const uint32_t s = s0 + (uint32_t)u;
             if (s >= nsteps) break;  // wave-uniform
-            MzCand cd = mz_candidates(bk[u], fp[u]);
+            const uint64_t Fw = (uint64_t)bk[u].x | ((uint64_t)bk[u].y << 32);  // (the same load brought slot 1 along)
+            MzCand cd = mz_candidates(Fw, fp[u]);
             bool hit = false;
             uint64_t e = 0;
             while (__ballot(valid[u] && !hit && cd.any())) {
@@ -296,7 +295,7 @@ __device__ __forceinline__ MzTileOut mz_tile(const MzView &mz, const TableView &
                     }
                 }
             }
-            if (valid[u] && !hit && mz_region_full(bk[u])) {  // 14 keys in the region and none is it: the generic table
+            if (valid[u] && !hit && mz_region_full(Fw)) {  // the region is full and no key of it is this one: the generic table
                 const MzWin ww = mz_window(W0, W1, (int)s, lane, k, m, kmask, mmask);
                 const uint64_t c = ww.f < ww.r ? ww.f : ww.r;
                 uint64_t hh = slot_of(c, tab.shift);
@@ -381,11 +380,11 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 // k_probe_mz: the fast form.  One wavefront per tile, lane = window, and per step of 64 windows:
 //
 //   stage    minimiser -> region of every window; a RUN = adjacent lanes with the same region (its first lane is the
-//            leader).  The whole 128-byte region of every run is fetched ONCE, straight into LDS: 8 lanes x 16 bytes per
-//            run by LDS-DMA (global_load_lds_dwordx4), kMzDma wave-instructions per step whatever the run count (runs
+//            leader).  The whole 64-byte region of every run is fetched ONCE, straight into LDS:
+//            run by LDS-DMA (global_load_lds_dwordx4): 4 lanes x 16 bytes per run, 16 runs per wave-instruction (runs
 //            past the last one repeat it: same line, no new request).  One request per run is what the fabric sees.
-//   consume  (kMzStages - 1 steps later, behind a counted vmcnt) a window reads its region's 16 fingerprint bytes from LDS,
-//            then the slots whose fingerprint matches.  Outcome: hit (loc), miss, or -- 14 keys in the region and none is
+//   consume  (kMzStages - 1 steps later, behind a counted vmcnt) a window reads its region's fingerprint word from LDS,
+//            then the slots whose fingerprint matches.  Outcome: hit (loc), miss, or -- 7 keys in the region and none is
 //            it -- "ask the generic table", which is deferred: such a window takes a place in the tile's hit list like a
 //            hit does.  A step with more than kMzRunCap runs (rare) is consumed in two halves, the second fetched on the spot.
 //   after the last step: the deferred lookups of the tile go to the generic table 64 at a time (their latencies overlap),
@@ -394,21 +393,24 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 // A tile with more maybe-hits than the list holds (kMzListCap) or more deferred lookups than their queue (kMzDeferCap) is
 // done over by mz_tile_exact: exactness never depends on the budgets.
 // ------------------------------------------------------------------------------------------
-constexpr int kMzRunCap = 32;                  // runs of a step whose regions fit the LDS cache slot (4 KiB)
-constexpr int kMzDma = kMzRunCap * 8 / 64;     // LDS-DMA wave-instructions per step
+constexpr int kMzRunCap = 32;                  // runs of a step whose regions fit the LDS cache slot (2 KiB)
+constexpr int kMzDma = kMzRunCap * kMzPieces / 64;  // LDS-DMA wave-instructions per step
 constexpr int kMzStages = 2;                   // steps whose region fetches are in flight together
-constexpr int kMzListCap = 960;                // maybe-hits of a tile
-constexpr int kMzDeferCap = 256;               // deferred generic-table lookups of a tile
+constexpr int kMzListCap = 1280;               // maybe-hits of a tile
+constexpr int kMzDeferCap = 384;               // deferred generic-table lookups of a tile
 constexpr int kMzWaves = 2;                    // waves per workgroup
 constexpr uint32_t kMzPending = 0xFFFFFFFFu;
 
 struct MzWaveLds {
-    uint4 cache[kMzStages][kMzRunCap * 8];  // after the last step: the tile's candidates (2048 x u32: a whole tile's worth)
+    uint4 cache[kMzStages][kMzRunCap * kMzPieces];
     uint32_t list[kMzListCap];
     uint32_t defer[kMzDeferCap];
     uint64_t words[kTileWords + 2];         // the tile's packed bases
 };
-static_assert(sizeof(uint4) * kMzStages * kMzRunCap * 8 >= sizeof(uint32_t) * kTileWindows, "candidate overlay");
+// after the last step the region cache is free: the ordered pass keeps the tile's candidates there and, past its end, in the
+// hit list itself (the struct's next member): candidate number i is written while list entry >= i is being read (a candidate is
+// a hit, hits are list entries), so candidate i lands on list entry i - cache_words < i, which has been consumed
+static_assert(offsetof(MzWaveLds, list) == sizeof(uint4) * kMzStages * kMzRunCap * kMzPieces, "the hit list follows the cache");
 
 // LDS accesses of the main loop are written as asm: while an LDS-DMA is in flight hipcc puts `s_waitcnt vmcnt(0)` in
 // front of every LDS access it knows of (it cannot tell which bytes the DMA writes), which would serialise the steps.
@@ -477,16 +479,17 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
     bool redo = false;  // wave-uniform: a budget was exceeded, the exact form does the tile over
 
     // LDS-DMA wave-instructions that fetch the regions of (the first kMzRunCap of) R runs: 8 runs each
-    auto dma_count = [](uint32_t R) { return min((R + 7u) / 8u, (uint32_t)kMzDma); };
+    constexpr uint32_t kRunsPerDma = 64 / kMzPieces;
+    auto dma_count = [](uint32_t R) { return min((R + kRunsPerDma - 1u) / kRunsPerDma, (uint32_t)kMzDma); };
     // the regions of runs [r0, r0 + kMzRunCap) of a step into cache slot `slot`
     auto fetch = [&](int slot, uint32_t rr_lane, uint32_t R, uint32_t r0) {
         const uint32_t ni = dma_count(R - r0);
 #pragma unroll
         for (int it = 0; it < kMzDma; it++) {
             if ((uint32_t)it >= ni) break;  // wave-uniform
-            const uint32_t q = min(r0 + (uint32_t)(it * 8 + (lane >> 3)), R - 1u);
+            const uint32_t q = min(r0 + (uint32_t)(it * (int)kRunsPerDma + lane / kMzPieces), R - 1u);
             const uint32_t rr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q * 4u), (int)rr_lane);
-            const uint4 *src = mz.regions + (uint64_t)rr * kMzPieces + (lane & 7);
+            const uint4 *src = mz.regions + (uint64_t)rr * kMzPieces + (lane % kMzPieces);
             __builtin_amdgcn_global_load_lds(src, &L.cache[slot][it * 64], 16, 0, 0);
         }
     };
@@ -528,9 +531,9 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
     auto lookups = [&](uint32_t s, int u, uint32_t r0) {
         const uint32_t fp = meta[u] & 0xFFu, myrun = (meta[u] >> 8) & 63u;
         const bool mine = ((meta[u] >> 14) & 1u) && myrun >= r0 && myrun < r0 + (uint32_t)kMzRunCap;
-        const uint32_t reg_a = lds_addr(&L.cache[u][0]) + (myrun - r0) * 128u;
-        uint4 F = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (mine) F = lds_read_b128(reg_a);
+        const uint32_t reg_a = lds_addr(&L.cache[u][0]) + (myrun - r0) * (uint32_t)(kMzWords * 8);
+        uint64_t F = ~0ULL;
+        if (mine) F = lds_read_b64(reg_a);
         MzCand cd = mz_candidates(F, fp);
         bool hit = false;
         uint64_t e = 0;
@@ -570,12 +573,11 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
             const uint32_t s = s0 + (uint32_t)u;
             if (s >= nsteps || redo) break;  // wave-uniform
             // the fetches of step s have landed once at most those of the next step (1 to kMzDma instructions) are outstanding
+            static_assert(kMzDma == 2, "the waits below count at most two instructions of the next step");
             switch (s + 1 < nsteps ? dma_count(nruns[u ^ 1]) : 0u) {  // wave-uniform
                 case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
                 case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
             }
             if (nruns[u] <= (uint32_t)kMzRunCap) {
                 lookups(s, u, 0u);
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ordered pass over the hit list: the same bookkeeping as mz_tile; the candidates go to LDS (the cache slots are free
-    // now and hold a whole tile's worth), then to their place
+    // now), then to their place
     uint32_t *cbuf = reinterpret_cast<uint32_t *>(&L.cache[0][0]);
     uint32_t n_raw = 0, n_cand = 0, first_loc = GS_NONE, carry = GS_NONE, run = 0;
     for (uint32_t s = 0; s < nsteps; s++) {
