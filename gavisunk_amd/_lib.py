@@ -72,6 +72,9 @@ SIGNATURES = {
     "gs_table_layout": (C.c_char_p, [P]),
     "gs_reads_upload": (I, [I, P, U64, P, P, U32, I, C.POINTER(P)]),
     "gs_reads_upload_ascii": (I, [I, P, P, U32, I, C.POINTER(P)]),
+    "gs_reads_upload_ordered": (I, [I, P, U64, P, P, U32, P, U32, I, C.POINTER(P)]),
+    "gs_reads_set_seeds": (I, [P, P, P, U32]),
+    "gs_tag_segment_carries": (I, [P, P, P]),
     "gs_reads_from_device_ascii": (I, [I, P, P, U32, I, C.POINTER(P)]),
     "gs_reads_destroy": (None, [P]),
     "gs_reads_n_bases": (U64, [P]),

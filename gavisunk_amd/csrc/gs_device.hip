@@ -82,7 +82,12 @@ struct ReadsView {
 struct TileArrays {
     uint32_t *n_raw, *n_cand, *first_loc, *last_loc, *cand_off, *n_emit, *carry_loc;
     uint64_t *raw_prefix, *emit_prefix;
+    // scatter-chunk emulation (gs_reads_set_seeds): seed[t] != kNoSeed forces the loc carried INTO tile t (GS_NONE = the fresh
+    // prevLoc of a new chunk file); seg_carry[t] then receives the loc that was carried up to there.  NULL = no seeds.
+    const uint32_t *seed;
+    uint32_t *seg_carry;
 };
+constexpr uint32_t kNoSeed = 0xFFFFFFFDu;
 
 __device__ __forceinline__ uint64_t revpairs(uint64_t x) {
     x = __brevll(x);
@@ -1554,13 +1559,18 @@ __global__ __launch_bounds__(1024, 8) void k_join_merge(JoinQ jq, uint32_t batch
 struct Agg {
     uint64_t sum;
     uint32_t loc;
-    uint32_t has;
+    uint32_t has;  // bit 0: a loc is carried out of this stretch; bit 1: the stretch contains a seed (what came before it is cut off)
 };
 __device__ __forceinline__ Agg combine(const Agg &l, const Agg &r) {
     Agg o;
     o.sum = l.sum + r.sum;
-    o.has = l.has | r.has;
-    o.loc = r.has ? r.loc : l.loc;
+    if (r.has & 2u) {  // r starts over at its seed: nothing of l's carry survives it
+        o.has = r.has;
+        o.loc = r.loc;
+    } else {
+        o.has = (l.has | r.has);
+        o.loc = (r.has & 1u) ? r.loc : l.loc;
+    }
     return o;
 }
 __device__ __forceinline__ Agg agg_shfl_up(const Agg &a, int d) {
@@ -1591,6 +1601,13 @@ __device__ __forceinline__ Agg scan_elem(const TileArrays &ta, uint32_t t, uint3
             e.sum = nr;
             e.has = nr ? 1u : 0u;
             e.loc = nr ? ta.last_loc[t] : GS_NONE;
+            if (ta.seed && ta.seed[t] != kNoSeed) {  // the tile starts from its seed
+                e.has |= 2u;
+                if (!nr && ta.seed[t] != GS_NONE) {
+                    e.has |= 1u;
+                    e.loc = ta.seed[t];
+                }
+            }
         } else {
             e.sum = ta.n_emit[t];
         }
@@ -1667,7 +1684,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(TileArrays ta, uint
         if (t < n) {
             if (mode == 0) {
                 ta.raw_prefix[t] = run.sum;
-                const uint32_t carry = run.has ? run.loc : GS_NONE;
+                uint32_t carry = (run.has & 1u) ? run.loc : GS_NONE;
+                if (ta.seed && ta.seed[t] != kNoSeed) {
+                    ta.seg_carry[t] = carry;  // what the reads before this seed carried out
+                    carry = ta.seed[t];
+                }
                 ta.carry_loc[t] = carry;
                 // k_resolve fused: the tile's first candidate is suppressed when it repeats the carried loc
                 const uint32_t nr = ta.n_raw[t];
@@ -1931,6 +1952,9 @@ struct gs_reads {
     gs_hit *hits = nullptr;
     gs_hit *hits_host = nullptr;       // pinned mirror written by k_emit itself: no device-to-host copy after the pass
     uint64_t hit_cap = 0;
+    uint32_t *d_seed = nullptr, *d_seg_carry = nullptr;  // [n_tiles], scatter-chunk emulation (gs_reads_set_seeds)
+    std::vector<uint32_t> seed_tiles;                    // tiles that carry a seed, in the order they were given
+    std::vector<uint32_t> read_tile0_host;               // first tile of every read
     TileDesc *tile_desc = nullptr;     // [n_tiles]
     PartRec *part_recs = nullptr;      // [n_tiles * kNPart], fast path only
     uint32_t *complex_list = nullptr;  // [n_tiles]
@@ -2585,8 +2609,9 @@ uint64_t gs_table_bytes(const gs_table *t) {
 }
 
 // index building + allocations shared by the two upload entry points; the packed words are zeroed, not filled
+// `order` (may be NULL = identity): the batch reads in the order they are tagged; n_reads = its length
 static int reads_setup(int device, uint64_t n_words, const uint64_t *word_off, const uint32_t *len, uint32_t n_reads, int k,
-                       gs_reads **out) {
+                       gs_reads **out, const uint32_t *order = nullptr, uint32_t n_batch_reads = 0) {
     if (!out || k < 1 || k > 32 || (n_reads && (!word_off || !len))) {
         set_error("gs_reads_upload: bad argument");
         return GS_E_ARG;
@@ -2607,10 +2632,17 @@ static int reads_setup(int device, uint64_t n_words, const uint64_t *word_off, c
     std::vector<uint32_t> tile_read;
     std::vector<TileDesc> tdesc;
     uint64_t tiles = 0;
+    std::vector<uint64_t> start((size_t)n_reads + 1, 0);
     for (uint32_t i = 0; i < n_reads; i++) {
-        const uint32_t l = len[i];
+        const uint32_t src = order ? order[i] : i;
+        if (order && src >= n_batch_reads) {
+            set_error("gs_reads_upload_ordered: order[%u] = %u is not a read of the batch", i, src);
+            return GS_E_ARG;
+        }
+        const uint32_t l = len[src];
+        start[i] = word_off[src];
         // the kernel reads words [w, w+1] of a window's first base: check the packing promise
-        const uint64_t have = word_off[i + 1] - word_off[i];
+        const uint64_t have = word_off[src + 1] - word_off[src];
         if (have < (uint64_t)(l + 31) / 32 + 1) {
             set_error("gs_reads_upload: read %u has %llu words for %u bases; need ceil(len/32)+1", i,
                       (unsigned long long)have, l);
@@ -2626,11 +2658,12 @@ static int reads_setup(int device, uint64_t n_words, const uint64_t *word_off, c
         }
         tile_read.insert(tile_read.end(), nt, i);
         for (uint32_t q = 0; q < nt; q++)
-            tdesc.push_back(TileDesc{word_off[i] + (uint64_t)q * kTileWords, nwin[i] - q * kTileWindows, i});
+            tdesc.push_back(TileDesc{start[i] + (uint64_t)q * kTileWords, nwin[i] - q * kTileWindows, i});
         r->n_bases += l;
         r->n_windows += nwin[i];
     }
     r->n_tiles = (uint32_t)tiles;
+    r->read_tile0_host = tile0;
     int rc;
     // zero slack after the last read: every lane of a tile loads words [l, l+1] unconditionally
     const uint64_t slack = kTileWords + 2;
@@ -2641,7 +2674,7 @@ static int reads_setup(int device, uint64_t n_words, const uint64_t *word_off, c
         (rc = dev_alloc(&r->tile_read, tiles)))
         return rc;
     if (n_reads) {
-        HIP_TRY(hipMemcpy(r->read_word_off, word_off, ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(r->read_word_off, start.data(), ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(r->read_nwin, nwin.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(r->read_tile0, tile0.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
@@ -2679,6 +2712,56 @@ int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const u
             return GS_E_NODEVICE;
         }
     }
+    return GS_OK;
+}
+
+int gs_reads_upload_ordered(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off, const uint32_t *len,
+                            uint32_t n_reads, const uint32_t *order, uint32_t n_order, int k, gs_reads **out) {
+    if ((n_reads && !words) || (n_order && !order)) {
+        set_error("gs_reads_upload_ordered: bad argument");
+        return GS_E_ARG;
+    }
+    int rc = reads_setup(device, n_words, word_off, len, n_order, k, out, order ? order : &n_order /* unused when 0 */, n_reads);
+    if (rc) return rc;
+    if (n_words) {
+        hipError_t e = hipMemcpy((*out)->words, words, n_words * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("hipMemcpy of the packed reads failed: %s", hipGetErrorString(e));
+            gs_reads_destroy(*out);
+            *out = nullptr;
+            return GS_E_NODEVICE;
+        }
+    }
+    return GS_OK;
+}
+
+int gs_reads_set_seeds(gs_reads *r, const uint32_t *seed_at, const uint32_t *seed, uint32_t n) {
+    if (!r || (n && (!seed_at || !seed))) {
+        set_error("gs_reads_set_seeds: bad argument");
+        return GS_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint32_t> h(std::max<uint32_t>(r->n_tiles, 1), kNoSeed);
+    r->seed_tiles.clear();
+    for (uint32_t j = 0; j < n; j++) {
+        if (seed_at[j] >= r->n_reads) {
+            set_error("gs_reads_set_seeds: read %u of %u", seed_at[j], r->n_reads);
+            return GS_E_ARG;
+        }
+        if (seed[j] == kNoSeed) {
+            set_error("gs_reads_set_seeds: 0x%X is not a location id", kNoSeed);
+            return GS_E_ARG;
+        }
+        const uint32_t t = r->read_tile0_host[seed_at[j]];
+        h[t] = seed[j];
+        r->seed_tiles.push_back(t);
+    }
+    int rc;
+    if (!r->d_seed && ((rc = dev_alloc(&r->d_seed, r->n_tiles)) || (rc = dev_alloc(&r->d_seg_carry, r->n_tiles)))) return rc;
+    if (r->n_tiles) HIP_TRY(hipMemcpy(r->d_seed, h.data(), (size_t)r->n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+    r->ta.seed = n ? r->d_seed : nullptr;
+    r->ta.seg_carry = r->d_seg_carry;
     return GS_OK;
 }
 
@@ -2795,6 +2878,8 @@ void gs_reads_destroy(gs_reads *r) {
     (void)hipFree(r->hits);
     if (r->hits_host) (void)hipHostFree(r->hits_host);
     (void)hipFree(r->tile_desc);
+    (void)hipFree(r->d_seed);
+    (void)hipFree(r->d_seg_carry);
     (void)hipFree(r->part_recs);
     (void)hipFree(r->jq.item);
     (void)hipFree(r->jq.woff);
@@ -2845,8 +2930,8 @@ int gs_tag_phase1(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_lo
     Agg tot;
     HIP_TRY(hipMemcpyAsync(&tot, t->d_totals, sizeof tot, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(wait_stream(t->stream));
-    if (has_raw) *has_raw = tot.has;
-    if (last_loc) *last_loc = tot.has ? tot.loc : GS_NONE;
+    if (has_raw) *has_raw = tot.has & 1u;
+    if (last_loc) *last_loc = (tot.has & 1u) ? tot.loc : GS_NONE;
     return GS_OK;
 }
 
@@ -2899,7 +2984,7 @@ static int settle(gs_table *t, gs_reads *r) {
         t->ctr.raw_hits = tot[0].sum;
         t->ctr.emitted = tot[1].sum;
         t->res_n = tot[1].sum;
-        t->res_carry = tot[0].has ? tot[0].loc : GS_NONE;
+        t->res_carry = (tot[0].has & 1u) ? tot[0].loc : GS_NONE;
         t->res_keyerr = err != ~0ULL;
         if (t->res_keyerr) {
             // hits emitted before the offending window = emit_prefix of its tile + its earlier candidates
@@ -2969,6 +3054,15 @@ int gs_tag_hits_to_host(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uin
     int rc;
     if ((rc = check_pair(t, r, "gs_tag_hits_to_host"))) return rc;
     return copy_hits(t, r, out, cap, n_out, hipMemcpyDeviceToHost);
+}
+
+int gs_tag_segment_carries(gs_table *t, gs_reads *r, uint32_t *out) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_segment_carries"))) return rc;
+    if ((rc = settle(t, r))) return rc;
+    for (size_t j = 0; j < r->seed_tiles.size(); j++)
+        HIP_TRY(hipMemcpy(out + j, r->d_seg_carry + r->seed_tiles[j], sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return GS_OK;
 }
 
 int gs_tag_hits_view(gs_table *t, gs_reads *r, const gs_hit **out, uint64_t *n_out) {

@@ -171,6 +171,33 @@ class DeviceReads:
         self.n_windows = lib().gs_reads_n_windows(h)
         return self
 
+    @classmethod
+    def ordered(cls, batch: ReadBatch, order: np.ndarray, k: int, device: int = 0) -> "DeviceReads":
+        """The batch's reads tagged in `order` (gs_reads_upload_ordered): hit.read is then the position in `order`."""
+        order = np.ascontiguousarray(order, np.uint32)
+        h = C.c_void_p()
+        check(lib().gs_reads_upload_ordered(device, batch.words.ctypes.data if batch.n_words else None, batch.n_words,
+                                            batch.word_off.ctypes.data, batch.len.ctypes.data if batch.n_reads else None,
+                                            batch.n_reads, order.ctypes.data if len(order) else None, len(order), k, C.byref(h)))
+        self = cls.__new__(cls)
+        self._h, self.k, self.device = h, k, device
+        self.n_reads, self.n_bases = len(order), int(batch.len[order].sum()) if len(order) else 0
+        self.n_windows = lib().gs_reads_n_windows(h)
+        return self
+
+    def set_seeds(self, seed_at, seed) -> None:
+        """Force the carried location to seed[j] before the read at tagging position seed_at[j] (gs_reads_set_seeds)."""
+        seed_at = np.ascontiguousarray(seed_at, np.uint32)
+        seed = np.ascontiguousarray(seed, np.uint32)
+        check(lib().gs_reads_set_seeds(self._h, seed_at.ctypes.data if len(seed_at) else None,
+                                       seed.ctypes.data if len(seed) else None, len(seed_at)))
+        self._n_seeds = len(seed_at)
+
+    def segment_carries(self, table: "DeviceTable") -> np.ndarray:
+        out = np.zeros(max(getattr(self, "_n_seeds", 0), 1), np.uint32)
+        check(lib().gs_tag_segment_carries(table._h, self._h, out.ctypes.data))
+        return out[: getattr(self, "_n_seeds", 0)]
+
     def close(self):
         if getattr(self, "_h", None):
             lib().gs_reads_destroy(self._h)

@@ -7,6 +7,13 @@ has no loc row (the reference's KeyError).  Tagging runs on the GPU through libg
 
 Environment: GAVISUNK_DEVICE (GPU index, default 0), GAVISUNK_BATCH_BASES (bases per device
 batch, default 2^31).
+
+`--emulate-chunks N` (after the four positionals): <reads> is a WHOLE haplotype's read file
+and <out> becomes what the workflow's scatter produces for it -- the reads dealt to N chunk files record by record
+(`seqtk seq -F '#' | rustybam fastq-split`, tagONT.smk:2-18; round-robin, as rustybam is believed to deal them: the tool is
+not in the build image), the tagger run per chunk with a fresh `prevLoc` (tagONT.smk:19-37), outputs concatenated in
+scatter order (tagONT.smk:112-131) -- in ONE run: every device batch is tagged in chunk-major order in a single pass, each
+chunk's carried location seeded from what that chunk carried out of the previous batch.
 """
 from __future__ import annotations
 
@@ -99,13 +106,69 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
     return rc
 
 
+def run_chunked(reads: str, kmers: str, locs: str, ofile: str, nchunks: int, device: int = 0, batch_bases: int = 1 << 31) -> int:
+    import numpy as np
+
+    batches = _Prefetch(reads, batch_bases)
+    try:
+        db = engine.SunkDB(kmers, locs)
+    except _lib.GsError as e:
+        batches.close()
+        sys.stderr.write(e.msg + "\n")
+        return 1
+    sys.stderr.write("FINISHED READING KMERS\n")
+    sys.stderr.write("FINISHED READING LOCS\n")
+    table = engine.DeviceTable.from_db(db, device)
+    carry = [_lib.GS_NONE] * nchunks          # per chunk: the location its reads so far carry (prevLoc of that chunk's run)
+    texts = [[] for _ in range(nchunks)]
+    rec = 0                                   # records seen: record i goes to chunk i mod nchunks
+    rc = 0
+    for batch in batches:
+        n = batch.n_reads
+        chunk_of = (rec + np.arange(n, dtype=np.int64)) % nchunks
+        order = np.argsort(chunk_of, kind="stable").astype(np.uint32)  # chunk-major, file order inside a chunk
+        present = np.unique(chunk_of)
+        starts = np.searchsorted(chunk_of[order], present)              # tagging position of each present chunk's first read
+        dev = engine.DeviceReads.ordered(batch, order, db.k, device)
+        dev.set_seeds(starts, [carry[int(c)] for c in present])
+        st, hits, last, _ = engine.tag(table, dev)
+        seg = dev.segment_carries(table)  # seg[j] = carried up to starts[j] = what chunk present[j-1] carries now
+        for j, c in enumerate(present.tolist()):
+            carry[c] = int(seg[j + 1]) if j + 1 < len(present) else int(last)
+        names = batch.names
+        names_ord = [names[i] for i in order.tolist()]
+        bounds = np.searchsorted(hits["read"], np.append(starts, n))
+        for j, c in enumerate(present.tolist()):
+            texts[c].append(engine.format_sunkpos(hits[bounds[j]:bounds[j + 1]], names_ord, db))
+        dev.close()
+        batch.close()
+        rec += n
+        if st == _lib.GS_E_KEYERROR:
+            sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
+            rc = 1
+            break
+    with open(ofile, "w") as out:
+        for c in range(nchunks):
+            out.write("".join(texts[c]))
+    batches.close()
+    table.close()
+    db.close()
+    return rc
+
+
 def main(argv=None) -> int:
     argv = sys.argv[1:] if argv is None else argv
-    if len(argv) != 4:
-        sys.stderr.write("usage: kmerpos_annot3 <reads.fa|fq[.gz]> <kmers.db> <kmer.loc> <out.sunkpos>\n")
+    nchunks = 0
+    if len(argv) == 6 and argv[4] == "--emulate-chunks":
+        nchunks = int(argv[5])
+        argv = argv[:4]
+    if len(argv) != 4 or nchunks < 0:
+        sys.stderr.write("usage: kmerpos_annot3 <reads.fa|fq[.gz]> <kmers.db> <kmer.loc> <out.sunkpos> [--emulate-chunks N]\n")
         return 2
-    return run(argv[0], argv[1], argv[2], argv[3], device=int(os.environ.get("GAVISUNK_DEVICE", "0")),
-               batch_bases=int(os.environ.get("GAVISUNK_BATCH_BASES", str(1 << 31))))
+    dev, bb = int(os.environ.get("GAVISUNK_DEVICE", "0")), int(os.environ.get("GAVISUNK_BATCH_BASES", str(1 << 31)))
+    if nchunks:
+        return run_chunked(argv[0], argv[1], argv[2], argv[3], nchunks, device=dev, batch_bases=bb)
+    return run(argv[0], argv[1], argv[2], argv[3], device=dev, batch_bases=bb)
 
 
 if __name__ == "__main__":

@@ -130,6 +130,19 @@ const char *gs_table_layout(const gs_table *t);
 typedef struct gs_reads gs_reads;
 int gs_reads_upload(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off,
                     const uint32_t *len, uint32_t n_reads, int k, gs_reads **out);
+/* Scatter-chunk emulation.  GAVISUNK's workflow cuts a haplotype's reads into `nchunks` files
+ * (`seqtk seq -F '#' | rustybam fastq-split`, tagONT.smk:2-18), runs the tagger once per file -- `prevLoc` starts empty in each
+ * (tagONT.smk:19-37) -- and concatenates the outputs in scatter order (tagONT.smk:112-131).  One pass can reproduce that:
+ *   gs_reads_upload_ordered   the batch's reads are tagged in `order` (tagging position i = batch read order[i]: chunk 0's reads
+ *                             first, then chunk 1's, ...); gs_hit.read is the tagging position
+ *   gs_reads_set_seeds        before the read at tagging position seed_at[j] the carried location is FORCED to seed[j]: GS_NONE at
+ *                             the first read of a chunk, or what that chunk carried out of the previous device batch
+ *   gs_tag_segment_carries    after a pass: out[j] = the location carried up to seed_at[j] (by the reads of the segment before
+ *                             it); the last segment's is the pass's carry_out */
+int gs_reads_upload_ordered(int device, const uint64_t *words, uint64_t n_words, const uint64_t *word_off, const uint32_t *len,
+                            uint32_t n_reads, const uint32_t *order, uint32_t n_order, int k, gs_reads **out);
+int gs_reads_set_seeds(gs_reads *r, const uint32_t *seed_at, const uint32_t *seed, uint32_t n);
+int gs_tag_segment_carries(gs_table *t, gs_reads *r, uint32_t *out);
 /* The same from unpacked reads: ASCII bases back to back, off[n_reads+1] in bytes; the 2-bit packing (with the
  * `encode` table above) runs on the GPU. */
 int gs_reads_upload_ascii(int device, const uint8_t *seq, const uint64_t *off, uint32_t n_reads, int k, gs_reads **out);

@@ -204,6 +204,22 @@ def tag_files(reads: str, db: str, loc: str) -> Tuple[int, str]:
     return (1 if rc == -2 else 0), txt
 
 
+def tag_files_chunked(reads: str, db: str, loc: str, nchunks: int) -> Tuple[int, str]:
+    """The workflow's scatter (tagONT.smk:2-37,112-131): records dealt round-robin to `nchunks` files, the tagger run on each
+    with a fresh `prevLoc`, outputs concatenated in scatter order."""
+    k, dbc = load_db(db)
+    cnames, cid, start, code, group = load_loc(loc)
+    t = Table(k, dbc, code, cid, group)
+    names, seqs = parse_reads(reads)
+    out, code_rc = [], 0
+    for c in range(nchunks):
+        buf, off = concat_reads(seqs[c::nchunks])
+        rc, hits, _, _ = t.tag(buf, off)
+        out.append(format_sunkpos(hits, names[c::nchunks], cnames, cid, start, group))
+        code_rc = code_rc or (1 if rc == -2 else 0)
+    return code_rc, "".join(out)
+
+
 def format_sunkpos(hits, names, cnames, cid, start, group) -> str:
     """kmerpos_annot3.nim:93: name, i, chrom, start, group."""
     return "".join(f"{names[h['read']]}\t{h['pos']}\t{cnames[cid[h['row']]]}\t{start[h['row']]}\t{group[h['row']]}\n"

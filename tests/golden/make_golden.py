@@ -97,6 +97,45 @@ class Case:
         assert rcode == 0, err
         self.meta.setdefault("diag", []).append({"sunkpos": sunkpos, "fai": fai, "out": out, "out2": out2})
 
+    def tag_chunked(self, reads: str, nchunks: int, out: str, db: str = "db", loc: str = "loc"):
+        """What the workflow does with a haplotype's reads (tagONT.smk:2-37,112-131): cut them into `nchunks` files record by
+        record (`rustybam fastq-split` deals records round-robin -- third-party, not in this image: believed), run
+        the reference tagger on every file, concatenate the outputs in scatter order."""
+        data = gzip.open(self.p(reads), "rb").read() if reads.endswith(".gz") else open(self.p(reads), "rb").read()
+        lines = data.split(b"\n")
+        recs, cur = [], []
+        fastq = data[:1] == b"@"
+        i = 0
+        while i < len(lines):
+            if fastq:
+                if lines[i][:1] == b"@" and i + 3 < len(lines) + 1:
+                    recs.append(b"\n".join(lines[i:i + 4]) + b"\n")
+                    i += 4
+                    continue
+                i += 1
+            else:
+                if lines[i][:1] == b">":
+                    if cur:
+                        recs.append(b"\n".join(cur) + b"\n")
+                    cur = [lines[i]]
+                elif cur and lines[i]:
+                    cur.append(lines[i])
+                i += 1
+        if cur and not fastq:
+            recs.append(b"\n".join(cur) + b"\n")
+        parts = []
+        with tempfile.TemporaryDirectory() as t:
+            for c in range(nchunks):
+                f = os.path.join(t, f"chunk{c}.{'fq' if fastq else 'fa'}")
+                open(f, "wb").write(b"".join(recs[c::nchunks]))
+                o = os.path.join(t, f"chunk{c}.sunkpos")
+                rcode, err = run([os.path.join(BIN, "kmerpos_annot3"), f, self.p(db), self.p(loc), o])
+                assert rcode == 0, err
+                parts.append(open(o, "rb").read())
+        open(self.p(out), "wb").write(b"".join(parts))
+        self.meta.setdefault("tag_chunked", []).append({"reads": reads, "db": db, "loc": loc, "nchunks": nchunks, "out": out,
+                                                        "records": len(recs)})
+
     def finish(self):
         with open(self.p("case.json"), "w") as fh:
             json.dump(self.meta, fh, indent=1, sort_keys=True)
@@ -129,6 +168,8 @@ def case_kat1(root):
     assert c.tag("reads.fq", out="expected_fq.sunkpos") == 0
     assert c.tag("reads.fq.gz", out="expected_fqgz.sunkpos") == 0
     c.rlen("reads.fa")
+    c.tag_chunked("reads.fa", 2, "expected_chunks2.sunkpos")  # r4 and r5 part ways: r5 no longer vanishes
+    c.tag_chunked("reads.fa", 3, "expected_chunks3.sunkpos")
     c.meta["k"] = k
     c.finish()
 
@@ -318,6 +359,7 @@ def case_multi(root, k):
     assert c.tag("reads.fa") == 0
     assert c.tag("reads.fq.gz", out="expected_fqgz.sunkpos") == 0
     c.rlen("reads.fa")
+    c.tag_chunked("reads.fa", 4, "expected_chunks4.sunkpos")
     c.diag("expected.sunkpos", "fai")
     for f in ("db", "loc"):
         gz_write(c.p(f + ".gz"), open(c.p(f), "rb").read())
@@ -354,6 +396,7 @@ def case_amy(root):
     gz_write(c.p("reads.fq.gz"), buf)
     assert c.tag("reads.fq.gz") == 0
     c.rlen("reads.fq.gz")
+    c.tag_chunked("reads.fq.gz", 10, "expected_chunks10.sunkpos")  # the workflow's default nchunks (Snakefile:23-24)
     c.diag("expected.sunkpos", "fai")
     os.remove(c.p("db"))
     os.remove(c.p("loc"))

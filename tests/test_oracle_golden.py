@@ -14,6 +14,17 @@ def test_tagger_matches_reference_binary(golden, name):
         assert txt == c.text(run["out"]), f"{name}: {run['reads']}"
 
 
+@pytest.mark.parametrize("name", ["kat1", "multi_k20", "multi_k25", "amy"])
+def test_tagger_per_scatter_chunk_matches_reference_binary(golden, name):
+    """tests/golden/*/expected_chunks<N>.sunkpos: the reference binary run once per scatter chunk (records dealt round-robin,
+    as `rustybam fastq-split` is believed to), outputs concatenated in scatter order (tagONT.smk:2-37,112-131)."""
+    c = golden(name)
+    assert c.meta["tag_chunked"]
+    for run in c.meta["tag_chunked"]:
+        rc, txt = oracle.tag_files_chunked(c.path(run["reads"]), c.path(run["db"]), c.path(run["loc"]), run["nchunks"])
+        assert rc == 0 and txt == c.text(run["out"]) and txt != c.text("expected.sunkpos")
+
+
 def test_tagger_keyerror_exit_code(golden):
     c = golden("kat2_missing")
     run = c.meta["tag"][0]

@@ -79,6 +79,21 @@ def test_cli_in_small_device_batches(golden, name, tmp_path, monkeypatch):
     assert out.read_text() == c.text(run["out"])
 
 
+@pytest.mark.parametrize("name", ["kat1", "multi_k20", "multi_k25", "amy"])
+@pytest.mark.parametrize("batch_bases", [None, "900"])
+def test_cli_emulates_the_workflows_scatter_chunks(golden, name, batch_bases, tmp_path, monkeypatch):
+    """`--emulate-chunks N` on the whole read file = the reference binary run once per scatter chunk, outputs concatenated in
+    scatter order (tests/golden/*/expected_chunks<N>.sunkpos, tagONT.smk:2-37,112-131) -- in one run, and also when the file
+    spans many device batches (every chunk's `prevLoc` is threaded from batch to batch on its own)."""
+    if batch_bases:
+        monkeypatch.setenv("GAVISUNK_BATCH_BASES", batch_bases)
+    c = golden(name)
+    for run in c.meta["tag_chunked"]:
+        out = tmp_path / "out.sunkpos"
+        rc = kmerpos_annot3.main([c.path(run["reads"]), c.path(run["db"]), c.path(run["loc"]), str(out), "--emulate-chunks", str(run["nchunks"])])
+        assert rc == 0 and out.read_text() == c.text(run["out"]), f"{name}: {run['nchunks']} chunks"
+
+
 @pytest.mark.parametrize("k", [11, 16, 18, 20, 21, 25, 31, 32])
 @pytest.mark.parametrize("seed", [1, 2])
 def test_random_inputs_match_oracle(k, seed):
