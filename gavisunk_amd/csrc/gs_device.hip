@@ -1856,6 +1856,83 @@ __global__ void k_compact_insert64(unsigned long long *slots, uint32_t *slot_pay
     overflow_list[atomicAdd(overflow, 1ULL)] = (uint32_t)i;
 }
 
+// Deterministic compact-table build (what gs_table_create runs): the keys are sorted by home bucket (stable radix sort, so the
+// caller's order breaks ties), a key's rank in its bucket comes from its neighbours, and the second-chance buckets are filled
+// in a second sorted pass with whatever the home keys left free.  No race decides which keys are displaced: the same input
+// gives the same table and the same overflow keys every time (the CAS kernels above remain as the concurrent form).
+struct CompactGeom {
+    int k, qb, rembits, locbits, has_flag;
+};
+__device__ __forceinline__ uint64_t compact_home(uint64_t c, const CompactGeom &g, BucketRem &br) {
+    const int kbits = 2 * g.k - 4;
+    br = hmix2((c >> 4) & ((1ULL << kbits) - 1ULL), kbits, g.qb);
+    return ((uint64_t)part_of(c, g.k) << g.qb) + br.bucket;
+}
+__global__ void k_compact_home_ids(const uint64_t *keys, uint64_t n, CompactGeom g, uint64_t *home) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    BucketRem br;
+    home[i] = compact_home(keys[i], g, br);
+}
+// pass 1 over the keys sorted by home bucket: ranks 0..3 take the bucket's slots, the others are left over (flag = 1)
+template <typename SlotT>
+__global__ void k_compact_place_home(SlotT *slots, uint32_t *slot_payload, uint8_t *home_count, CompactGeom g, const uint64_t *keys,
+                                     const uint32_t *loc, const uint32_t *payload, const uint64_t *home_sorted,
+                                     const uint32_t *idx_sorted, uint64_t n, uint8_t *left_flag) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t b = home_sorted[p];
+    uint32_t rank = 0;
+    while (rank < 4u && p > rank && home_sorted[p - 1 - rank] == b) rank++;
+    left_flag[p] = rank >= 4u ? 1 : 0;
+    if (rank == 0) {
+        uint32_t len = 1;
+        while (len < 4u && p + len < n && home_sorted[p + len] == b) len++;
+        home_count[b] = (uint8_t)len;
+    }
+    if (rank >= 4u) return;
+    const uint32_t i = idx_sorted[p];
+    BucketRem br;
+    compact_home(keys[i], g, br);
+    slots[b * 4 + rank] = ((SlotT)br.rem << g.locbits) | (SlotT)loc[i];
+    slot_payload[b * 4 + rank] = payload[i];
+}
+// the second-chance bucket of every left-over key (keys without one sort last)
+__global__ void k_compact_alt_ids(const uint64_t *keys, const uint32_t *left_idx, uint64_t n_left, CompactGeom g, uint64_t *alt) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_left) return;
+    BucketRem br;
+    const uint64_t home = compact_home(keys[left_idx[j]], g, br);
+    alt[j] = g.has_flag ? (home - br.bucket) + alt_bucket(br.bucket, br.rem, g.qb) : 0xFFFFFFFFull;
+}
+// pass 2 over the left-over keys sorted by second-chance bucket: they take the slots the home keys left free, in order
+template <typename SlotT>
+__global__ void k_compact_place_alt(SlotT *slots, uint32_t *slot_payload, const uint8_t *home_count, CompactGeom g,
+                                    const uint64_t *keys, const uint32_t *loc, const uint32_t *payload, const uint64_t *alt_sorted,
+                                    const uint32_t *idx_sorted, uint64_t n_left, unsigned long long *overflow, uint32_t *overflow_list) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_left) return;
+    const uint64_t a = alt_sorted[p];
+    const uint32_t i = idx_sorted[p];
+    BucketRem br;
+    const uint64_t home = compact_home(keys[i], g, br);
+    constexpr int kTop = 8 * (int)sizeof(SlotT) - 1;
+    if (g.has_flag) {
+        uint32_t rank = 0;
+        while (rank < 4u && p > rank && alt_sorted[p - 1 - rank] == a) rank++;
+        const uint32_t used = home_count[a];  // 0 for a bucket without home keys (the array starts zeroed)
+        if (used + rank < 4u) {
+            const SlotT v = ((SlotT)br.rem << g.locbits) | (SlotT)loc[i] | ((SlotT)1 << (g.rembits + g.locbits));
+            slots[a * 4 + used + rank] = v;
+            slot_payload[a * 4 + used + rank] = payload[i];
+            atomicOr(slots + home * 4, (SlotT)1 << kTop);  // "a key of this bucket lives in its second-chance bucket"
+            return;
+        }
+        atomicOr(slots + home * 4, (SlotT)1 << (kTop - 1));  // "... lives in the generic table only"
+    }
+    overflow_list[atomicAdd(overflow, 1ULL)] = i;
+}
+
 // generic-table insert of a subset of the keys (those the compact table could not take)
 __global__ void k_table_insert_list(Slot *slots, uint64_t mask, int shift, const uint64_t *keys, const uint32_t *loc,
                                     const uint32_t *payload, const uint32_t *list, uint64_t n_list) {
@@ -2383,9 +2460,19 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
             return rc;
         HIP_TRY(hipMemsetAsync(t->mz_regions, 0xFF, nslots * sizeof(unsigned long long), t->stream));
         HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
-        hipLaunchKernelGGL(k_mz_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream,
-                           reinterpret_cast<unsigned long long *>(t->mz_regions), t->mz_pay, t->mz_n_regions, k, t->mz_m, t->mz_locbits,
-                           dk, dl, dp, n, dov, dlist, ocap);
+        {  // keys sorted by region, stable (rocPRIM radix sort on the 32 region bits; a key's index rides along)
+            DevBufs st;
+            uint64_t *reg0 = nullptr, *reg1 = nullptr;
+            uint32_t *idx0 = nullptr, *idx1 = nullptr;
+            if ((rc = st.get(&reg0, n)) || (rc = st.get(&reg1, n)) || (rc = st.get(&idx0, n)) || (rc = st.get(&idx1, n))) return rc;
+            const unsigned nb = (unsigned)((n + 255) / 256);
+            hipLaunchKernelGGL(k_mz_regions, dim3(nb), dim3(256), 0, t->stream, dk, n, k, t->mz_m, t->mz_n_regions, reg0);
+            hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, t->stream, idx0, n);
+            if ((rc = sort_pairs_u64_u32(reg0, reg1, idx0, idx1, n, 32, t->stream))) return rc;
+            hipLaunchKernelGGL(k_mz_place, dim3(nb), dim3(256), 0, t->stream, reinterpret_cast<unsigned long long *>(t->mz_regions),
+                               t->mz_pay, k, t->mz_locbits, dk, dl, dp, (const uint64_t *)reg1, (const uint32_t *)idx1, n, dov, dlist, ocap);
+            HIP_TRY(hipStreamSynchronize(t->stream));
+        }
         unsigned long long ov = 0;
         HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
@@ -2409,13 +2496,46 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
         if ((rc = dev_alloc(&t->cpayload, nslots)) || (rc = tmp.get(&dov, 1)) || (rc = tmp.get(&dlist, n))) return rc;
         HIP_TRY(hipMemsetAsync(d, 0xFF, slot_words * sizeof(uint32_t), t->stream));
         HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
-        if (t->c_w64)
-            hipLaunchKernelGGL(k_compact_insert64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream,
-                               reinterpret_cast<unsigned long long *>(d), t->cpayload, k, t->c_qb, t->c_rembits, t->c_locbits, dk,
-                               dl, dp, n, dov, dlist);
-        else
-            hipLaunchKernelGGL(k_compact_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, d, t->cpayload, k,
-                               t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, dk, dl, dp, n, dov, dlist);
+        {
+            const CompactGeom g{k, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag};
+            const uint64_t nbuckets = (uint64_t)kNPart << t->c_qb;
+            DevBufs st;
+            uint64_t *id0 = nullptr, *id1 = nullptr;
+            uint32_t *ix0 = nullptr, *ix1 = nullptr, *left = nullptr;
+            uint8_t *hcount = nullptr, *lflag = nullptr;
+            unsigned long long *dnl = nullptr;
+            if ((rc = st.get(&id0, n)) || (rc = st.get(&id1, n)) || (rc = st.get(&ix0, n)) || (rc = st.get(&ix1, n)) ||
+                (rc = st.get(&left, n)) || (rc = st.get(&hcount, nbuckets)) || (rc = st.get(&lflag, n)) || (rc = st.get(&dnl, 1)))
+                return rc;
+            const unsigned nb = (unsigned)((n + 255) / 256);
+            HIP_TRY(hipMemsetAsync(hcount, 0, nbuckets, t->stream));
+            hipLaunchKernelGGL(k_compact_home_ids, dim3(nb), dim3(256), 0, t->stream, dk, n, g, id0);
+            hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, t->stream, ix0, n);
+            if ((rc = sort_pairs_u64_u32(id0, id1, ix0, ix1, n, 4 + t->c_qb, t->stream))) return rc;
+            if (t->c_w64)
+                hipLaunchKernelGGL((k_compact_place_home<unsigned long long>), dim3(nb), dim3(256), 0, t->stream,
+                                   reinterpret_cast<unsigned long long *>(d), t->cpayload, hcount, g, dk, dl, dp, (const uint64_t *)id1,
+                                   (const uint32_t *)ix1, n, lflag);
+            else
+                hipLaunchKernelGGL((k_compact_place_home<uint32_t>), dim3(nb), dim3(256), 0, t->stream, d, t->cpayload, hcount, g, dk, dl,
+                                   dp, (const uint64_t *)id1, (const uint32_t *)ix1, n, lflag);
+            // the left-over keys, in sorted order (stable selection), then sorted by their second-chance bucket
+            uint64_t n_left = 0;
+            if ((rc = select_flagged_u32(ix1, lflag, left, dnl, n, &n_left, t->stream))) return rc;
+            if (n_left) {
+                const unsigned nbl = (unsigned)((n_left + 255) / 256);
+                hipLaunchKernelGGL(k_compact_alt_ids, dim3(nbl), dim3(256), 0, t->stream, dk, (const uint32_t *)left, n_left, g, id0);
+                if ((rc = sort_pairs_u64_u32(id0, id1, left, ix0, n_left, 33, t->stream))) return rc;
+                if (t->c_w64)
+                    hipLaunchKernelGGL((k_compact_place_alt<unsigned long long>), dim3(nbl), dim3(256), 0, t->stream,
+                                       reinterpret_cast<unsigned long long *>(d), t->cpayload, (const uint8_t *)hcount, g, dk, dl, dp,
+                                       (const uint64_t *)id1, (const uint32_t *)ix0, n_left, dov, dlist);
+                else
+                    hipLaunchKernelGGL((k_compact_place_alt<uint32_t>), dim3(nbl), dim3(256), 0, t->stream, d, t->cpayload,
+                                       (const uint8_t *)hcount, g, dk, dl, dp, (const uint64_t *)id1, (const uint32_t *)ix0, n_left, dov, dlist);
+            }
+            HIP_TRY(hipStreamSynchronize(t->stream));
+        }
         unsigned long long ov = 0;
         HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));

@@ -101,35 +101,41 @@ __host__ __device__ __forceinline__ uint32_t mz_minimizer(uint64_t c, int k, int
 }
 
 // ------------------------------------------------------------------------------------------
-// build: one thread per key; the region's count byte hands out the slots in arrival order
+// build, deterministic: the keys are sorted by region (stable radix sort: inside a region they keep the caller's order), then
+// every key knows its rank in its region from its neighbours: the first 7 take the slots in that order, the others stay in the
+// generic table.  No atomics on the table, and the same input gives the same bytes and the same overflow keys every time.
 // ------------------------------------------------------------------------------------------
-__global__ void k_mz_insert(unsigned long long *slots, uint32_t *pay, uint32_t n_regions, int k, int m, int locbits,
-                            const uint64_t *keys, const uint32_t *loc, const uint32_t *payload, uint64_t n,
-                            unsigned long long *overflow, uint32_t *overflow_list, uint64_t overflow_cap) {
+__global__ void k_mz_regions(const uint64_t *keys, uint64_t n, int k, int m, uint32_t n_regions, uint64_t *reg) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t c = keys[i];
-    const uint32_t reg = mz_region(mz_minimizer(c, k, m), n_regions);
-    const MzKey key = mz_key(c, k);
-    unsigned long long *base = slots + (uint64_t)reg * kMzWords;
-    uint32_t *fpw = reinterpret_cast<uint32_t *>(base);  // the two 32-bit halves of the fingerprint word
-    uint32_t old = fpw[0], cnt;
-    for (;;) {
-        cnt = 0xFFu - (old & 0xFFu);
-        if (cnt >= (uint32_t)kMzSlots) break;
-        const uint32_t seen = atomicCAS(fpw, old, old - 1u);
-        if (seen == old) break;
-        old = seen;
-    }
-    if (cnt >= (uint32_t)kMzSlots) {  // the region is full: the key stays in the generic table
+    if (i < n) reg[i] = mz_region(mz_minimizer(keys[i], k, m), n_regions);
+}
+
+__global__ void k_mz_place(unsigned long long *slots, uint32_t *pay, int k, int locbits, const uint64_t *keys, const uint32_t *loc,
+                           const uint32_t *payload, const uint64_t *reg_sorted, const uint32_t *idx_sorted, uint64_t n,
+                           unsigned long long *overflow, uint32_t *overflow_list, uint64_t overflow_cap) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t reg = reg_sorted[p];
+    uint32_t rank = 0;  // keys of this region before this one, counted up to a full region
+    while (rank < (uint32_t)kMzSlots && p > rank && reg_sorted[p - 1 - rank] == reg) rank++;
+    const uint32_t i = idx_sorted[p];
+    if (rank >= (uint32_t)kMzSlots) {  // the region is full: the key stays in the generic table
         const unsigned long long o = atomicAdd(overflow, 1ULL);
-        if (o < overflow_cap) overflow_list[o] = (uint32_t)i;
+        if (o < overflow_cap) overflow_list[o] = i;
         return;
     }
-    const uint32_t slot = 1u + cnt;
+    const MzKey key = mz_key(keys[i], k);
+    unsigned long long *base = slots + reg * kMzWords;
+    const uint32_t slot = 1u + rank;
     base[slot] = (key.tag << locbits) | (unsigned long long)loc[i];
-    pay[(uint64_t)reg * kMzWords + slot] = payload[i];
-    atomicAnd(fpw + (slot >> 2), ~(0xFFu << (8u * (slot & 3u))) | (key.fp << (8u * (slot & 3u))));
+    pay[reg * kMzWords + slot] = payload[i];
+    uint8_t *fpb = reinterpret_cast<uint8_t *>(base);
+    fpb[slot] = (uint8_t)key.fp;
+    if (rank == 0) {  // the count byte: 0xFF - keys stored
+        uint32_t len = 1;
+        while (len < (uint32_t)kMzSlots && p + len < n && reg_sorted[p + len] == reg) len++;
+        fpb[0] = (uint8_t)(0xFFu - len);
+    }
 }
 
 // bit 7 of every byte of x that equals the byte replicated in T (exact: no borrow between bytes)

@@ -300,6 +300,28 @@ int check_define_args(const char *who, int device, int k, uint32_t n_contigs, co
 
 }  // namespace
 
+int gs::select_flagged_u32(const uint32_t *in, const uint8_t *flag, uint32_t *out, unsigned long long *d_count, uint64_t n,
+                           uint64_t *n_out, void *stream) {
+    *n_out = 0;
+    if (!n) return GS_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    size_t tb = 0;
+    HIP_TRY(rocprim::select(nullptr, tb, in, flag, out, d_count, n, st));
+    void *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+    hipError_t e = rocprim::select(tmp, tb, in, flag, out, d_count, n, st);
+    unsigned long long cnt = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) {
+        set_error("select failed: %s", hipGetErrorString(e));
+        return GS_E_NODEVICE;
+    }
+    *n_out = cnt;
+    return GS_OK;
+}
+
 extern "C" {
 
 void gs_sunkset_dev_free(gs_sunkset_dev *s) {

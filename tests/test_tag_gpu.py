@@ -366,6 +366,31 @@ def test_join_overflow_lists_longer_than_lds_are_searched_in_hbm(monkeypatch, ta
     assert gh["pos"][0] == oh["pos"][0] and gh["payload"][0] == oh["row"][0]
 
 
+def test_table_build_is_deterministic(table_layout, monkeypatch):
+    """Tables are built from stable sorts (by minimiser region / by home bucket, then by second-chance bucket): the same keys
+    give the same overflow keys -- the ones a crowded region or bucket could not take -- every time, whatever the GPU's
+    scheduling did.  (An undersized compact table makes sure there are many of them.)"""
+    if table_layout in ("generic", "minimizer-exact"):
+        pytest.skip("nothing to overflow")
+    if table_layout != "minimizer":
+        monkeypatch.setenv("GAVISUNK_COMPACT_QB", "9")
+    keys, loc, seqs = _random_case(57, 20, n_reads=30, glen=300000, median=3000)
+    loc = (loc % 7).astype(np.uint32)
+    seen, hits = set(), []
+    for _ in range(4):
+        tab = engine.DeviceTable(20, keys, loc, np.arange(len(keys), dtype=np.uint32))
+        seen.add(tab.layout)
+        dev = engine.DeviceReads(engine.ReadBatch.from_ascii(seqs), 20)
+        st, h, _, _ = engine.tag(tab, dev)
+        hits.append(h)
+        dev.close()
+        tab.close()
+    assert len(seen) == 1 and int(next(iter(seen)).split("), ")[-1].split(" overflow")[0]) > 100
+    assert all(np.array_equal(h, hits[0]) for h in hits[1:])
+    rc, oh, _, _ = _oracle_hits(20, keys, loc, seqs)
+    assert len(oh) == len(hits[0]) and np.array_equal(hits[0]["pos"], oh["pos"]) and np.array_equal(hits[0]["payload"], oh["row"])
+
+
 def test_table_without_keys():
     st, h, carry, ctr = _engine_hits(20, np.zeros(0, np.uint64), np.zeros(0, np.uint32), [b"ACGT" * 100, b""])
     assert st == 0 and len(h) == 0 and carry == _lib.GS_NONE and ctr["raw_hits"] == 0
