@@ -2588,7 +2588,9 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
         }
     }
     int lg;
-    t->cap = pow2_cap(2 * n_generic, lg);
+    // (behind a minimiser-addressed table the generic slots are probed by deferred lookups, most of which miss: a load of 1/4
+    // keeps such a probe at ~1.2 requests)
+    t->cap = pow2_cap((t->mz ? 4 : 2) * n_generic, lg);
     t->shift = 64 - lg;
     if ((rc = dev_alloc(&t->slots, t->cap))) return rc;
     hipLaunchKernelGGL(k_table_fill, dim3((unsigned)((t->cap + 255) / 256)), dim3(256), 0, t->stream, t->slots, t->cap);

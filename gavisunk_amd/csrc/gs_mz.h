@@ -19,7 +19,7 @@
 //   tag     = (l & 0x1FFFFFFF) << (2k - 32) | hi                                                    2k - 3 bits
 //
 //   region  = 64 bytes = 8 words of 64 bits: word 0 = 8 fingerprint bytes, words 1..7 = slots
-//             byte 0      0xFF - (keys in the region): a region is full at 7
+//             byte 0      0xFF - (keys of the region), counted up to 8 = "one more than fits": some live in the generic table
 //             byte i      fingerprint of slot i (i = 1..7), 0xFF = empty
 //             word i      tag << locbits | loc            (all ones = empty; the all-ones loc is never stored)
 //
@@ -131,9 +131,9 @@ __global__ void k_mz_place(unsigned long long *slots, uint32_t *pay, int k, int 
     pay[reg * kMzWords + slot] = payload[i];
     uint8_t *fpb = reinterpret_cast<uint8_t *>(base);
     fpb[slot] = (uint8_t)key.fp;
-    if (rank == 0) {  // the count byte: 0xFF - keys stored
+    if (rank == 0) {  // the count byte: 0xFF - keys of the region, counted up to kMzSlots + 1 (= some of them did not fit)
         uint32_t len = 1;
-        while (len < (uint32_t)kMzSlots && p + len < n && reg_sorted[p + len] == reg) len++;
+        while (len <= (uint32_t)kMzSlots && p + len < n && reg_sorted[p + len] == reg) len++;
         fpb[0] = (uint8_t)(0xFFu - len);
     }
 }
@@ -164,7 +164,8 @@ __device__ __forceinline__ MzCand mz_candidates(uint64_t F, uint32_t fp) {
     c.m1 = mz_byte_eq((uint32_t)(F >> 32), T);
     return c;
 }
-__device__ __forceinline__ bool mz_region_full(uint64_t F) { return ((uint32_t)F & 0xFFu) <= 0xFFu - (uint32_t)kMzSlots; }
+// some key of this region lives in the generic table only (the count byte says "more than kMzSlots")
+__device__ __forceinline__ bool mz_region_overflowed(uint64_t F) { return ((uint32_t)F & 0xFFu) == 0xFFu - (uint32_t)(kMzSlots + 1); }
 
 // payload of a key that is known to be in the table (k_emit, one emitted row at a time)
 __device__ __forceinline__ uint32_t mz_payload(const MzView &mz, const TableView &tab, uint64_t c) {
@@ -301,7 +302,7 @@ __device__ __forceinline__ MzTileOut mz_tile(const MzView &mz, const TableView &
                     }
                 }
             }
-            if (valid[u] && !hit && mz_region_full(Fw)) {  // the region is full and no key of it is this one: the generic table
+            if (valid[u] && !hit && mz_region_overflowed(Fw)) {  // the region is full and no key of it is this one: the generic table
                 const MzWin ww = mz_window(W0, W1, (int)s, lane, k, m, kmask, mmask);
                 const uint64_t c = ww.f < ww.r ? ww.f : ww.r;
                 uint64_t hh = slot_of(c, tab.shift);
@@ -390,8 +391,8 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 //            run by LDS-DMA (global_load_lds_dwordx4): 4 lanes x 16 bytes per run, 16 runs per wave-instruction (runs
 //            past the last one repeat it: same line, no new request).  One request per run is what the fabric sees.
 //   consume  (kMzStages - 1 steps later, behind a counted vmcnt) a window reads its region's fingerprint word from LDS,
-//            then the slots whose fingerprint matches.  Outcome: hit (loc), miss, or -- 7 keys in the region and none is
-//            it -- "ask the generic table", which is deferred: such a window takes a place in the tile's hit list like a
+//            then the slots whose fingerprint matches.  Outcome: hit (loc), miss, or -- the region's count byte says that keys
+//            of it did not fit (mz_region_overflowed) and none of its 7 is this one -- "ask the generic table", which is deferred: such a window takes a place in the tile's hit list like a
 //            hit does.  A step with more than kMzRunCap runs (rare) is consumed in two halves, the second fetched on the spot.
 //   after the last step: the deferred lookups of the tile go to the generic table 64 at a time (their latencies overlap),
 //            then one ordered pass over the hit list does the tile's bookkeeping exactly as mz_tile does.
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
                 }
             }
         }
-        const bool defer = mine && !hit && mz_region_full(F);  // generic table, after the last step
+        const bool defer = mine && !hit && mz_region_overflowed(F);  // generic table, after the last step
         const bool mb_mine = hit || defer;
         const unsigned long long mb = __ballot(mb_mine), db = __ballot(defer);
         if (mb) {
