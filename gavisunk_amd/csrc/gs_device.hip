@@ -2627,6 +2627,62 @@ int gs_device_synchronize(int device) {
     return GS_OK;
 }
 
+int gs_selftest_minimizer_rule(int device, int k, int m, uint64_t seed, uint32_t n_tiles, uint64_t *mismatches, uint32_t first_bad[4],
+                               uint32_t lane_hist[64]) {
+    if (!mismatches || !first_bad || k < 16 || k > 32 || m < 8 || m > k || m > 31 || k - m > 7 || !n_tiles || n_tiles > (1u << 20)) {
+        set_error("gs_selftest_minimizer_rule: bad argument (16 <= k <= 32, max(8, k - 7) <= m <= min(k, 31), 1 .. 2^20 tiles)");
+        return GS_E_ARG;
+    }
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_selftest_minimizer_rule: HIP device %d not available", device);
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    const size_t nw = (size_t)n_tiles * kTileWords + 4;
+    std::vector<uint64_t> h(nw);
+    uint64_t x = seed;
+    for (size_t i = 0; i < nw; i++) {  // splitmix64; every fourth tile is low-complexity (many equal t-mers: the tie rule)
+        x += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        if ((i / kTileWords) % 4 == 3) z = (z & 0x0303030303030303ULL) * 0x15ULL;  // runs of four equal bases
+        h[i] = z;
+    }
+    uint64_t *d_words = nullptr;
+    unsigned long long *d_mis = nullptr;
+    uint32_t *d_bad = nullptr;
+    HIP_TRY(hipMalloc(&d_words, nw * 8));
+    HIP_TRY(hipMalloc(&d_mis, 8));
+    HIP_TRY(hipMalloc(&d_bad, 4 * 68));
+    HIP_TRY(hipMemcpy(d_words, h.data(), nw * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_mis, 0, 8));
+    HIP_TRY(hipMemset(d_bad, 0, 4 * 68));
+    const dim3 grid(std::min<uint32_t>(n_tiles, 4096u)), block(64);
+#define GS_CHECK_MZ(KT, MT) hipLaunchKernelGGL((k_mz_rule_check<KT, MT>), grid, block, 0, 0, k, m, d_words, n_tiles, d_mis, d_bad)
+    if (k == 20 && m == 16)
+        GS_CHECK_MZ(20, 16);
+    else if (k == 20 && m == 17)
+        GS_CHECK_MZ(20, 17);
+    else if (k == 20 && m == 18)
+        GS_CHECK_MZ(20, 18);
+    else
+        GS_CHECK_MZ(0, 0);
+#undef GS_CHECK_MZ
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long mis = 0;
+    HIP_TRY(hipMemcpy(&mis, d_mis, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(first_bad, d_bad, 16, hipMemcpyDeviceToHost));
+    if (lane_hist) HIP_TRY(hipMemcpy(lane_hist, d_bad + 4, 4 * 64, hipMemcpyDeviceToHost));
+    *mismatches = mis;
+    HIP_TRY(hipFree(d_words));
+    HIP_TRY(hipFree(d_mis));
+    HIP_TRY(hipFree(d_bad));
+    return GS_OK;
+}
+
 int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const uint32_t *loc, const uint32_t *payload,
                     gs_table **out) {
     if (!out || k < 1 || k > 32 || (n && (!keys || !loc || !payload)) || n > 0xFFFFFFF0ull) {

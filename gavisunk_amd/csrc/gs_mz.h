@@ -8,12 +8,20 @@
 // 47 G lines/s x L windows (L = 3: 142, L = 4: 186, L = 6: 270 G windows/s).  Since requests, not bytes, are what is
 // scarce first, a region is 64 bytes: half a line, half the HBM traffic and half the LDS of a 128-byte one.
 //
-// So (1) a lane is a WINDOW (consecutive lanes = consecutive windows of a read), and (2) the 128-byte region a k-mer lives
-// in is chosen by its MINIMISER -- the smallest hash among the canonical m-mers inside it -- which consecutive windows
-// share ((w + 1) / 2 of them on average, w = k - m + 1).  A region is fetched ONCE per run of windows, whole, into LDS.
+// So (1) a lane is a WINDOW (consecutive lanes = consecutive windows of a read), and (2) the 64-byte region a k-mer lives
+// in is chosen by one of the w = k - m + 1 m-mers inside it, picked so that consecutive windows mostly pick the SAME m-mer.
+// A region is fetched ONCE per run of windows, whole, into LDS.  The pick is the mod-minimiser rule (Groot Koerkamp &
+// Pibiri 2024): look for the smallest short t-mer of the k-mer (t = 5 .. 5 + w - 1, t = m mod w; there are k - t + 1 of them, a
+// multiple of w), at position x, and take the m-mer at position x mod w.  The smallest t-mer stays the same over ~k - t
+// windows while x mod w walks with the windows: runs of 1 / 0.31 = 3.2 windows for k = 20, m = 17, where the plain
+// minimiser (smallest m-mer hash) gives 2.5 -- a fifth fewer requests on the same table geometry.  Everything is canonical
+// (a t-mer or m-mer counts as the smaller of itself and its reverse complement) and ties go to the leftmost t-mer of the
+// k-mer IN ITS CANONICAL ORIENTATION, so both strands of a k-mer pick the same m-mer (k - t + 1 = 0 mod w makes x mod w
+// mirror correctly).
 //
-//   H       = min over the w m-mers of the k-mer of mix_a(min(m-mer, its reverse complement))     strand-symmetric
-//   region  = mul_hi(mix_b(H), n_regions)                                                          128 bytes each
+//   x       = leftmost argmin over the k - t + 1 t-mers of the canonical k-mer of (t-mer or its rc, the smaller) * c >> 23
+//   H       = mix_a(min(m-mer at x mod w, its reverse complement))                                 strand-symmetric
+//   region  = mul_hi(H, n_regions)                                                                 64 bytes each
 //   l | hi  = mix_a(low 32 bits of the canonical code) ^ mix_b(high bits), high bits               a bijection
 //   fp      = min(l >> 24, 0xFE)                                                                    fingerprint byte
 //   tag     = (l & 0x1FFFFFFF) << (2k - 32) | hi                                                    2k - 3 bits
@@ -78,26 +86,38 @@ __host__ __device__ __forceinline__ MzKey mz_key(uint64_t c, int k) {
     o.tag = ((uint64_t)(l & 0x1FFFFFFFu) << (2 * k - 32)) | (uint64_t)hi;  // k = 16: hi = 0, no shift
     return o;
 }
-__host__ __device__ __forceinline__ uint32_t mz_region(uint32_t H, uint32_t n_regions) {
-    return (uint32_t)(((uint64_t)mz_mix_b(H) * (uint64_t)n_regions) >> 32);
+__host__ __device__ __forceinline__ uint32_t mz_region(uint32_t H, uint32_t n_regions) {  // H: a hash already
+    return (uint32_t)(((uint64_t)H * (uint64_t)n_regions) >> 32);
 }
 // hash of a canonical m-mer (m <= 31); for m <= 16 the high word is 0 and mz_mix_b(0) = 0: a bijection of the m-mer
 __host__ __device__ __forceinline__ uint32_t mz_mmer_hash(uint64_t cm) { return mz_mix_a((uint32_t)cm ^ mz_mix_b((uint32_t)(cm >> 32))); }
-// minimiser hash of a k-mer code (either strand gives the same value); build side and slow paths
+// the mod-minimiser rule: length of the short t-mers whose minimum anchors the pick (t = m mod w, 5 <= t <= 12), their
+// order (9 bits: with the 7-bit position it fills the 16-bit halves the sliding minimum of k_probe_mz works on)
+__host__ __device__ constexpr int mz_t_of(int k, int m) { return 5 + (m - 5) % (k - m + 1); }
+__host__ __device__ __forceinline__ uint32_t mz_tmer_order(uint32_t ct) { return (ct * 0x9E3779B1u) >> 23; }
+// region hash of a k-mer from its CANONICAL code (so either strand of a k-mer gives the same value); build side and slow paths
 __host__ __device__ __forceinline__ uint32_t mz_minimizer(uint64_t c, int k, int m) {
     uint64_t r = 0, x = c;
     for (int i = 0; i < k; i++) {
         r = (r << 2) | (3ULL - (x & 3ULL));
         x >>= 2;
     }
-    const uint64_t mmask = (1ULL << (2 * m)) - 1ULL;
-    uint32_t H = 0xFFFFFFFFu;
-    for (int j = 0; j <= k - m; j++) {
-        const uint64_t fm = (c >> (2 * (k - m - j))) & mmask, rm = (r >> (2 * j)) & mmask;
-        const uint32_t h = mz_mmer_hash(fm < rm ? fm : rm);
-        H = h < H ? h : H;
+    const int w = k - m + 1, t = mz_t_of(k, m), nt = k - t + 1;
+    const uint32_t tmask = (1u << (2 * t)) - 1u;
+    uint32_t best = 0xFFFFFFFFu;
+    int at = 0;
+    for (int j = 0; j < nt; j++) {  // c is the canonical strand: leftmost minimum in canonical orientation
+        const uint32_t ft = (uint32_t)(c >> (2 * (k - t - j))) & tmask, rt = (uint32_t)(r >> (2 * j)) & tmask;
+        const uint32_t o = mz_tmer_order(ft < rt ? ft : rt);
+        if (o < best) {
+            best = o;
+            at = j;
+        }
     }
-    return H;
+    const int p = at % w;
+    const uint64_t mmask = (1ULL << (2 * m)) - 1ULL;
+    const uint64_t fm = (c >> (2 * (k - m - p))) & mmask, rm = (r >> (2 * p)) & mmask;
+    return mz_mmer_hash(fm < rm ? fm : rm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -202,6 +222,7 @@ __device__ __forceinline__ uint64_t mz_word(uint64_t W0, uint64_t W1, int idx) {
 struct MzWin {
     uint64_t f, r;  // forward code and reverse-complement code of the window that starts at this lane's base
     uint32_t h;     // hash of the canonical m-mer that starts there
+    uint32_t o;     // order (mz_tmer_order) of the canonical t-mer that starts there
 };
 // the window whose first base is base (lane & 31) of the 64-base string a:b
 __device__ __forceinline__ MzWin mz_win_of(uint64_t a, uint64_t b, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
@@ -217,6 +238,10 @@ __device__ __forceinline__ MzWin mz_win_of(uint64_t a, uint64_t b, int lane, int
         const uint64_t fm = o.f >> (2 * (k - m)), rm = o.r & mmask;
         o.h = mz_mmer_hash(fm < rm ? fm : rm);
     }
+    const int t = mz_t_of(k, m);
+    const uint32_t tmask = (1u << (2 * t)) - 1u;
+    const uint32_t ft = (uint32_t)(o.f >> (2 * (k - t))), rt = (uint32_t)o.r & tmask;
+    o.o = mz_tmer_order(ft < rt ? ft : rt);
     return o;
 }
 // step s (wave-uniform, 0..32) of a tile whose 66 words are held as W0 (word = lane) and W1 (word 64 + (lane & 1))
@@ -269,14 +294,9 @@ __device__ __forceinline__ MzTileOut mz_tile(const MzView &mz, const TableView &
             bk[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
             if (s >= nsteps) continue;  // wave-uniform
             const MzWin nxt = mz_window(W0, W1, (int)s + 1, lane, k, m, kmask, mmask);
-            uint32_t H = cur.h, x = cur.h;
-            for (int j = 1; j < w; j++) {
-                x = mz_shift_down(x, lane_value(nxt.h, j - 1));
-                H = min(H, x);
-            }
             const uint64_t c = cur.f < cur.r ? cur.f : cur.r;
             const MzKey key = mz_key(c, k);
-            addr[u] = mz.regions + (uint64_t)mz_region(H, mz.n_regions) * kMzPieces;
+            addr[u] = mz.regions + (uint64_t)mz_region(mz_minimizer(c, k, m), mz.n_regions) * kMzPieces;  // (the rule, lane by lane)
             want[u] = key.tag << locbits;
             fp[u] = key.fp;
             valid[u] = s * 64u + (uint32_t)lane < td.nwin_left;
@@ -453,6 +473,124 @@ __device__ __forceinline__ uint32_t mz_shift_up(uint32_t x, uint32_t fill) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 }
 
+// ---- the sliding leftmost / rightmost minimum over the NT t-mers of every window -----------------------------------------
+// One 32-bit value per t-mer position = two 16-bit halves, order << 7 | position: the low half with the position counted up
+// (its minimum = the leftmost smallest t-mer), the high half with it counted down (the rightmost one); v_pk_min_u16 works on
+// both at once.  Positions are in the frame of a step: lane + 32, so that the step before (-64) and the step after (+64)
+// fit the 7 bits too.  E[T] = minimum over t-mers T - NT + 1 .. T, by doubling (levels of spans 1, 2, 4 ..; lanes are shifted
+// by wave_shr:1 or ds_bpermute), the low lanes taking what they need from the same level of the step before.
+__device__ __forceinline__ uint32_t mz_pk_min(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+constexpr uint32_t kMzPrevFrame = 0x003FFFC0u;  // + : a value of the step before in this step's frame (low half - 64, high + 64)
+constexpr uint32_t kMzNextFrame = 0xFFC00040u;  // + : a value of the step after in this step's frame
+__device__ __forceinline__ uint32_t mz_pk_of(uint32_t order, int lane) {
+    return order * 0x00800080u + (uint32_t)(lane + 32) + ((uint32_t)(95 - lane) << 16);
+}
+constexpr int mz_log2_floor(int x) { return x < 2 ? 0 : 1 + mz_log2_floor(x / 2); }
+
+template <int NT>  // NT > 0: compile-time count of t-mers per window;  NT = 0: taken at run time (shifts of one lane)
+struct MzSlide {
+    static constexpr int L = mz_log2_floor(NT ? NT : 1);
+    static constexpr int kLevels = NT ? L + ((1 << L) != NT ? 1 : 0) : 1;
+    uint32_t b[kLevels];  // inputs of every level, of the step this was last advanced to
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int l = 0; l < kLevels; l++) b[l] = 0xFFFFFFFFu;  // "no step before": never the minimum
+    }
+    // advance to the step whose packed t-mer values are n0: returns its E
+    __device__ __forceinline__ uint32_t advance(uint32_t n0, int lane, int nt_runtime) {
+        uint32_t x = n0;
+        if constexpr (NT == 0) {
+            const uint32_t prev = b[0] + kMzPrevFrame;
+            b[0] = n0;
+            uint32_t y = n0;
+            for (int j = 1; j < nt_runtime; j++) {
+                y = mz_shift_up(y, lane_value(prev, 64 - j));
+                x = mz_pk_min(x, y);
+            }
+        } else {
+#pragma unroll
+            for (int l = 0; l < kLevels; l++) {
+                const int sft = l < L ? (1 << l) : NT - (1 << L);
+                const uint32_t prev = b[l] + kMzPrevFrame;
+                b[l] = x;
+                uint32_t y;
+                if (sft == 1) {
+                    y = mz_shift_up(x, lane_value(prev, 63));
+                } else {
+                    const uint32_t comb = lane >= 64 - sft ? prev : x;
+                    y = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane - sft) & 63) * 4, (int)comb);
+                }
+                x = mz_pk_min(x, y);
+            }
+        }
+        return x;
+    }
+};
+
+// The region hash of the window that starts at this lane in the step `cur` is the window of (e_cur = its E; `nxt` = the
+// step after; the slide is advanced to it).  The smallest t-mer of a window ends nt - 1 positions on (in the next step for
+// the last lanes), leftmost or rightmost as the canonical strand reads; the m-mer at (its offset mod w) is the one.
+template <int WT, int NT>  // WT: w at compile time or 0
+__device__ __forceinline__ uint32_t mz_pick(MzSlide<NT> &slide, uint32_t &e_cur, const MzWin &cur, const MzWin &nxt, bool rc_strand,
+                                           int lane, int w, int nt) {
+    const uint32_t e_nxt = slide.advance(mz_pk_of(nxt.o, lane), lane, nt);
+    const uint32_t ew = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + nt - 1) & 63) * 4,
+                                                               (int)(lane < nt - 1 ? e_nxt + kMzNextFrame : e_cur));
+    e_cur = e_nxt;
+    const uint32_t at = rc_strand ? 95u - ((ew >> 16) & 0x7Fu) : (ew & 0x7Fu) - 32u;  // lane of the chosen t-mer (64.. = next step)
+    const uint32_t xoff = at - (uint32_t)lane;                                          // 0 .. nt - 1
+    const uint32_t pm = WT == 4 ? (xoff & 3u) : xoff % (uint32_t)(WT ? WT : w);
+    // the m-mer hash of lane + pm: of this step, or (last lanes) of the next one
+    const int src = (int)(((uint32_t)lane + pm) & 63u) * 4;
+    const uint32_t h_here = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.h);
+    const uint32_t h_next = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)nxt.h);
+    return (uint32_t)lane + pm < 64u ? h_here : h_next;
+}
+
+// self-test: the sliding pick against the rule applied lane by lane (mz_minimizer), on every window of the given tiles
+template <int KT, int MT>
+__global__ __launch_bounds__(64) void k_mz_rule_check(int k_rt, int m_rt, const uint64_t *__restrict__ words, uint32_t n_tiles,
+                                                      unsigned long long *mismatches, uint32_t *first_bad) {
+    __shared__ uint64_t s_words[kTileWords + 3];
+    const int lane = threadIdx.x;
+    const int k = KT ? KT : k_rt, m = MT ? MT : m_rt, w = k - m + 1;
+    constexpr int NT = KT ? KT - mz_t_of(KT ? KT : 20, KT ? MT : 17) + 1 : 0;
+    const int nt = k - mz_t_of(k, m) + 1;
+    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+    const uint64_t mmask = (1ULL << (2 * m)) - 1ULL;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        s_words[lane] = words[(uint64_t)tile * kTileWords + lane];
+        if (lane < 3) s_words[64 + lane] = words[(uint64_t)tile * kTileWords + 64 + lane];
+        __syncthreads();
+        const uint32_t words_a = lds_addr(&s_words[0]);
+        MzWin cur = mz_window_lds(words_a, 0, lane, k, m, kmask, mmask);
+        MzSlide<NT> slide;
+        slide.reset();
+        uint32_t e_cur = slide.advance(mz_pk_of(cur.o, lane), lane, nt);
+        for (uint32_t s = 0; s < 32u; s++) {
+            const MzWin nxt = mz_window_lds(words_a, s + 1u, lane, k, m, kmask, mmask);
+            const bool rc_strand = cur.r < cur.f;
+            const uint32_t H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
+            const uint32_t want = mz_minimizer(rc_strand ? cur.r : cur.f, k, m);
+            if (H != want) {
+                atomicAdd(&first_bad[4 + lane], 1u);  // per-lane histogram
+                if (atomicAdd(mismatches, 1ULL) == 0ULL) {
+                    first_bad[0] = tile;
+                    first_bad[1] = s * 64u + (uint32_t)lane;
+                    first_bad[2] = H;
+                    first_bad[3] = want;
+                }
+            }
+            cur = nxt;
+        }
+    }
+}
+
 // KT / MT: k and m as compile-time constants (0 = take them from the table)
 template <int KT, int MT>
 __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView tab, const uint64_t *__restrict__ words,
@@ -460,12 +598,16 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
                                                            uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
                                                            uint32_t *g_fallback_tiles) {
     __shared__ MzWaveLds s_lds[kMzWaves];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the wave index through readfirstlane: the compiler then knows that the tile, its descriptor and every loop bound
+    // derived from it are wave-uniform, and keeps them and the control flow on the scalar unit)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t tile = blockIdx.x * (uint32_t)kMzWaves + (uint32_t)wave;
     if (tile >= n_tiles) return;
     MzWaveLds &L = s_lds[wave];
     const TileDesc td = tdesc[tile];
     const int k = KT ? KT : mz.k, m = MT ? MT : mz.m, w = k - m + 1, locbits = mz.locbits;
+    constexpr int NT = KT ? KT - mz_t_of(KT ? KT : 20, KT ? MT : 17) + 1 : 0;
+    const int nt = k - mz_t_of(k, m) + 1;  // t-mers per window
     const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
     const uint64_t mmask = (1ULL << (2 * m)) - 1ULL;
     const uint64_t locmask = (1ULL << locbits) - 1ULL;
@@ -483,6 +625,9 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
     uint32_t meta[kMzStages], runreg[kMzStages], nruns[kMzStages];
     uint64_t want[kMzStages];
     MzWin cur = mz_window_lds(words_a, 0, lane, k, m, kmask, mmask);
+    MzSlide<NT> slide;
+    slide.reset();
+    uint32_t e_cur = slide.advance(mz_pk_of(cur.o, lane), lane, nt);  // E of the step `cur` is the window of
     bool redo = false;  // wave-uniform: a budget was exceeded, the exact form does the tile over
 
     // LDS-DMA wave-instructions that fetch the regions of (the first kMzRunCap of) R runs: 8 runs each
@@ -502,20 +647,9 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
     };
     auto stage = [&](uint32_t s, int slot) {
         const MzWin nxt = mz_window_lds(words_a, s + 1u, lane, k, m, kmask, mmask);
-        uint32_t H = cur.h, x = cur.h;
-        if constexpr (MT != 0) {
-#pragma unroll
-            for (int j = 1; j < KT - MT + 1; j++) {
-                x = mz_shift_down(x, lane_value(nxt.h, j - 1));
-                H = min(H, x);
-            }
-        } else {
-            for (int j = 1; j < w; j++) {
-                x = mz_shift_down(x, lane_value(nxt.h, j - 1));
-                H = min(H, x);
-            }
-        }
-        const uint64_t c = cur.f < cur.r ? cur.f : cur.r;
+        const bool rc_strand = cur.r < cur.f;
+        const uint32_t H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
+        const uint64_t c = rc_strand ? cur.r : cur.f;
         cur = nxt;
         const MzKey key = mz_key(c, k);
         const uint32_t reg = mz_region(H, mz.n_regions);

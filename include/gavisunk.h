@@ -45,6 +45,13 @@ const char *gs_version(void);
 int gs_device_count(void);
 /* hipDeviceSynchronize on `device`: everything the library (or RCCL through gs_comm_*) enqueued there has finished */
 int gs_device_synchronize(int device);
+/* Self-test of the minimiser-addressed table's window -> region rule (gs_mz.h): on `n_tiles` tiles of 2048 windows of
+ * pseudo-random and low-complexity sequence (from `seed`), the wave-parallel sliding form the tagging kernel uses is compared
+ * with the rule applied window by window (the form the table build uses).  *mismatches = windows that differ (0 = pass);
+ * first_bad = {tile, window, got, expected} of one of them; lane_hist (may be NULL) = mismatches by wavefront lane.
+ * No reference counterpart: the table layout is this library's. */
+int gs_selftest_minimizer_rule(int device, int k, int m, uint64_t seed, uint32_t n_tiles, uint64_t *mismatches, uint32_t first_bad[4],
+                               uint32_t lane_hist[64]);
 
 /* ------------------------------------------------------------------------------------------
  * Host-side parsing (native, like the reference's Nim programs).  No GPU needed.
