@@ -426,7 +426,10 @@ constexpr int kMzStages = 2;                   // steps whose region fetches are
 constexpr int kMzListCap = 1280;               // maybe-hits of a tile
 constexpr int kMzDeferCap = 384;               // deferred generic-table lookups of a tile
 constexpr int kMzWaves = 2;                    // waves per workgroup
-constexpr uint32_t kMzPending = 0xFFFFFFFFu;
+constexpr int kMzListLocBits = 21;             // a list entry = window offset in the tile << 21 | loc + 1 (0 = no hit after all)
+constexpr uint32_t kMzListLocMask = (1u << kMzListLocBits) - 1u;
+constexpr uint32_t kMzPending = kMzListLocMask;  // loc field of an entry whose generic-table lookup is still to come
+constexpr int kMzFastLocBits = kMzListLocBits - 1;  // tables with longer loc ids take the exact kernel
 
 struct MzWaveLds {
     uint4 cache[kMzStages][kMzRunCap * kMzPieces];
@@ -666,7 +669,6 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
         fetch(slot, runreg[slot], R, 0u);
     };
 
-    uint32_t maybe = 0;                  // bit s: this lane's window of step s has a place in the hit list
     uint32_t lcount = 0, dcount = 0;     // wave-uniform: entries of the list / of the deferred queue
     // the windows of step s whose run is in [r0, r0 + kMzRunCap): their regions are in cache slot u
     auto lookups = [&](uint32_t s, int u, uint32_t r0) {
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
         if (mb) {
             // (a big step calls this twice, lower lanes first: its entries still land in lane order)
             const uint32_t idx = lcount + (uint32_t)__popcll(mb & lt);
-            if (mb_mine && idx < (uint32_t)kMzListCap) lds_write_b32(list_a + idx * 4u, hit ? (uint32_t)e + 1u : kMzPending);
+            if (mb_mine && idx < (uint32_t)kMzListCap) lds_write_b32(list_a + idx * 4u, ((s * 64u + (uint32_t)lane) << kMzListLocBits) | (hit ? (uint32_t)e + 1u : kMzPending));
             if (defer) {
                 const uint32_t qi = dcount + (uint32_t)__popcll(db & lt);
                 if (qi < (uint32_t)kMzDeferCap) lds_write_b32(defer_a + qi * 4u, (s * 64u + (uint32_t)lane) | (idx << 16));
@@ -701,7 +703,6 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
             lcount += (uint32_t)__popcll(mb);
             dcount += (uint32_t)__popcll(db);
             if (lcount > (uint32_t)kMzListCap || dcount > (uint32_t)kMzDeferCap) redo = true;
-            maybe |= (mb_mine ? 1u : 0u) << s;
         }
     };
 
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
                 hh = (hh + 1) & tab.mask;
                 sl = load_slot(tab.slots + hh);
             }
-            L.list[ent >> 16] = sl.key == c ? sl.loc + 1u : 0u;
+            L.list[ent >> 16] = (wi << kMzListLocBits) | (sl.key == c ? sl.loc + 1u : 0u);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -766,15 +767,12 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
     // ordered pass over the hit list: the same bookkeeping as mz_tile; the candidates go to LDS (the cache slots are free
     // now), then to their place
     uint32_t *cbuf = reinterpret_cast<uint32_t *>(&L.cache[0][0]);
-    uint32_t n_raw = 0, n_cand = 0, first_loc = GS_NONE, carry = GS_NONE, run = 0;
-    for (uint32_t s = 0; s < nsteps; s++) {
-        const bool mine = (maybe >> s) & 1u;
-        const unsigned long long mb = __ballot(mine);
-        if (!mb) continue;
-        const uint32_t v = mine ? L.list[run + (uint32_t)__popcll(mb & lt)] : 0u;
-        run += (uint32_t)__popcll(mb);
-        const bool hit = v != 0u;
-        const uint32_t loc = v - 1u;
+    uint32_t n_raw = 0, n_cand = 0, first_loc = GS_NONE, carry = GS_NONE;
+    for (uint32_t i0 = 0; i0 < lcount; i0 += 64u) {  // the list is dense: 64 maybe-hits at a time, whatever steps they came from
+        const uint32_t v = i0 + (uint32_t)lane < lcount ? L.list[i0 + (uint32_t)lane] : 0u;
+        const uint32_t lv = v & kMzListLocMask, woff = v >> kMzListLocBits;
+        const bool hit = lv != 0u;
+        const uint32_t loc = lv - 1u;
         const unsigned long long hb = __ballot(hit);
         if (!hb) continue;
         const unsigned long long below = hb & lt;
@@ -783,7 +781,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
         const uint32_t prev = below ? pl : carry;
         const bool chg = hit && loc != prev;
         const unsigned long long cb = __ballot(chg);
-        if (chg) cbuf[n_cand + (uint32_t)__popcll(cb & lt)] = ((n_raw + (uint32_t)__popcll(below)) << 16) | (s * 64u + (uint32_t)lane);
+        if (chg) cbuf[n_cand + (uint32_t)__popcll(cb & lt)] = ((n_raw + (uint32_t)__popcll(below)) << 16) | woff;
         n_cand += (uint32_t)__popcll(cb);
         if (first_loc == GS_NONE) first_loc = lane_value(loc, __ffsll((unsigned long long)hb) - 1);
         carry = lane_value(loc, 63 - __clzll((long long)hb));
