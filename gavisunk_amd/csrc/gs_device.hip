@@ -2750,8 +2750,9 @@ const char *gs_table_layout(const gs_table *t) {
     static thread_local char buf[256];
     if (!t) return "";
     if (t->mz)
-        snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 64 B (8 fingerprint bytes + 7 x u64 [%d-bit tag | %d-bit loc]), minimiser length %d (w = %d), %llu overflow keys in a generic 16 B-slot side table",
-                 t->mz_n_regions, 2 * t->k - 3, t->mz_locbits, t->mz_m, t->k - t->mz_m + 1, (unsigned long long)t->mz_overflow);
+        snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 64 B (8 fingerprint bytes + 7 x u64 [%d-bit %s | %d-bit loc]), mod-minimiser of length %d (w = %d, t = %d), %llu overflow keys in a generic 16 B-slot side table",
+                 t->mz_n_regions, mz_raw(t->k, t->mz_locbits) ? 2 * t->k : 2 * t->k - 3, mz_raw(t->k, t->mz_locbits) ? "key" : "tag", t->mz_locbits,
+                 t->mz_m, t->k - t->mz_m + 1, mz_t_of(t->k, t->mz_m), (unsigned long long)t->mz_overflow);
     else if (t->compact)
         snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x %s (%d-bit remainder, %d-bit loc%s), %llu overflow keys in a generic 16 B-slot side table",
                  t->compact == 1 ? (t->join ? "compact-lds" : "compact-l2") : "compact-hbm", t->c_qb, t->c_w64 ? "u64" : "u32", t->c_rembits, t->c_locbits,

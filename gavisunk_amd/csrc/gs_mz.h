@@ -22,9 +22,9 @@
 //   x       = leftmost argmin over the k - t + 1 t-mers of the canonical k-mer of (t-mer or its rc, the smaller) * c >> 23
 //   H       = mix_a(min(m-mer at x mod w, its reverse complement))                                 strand-symmetric
 //   region  = mul_hi(H, n_regions)                                                                 64 bytes each
-//   l | hi  = mix_a(low 32 bits of the canonical code) ^ mix_b(high bits), high bits               a bijection
-//   fp      = min(l >> 24, 0xFE)                                                                    fingerprint byte
-//   tag     = (l & 0x1FFFFFFF) << (2k - 32) | hi                                                    2k - 3 bits
+//   RAW slots (2k + locbits <= 64):      tag = the canonical code,  fp = min((low word * c) >> 24, 0xFE)
+//   HASHED slots (longer k-mers):        l | hi = mix_a(low word) ^ mix_b(high bits), high bits      a bijection
+//                                        fp = min(l >> 24, 0xFE),  tag = (l & 0x1FFFFFFF) << (2k - 32) | hi   (2k - 3 bits)
 //
 //   region  = 64 bytes = 8 words of 64 bits: word 0 = 8 fingerprint bytes, words 1..7 = slots
 //             byte 0      0xFF - (keys of the region), counted up to 8 = "one more than fits": some live in the generic table
@@ -77,11 +77,20 @@ struct MzKey {
     uint32_t fp;  // fingerprint byte, 0..0xFE
     uint64_t tag;
 };
-// k >= 16: the canonical code has 2k - 32 >= 0 bits above its low word
-__host__ __device__ __forceinline__ MzKey mz_key(uint64_t c, int k) {
+// Two slot formats.  RAW, when the whole canonical code fits the slot beside the loc (2k + locbits <= 64: k = 20 with any
+// loc the fast kernel takes): tag = the code itself, fingerprint = any hash byte of it (one multiply).  HASHED otherwise:
+// l = a bijection of the low word, fingerprint = its top byte, tag = its other 29 bits and the code's high bits, so that
+// (fingerprint, tag) still determine the key (k >= 16: the code has 2k - 32 >= 0 bits above its low word).
+__host__ __device__ constexpr bool mz_raw(int k, int locbits) { return 2 * k + locbits <= 64; }
+__host__ __device__ __forceinline__ MzKey mz_key(uint64_t c, int k, int locbits) {
     const uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
-    const uint32_t l = mz_mix_a(lo) ^ mz_mix_b(hi + 0x632BE5ABu);
     MzKey o;
+    if (mz_raw(k, locbits)) {
+        o.fp = min((lo * 0x9E3779B1u) >> 24, 0xFEu);
+        o.tag = c;
+        return o;
+    }
+    const uint32_t l = mz_mix_a(lo) ^ mz_mix_b(hi + 0x632BE5ABu);
     o.fp = min(l >> 24, 0xFEu);
     o.tag = ((uint64_t)(l & 0x1FFFFFFFu) << (2 * k - 32)) | (uint64_t)hi;  // k = 16: hi = 0, no shift
     return o;
@@ -89,8 +98,12 @@ __host__ __device__ __forceinline__ MzKey mz_key(uint64_t c, int k) {
 __host__ __device__ __forceinline__ uint32_t mz_region(uint32_t H, uint32_t n_regions) {  // H: a hash already
     return (uint32_t)(((uint64_t)H * (uint64_t)n_regions) >> 32);
 }
-// hash of a canonical m-mer (m <= 31); for m <= 16 the high word is 0 and mz_mix_b(0) = 0: a bijection of the m-mer
-__host__ __device__ __forceinline__ uint32_t mz_mmer_hash(uint64_t cm) { return mz_mix_a((uint32_t)cm ^ mz_mix_b((uint32_t)(cm >> 32))); }
+// hash of a canonical m-mer (m <= 31): the region index is mul_hi of it
+__host__ __device__ __forceinline__ uint32_t mz_mmer_hash(uint64_t cm) {
+    uint32_t x = (uint32_t)cm ^ ((uint32_t)(cm >> 32) * 0x7FEB352Du);
+    x ^= x >> 15;  // (the region is taken from the top bits of the product: the high input bits reach them through this)
+    return x * 0x9E3779B1u;
+}
 // the mod-minimiser rule: length of the short t-mers whose minimum anchors the pick (t = m mod w, 5 <= t <= 12), their
 // order (9 bits: with the 7-bit position it fills the 16-bit halves the sliding minimum of k_probe_mz works on)
 __host__ __device__ constexpr int mz_t_of(int k, int m) { return 5 + (m - 5) % (k - m + 1); }
@@ -144,7 +157,7 @@ __global__ void k_mz_place(unsigned long long *slots, uint32_t *pay, int k, int 
         if (o < overflow_cap) overflow_list[o] = i;
         return;
     }
-    const MzKey key = mz_key(keys[i], k);
+    const MzKey key = mz_key(keys[i], k, locbits);
     unsigned long long *base = slots + reg * kMzWords;
     const uint32_t slot = 1u + rank;
     base[slot] = (key.tag << locbits) | (unsigned long long)loc[i];
@@ -190,7 +203,7 @@ __device__ __forceinline__ bool mz_region_overflowed(uint64_t F) { return ((uint
 // payload of a key that is known to be in the table (k_emit, one emitted row at a time)
 __device__ __forceinline__ uint32_t mz_payload(const MzView &mz, const TableView &tab, uint64_t c) {
     const uint32_t reg = mz_region(mz_minimizer(c, mz.k, mz.m), mz.n_regions);
-    const MzKey key = mz_key(c, mz.k);
+    const MzKey key = mz_key(c, mz.k, mz.locbits);
     const uint64_t want = key.tag << mz.locbits, locmask = (1ULL << mz.locbits) - 1ULL;
     const uint64_t *rp = reinterpret_cast<const uint64_t *>(mz.regions) + (uint64_t)reg * kMzWords;
     MzCand cd = mz_candidates(rp[0], key.fp);
@@ -233,7 +246,7 @@ __device__ __forceinline__ MzWin mz_win_of(uint64_t a, uint64_t b, int lane, int
     o.r = ~revpairs(x) & kmask;  // base i of x, complemented, at bits 2i+1:2i
     if (m <= 16) {  // wave-uniform: the m-mer fits a word
         const uint32_t fm = (uint32_t)(o.f >> (2 * (k - m))), rm = (uint32_t)o.r & (uint32_t)mmask;
-        o.h = mz_mix_a(fm < rm ? fm : rm);
+        o.h = mz_mmer_hash((uint64_t)(fm < rm ? fm : rm));
     } else {
         const uint64_t fm = o.f >> (2 * (k - m)), rm = o.r & mmask;
         o.h = mz_mmer_hash(fm < rm ? fm : rm);
@@ -295,7 +308,7 @@ __device__ __forceinline__ MzTileOut mz_tile(const MzView &mz, const TableView &
             if (s >= nsteps) continue;  // wave-uniform
             const MzWin nxt = mz_window(W0, W1, (int)s + 1, lane, k, m, kmask, mmask);
             const uint64_t c = cur.f < cur.r ? cur.f : cur.r;
-            const MzKey key = mz_key(c, k);
+            const MzKey key = mz_key(c, k, locbits);
             addr[u] = mz.regions + (uint64_t)mz_region(mz_minimizer(c, k, m), mz.n_regions) * kMzPieces;  // (the rule, lane by lane)
             want[u] = key.tag << locbits;
             fp[u] = key.fp;
@@ -414,17 +427,19 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 //            then the slots whose fingerprint matches.  Outcome: hit (loc), miss, or -- the region's count byte says that keys
 //            of it did not fit (mz_region_overflowed) and none of its 7 is this one -- "ask the generic table", which is deferred: such a window takes a place in the tile's hit list like a
 //            hit does.  A step with more than kMzRunCap runs (rare) is consumed in two halves, the second fetched on the spot.
-//   after the last step: the deferred lookups of the tile go to the generic table 64 at a time (their latencies overlap),
-//            then one ordered pass over the hit list does the tile's bookkeeping exactly as mz_tile does.
+//   flush    when the hit list or the deferred queue might not hold one more step, and after the last step: the deferred
+//            lookups go to the generic table 64 at a time (their latencies overlap), then one ordered pass over the dense hit
+//            list does the bookkeeping exactly as mz_tile does, and the list starts over (the small list is what lets 20
+//            waves share a CU's LDS).
 //
-// A tile with more maybe-hits than the list holds (kMzListCap) or more deferred lookups than their queue (kMzDeferCap) is
-// done over by mz_tile_exact: exactness never depends on the budgets.
+// A tile with more candidates (location changes) than the LDS buffer holds (kMzCandLds) is done over by mz_tile_exact:
+// exactness never depends on the budgets.
 // ------------------------------------------------------------------------------------------
 constexpr int kMzRunCap = 32;                  // runs of a step whose regions fit the LDS cache slot (2 KiB)
 constexpr int kMzDma = kMzRunCap * kMzPieces / 64;  // LDS-DMA wave-instructions per step
 constexpr int kMzStages = 2;                   // steps whose region fetches are in flight together
-constexpr int kMzListCap = 1280;               // maybe-hits of a tile
-constexpr int kMzDeferCap = 384;               // deferred generic-table lookups of a tile
+constexpr int kMzListCap = 512;                // maybe-hits held before the list is flushed (a step adds up to 64)
+constexpr int kMzDeferCap = 128;               // deferred generic-table lookups held before a flush
 constexpr int kMzWaves = 2;                    // waves per workgroup
 constexpr int kMzListLocBits = 21;             // a list entry = window offset in the tile << 21 | loc + 1 (0 = no hit after all)
 constexpr uint32_t kMzListLocMask = (1u << kMzListLocBits) - 1u;
@@ -435,12 +450,9 @@ struct MzWaveLds {
     uint4 cache[kMzStages][kMzRunCap * kMzPieces];
     uint32_t list[kMzListCap];
     uint32_t defer[kMzDeferCap];
+    uint32_t cand[kMzCandLds];              // the tile's candidates (a tile with more is done over by the exact form)
     uint64_t words[kTileWords + 2];         // the tile's packed bases
 };
-// after the last step the region cache is free: the ordered pass keeps the tile's candidates there and, past its end, in the
-// hit list itself (the struct's next member): candidate number i is written while list entry >= i is being read (a candidate is
-// a hit, hits are list entries), so candidate i lands on list entry i - cache_words < i, which has been consumed
-static_assert(offsetof(MzWaveLds, list) == sizeof(uint4) * kMzStages * kMzRunCap * kMzPieces, "the hit list follows the cache");
 
 // LDS accesses of the main loop are written as asm: while an LDS-DMA is in flight hipcc puts `s_waitcnt vmcnt(0)` in
 // front of every LDS access it knows of (it cannot tell which bytes the DMA writes), which would serialise the steps.
@@ -631,7 +643,6 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
     MzSlide<NT> slide;
     slide.reset();
     uint32_t e_cur = slide.advance(mz_pk_of(cur.o, lane), lane, nt);  // E of the step `cur` is the window of
-    bool redo = false;  // wave-uniform: a budget was exceeded, the exact form does the tile over
 
     // LDS-DMA wave-instructions that fetch the regions of (the first kMzRunCap of) R runs: 8 runs each
     constexpr uint32_t kRunsPerDma = 64 / kMzPieces;
@@ -654,7 +665,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
         const uint32_t H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
         const uint64_t c = rc_strand ? cur.r : cur.f;
         cur = nxt;
-        const MzKey key = mz_key(c, k);
+        const MzKey key = mz_key(c, k, KT && 2 * KT + kMzFastLocBits <= 64 ? kMzFastLocBits : locbits);
         const uint32_t reg = mz_region(H, mz.n_regions);
         const bool valid = s * 64u + (uint32_t)lane < td.nwin_left;
         const bool leader = valid && (lane == 0 || reg != mz_shift_up(reg, ~reg));
@@ -695,25 +706,72 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
         if (mb) {
             // (a big step calls this twice, lower lanes first: its entries still land in lane order)
             const uint32_t idx = lcount + (uint32_t)__popcll(mb & lt);
-            if (mb_mine && idx < (uint32_t)kMzListCap) lds_write_b32(list_a + idx * 4u, ((s * 64u + (uint32_t)lane) << kMzListLocBits) | (hit ? (uint32_t)e + 1u : kMzPending));
-            if (defer) {
-                const uint32_t qi = dcount + (uint32_t)__popcll(db & lt);
-                if (qi < (uint32_t)kMzDeferCap) lds_write_b32(defer_a + qi * 4u, (s * 64u + (uint32_t)lane) | (idx << 16));
-            }
+            if (mb_mine) lds_write_b32(list_a + idx * 4u, ((s * 64u + (uint32_t)lane) << kMzListLocBits) | (hit ? (uint32_t)e + 1u : kMzPending));
+            if (defer) lds_write_b32(defer_a + (dcount + (uint32_t)__popcll(db & lt)) * 4u, (s * 64u + (uint32_t)lane) | (idx << 16));
             lcount += (uint32_t)__popcll(mb);
             dcount += (uint32_t)__popcll(db);
-            if (lcount > (uint32_t)kMzListCap || dcount > (uint32_t)kMzDeferCap) redo = true;
         }
+    };
+
+    // flush: the deferred lookups held so far go to the generic table 64 at a time (their latencies overlap), then one ordered
+    // pass over the (dense) hit list does the bookkeeping exactly as mz_tile does -- 64 maybe-hits at a time, whatever steps
+    // they came from -- and the list starts over.  Runs when a step might not fit any more, and after the last step.
+    uint32_t n_raw = 0, n_cand = 0, first_loc = GS_NONE, carry = GS_NONE;  // of the tile so far
+    auto flush = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j0 = 0; j0 < dcount; j0 += 64u) {
+            if (j0 + (uint32_t)lane < dcount) {
+                const uint32_t ent = L.defer[j0 + lane];
+                const uint32_t wi = ent & 0xFFFFu;
+                const uint64_t a = L.words[wi >> 5], b2 = L.words[(wi >> 5) + 1];
+                const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(wi & 31u), k, kmask);
+                uint64_t hh = slot_of(c, tab.shift);
+                Slot sl = load_slot(tab.slots + hh);
+                while (sl.key != c && sl.key != kEmptyKey) {
+                    hh = (hh + 1) & tab.mask;
+                    sl = load_slot(tab.slots + hh);
+                }
+                L.list[ent >> 16] = (wi << kMzListLocBits) | (sl.key == c ? sl.loc + 1u : 0u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i0 = 0; i0 < lcount; i0 += 64u) {
+            const uint32_t v = i0 + (uint32_t)lane < lcount ? L.list[i0 + (uint32_t)lane] : 0u;
+            const uint32_t lv = v & kMzListLocMask, woff = v >> kMzListLocBits;
+            const bool hit = lv != 0u;
+            const uint32_t loc = lv - 1u;
+            const unsigned long long hb = __ballot(hit);
+            if (!hb) continue;
+            const unsigned long long below = hb & lt;
+            const int src = below ? 63 - __clzll((long long)below) : 0;
+            const uint32_t pl = __shfl(loc, src);
+            const uint32_t prev = below ? pl : carry;
+            const bool chg = hit && loc != prev;
+            const unsigned long long cb = __ballot(chg);
+            const uint32_t ci = n_cand + (uint32_t)__popcll(cb & lt);
+            if (chg && ci < (uint32_t)kMzCandLds) L.cand[ci] = ((n_raw + (uint32_t)__popcll(below)) << 16) | woff;
+            n_cand += (uint32_t)__popcll(cb);
+            if (first_loc == GS_NONE) first_loc = lane_value(loc, __ffsll((unsigned long long)hb) - 1);
+            carry = lane_value(loc, 63 - __clzll((long long)hb));
+            n_raw += (uint32_t)__popcll(hb);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        lcount = dcount = 0;
     };
 
     static_assert(kMzStages == 2, "the prologue below stages steps 0 and 1 by hand (slot indices must be compile-time)");
     stage(0, 0);
     if (nsteps > 1) stage(1, 1);
-    for (uint32_t s0 = 0; s0 < nsteps && !redo; s0 += kMzStages) {
+    for (uint32_t s0 = 0; s0 < nsteps; s0 += kMzStages) {
 #pragma unroll
         for (int u = 0; u < kMzStages; u++) {
             const uint32_t s = s0 + (uint32_t)u;
-            if (s >= nsteps || redo) break;  // wave-uniform
+            if (s >= nsteps) break;  // wave-uniform
+            if (lcount + 64u > (uint32_t)kMzListCap || dcount + 64u > (uint32_t)kMzDeferCap) flush();  // (wave-uniform) room for this step
             // the fetches of step s have landed once at most those of the next step (1 to kMzDma instructions) are outstanding
             static_assert(kMzDma == 2, "the waits below count at most two instructions of the next step");
             switch (s + 1 < nsteps ? dma_count(nruns[u ^ 1]) : 0u) {  // wave-uniform
@@ -732,61 +790,20 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lookups(s, u, (uint32_t)kMzRunCap);
             }
-            if (s + kMzStages < nsteps && !redo) {
+            if (s + kMzStages < nsteps) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of this slot are done before it is refilled
                 stage(s + kMzStages, u);
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (redo) {
+    flush();
+    if (n_cand > (uint32_t)kMzCandLds) {  // (wave-uniform, rare) more location changes than the candidate buffer holds
         if (lane == 0) atomicAdd(g_fallback_tiles, 1u);
-        mz_tile_exact(mz, tab, words, td, tile, n_tiles, ta, cand, cand_cap, g_cand_count, reinterpret_cast<uint32_t *>(&L.cache[0][0]));
+        mz_tile_exact(mz, tab, words, td, tile, n_tiles, ta, cand, cand_cap, g_cand_count, L.cand);
         return;
     }
-    // the deferred lookups, 64 at a time
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t j0 = 0; j0 < dcount; j0 += 64u) {
-        if (j0 + (uint32_t)lane < dcount) {
-            const uint32_t ent = L.defer[j0 + lane];
-            const uint32_t wi = ent & 0xFFFFu;
-            const uint64_t a = L.words[wi >> 5], b2 = L.words[(wi >> 5) + 1];
-            const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(wi & 31u), k, kmask);
-            uint64_t hh = slot_of(c, tab.shift);
-            Slot sl = load_slot(tab.slots + hh);
-            while (sl.key != c && sl.key != kEmptyKey) {
-                hh = (hh + 1) & tab.mask;
-                sl = load_slot(tab.slots + hh);
-            }
-            L.list[ent >> 16] = (wi << kMzListLocBits) | (sl.key == c ? sl.loc + 1u : 0u);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ordered pass over the hit list: the same bookkeeping as mz_tile; the candidates go to LDS (the cache slots are free
-    // now), then to their place
-    uint32_t *cbuf = reinterpret_cast<uint32_t *>(&L.cache[0][0]);
-    uint32_t n_raw = 0, n_cand = 0, first_loc = GS_NONE, carry = GS_NONE;
-    for (uint32_t i0 = 0; i0 < lcount; i0 += 64u) {  // the list is dense: 64 maybe-hits at a time, whatever steps they came from
-        const uint32_t v = i0 + (uint32_t)lane < lcount ? L.list[i0 + (uint32_t)lane] : 0u;
-        const uint32_t lv = v & kMzListLocMask, woff = v >> kMzListLocBits;
-        const bool hit = lv != 0u;
-        const uint32_t loc = lv - 1u;
-        const unsigned long long hb = __ballot(hit);
-        if (!hb) continue;
-        const unsigned long long below = hb & lt;
-        const int src = below ? 63 - __clzll((long long)below) : 0;
-        const uint32_t pl = __shfl(loc, src);
-        const uint32_t prev = below ? pl : carry;
-        const bool chg = hit && loc != prev;
-        const unsigned long long cb = __ballot(chg);
-        if (chg) cbuf[n_cand + (uint32_t)__popcll(cb & lt)] = ((n_raw + (uint32_t)__popcll(below)) << 16) | woff;
-        n_cand += (uint32_t)__popcll(cb);
-        if (first_loc == GS_NONE) first_loc = lane_value(loc, __ffsll((unsigned long long)hb) - 1);
-        carry = lane_value(loc, 63 - __clzll((long long)hb));
-        n_raw += (uint32_t)__popcll(hb);
-    }
+    const uint32_t *cbuf = L.cand;
     const MzTileOut o{n_raw, n_cand, first_loc, carry};
     uint32_t off = tile * (uint32_t)kDirectCand;
     if (o.n_cand > (uint32_t)kDirectCand) {

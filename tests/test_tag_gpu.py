@@ -199,7 +199,7 @@ def test_layout_selection(table_layout):
     if table_layout == "generic":
         assert tab.layout.startswith("generic")
     elif table_layout in ("auto", "minimizer", "minimizer-exact", "compact-l2"):
-        assert tab.layout.startswith("minimizer-hbm") and "47-bit tag" in tab.layout and "minimiser length 21 " in tab.layout
+        assert tab.layout.startswith("minimizer-hbm") and "50-bit key" in tab.layout and "mod-minimiser of length 21 " in tab.layout
     else:
         assert "compact-hbm" in tab.layout and "x u64" in tab.layout
     tab.close()
@@ -334,7 +334,7 @@ def test_minimizer_table_walks_and_overflows(m, load, monkeypatch, table_layout)
     k = 20
     keys, loc, seqs = _random_case(56, k, n_reads=60, glen=60000, median=4000)
     tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
-    assert tab.layout.startswith("minimizer-hbm") and f"minimiser length {m} " in tab.layout
+    assert tab.layout.startswith("minimizer-hbm") and f"mod-minimiser of length {m} " in tab.layout
     n_ovf = int(tab.layout.split("), ")[-1].split(" overflow")[0])
     assert n_ovf > (10000 if m == "6" else 50 if load in ("8", "6") else -1)
     tab.close()
