@@ -27,7 +27,10 @@
 //                                        fp = min(l >> 24, 0xFE),  tag = (l & 0x1FFFFFFF) << (2k - 32) | hi   (2k - 3 bits)
 //
 //   region  = 64 bytes = 8 words of 64 bits: word 0 = 8 fingerprint bytes, words 1..7 = slots
-//             byte 0      0xFF - (keys of the region), counted up to 8 = "one more than fits": some live in the generic table
+//             byte 0      0xFF - (keys of the region), counted up to 8 = "one more than fits": the region OVERFLOWED -- it keeps
+//                         its first 6 keys, the others live in the generic table, and word 7 is a filter of those: two bits
+//                         per key (mz_filter_bits), a CLEARED bit = seen (~6 % false positives at 8 keys: an overflowed region
+//                         answers most of its misses itself)
 //             byte i      fingerprint of slot i (i = 1..7), 0xFF = empty
 //             word i      tag << locbits | loc            (all ones = empty; the all-ones loc is never stored)
 //
@@ -95,6 +98,13 @@ __host__ __device__ __forceinline__ MzKey mz_key(uint64_t c, int k, int locbits)
     o.tag = ((uint64_t)(l & 0x1FFFFFFFu) << (2 * k - 32)) | (uint64_t)hi;  // k = 16: hi = 0, no shift
     return o;
 }
+// the two bits of a key in the 64-bit filter word of an overflowed region (from its tag: both slot formats have it at hand)
+__host__ __device__ __forceinline__ unsigned long long mz_filter_bits(uint64_t tag) {
+    const uint32_t g = ((uint32_t)tag ^ ((uint32_t)(tag >> 32) * 0x7FEB352Du)) * 0x85EBCA6Bu;
+    return (1ULL << (g >> 26)) | (1ULL << ((g >> 20) & 63u));
+}
+// filter word B of an overflowed region: can the key with these bits be among the keys that did not fit?
+__host__ __device__ __forceinline__ bool mz_filter_maybe(unsigned long long B, unsigned long long bits) { return (B & bits) == 0ULL; }
 __host__ __device__ __forceinline__ uint32_t mz_region(uint32_t H, uint32_t n_regions) {  // H: a hash already
     return (uint32_t)(((uint64_t)H * (uint64_t)n_regions) >> 32);
 }
@@ -151,24 +161,27 @@ __global__ void k_mz_place(unsigned long long *slots, uint32_t *pay, int k, int 
     const uint64_t reg = reg_sorted[p];
     uint32_t rank = 0;  // keys of this region before this one, counted up to a full region
     while (rank < (uint32_t)kMzSlots && p > rank && reg_sorted[p - 1 - rank] == reg) rank++;
+    // the region overflows when an 8th key exists: then it keeps 6 keys, and its last word is a filter of the others
+    const bool over = rank >= (uint32_t)kMzSlots || (p + (kMzSlots - rank) < n && reg_sorted[p + (kMzSlots - rank)] == reg);
     const uint32_t i = idx_sorted[p];
-    if (rank >= (uint32_t)kMzSlots) {  // the region is full: the key stays in the generic table
-        const unsigned long long o = atomicAdd(overflow, 1ULL);
-        if (o < overflow_cap) overflow_list[o] = i;
-        return;
-    }
     const MzKey key = mz_key(keys[i], k, locbits);
     unsigned long long *base = slots + reg * kMzWords;
-    const uint32_t slot = 1u + rank;
-    base[slot] = (key.tag << locbits) | (unsigned long long)loc[i];
-    pay[reg * kMzWords + slot] = payload[i];
     uint8_t *fpb = reinterpret_cast<uint8_t *>(base);
-    fpb[slot] = (uint8_t)key.fp;
     if (rank == 0) {  // the count byte: 0xFF - keys of the region, counted up to kMzSlots + 1 (= some of them did not fit)
         uint32_t len = 1;
         while (len <= (uint32_t)kMzSlots && p + len < n && reg_sorted[p + len] == reg) len++;
         fpb[0] = (uint8_t)(0xFFu - len);
     }
+    if (over && rank >= (uint32_t)kMzSlots - 1u) {  // the key stays in the generic table; the filter learns it
+        atomicAnd(base + kMzSlots, ~mz_filter_bits(key.tag));  // (the word starts as all ones: a CLEARED bit = "seen")
+        const unsigned long long o = atomicAdd(overflow, 1ULL);
+        if (o < overflow_cap) overflow_list[o] = i;
+        return;
+    }
+    const uint32_t slot = 1u + rank;
+    base[slot] = (key.tag << locbits) | (unsigned long long)loc[i];
+    pay[reg * kMzWords + slot] = payload[i];
+    fpb[slot] = (uint8_t)key.fp;
 }
 
 // bit 7 of every byte of x that equals the byte replicated in T (exact: no borrow between bytes)
@@ -335,7 +348,9 @@ __device__ __forceinline__ MzTileOut mz_tile(const MzView &mz, const TableView &
                     }
                 }
             }
-            if (valid[u] && !hit && mz_region_overflowed(Fw)) {  // the region is full and no key of it is this one: the generic table
+            // the region overflowed, none of its keys is this one, and its filter word does not rule the key out: the generic table
+            if (valid[u] && !hit && mz_region_overflowed(Fw) &&
+                mz_filter_maybe(reinterpret_cast<const uint64_t *>(addr[u])[kMzSlots], mz_filter_bits(want[u] >> locbits))) {
                 const MzWin ww = mz_window(W0, W1, (int)s, lane, k, m, kmask, mmask);
                 const uint64_t c = ww.f < ww.r ? ww.f : ww.r;
                 uint64_t hh = slot_of(c, tab.shift);
@@ -425,7 +440,8 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 //            past the last one repeat it: same line, no new request).  One request per run is what the fabric sees.
 //   consume  (kMzStages - 1 steps later, behind a counted vmcnt) a window reads its region's fingerprint word from LDS,
 //            then the slots whose fingerprint matches.  Outcome: hit (loc), miss, or -- the region's count byte says that keys
-//            of it did not fit (mz_region_overflowed) and none of its 7 is this one -- "ask the generic table", which is deferred: such a window takes a place in the tile's hit list like a
+//            of it did not fit (mz_region_overflowed), none of its 6 is this one and its filter word does not rule the key out
+//            -- "ask the generic table", which is deferred: such a window takes a place in the tile's hit list like a
 //            hit does.  A step with more than kMzRunCap runs (rare) is consumed in two halves, the second fetched on the spot.
 //   flush    when the hit list or the deferred queue might not hold one more step, and after the last step: the deferred
 //            lookups go to the generic table 64 at a time (their latencies overlap), then one ordered pass over the dense hit
@@ -700,7 +716,8 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
                 }
             }
         }
-        const bool defer = mine && !hit && mz_region_overflowed(F);  // generic table, after the last step
+        bool defer = mine && !hit && mz_region_overflowed(F);  // generic table, later -- unless the region's filter word says no
+        if (defer) defer = mz_filter_maybe(lds_read_b64(reg_a + (uint32_t)kMzSlots * 8u), mz_filter_bits(want[u] >> locbits));
         const bool mb_mine = hit || defer;
         const unsigned long long mb = __ballot(mb_mine), db = __ballot(defer);
         if (mb) {
