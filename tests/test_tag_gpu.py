@@ -346,6 +346,37 @@ def test_minimizer_table_walks_and_overflows(m, load, monkeypatch, table_layout)
     assert np.array_equal(gh["payload"], oh["row"]) and carry == (loc[oprev] if oprev != oracle.NONE else _lib.GS_NONE)
 
 
+@pytest.mark.parametrize("k,m", [(20, 17), (20, 16), (20, 18), (21, 17), (25, 21), (20, 13), (16, 16), (32, 28), (31, 31), (24, 17)])
+def test_minimizer_rule_selftest(k, m):
+    """The window -> region rule of the minimiser-addressed table has two forms: lane by lane (table build, exact kernel) and
+    sliding over the wavefront (k_probe_mz: packed 16-bit minima, halos from the neighbouring steps).  The library compares
+    them on random and low-complexity tiles (equal t-mers: the tie rule, both strands): they never differ."""
+    mis, bad, hist = C.c_uint64(1), (C.c_uint32 * 4)(), (C.c_uint32 * 64)()
+    _lib.check(_lib.lib().gs_selftest_minimizer_rule(0, k, m, 20260 + k * 32 + m, 96, C.byref(mis), bad, hist))
+    assert mis.value == 0, (list(bad), list(hist))
+
+
+@pytest.mark.parametrize("groups_div", [1, 40, 100000])
+def test_exact_reads_fill_and_flush_the_hit_list(groups_div, table_layout):
+    """Error-free reads: every window is a hit.  The fast minimiser kernel's hit list (512 entries in LDS) is flushed every
+    seven steps; with one location group per SUNK every hit is a candidate (2048 per tile: more than the LDS candidate
+    buffer, the tile is done over by the exact form), with one group in all none but the first is."""
+    k = 20
+    rng = np.random.default_rng(77)
+    g = rng.integers(0, 4, 50000, dtype=np.uint8)
+    sunks = synth.define_sunks([("c", synth.codes_to_ascii(g))], k)
+    keys, loc = sunks.code, (sunks.start // groups_div).astype(np.uint32)
+    asc = synth.codes_to_ascii(g)
+    seqs = [asc[100:9000], asc[20000:20019], asc[30000:49999], synth.codes_to_ascii((3 - g[::-1])[1000:7000])]
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] >= ctr["windows"] - 1  # (the 19-base read is one padded window)
+    assert len(gh) == len(oh) and np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"])
+    assert np.array_equal(gh["payload"], oh["row"]) and carry == loc[oprev]
+    if table_layout == "minimizer":
+        assert (ctr["fallback_tiles"] > 10) == (groups_div == 1)
+
+
 def test_join_overflow_lists_longer_than_lds_are_searched_in_hbm(monkeypatch, table_layout):
     """32 buckets per partition for a quarter of a million keys: nearly every key overflows, ~900 per table slice -- more
     than the 512 the LDS join keeps in LDS, so its probe kernel binary-searches the slice's sorted overflow list in HBM.
