@@ -2118,6 +2118,10 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                 GS_LAUNCH_MZ(20, 17);
             else if (t->k == 20 && t->mz_m == 18)
                 GS_LAUNCH_MZ(20, 18);
+            else if (t->k == 21 && t->mz_m == 17)
+                GS_LAUNCH_MZ(21, 17);  // BASELINE.json configs[4]: k = 21 and 25 (tables up to ~10^9 keys)
+            else if (t->k == 25 && t->mz_m == 21)
+                GS_LAUNCH_MZ(25, 21);
             else
                 GS_LAUNCH_MZ(0, 0);
 #undef GS_LAUNCH_MZ
@@ -2669,6 +2673,10 @@ int gs_selftest_minimizer_rule(int device, int k, int m, uint64_t seed, uint32_t
         GS_CHECK_MZ(20, 17);
     else if (k == 20 && m == 18)
         GS_CHECK_MZ(20, 18);
+    else if (k == 21 && m == 17)
+        GS_CHECK_MZ(21, 17);
+    else if (k == 25 && m == 21)
+        GS_CHECK_MZ(25, 21);
     else
         GS_CHECK_MZ(0, 0);
 #undef GS_CHECK_MZ
