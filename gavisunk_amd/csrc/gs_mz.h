@@ -675,7 +675,9 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
             __builtin_amdgcn_global_load_lds(src, &L.cache[slot][it * 64], 16, 0, 0);
         }
     };
-    auto stage = [&](uint32_t s, int slot) {
+    // FULL (compile-time): all 2048 windows of the tile exist (every tile of a read but its last), no lane is ever invalid
+    auto stage = [&](uint32_t s, int slot, auto full_tile) {
+        constexpr bool FULL = decltype(full_tile)::value;
         const MzWin nxt = mz_window_lds(words_a, s + 1u, lane, k, m, kmask, mmask);
         const bool rc_strand = cur.r < cur.f;
         const uint32_t H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
         cur = nxt;
         const MzKey key = mz_key(c, k, KT && 2 * KT + kMzFastLocBits <= 64 ? kMzFastLocBits : locbits);
         const uint32_t reg = mz_region(H, mz.n_regions);
-        const bool valid = s * 64u + (uint32_t)lane < td.nwin_left;
+        const bool valid = FULL || s * 64u + (uint32_t)lane < td.nwin_left;
         const bool leader = valid && (lane == 0 || reg != mz_shift_up(reg, ~reg));
         const unsigned long long lb = __ballot(leader);
         const uint32_t R = (uint32_t)__popcll(lb);  // >= 1: lane 0 of an existing step is valid
@@ -698,21 +700,44 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
 
     uint32_t lcount = 0, dcount = 0;     // wave-uniform: entries of the list / of the deferred queue
     // the windows of step s whose run is in [r0, r0 + kMzRunCap): their regions are in cache slot u
-    auto lookups = [&](uint32_t s, int u, uint32_t r0) {
+    // BIG (compile-time): the step has more runs than a cache slot holds and is looked up in two halves
+    auto lookups = [&](uint32_t s, int u, uint32_t r0, auto full_tile, auto big_step) {
+        constexpr bool FULL = decltype(full_tile)::value, BIG = decltype(big_step)::value;
         const uint32_t fp = meta[u] & 0xFFu, myrun = (meta[u] >> 8) & 63u;
-        const bool mine = ((meta[u] >> 14) & 1u) && myrun >= r0 && myrun < r0 + (uint32_t)kMzRunCap;
+        const bool mine = (FULL || ((meta[u] >> 14) & 1u)) && (!BIG || (myrun >= r0 && myrun < r0 + (uint32_t)kMzRunCap));
         const uint32_t reg_a = lds_addr(&L.cache[u][0]) + (myrun - r0) * (uint32_t)(kMzWords * 8);
         uint64_t F = ~0ULL;
-        if (mine) F = lds_read_b64(reg_a);
+        if (FULL && !BIG)
+            F = lds_read_b64(reg_a);
+        else if (mine)
+            F = lds_read_b64(reg_a);
         MzCand cd = mz_candidates(F, fp);
+        // the first slot whose fingerprint matches: the hit, nearly always (a second candidate needs a fingerprint collision)
         bool hit = false;
         uint64_t e = 0;
-        while (__ballot(mine && !hit && cd.any())) {  // one round for a hit; a second one only after a fingerprint collision
-            if (mine && !hit && cd.any()) {
-                const uint64_t e2 = lds_read_b64(reg_a + cd.pop() * 8u) ^ want[u];
+        {
+            const bool lo = cd.m0 != 0u;
+            const uint32_t x = lo ? cd.m0 : cd.m1;
+            const bool any = mine && x != 0u;
+            if (any) {
+                const uint32_t slot = (lo ? 0u : 4u) + (((uint32_t)__ffs((int)x) - 1u) >> 3);
+                const uint64_t e2 = lds_read_b64(reg_a + slot * 8u) ^ want[u];
                 if (e2 < locmask) {
                     hit = true;
                     e = e2;
+                }
+            }
+            const bool more = any && !hit && (((x & (x - 1u)) | (lo ? cd.m1 : 0u)) != 0u);
+            if (__ballot(more)) {  // (wave-uniform, rare) walk the other candidates
+                if (any) cd.pop();
+                while (__ballot(mine && !hit && cd.any())) {
+                    if (mine && !hit && cd.any()) {
+                        const uint64_t e2 = lds_read_b64(reg_a + cd.pop() * 8u) ^ want[u];
+                        if (e2 < locmask) {
+                            hit = true;
+                            e = e2;
+                        }
+                    }
                 }
             }
         }
@@ -781,38 +806,46 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
     };
 
     static_assert(kMzStages == 2, "the prologue below stages steps 0 and 1 by hand (slot indices must be compile-time)");
-    stage(0, 0);
-    if (nsteps > 1) stage(1, 1);
-    for (uint32_t s0 = 0; s0 < nsteps; s0 += kMzStages) {
+    auto steps = [&](auto full_tile) {
+        constexpr std::false_type small_step{};
+        constexpr std::true_type big_step{};
+        stage(0, 0, full_tile);
+        if (nsteps > 1) stage(1, 1, full_tile);
+        for (uint32_t s0 = 0; s0 < nsteps; s0 += kMzStages) {
 #pragma unroll
-        for (int u = 0; u < kMzStages; u++) {
-            const uint32_t s = s0 + (uint32_t)u;
-            if (s >= nsteps) break;  // wave-uniform
-            if (lcount + 64u > (uint32_t)kMzListCap || dcount + 64u > (uint32_t)kMzDeferCap) flush();  // (wave-uniform) room for this step
-            // the fetches of step s have landed once at most those of the next step (1 to kMzDma instructions) are outstanding
-            static_assert(kMzDma == 2, "the waits below count at most two instructions of the next step");
-            switch (s + 1 < nsteps ? dma_count(nruns[u ^ 1]) : 0u) {  // wave-uniform
-                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            }
-            if (nruns[u] <= (uint32_t)kMzRunCap) {
-                lookups(s, u, 0u);
-            } else {
-                // a big step: its windows in lane order are runs 0..31 then 32..63, and a hit list entry is written at its
-                // rank among the step's maybe-hits -- so the first half is looked up first, and the ranks line up
-                lookups(s, u, 0u);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                fetch(u, runreg[u], nruns[u], (uint32_t)kMzRunCap);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                lookups(s, u, (uint32_t)kMzRunCap);
-            }
-            if (s + kMzStages < nsteps) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of this slot are done before it is refilled
-                stage(s + kMzStages, u);
+            for (int u = 0; u < kMzStages; u++) {
+                const uint32_t s = s0 + (uint32_t)u;
+                if (s >= nsteps) break;  // wave-uniform
+                if (lcount + 64u > (uint32_t)kMzListCap || dcount + 64u > (uint32_t)kMzDeferCap) flush();  // (wave-uniform) room for this step
+                // the fetches of step s have landed once at most those of the next step (1 to kMzDma instructions) are outstanding
+                static_assert(kMzDma == 2, "the waits below count at most two instructions of the next step");
+                switch (s + 1 < nsteps ? dma_count(nruns[u ^ 1]) : 0u) {  // wave-uniform
+                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                }
+                if (nruns[u] <= (uint32_t)kMzRunCap) {
+                    lookups(s, u, 0u, full_tile, small_step);
+                } else {
+                    // a big step: its windows in lane order are runs 0..31 then 32..63, and a hit list entry is written at its
+                    // rank among the step's maybe-hits -- so the first half is looked up first, and the ranks line up
+                    lookups(s, u, 0u, full_tile, big_step);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    fetch(u, runreg[u], nruns[u], (uint32_t)kMzRunCap);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lookups(s, u, (uint32_t)kMzRunCap, full_tile, big_step);
+                }
+                if (s + kMzStages < nsteps) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of this slot are done before it is refilled
+                    stage(s + kMzStages, u, full_tile);
+                }
             }
         }
-    }
+    };
+    if (td.nwin_left >= (uint32_t)kTileWindows)  // wave-uniform
+        steps(std::true_type{});
+    else
+        steps(std::false_type{});
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     flush();
     if (n_cand > (uint32_t)kMzCandLds) {  // (wave-uniform, rare) more location changes than the candidate buffer holds
