@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAVISUNK_LIB") or os.path.join(HERE, "libgavisunk.so")  # override: tuning experiments
 
-GS_OK, GS_E_ARG, GS_E_KEYERROR, GS_E_CAPACITY, GS_E_NODEVICE, GS_E_IO, GS_E_NOMEM = 0, -1, -2, -3, -4, -5, -6
+GS_OK, GS_E_ARG, GS_E_KEYERROR, GS_E_CAPACITY, GS_E_NODEVICE, GS_E_IO, GS_E_NOMEM, GS_E_IRREGULAR = 0, -1, -2, -3, -4, -5, -6, -7
 GS_NONE = 0xFFFFFFFF
 GS_MISSING = 0xFFFFFFFE
 
@@ -77,6 +77,12 @@ SIGNATURES = {
     "gs_reads_set_seeds": (I, [P, P, P, U32]),
     "gs_tag_segment_carries": (I, [P, P, P]),
     "gs_reads_from_device_ascii": (I, [I, P, P, U32, I, C.POINTER(P)]),
+    "gs_reads_from_text": (I, [I, P, U64, I, C.POINTER(P), C.POINTER(P)]),
+    "gs_textindex_free": (None, [P]),
+    "gs_textindex_n_reads": (U32, [P]),
+    "gs_textindex_name_off": (P, [P]),
+    "gs_textindex_name_len": (P, [P]),
+    "gs_textindex_len": (P, [P]),
     "gs_reads_destroy": (None, [P]),
     "gs_reads_n_bases": (U64, [P]),
     "gs_reads_n_windows": (U64, [P]),

@@ -1,0 +1,280 @@
+// On-device FASTA / FASTQ record parsing: the bytes of a block of whole records go to the GPU as
+// they are; line starts, record boundaries, names and sequence lengths are found there, the bases are gathered (newlines and
+// headers dropped) and 2-bit packed by the same kernels as every other read batch.  The host keeps only the text (for the
+// names) and gets back four small arrays.
+//
+// What is parsed is the REGULAR subset of what the reference's reader accepts (`readfq`, kmerpos_annot3.nim:85; the host
+// parser gs_fastx_* in gs_host.cpp restates its rules and is the fallback):
+//   FASTA  first byte '>'; a line that starts with '>' is a header, every other line is sequence (may be empty) and starts
+//          with neither '@' nor '+' (such a line would end the record in readfq)
+//   FASTQ  first byte '@'; records of exactly four lines: '@' header, non-empty sequence line that starts with none of
+//          '>', '@', '+', a '+' line, a quality line at least as long as the sequence; only empty lines after the last one
+// '\r' before '\n' is dropped; name = header up to the first white space.  Anything else returns GS_E_IRREGULAR and the caller
+// reads the file with gs_fastx_*: the same bytes give the same reads either way (tests/test_ingest_gpu.py compares them).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/functional.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include "gs_common.h"
+
+using gs::set_error;
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GS_E_NODEVICE;                                                             \
+        }                                                                                     \
+    } while (0)
+
+struct gs_textindex {
+    std::vector<uint64_t> name_off;  // into the caller's text
+    std::vector<uint32_t> name_len, len;
+};
+
+namespace {
+
+struct DevMem {  // frees what it was given when it goes out of scope
+    std::vector<void *> p;
+    ~DevMem() {
+        for (void *q : p) (void)hipFree(q);
+    }
+    template <typename T>
+    hipError_t get(T **out, size_t n) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) p.push_back(q);
+        *out = static_cast<T *>(q);
+        return e;
+    }
+};
+
+__global__ void k_line_start_flags(const uint8_t *__restrict__ text, uint32_t n, uint8_t *__restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0u || text[i - 1] == '\n') ? 1 : 0;
+}
+
+// per line: its length without '\n' / '\r', its first byte (0 for an empty line); the index of the last non-empty line
+__global__ void k_line_info(const uint8_t *__restrict__ text, uint32_t n, const uint32_t *__restrict__ ls, uint32_t n_lines,
+                            uint32_t *__restrict__ llen, uint8_t *__restrict__ c0, uint32_t *last_nonempty_plus1) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_lines) return;
+    const uint32_t a = ls[j];
+    uint32_t b = j + 1 < n_lines ? ls[j + 1] - 1u : (text[n - 1] == '\n' ? n - 1u : n);
+    if (b > a && text[b - 1] == '\r') b--;
+    llen[j] = b - a;
+    c0[j] = b > a ? text[a] : 0;
+    if (b > a) atomicMax(last_nonempty_plus1, j + 1u);
+}
+
+// FASTA: header flags, sequence bytes per line, validity
+__global__ void k_fasta_lines(const uint32_t *__restrict__ llen, const uint8_t *__restrict__ c0, uint32_t n_lines,
+                              uint8_t *__restrict__ hdr, uint32_t *__restrict__ seqbytes, uint32_t *bad) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_lines) return;
+    const uint8_t c = c0[j];
+    const bool h = c == '>';
+    hdr[j] = h ? 1 : 0;
+    seqbytes[j] = h ? 0u : llen[j];
+    if ((j == 0 && !h) || c == '@' || c == '+') atomicOr(bad, 1u);
+}
+
+// FASTQ: the same per line from the line's place in its record; lines past the last record are empty by construction
+__global__ void k_fastq_lines(const uint32_t *__restrict__ llen, const uint8_t *__restrict__ c0, uint32_t n_lines, uint32_t n_rec_lines,
+                              uint8_t *__restrict__ hdr, uint32_t *__restrict__ seqbytes, uint32_t *bad) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_lines) return;
+    uint8_t h = 0;
+    uint32_t sb = 0;
+    if (j < n_rec_lines) {
+        const uint8_t c = c0[j];
+        switch (j & 3u) {
+            case 0:
+                h = 1;
+                if (c != '@') atomicOr(bad, 1u);
+                break;
+            case 1:
+                sb = llen[j];
+                if (sb == 0u || c == '>' || c == '@' || c == '+') atomicOr(bad, 1u);
+                break;
+            case 2:
+                if (c != '+') atomicOr(bad, 1u);
+                break;
+            default:
+                if (llen[j] < llen[j - 2]) atomicOr(bad, 1u);
+                break;
+        }
+    }
+    hdr[j] = h;
+    seqbytes[j] = sb;
+}
+
+// per record: where its name is in the text, and where its bases start in the gathered stream
+__global__ void k_records(const uint8_t *__restrict__ text, const uint32_t *__restrict__ ls, const uint32_t *__restrict__ llen,
+                          const uint32_t *__restrict__ base_off, const uint32_t *__restrict__ hdr_line, uint32_t n_rec,
+                          uint32_t *__restrict__ name_off, uint32_t *__restrict__ name_len, uint32_t *__restrict__ rec_off) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    const uint32_t j = hdr_line[r], a = ls[j] + 1u, e = ls[j] + llen[j];
+    uint32_t q = a;
+    while (q < e) {  // isspace of the C locale
+        const uint8_t c = text[q];
+        if (c == ' ' || (c >= '\t' && c <= '\r')) break;
+        q++;
+    }
+    name_off[r] = a;
+    name_len[r] = q - a;
+    rec_off[r] = base_off[j];
+}
+
+// the bases of every sequence line to their place in the gathered stream: one wavefront per line
+__global__ __launch_bounds__(256) void k_gather_lines(const uint8_t *__restrict__ text, const uint32_t *__restrict__ ls,
+                                                      const uint32_t *__restrict__ seqbytes, const uint32_t *__restrict__ base_off,
+                                                      uint32_t n_lines, uint8_t *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6); j < n_lines; j += gridDim.x * 4u) {
+        const uint32_t nb = seqbytes[j];
+        if (!nb) continue;
+        const uint8_t *src = text + ls[j];
+        uint8_t *dst = out + base_off[j];
+        for (uint32_t i = lane; i < nb; i += 64u) dst[i] = src[i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gs_reads_from_text(int device, const uint8_t *text, uint64_t n_bytes, int k, gs_reads **out, gs_textindex **index) {
+    if (!out || !index || (!text && n_bytes) || k < 1 || k > 32) {
+        set_error("gs_reads_from_text: bad argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    *index = nullptr;
+    if (n_bytes >= 0xFFFFFF00ull) {
+        set_error("gs_reads_from_text: a block of %llu bytes (cut the text at record boundaries into blocks below 4 GiB)", (unsigned long long)n_bytes);
+        return GS_E_ARG;
+    }
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_reads_from_text: HIP device %d not available -- there is no CPU fallback", device);
+        return GS_E_NODEVICE;
+    }
+    if (n_bytes == 0 || (text[0] != '>' && text[0] != '@')) {
+        set_error("gs_reads_from_text: the text does not start with '>' or '@'");
+        return GS_E_IRREGULAR;
+    }
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t n = (uint32_t)n_bytes;
+    const bool fastq = text[0] == '@';
+    DevMem mem;
+    uint8_t *d_text, *d_flag, *d_c0, *d_hdr, *d_seq;
+    uint32_t *d_ls, *d_llen, *d_seqbytes, *d_base, *d_scalars, *d_hdr_line, *d_name_off, *d_name_len, *d_rec_off;
+    unsigned long long *d_count;
+    HIP_TRY(mem.get(&d_text, n));
+    HIP_TRY(mem.get(&d_flag, n));
+    HIP_TRY(mem.get(&d_count, 2));
+    HIP_TRY(mem.get(&d_scalars, 4));
+    HIP_TRY(hipMemcpy(d_text, text, n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_scalars, 0, 16));
+    hipLaunchKernelGGL(k_line_start_flags, dim3((n + 255) / 256), dim3(256), 0, 0, d_text, n, d_flag);
+    // line starts = the positions whose flag is set, in order
+    HIP_TRY(mem.get(&d_ls, (size_t)n));  // (at most one line per byte; freed with the rest)
+    size_t tb = 0;
+    void *d_tmp = nullptr;
+    rocprim::counting_iterator<uint32_t> iota(0u);
+    HIP_TRY(rocprim::select(nullptr, tb, iota, d_flag, d_ls, d_count, (size_t)n));
+    HIP_TRY(mem.get(reinterpret_cast<uint8_t **>(&d_tmp), tb));
+    HIP_TRY(rocprim::select(d_tmp, tb, iota, d_flag, d_ls, d_count, (size_t)n));
+    unsigned long long n_lines64 = 0;
+    HIP_TRY(hipMemcpy(&n_lines64, d_count, 8, hipMemcpyDeviceToHost));
+    const uint32_t n_lines = (uint32_t)n_lines64;
+    HIP_TRY(mem.get(&d_llen, n_lines));
+    HIP_TRY(mem.get(&d_c0, n_lines));
+    HIP_TRY(mem.get(&d_hdr, n_lines));
+    HIP_TRY(mem.get(&d_seqbytes, (size_t)n_lines + 1));
+    HIP_TRY(mem.get(&d_base, (size_t)n_lines + 1));
+    const dim3 lgrid((n_lines + 255) / 256), lblock(256);
+    hipLaunchKernelGGL(k_line_info, lgrid, lblock, 0, 0, d_text, n, d_ls, n_lines, d_llen, d_c0, d_scalars + 0);
+    uint32_t n_rec_lines = 0;
+    if (fastq) {
+        HIP_TRY(hipMemcpy(&n_rec_lines, d_scalars + 0, 4, hipMemcpyDeviceToHost));
+        if (n_rec_lines % 4u) {
+            set_error("gs_reads_from_text: FASTQ text whose last record is not four lines");
+            return GS_E_IRREGULAR;
+        }
+        hipLaunchKernelGGL(k_fastq_lines, lgrid, lblock, 0, 0, d_llen, d_c0, n_lines, n_rec_lines, d_hdr, d_seqbytes, d_scalars + 1);
+    } else {
+        hipLaunchKernelGGL(k_fasta_lines, lgrid, lblock, 0, 0, d_llen, d_c0, n_lines, d_hdr, d_seqbytes, d_scalars + 1);
+    }
+    HIP_TRY(hipMemset(d_seqbytes + n_lines, 0, 4));
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpy(&bad, d_scalars + 1, 4, hipMemcpyDeviceToHost));
+    if (bad) {
+        set_error("gs_reads_from_text: not a regular %s text (see gs_ingest.hip): read it with gs_fastx_*", fastq ? "four-line FASTQ" : "FASTA");
+        return GS_E_IRREGULAR;
+    }
+    // where each line's bases go in the gathered stream (exclusive prefix over n_lines + 1 values: the last one is the total)
+    size_t tb2 = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb2, d_seqbytes, d_base, 0u, (size_t)n_lines + 1, rocprim::plus<uint32_t>()));
+    void *d_tmp2 = nullptr;
+    HIP_TRY(mem.get(reinterpret_cast<uint8_t **>(&d_tmp2), tb2));
+    HIP_TRY(rocprim::exclusive_scan(d_tmp2, tb2, d_seqbytes, d_base, 0u, (size_t)n_lines + 1, rocprim::plus<uint32_t>()));
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpy(&total, d_base + n_lines, 4, hipMemcpyDeviceToHost));
+    // records = header lines
+    HIP_TRY(mem.get(&d_hdr_line, n_lines));
+    size_t tb3 = 0;
+    HIP_TRY(rocprim::select(nullptr, tb3, iota, d_hdr, d_hdr_line, d_count + 1, (size_t)n_lines));
+    void *d_tmp3 = nullptr;
+    HIP_TRY(mem.get(reinterpret_cast<uint8_t **>(&d_tmp3), tb3));
+    HIP_TRY(rocprim::select(d_tmp3, tb3, iota, d_hdr, d_hdr_line, d_count + 1, (size_t)n_lines));
+    unsigned long long n_rec64 = 0;
+    HIP_TRY(hipMemcpy(&n_rec64, d_count + 1, 8, hipMemcpyDeviceToHost));
+    const uint32_t n_rec = (uint32_t)n_rec64;
+    HIP_TRY(mem.get(&d_name_off, n_rec));
+    HIP_TRY(mem.get(&d_name_len, n_rec));
+    HIP_TRY(mem.get(&d_rec_off, n_rec));
+    hipLaunchKernelGGL(k_records, dim3((n_rec + 255) / 256), dim3(256), 0, 0, d_text, d_ls, d_llen, d_base, d_hdr_line, n_rec, d_name_off,
+                       d_name_len, d_rec_off);
+    HIP_TRY(mem.get(&d_seq, (size_t)total + 64));
+    hipLaunchKernelGGL(k_gather_lines, dim3(std::min<uint32_t>((n_lines + 3) / 4, 1u << 16)), dim3(256), 0, 0, d_text, d_ls, d_seqbytes, d_base,
+                       n_lines, d_seq);
+    HIP_TRY(hipGetLastError());
+    auto *ix = new gs_textindex();
+    std::vector<uint32_t> h32(n_rec);
+    ix->name_len.resize(n_rec);
+    ix->name_off.resize(n_rec);
+    ix->len.resize(n_rec);
+    HIP_TRY(hipMemcpy(h32.data(), d_name_off, (size_t)n_rec * 4, hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < n_rec; r++) ix->name_off[r] = h32[r];
+    HIP_TRY(hipMemcpy(ix->name_len.data(), d_name_len, (size_t)n_rec * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h32.data(), d_rec_off, (size_t)n_rec * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> off((size_t)n_rec + 1);
+    for (uint32_t r = 0; r < n_rec; r++) off[r] = h32[r];
+    off[n_rec] = total;
+    for (uint32_t r = 0; r < n_rec; r++) ix->len[r] = (uint32_t)(off[r + 1] - off[r]);
+    const int rc = gs_reads_from_device_ascii(device, d_seq, off.data(), n_rec, k, out);  // (synchronises the device first)
+    if (rc != GS_OK) {
+        delete ix;
+        return rc;
+    }
+    *index = ix;
+    return GS_OK;
+}
+
+void gs_textindex_free(gs_textindex *ix) { delete ix; }
+uint32_t gs_textindex_n_reads(const gs_textindex *ix) { return ix ? (uint32_t)ix->len.size() : 0u; }
+const uint64_t *gs_textindex_name_off(const gs_textindex *ix) { return ix ? ix->name_off.data() : nullptr; }
+const uint32_t *gs_textindex_name_len(const gs_textindex *ix) { return ix ? ix->name_len.data() : nullptr; }
+const uint32_t *gs_textindex_len(const gs_textindex *ix) { return ix ? ix->len.data() : nullptr; }
+
+}  // extern "C"

@@ -111,6 +111,41 @@ def read_batches(path: str, max_bases: int = 1 << 30, max_reads: int = 1 << 22) 
         lib().gs_fastx_close(fx)
 
 
+def text_blocks(path: str, max_bytes: int = 1 << 30) -> Iterator[bytes]:
+    """The (decompressed) text of a FASTA / FASTQ file in blocks of whole records, for DeviceReads.from_text: FASTA blocks end
+    before a line that starts with '>', FASTQ blocks after a multiple of four lines (the regular four-line form; anything
+    else is refused by gs_reads_from_text and read by the host parser instead)."""
+    import gzip
+
+    with open(path, "rb") as probe:
+        gz = probe.read(2) == b"\x1f\x8b"
+    f = gzip.open(path, "rb") if gz else open(path, "rb")
+    try:
+        rem = b""
+        while True:
+            chunk = f.read(max_bytes - len(rem) if max_bytes > len(rem) else max_bytes)  # (a record longer than a block: grow)
+            buf = rem + chunk if rem else chunk
+            if not chunk:  # end of file: what is left is the last block
+                if buf:
+                    yield buf
+                return
+            if buf[:1] == b">":
+                cut = buf.rfind(b"\n>") + 1  # 0 when the block holds no second record yet
+            else:
+                nl = buf.count(b"\n")
+                cut = len(buf)
+                for _ in range(nl % 4 + 1):  # back to the newline that ends the last whole four-line record
+                    cut = buf.rfind(b"\n", 0, cut)
+                cut = cut + 1 if nl >= 4 else 0
+            if cut <= 0:
+                rem = buf
+                continue
+            yield buf[:cut]
+            rem = buf[cut:]
+    finally:
+        f.close()
+
+
 class DeviceTable:
     """SUNK hash table resident on one GPU (gs_table)."""
 
@@ -183,6 +218,27 @@ class DeviceReads:
         self._h, self.k, self.device = h, k, device
         self.n_reads, self.n_bases = len(order), int(batch.len[order].sum()) if len(order) else 0
         self.n_windows = lib().gs_reads_n_windows(h)
+        return self
+
+    @classmethod
+    def from_text(cls, text: bytes, k: int, device: int = 0) -> "DeviceReads":
+        """Records parsed, gathered and packed on the GPU from the text of a FASTA / FASTQ block (gs_reads_from_text).  Raises
+        GsError with code GS_E_IRREGULAR for texts outside the regular subset: read those with read_batches.  The result
+        also has `names` and `len` (per read, file order), like a ReadBatch."""
+        L = lib()
+        h, ix = C.c_void_p(), C.c_void_p()
+        buf = np.frombuffer(text, dtype=np.uint8)
+        check(L.gs_reads_from_text(device, buf.ctypes.data if len(buf) else None, len(buf), k, C.byref(h), C.byref(ix)))
+        self = cls.__new__(cls)
+        self._h, self.k, self.device = h, k, device
+        n = L.gs_textindex_n_reads(ix)
+        no = _view(L.gs_textindex_name_off(ix), n, np.uint64).tolist()
+        nl = _view(L.gs_textindex_name_len(ix), n, np.uint32).tolist()
+        self.len = _view(L.gs_textindex_len(ix), n, np.uint32).copy()
+        self.names = [text[o:o + l].decode() for o, l in zip(no, nl)]
+        L.gs_textindex_free(ix)
+        self.n_reads, self.n_bases = n, int(self.len.sum())
+        self.n_windows = L.gs_reads_n_windows(h)
         return self
 
     def set_seeds(self, seed_at, seed) -> None:

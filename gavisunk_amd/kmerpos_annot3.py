@@ -6,7 +6,8 @@ stderr progress lines (kmerpos_annot3.nim:40,72), exit code 1 when a read hits a
 has no loc row (the reference's KeyError).  Tagging runs on the GPU through libgavisunk.so.
 
 Environment: GAVISUNK_DEVICE (GPU index, default 0), GAVISUNK_BATCH_BASES (bases per device
-batch, default 2^31).
+batch, default 2^31), GAVISUNK_PARSE=host (records parsed by the native host reader instead of on the GPU; the default
+falls back to it by itself for texts outside the regular FASTA / four-line FASTQ forms).
 
 `--emulate-chunks N` (after the four positionals): <reads> is a WHOLE haplotype's read file
 and <out> becomes what the workflow's scatter produces for it -- the reads dealt to N chunk files record by record
@@ -76,31 +77,65 @@ class _Prefetch:
         self._t.join(timeout=5)
 
 
+def _tag_text_blocks(reads: str, db, table, ofile: str, device: int, max_bytes: int):
+    """The reads file as text blocks parsed on the GPU (gs_reads_from_text).  -> exit code, or None
+    when the text is outside the regular FASTA / FASTQ subset the device parser takes (nothing useful is written then)."""
+    carry = _lib.GS_NONE
+    with open(ofile, "w") as out:
+        for text in engine.text_blocks(reads, max_bytes):
+            try:
+                dev = engine.DeviceReads.from_text(text, db.k, device)
+            except _lib.GsError as e:
+                if e.status == _lib.GS_E_IRREGULAR:
+                    return None
+                raise
+            st, hits, carry, _ = engine.tag(table, dev, carry)
+            out.write(engine.format_sunkpos(hits, dev.names, db))
+            dev.close()
+            if st == _lib.GS_E_KEYERROR:
+                sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
+                return 1
+    return 0
+
+
 def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_bases: int = 1 << 31) -> int:
-    batches = _Prefetch(reads, batch_bases)
+    host_parse = os.environ.get("GAVISUNK_PARSE", "device") == "host"
+    batches = _Prefetch(reads, batch_bases) if host_parse else None
     try:
         db = engine.SunkDB(kmers, locs)
     except _lib.GsError as e:
-        batches.close()
+        if batches is not None:
+            batches.close()
         sys.stderr.write(e.msg + "\n")
         return 1
     sys.stderr.write("FINISHED READING KMERS\n")
     sys.stderr.write("FINISHED READING LOCS\n")
     table = engine.DeviceTable.from_db(db, device)
-    carry = _lib.GS_NONE
-    rc = 0
-    with open(ofile, "w") as out:
-        for batch in batches:
-            dev = engine.DeviceReads(batch, db.k, device)
-            st, hits, carry, _ = engine.tag(table, dev, carry)
-            out.write(engine.format_sunkpos(hits, batch.names, db))
-            dev.close()
-            batch.close()
-            if st == _lib.GS_E_KEYERROR:
-                sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
-                rc = 1
-                break
-    batches.close()
+    rc = None
+    if not host_parse:  # records parsed on the GPU; texts it does not take (multi-line FASTQ, ...) go to the host parser
+        try:
+            rc = _tag_text_blocks(reads, db, table, ofile, device, min(batch_bases, 1 << 30))
+        except OSError as e:
+            sys.stderr.write(f"cannot open the file {reads}: {e}\n")
+            rc = 1
+        if rc is None:
+            batches = _Prefetch(reads, batch_bases)
+    if rc is None:
+        carry = _lib.GS_NONE
+        rc = 0
+        with open(ofile, "w") as out:
+            for batch in batches:
+                dev = engine.DeviceReads(batch, db.k, device)
+                st, hits, carry, _ = engine.tag(table, dev, carry)
+                out.write(engine.format_sunkpos(hits, batch.names, db))
+                dev.close()
+                batch.close()
+                if st == _lib.GS_E_KEYERROR:
+                    sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
+                    rc = 1
+                    break
+    if batches is not None:
+        batches.close()
     table.close()
     db.close()
     return rc

@@ -34,7 +34,8 @@ typedef enum gs_status {
     GS_E_CAPACITY = -3,  /* output buffer too small; *n_out holds the size needed */
     GS_E_NODEVICE = -4,  /* no HIP device / HIP runtime error */
     GS_E_IO = -5,        /* file cannot be opened or parsed (kmerpos_annot3.nim:59-60) */
-    GS_E_NOMEM = -6
+    GS_E_NOMEM = -6,
+    GS_E_IRREGULAR = -7 /* gs_reads_from_text: the text is outside the regular FASTA / FASTQ subset it parses: use gs_fastx_* */
 } gs_status;
 
 #define GS_NONE 0xFFFFFFFFu    /* "no previous location" (prevLoc before the first hit) */
@@ -156,6 +157,19 @@ int gs_reads_upload_ascii(int device, const uint8_t *seq, const uint64_t *off, u
 /* The same from bases that already are in DEVICE memory of `device` (d_seq: ASCII back to back; off: host offsets).  The
  * bases are read during the call only. */
 int gs_reads_from_device_ascii(int device, const void *d_seq, const uint64_t *off, uint32_t n_reads, int k, gs_reads **out);
+/* The same from the TEXT of a FASTA / FASTQ block (whole records, decompressed, below 4 GiB): records are parsed on the GPU
+ *  -- line starts, record boundaries, names, lengths -- and the bases gathered and packed there.
+ * Replaces `for rec in readfq(reads)` (kmerpos_annot3.nim:85) + `encode` for texts in the regular subset (one-line or
+ * multi-line FASTA; four-line FASTQ; see csrc/gs_ingest.hip); any other text returns GS_E_IRREGULAR and is read with
+ * gs_fastx_* instead, which gives the same reads for the texts both accept.  The index (host arrays, one entry per read in
+ * file order) says where each read's name is in `text` and how many bases it has. */
+typedef struct gs_textindex gs_textindex;
+int gs_reads_from_text(int device, const uint8_t *text, uint64_t n_bytes, int k, gs_reads **out, gs_textindex **index);
+void gs_textindex_free(gs_textindex *ix);
+uint32_t gs_textindex_n_reads(const gs_textindex *ix);
+const uint64_t *gs_textindex_name_off(const gs_textindex *ix);
+const uint32_t *gs_textindex_name_len(const gs_textindex *ix);
+const uint32_t *gs_textindex_len(const gs_textindex *ix);
 void gs_reads_destroy(gs_reads *r);
 uint64_t gs_reads_n_bases(const gs_reads *r);
 uint64_t gs_reads_n_windows(const gs_reads *r);

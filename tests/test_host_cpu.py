@@ -174,3 +174,27 @@ def test_no_cpu_fallback_without_gpu():
         engine.DeviceTable(20, keys, np.zeros(3, np.uint32), np.zeros(3, np.uint32))
     assert e.value.status == _lib.GS_E_NODEVICE
     assert "no CPU fallback" in e.value.msg
+
+
+def test_text_blocks_cut_at_record_boundaries(tmp_path):
+    """engine.text_blocks (input of the on-device record parser): blocks are whole records, their concatenation is the file."""
+    import gzip
+
+    from gavisunk_amd import engine
+
+    fa = b"".join(b">r%d d\n" % i + b"ACGTACGTAC\n" * (i % 5) for i in range(50))
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"ACGT" * (1 + i % 7), b"@II+" * (1 + i % 7)) for i in range(50))
+    for text, first in ((fa, b">"), (fq, b"@"), (fq[:-1], b"@")):
+        for gz in (False, True):
+            p = tmp_path / ("t.gz" if gz else "t")
+            p.write_bytes(gzip.compress(text) if gz else text)
+            for max_bytes in (1 << 20, 300, 40, 7):
+                blocks = list(engine.text_blocks(str(p), max_bytes))
+                assert b"".join(blocks) == text and all(b[:1] == first for b in blocks)
+                if first == b"@":
+                    assert all(b.count(b"\n") % 4 == 0 for b in blocks[:-1])
+                if max_bytes <= 300:
+                    assert len(blocks) >= 5
+    empty = tmp_path / "e"
+    empty.write_bytes(b"")
+    assert list(engine.text_blocks(str(empty))) == []
