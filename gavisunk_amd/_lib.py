@@ -78,6 +78,9 @@ SIGNATURES = {
     "gs_tag_segment_carries": (I, [P, P, P]),
     "gs_reads_from_device_ascii": (I, [I, P, P, U32, I, C.POINTER(P)]),
     "gs_reads_from_text": (I, [I, P, U64, I, C.POINTER(P), C.POINTER(P)]),
+    "gs_text_stage": (I, [I, P, U64, C.POINTER(P)]),
+    "gs_text_stage_free": (None, [P]),
+    "gs_reads_from_staged_text": (I, [P, I, C.POINTER(P), C.POINTER(P)]),
     "gs_textindex_free": (None, [P]),
     "gs_textindex_n_reads": (U32, [P]),
     "gs_textindex_name_off": (P, [P]),

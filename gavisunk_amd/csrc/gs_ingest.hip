@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <chrono>
+#include <cstdlib>
 #include <algorithm>
 #include <vector>
 
@@ -57,9 +59,12 @@ struct DevMem {  // frees what it was given when it goes out of scope
     }
 };
 
-__global__ void k_line_start_flags(const uint8_t *__restrict__ text, uint32_t n, uint8_t *__restrict__ flag) {
+__global__ void k_line_start_flags(const uint8_t *__restrict__ text, uint32_t n, uint8_t *__restrict__ flag, unsigned long long *n_lines) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = (i == 0u || text[i - 1] == '\n') ? 1 : 0;
+    const bool f = i < n && (i == 0u || text[i - 1] == '\n');
+    if (i < n) flag[i] = f ? 1 : 0;
+    const unsigned long long b = __ballot(f);
+    if ((threadIdx.x & 63u) == 0u && b) atomicAdd(n_lines, (unsigned long long)__popcll(b));
 }
 
 // per line: its length without '\n' / '\r', its first byte (0 for an empty line); the index of the last non-empty line
@@ -153,47 +158,132 @@ __global__ __launch_bounds__(256) void k_gather_lines(const uint8_t *__restrict_
 
 extern "C" {
 
-int gs_reads_from_text(int device, const uint8_t *text, uint64_t n_bytes, int k, gs_reads **out, gs_textindex **index) {
-    if (!out || !index || (!text && n_bytes) || k < 1 || k > 32) {
-        set_error("gs_reads_from_text: bad argument");
+struct gs_textstage {
+    int device = 0;
+    uint8_t *d_text = nullptr;
+    uint32_t n = 0;
+    uint8_t first = 0;
+};
+
+int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstage **out) {
+    if (!out || (!text && n_bytes)) {
+        set_error("gs_text_stage: bad argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    if (n_bytes >= 0xFFFFFF00ull) {
+        set_error("gs_text_stage: a block of %llu bytes (cut the text at record boundaries into blocks below 4 GiB)", (unsigned long long)n_bytes);
+        return GS_E_ARG;
+    }
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_text_stage: HIP device %d not available -- there is no CPU fallback", device);
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    auto *st = new gs_textstage();
+    st->device = device;
+    st->n = (uint32_t)n_bytes;
+    st->first = n_bytes ? text[0] : 0;
+    const size_t n = st->n;
+    if (hipMalloc(reinterpret_cast<void **>(&st->d_text), std::max<size_t>(n, 1)) != hipSuccess) {
+        delete st;
+        set_error("gs_text_stage: out of device memory (%zu bytes)", n);
+        return GS_E_NOMEM;
+    }
+    // the text through two small pinned buffers on a stream of its own (a pageable copy of a few hundred MB makes the runtime
+    // pin the whole range first); callable from a second thread while the first one loads the SUNK table
+    constexpr size_t kStage = 8u << 20;
+    struct Stage {
+        uint8_t *h[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipStream_t s = nullptr;
+        ~Stage() {
+            for (int i = 0; i < 2; i++) {
+                if (h[i]) (void)hipHostFree(h[i]);
+                if (ev[i]) (void)hipEventDestroy(ev[i]);
+            }
+            if (s) (void)hipStreamDestroy(s);
+        }
+    } sg;
+    auto fail = [&](hipError_t e) {
+        set_error("gs_text_stage: %s", hipGetErrorString(e));
+        (void)hipFree(st->d_text);
+        delete st;
+        return GS_E_NODEVICE;
+    };
+    hipError_t e = hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipHostMalloc(reinterpret_cast<void **>(&sg.h[i]), kStage, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sg.ev[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) return fail(e);
+    int b = 0;
+    for (size_t o = 0; o < n; o += kStage, b ^= 1) {
+        const size_t len = std::min(kStage, n - o);
+        if (o >= 2 * kStage && (e = hipEventSynchronize(sg.ev[b])) != hipSuccess) return fail(e);  // this buffer's last copy has left it
+        memcpy(sg.h[b], text + o, len);
+        if ((e = hipMemcpyAsync(st->d_text + o, sg.h[b], len, hipMemcpyHostToDevice, sg.s)) != hipSuccess) return fail(e);
+        if ((e = hipEventRecord(sg.ev[b], sg.s)) != hipSuccess) return fail(e);
+    }
+    if ((e = hipStreamSynchronize(sg.s)) != hipSuccess) return fail(e);
+    *out = st;
+    return GS_OK;
+}
+
+void gs_text_stage_free(gs_textstage *st) {
+    if (!st) return;
+    (void)hipSetDevice(st->device);
+    (void)hipFree(st->d_text);
+    delete st;
+}
+
+int gs_reads_from_staged_text(const gs_textstage *stage, int k, gs_reads **out, gs_textindex **index) {
+    if (!stage || !out || !index || k < 1 || k > 32) {
+        set_error("gs_reads_from_staged_text: bad argument");
         return GS_E_ARG;
     }
     *out = nullptr;
     *index = nullptr;
-    if (n_bytes >= 0xFFFFFF00ull) {
-        set_error("gs_reads_from_text: a block of %llu bytes (cut the text at record boundaries into blocks below 4 GiB)", (unsigned long long)n_bytes);
-        return GS_E_ARG;
-    }
-    if (gs_device_count() <= device || device < 0) {
-        set_error("gs_reads_from_text: HIP device %d not available -- there is no CPU fallback", device);
-        return GS_E_NODEVICE;
-    }
-    if (n_bytes == 0 || (text[0] != '>' && text[0] != '@')) {
+    const int device = stage->device;
+    const uint32_t n = stage->n;
+    if (n == 0 || (stage->first != '>' && stage->first != '@')) {
         set_error("gs_reads_from_text: the text does not start with '>' or '@'");
         return GS_E_IRREGULAR;
     }
     HIP_TRY(hipSetDevice(device));
-    const uint32_t n = (uint32_t)n_bytes;
-    const bool fastq = text[0] == '@';
+    const bool timing = getenv("GAVISUNK_INGEST_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ingest] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
+    const bool fastq = stage->first == '@';
     DevMem mem;
-    uint8_t *d_text, *d_flag, *d_c0, *d_hdr, *d_seq;
+    const uint8_t *d_text = stage->d_text;
+    uint8_t *d_flag, *d_c0, *d_hdr, *d_seq;
     uint32_t *d_ls, *d_llen, *d_seqbytes, *d_base, *d_scalars, *d_hdr_line, *d_name_off, *d_name_len, *d_rec_off;
     unsigned long long *d_count;
-    HIP_TRY(mem.get(&d_text, n));
     HIP_TRY(mem.get(&d_flag, n));
     HIP_TRY(mem.get(&d_count, 2));
     HIP_TRY(mem.get(&d_scalars, 4));
-    HIP_TRY(hipMemcpy(d_text, text, n, hipMemcpyHostToDevice));
+    lap("mallocs");
     HIP_TRY(hipMemset(d_scalars, 0, 16));
-    hipLaunchKernelGGL(k_line_start_flags, dim3((n + 255) / 256), dim3(256), 0, 0, d_text, n, d_flag);
+    HIP_TRY(hipMemset(d_count, 0, 16));
+    hipLaunchKernelGGL(k_line_start_flags, dim3((n + 255) / 256), dim3(256), 0, 0, d_text, n, d_flag, d_count + 1);
+    unsigned long long n_lines_counted = 0;
+    HIP_TRY(hipMemcpy(&n_lines_counted, d_count + 1, 8, hipMemcpyDeviceToHost));
     // line starts = the positions whose flag is set, in order
-    HIP_TRY(mem.get(&d_ls, (size_t)n));  // (at most one line per byte; freed with the rest)
+    HIP_TRY(mem.get(&d_ls, (size_t)n_lines_counted + 1));
     size_t tb = 0;
     void *d_tmp = nullptr;
     rocprim::counting_iterator<uint32_t> iota(0u);
     HIP_TRY(rocprim::select(nullptr, tb, iota, d_flag, d_ls, d_count, (size_t)n));
     HIP_TRY(mem.get(reinterpret_cast<uint8_t **>(&d_tmp), tb));
     HIP_TRY(rocprim::select(d_tmp, tb, iota, d_flag, d_ls, d_count, (size_t)n));
+    lap("line starts");
     unsigned long long n_lines64 = 0;
     HIP_TRY(hipMemcpy(&n_lines64, d_count, 8, hipMemcpyDeviceToHost));
     const uint32_t n_lines = (uint32_t)n_lines64;
@@ -230,6 +320,7 @@ int gs_reads_from_text(int device, const uint8_t *text, uint64_t n_bytes, int k,
     HIP_TRY(rocprim::exclusive_scan(d_tmp2, tb2, d_seqbytes, d_base, 0u, (size_t)n_lines + 1, rocprim::plus<uint32_t>()));
     uint32_t total = 0;
     HIP_TRY(hipMemcpy(&total, d_base + n_lines, 4, hipMemcpyDeviceToHost));
+    lap("lines, scan");
     // records = header lines
     HIP_TRY(mem.get(&d_hdr_line, n_lines));
     size_t tb3 = 0;
@@ -249,6 +340,7 @@ int gs_reads_from_text(int device, const uint8_t *text, uint64_t n_bytes, int k,
     hipLaunchKernelGGL(k_gather_lines, dim3(std::min<uint32_t>((n_lines + 3) / 4, 1u << 16)), dim3(256), 0, 0, d_text, d_ls, d_seqbytes, d_base,
                        n_lines, d_seq);
     HIP_TRY(hipGetLastError());
+    lap("records, gather");
     auto *ix = new gs_textindex();
     std::vector<uint32_t> h32(n_rec);
     ix->name_len.resize(n_rec);
@@ -263,12 +355,32 @@ int gs_reads_from_text(int device, const uint8_t *text, uint64_t n_bytes, int k,
     off[n_rec] = total;
     for (uint32_t r = 0; r < n_rec; r++) ix->len[r] = (uint32_t)(off[r + 1] - off[r]);
     const int rc = gs_reads_from_device_ascii(device, d_seq, off.data(), n_rec, k, out);  // (synchronises the device first)
+    lap("index copies, pack");
     if (rc != GS_OK) {
         delete ix;
         return rc;
     }
     *index = ix;
     return GS_OK;
+}
+
+int gs_reads_from_text(int device, const uint8_t *text, uint64_t n_bytes, int k, gs_reads **out, gs_textindex **index) {
+    if (!out || !index || (!text && n_bytes) || k < 1 || k > 32) {
+        set_error("gs_reads_from_text: bad argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    *index = nullptr;
+    if (n_bytes == 0 || (text[0] != '>' && text[0] != '@')) {
+        set_error("gs_reads_from_text: the text does not start with '>' or '@'");
+        return GS_E_IRREGULAR;
+    }
+    gs_textstage *st = nullptr;
+    int rc = gs_text_stage(device, text, n_bytes, &st);
+    if (rc != GS_OK) return rc;
+    rc = gs_reads_from_staged_text(st, k, out, index);
+    gs_text_stage_free(st);
+    return rc;
 }
 
 void gs_textindex_free(gs_textindex *ix) { delete ix; }

@@ -9,6 +9,7 @@ All compute happens in libgavisunk.so's HIP kernels; nothing here falls back to 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Iterator, List, Sequence
 
 import numpy as np
@@ -117,8 +118,14 @@ def text_blocks(path: str, max_bytes: int = 1 << 30) -> Iterator[bytes]:
     else is refused by gs_reads_from_text and read by the host parser instead)."""
     import gzip
 
+    import mmap
+
     with open(path, "rb") as probe:
         gz = probe.read(2) == b"\x1f\x8b"
+        size = os.fstat(probe.fileno()).st_size
+        if not gz and 0 < size <= max_bytes:  # one block: the file's pages as they are (no copy on the host at all)
+            yield mmap.mmap(probe.fileno(), 0, access=mmap.ACCESS_READ)  # (unmapped when its last user lets go of it)
+            return
     f = gzip.open(path, "rb") if gz else open(path, "rb")
     try:
         rem = b""
@@ -144,6 +151,25 @@ def text_blocks(path: str, max_bytes: int = 1 << 30) -> Iterator[bytes]:
             rem = buf[cut:]
     finally:
         f.close()
+
+
+class StagedText:
+    """The text of a FASTA / FASTQ block copied to the device (gs_text_stage) -- done by the reader thread of the command line
+    stub while the main thread still loads the SUNK table; DeviceReads.from_staged parses it there."""
+
+    def __init__(self, text, device: int = 0):
+        self.text, self.device = text, device
+        buf = np.frombuffer(text, dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib().gs_text_stage(device, buf.ctypes.data if len(buf) else None, len(buf), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_text_stage_free(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 class DeviceTable:
@@ -221,6 +247,29 @@ class DeviceReads:
         return self
 
     @classmethod
+    def from_staged(cls, staged: "StagedText", k: int) -> "DeviceReads":
+        """Parse a text that StagedText has already copied to the device (gs_reads_from_staged_text)."""
+        L = lib()
+        h, ix = C.c_void_p(), C.c_void_p()
+        check(L.gs_reads_from_staged_text(staged._h, k, C.byref(h), C.byref(ix)))
+        return cls._with_index(h, ix, staged.text, k, staged.device)
+
+    @classmethod
+    def _with_index(cls, h, ix, text, k: int, device: int) -> "DeviceReads":
+        L = lib()
+        self = cls.__new__(cls)
+        self._h, self.k, self.device = h, k, device
+        n = L.gs_textindex_n_reads(ix)
+        no = _view(L.gs_textindex_name_off(ix), n, np.uint64).tolist()
+        nl = _view(L.gs_textindex_name_len(ix), n, np.uint32).tolist()
+        self.len = _view(L.gs_textindex_len(ix), n, np.uint32).copy()
+        self.names = [bytes(text[o:o + l]).decode() for o, l in zip(no, nl)]
+        L.gs_textindex_free(ix)
+        self.n_reads, self.n_bases = n, int(self.len.sum())
+        self.n_windows = L.gs_reads_n_windows(h)
+        return self
+
+    @classmethod
     def from_text(cls, text: bytes, k: int, device: int = 0) -> "DeviceReads":
         """Records parsed, gathered and packed on the GPU from the text of a FASTA / FASTQ block (gs_reads_from_text).  Raises
         GsError with code GS_E_IRREGULAR for texts outside the regular subset: read those with read_batches.  The result
@@ -229,17 +278,7 @@ class DeviceReads:
         h, ix = C.c_void_p(), C.c_void_p()
         buf = np.frombuffer(text, dtype=np.uint8)
         check(L.gs_reads_from_text(device, buf.ctypes.data if len(buf) else None, len(buf), k, C.byref(h), C.byref(ix)))
-        self = cls.__new__(cls)
-        self._h, self.k, self.device = h, k, device
-        n = L.gs_textindex_n_reads(ix)
-        no = _view(L.gs_textindex_name_off(ix), n, np.uint64).tolist()
-        nl = _view(L.gs_textindex_name_len(ix), n, np.uint32).tolist()
-        self.len = _view(L.gs_textindex_len(ix), n, np.uint32).copy()
-        self.names = [text[o:o + l].decode() for o, l in zip(no, nl)]
-        L.gs_textindex_free(ix)
-        self.n_reads, self.n_bases = n, int(self.len.sum())
-        self.n_windows = L.gs_reads_n_windows(h)
-        return self
+        return cls._with_index(h, ix, text, k, device)
 
     def set_seeds(self, seed_at, seed) -> None:
         """Force the carried location to seed[j] before the read at tagging position seed_at[j] (gs_reads_set_seeds)."""

@@ -31,9 +31,12 @@ class _Prefetch:
     the first batch is ready when the k-mer list and the location table are, later ones while the GPU tags their
     predecessors.  Errors of the reads file surface where the reference meets them: when the batch is asked for."""
 
-    def __init__(self, path: str, max_bases: int):
+    def __init__(self, path: str, max_bases: int, text: bool = False, device: int = 0):
+        """text=True: blocks of the file's text, already copied to the device (engine.text_blocks -> engine.StagedText, for the
+        on-device record parser) instead of parsed batches"""
         self._q: queue.Queue = queue.Queue(maxsize=1)
         self._stop = threading.Event()
+        self._text, self._device = text, device
         self._t = threading.Thread(target=self._work, args=(path, max_bases), daemon=True)
         self._t.start()
 
@@ -48,7 +51,9 @@ class _Prefetch:
 
     def _work(self, path, max_bases):
         try:
-            for b in engine.read_batches(path, max_bases=max_bases):
+            src = (engine.StagedText(t, self._device) for t in engine.text_blocks(path, max_bases)) if self._text else \
+                engine.read_batches(path, max_bases=max_bases)
+            for b in src:
                 if not self._put(b):
                     b.close()
                     return
@@ -77,18 +82,20 @@ class _Prefetch:
         self._t.join(timeout=5)
 
 
-def _tag_text_blocks(reads: str, db, table, ofile: str, device: int, max_bytes: int):
+def _tag_text_blocks(blocks, db, table, ofile: str, device: int):
     """The reads file as text blocks parsed on the GPU (gs_reads_from_text).  -> exit code, or None
     when the text is outside the regular FASTA / FASTQ subset the device parser takes (nothing useful is written then)."""
     carry = _lib.GS_NONE
     with open(ofile, "w") as out:
-        for text in engine.text_blocks(reads, max_bytes):
+        for staged in blocks:
             try:
-                dev = engine.DeviceReads.from_text(text, db.k, device)
+                dev = engine.DeviceReads.from_staged(staged, db.k)
             except _lib.GsError as e:
+                staged.close()
                 if e.status == _lib.GS_E_IRREGULAR:
                     return None
                 raise
+            staged.close()
             st, hits, carry, _ = engine.tag(table, dev, carry)
             out.write(engine.format_sunkpos(hits, dev.names, db))
             dev.close()
@@ -101,11 +108,13 @@ def _tag_text_blocks(reads: str, db, table, ofile: str, device: int, max_bytes: 
 def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_bases: int = 1 << 31) -> int:
     host_parse = os.environ.get("GAVISUNK_PARSE", "device") == "host"
     batches = _Prefetch(reads, batch_bases) if host_parse else None
+    blocks = None if host_parse else _Prefetch(reads, min(batch_bases, 1 << 30), text=True, device=device)  # (read and copied meanwhile)
     try:
         db = engine.SunkDB(kmers, locs)
     except _lib.GsError as e:
-        if batches is not None:
-            batches.close()
+        for pf in (batches, blocks):
+            if pf is not None:
+                pf.close()
         sys.stderr.write(e.msg + "\n")
         return 1
     sys.stderr.write("FINISHED READING KMERS\n")
@@ -114,10 +123,11 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
     rc = None
     if not host_parse:  # records parsed on the GPU; texts it does not take (multi-line FASTQ, ...) go to the host parser
         try:
-            rc = _tag_text_blocks(reads, db, table, ofile, device, min(batch_bases, 1 << 30))
+            rc = _tag_text_blocks(blocks, db, table, ofile, device)
         except OSError as e:
             sys.stderr.write(f"cannot open the file {reads}: {e}\n")
             rc = 1
+        blocks.close()
         if rc is None:
             batches = _Prefetch(reads, batch_bases)
     if rc is None:

@@ -165,6 +165,13 @@ int gs_reads_from_device_ascii(int device, const void *d_seq, const uint64_t *of
  * file order) says where each read's name is in `text` and how many bases it has. */
 typedef struct gs_textindex gs_textindex;
 int gs_reads_from_text(int device, const uint8_t *text, uint64_t n_bytes, int k, gs_reads **out, gs_textindex **index);
+/* The two halves of gs_reads_from_text, for callers that overlap them with other work: gs_text_stage copies the text to the
+ * device (through pinned buffers, on a stream of its own; safe to call from a second thread while the first loads the SUNK
+ * table), gs_reads_from_staged_text parses what was staged.  `text` must stay readable for the names until the index is used. */
+typedef struct gs_textstage gs_textstage;
+int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstage **out);
+void gs_text_stage_free(gs_textstage *st);
+int gs_reads_from_staged_text(const gs_textstage *stage, int k, gs_reads **out, gs_textindex **index);
 void gs_textindex_free(gs_textindex *ix);
 uint32_t gs_textindex_n_reads(const gs_textindex *ix);
 const uint64_t *gs_textindex_name_off(const gs_textindex *ix);
