@@ -129,8 +129,8 @@ int gs_table_create_device(int device, int k, uint64_t n, const void *d_keys, co
 void gs_table_destroy(gs_table *t);
 uint64_t gs_table_bytes(const gs_table *t);
 /* Human-readable description of the layout chosen for this table: "compact-lds" / "compact-l2" (small tables: an exact
- * compact copy probed from LDS / the XCD-partitioned L2s), "minimizer-hbm" (tables that only fit HBM: 128-byte regions
- * addressed by the k-mer's minimiser, so that consecutive windows share one memory request), "compact-hbm", "generic".
+ * compact copy probed from LDS / the XCD-partitioned L2s), "minimizer-hbm" (tables that only fit HBM: 64-byte regions
+ * addressed by a mod-minimiser of the k-mer, so that consecutive windows share one memory request), "compact-hbm", "generic".
  * GAVISUNK_TABLE=generic|compact-l2|compact-hbm|minimizer (read once, when the table is created) forces one. */
 const char *gs_table_layout(const gs_table *t);
 
