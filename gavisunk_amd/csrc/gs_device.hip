@@ -2104,7 +2104,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
         // GAVISUNK_TABLE=minimizer-exact: every tile by the per-lane form (the fast form's fallback); also tables whose loc ids
         // are longer than a hit-list entry of the fast form holds (more than 2^20 location groups)
-        if (t->mz == 2 || t->mz_locbits > kMzFastLocBits) {
+        if (t->mz && (t->mz == 2 || t->mz_locbits > kMzFastLocBits)) {
             hipLaunchKernelGGL(k_probe_mz_exact, dim3(blocks), dim3(256), 0, t->stream, mz_view(t), view(t), (const uint64_t *)r->words,
                                (const TileDesc *)r->tile_desc, r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count);
         } else if (t->mz) {

@@ -377,6 +377,21 @@ def test_exact_reads_fill_and_flush_the_hit_list(groups_div, table_layout):
         assert (ctr["fallback_tiles"] > 10) == (groups_div == 1)
 
 
+@pytest.mark.parametrize("k", [20, 25])
+def test_more_than_a_million_location_groups(k, table_layout):
+    """Loc ids of 21 bits: more than an entry of the fast minimiser kernel's hit list holds -- such a table is tagged by the
+    exact per-lane kernel -- and, for k = 25, more than a 64-bit slot takes beside the key at all (the minimiser layout does
+    not apply and must not be launched: found by tools/fuzz_tag.py seed 9013)."""
+    keys, loc, seqs = _random_case(91, k, n_reads=12, glen=1_200_000, median=3000, n_groups_div=1)
+    assert int(loc.max()) >= 1 << 20
+    seqs = seqs + [seqs[0][:k - 1], b""]
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] > 1000 and len(gh) == len(oh)
+    assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"]) and np.array_equal(gh["payload"], oh["row"])
+    assert carry == (loc[oprev] if oprev != oracle.NONE else _lib.GS_NONE)
+
+
 def test_join_overflow_lists_longer_than_lds_are_searched_in_hbm(monkeypatch, table_layout):
     """32 buckets per partition for a quarter of a million keys: nearly every key overflows, ~900 per table slice -- more
     than the 512 the LDS join keeps in LDS, so its probe kernel binary-searches the slice's sorted overflow list in HBM.

@@ -112,6 +112,8 @@ def main():
         cuts = [0, n] if rng.random() < 0.5 else sorted({0, n, *(int(x) for x in rng.integers(0, n + 1, 3))})
         ref = None
         for layout in LAYOUTS:
+            if os.environ.get("FUZZ_VERBOSE"):  # which (seed, layout) a GPU fault belongs to
+                print(f"seed {seed} k {K} layout {layout} keys {len(keys)} reads {len(seqs)} env {env} cuts {cuts}", flush=True)
             got = tag(layout, keys, loc, seqs, cuts if layout != "generic" else [0, n])
             names[got[4]] = names.get(got[4], 0) + 1
             if ref is None:
