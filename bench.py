@@ -292,6 +292,12 @@ def main():
     ap.add_argument("--cli", action="store_true", help="config-2 leg: also time the command-line drop-in (.fa -> .sunkpos)")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: everything else any library prints there (gloo announces its connections on
+    # stdout from C++) goes to stderr -- fd 1 is pointed at fd 2 until the line is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     global K
     K = a.k
     rank = int(os.environ.get("RANK", "0"))
@@ -505,7 +511,8 @@ def main():
             dev_reads.close()
             table.close()
             out["config2"] = config2_leg(a, device)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         comm.barrier()
         comm.close()
