@@ -103,7 +103,10 @@ int bcast_array(Rccl *R, gs_comm *c, int root, T **p, uint64_t count) {
     if (!count) return GS_OK;
     int rc;
     if (c->rank != root && (rc = dev_alloc(p, count))) return rc;
-    NCCL_TRY(R->Broadcast(*p, *p, (size_t)count * sizeof(T), ncclUint8, root, c->comm, c->stream));
+    // in pieces of 1 GiB (config 3's region array is 74 GiB: no single collective of that size)
+    const size_t bytes = (size_t)count * sizeof(T), piece = (size_t)1 << 30;
+    uint8_t *b = reinterpret_cast<uint8_t *>(*p);
+    for (size_t o = 0; o < bytes; o += piece) NCCL_TRY(R->Broadcast(b + o, b + o, std::min(piece, bytes - o), ncclUint8, root, c->comm, c->stream));
     return GS_OK;
 }
 
@@ -246,7 +249,7 @@ int gs_table_broadcast(gs_comm *c, int root, gs_table *mine, gs_table **out) {
             if ((rc = bcast_array(R, c, root, &t->j_ovf_start, (uint64_t)kJoinSlices + 1))) return rc;
             if (!is_root && (rc = dev_alloc(&t->j_ovf_code, hm.n_ovf)) == GS_OK) rc = dev_alloc(&t->j_ovf_loc, hm.n_ovf);
             if (rc) return rc;
-            if (hm.n_ovf) {
+            if (hm.n_ovf) {  // (at most a few thousand keys per slice: small)
                 NCCL_TRY(R->Broadcast(t->j_ovf_code, t->j_ovf_code, (size_t)hm.n_ovf * sizeof(uint64_t), ncclUint8, root, c->comm, c->stream));
                 NCCL_TRY(R->Broadcast(t->j_ovf_loc, t->j_ovf_loc, (size_t)hm.n_ovf * sizeof(uint32_t), ncclUint8, root, c->comm, c->stream));
             }
