@@ -734,6 +734,76 @@ const char *gs_batch_name(const gs_batch *b, uint32_t r) {
 
 }  // extern "C"
 
+// ------------------------------------------------------------------------------------- diag_filter_step2
+extern "C" {
+
+// diag_filter_step2.nim:16-22 (best contig per read, a later line for the same read overwrites) and :41-64 (rname_prev starts
+// as "string"; a row passes when its contig is its read's best contig)
+int gs_diag_filter_step2_files(const char *sunkpos_path, const char *diag_path, const char *out_path, uint64_t *rows_out) {
+    if (!sunkpos_path || !diag_path) {
+        set_error("gs_diag_filter_step2_files: null argument");
+        return GS_E_ARG;
+    }
+    std::unordered_map<std::string, std::string> best;
+    std::string line;
+    {
+        LineReader rd(diag_path);
+        if (!rd.ok()) {
+            set_error("cannot open the file %s", diag_path);
+            return GS_E_IO;
+        }
+        while (rd.next(line)) {
+            const size_t t1 = line.find('\t');
+            if (t1 == std::string::npos) continue;  // fewer than two fields
+            size_t t2 = line.find('\t', t1 + 1);
+            if (t2 == std::string::npos) t2 = line.size();
+            best[line.substr(0, t1)] = line.substr(t1 + 1, t2 - t1 - 1);
+        }
+    }
+    LineReader rd(sunkpos_path);
+    if (!rd.ok()) {
+        set_error("cannot open the file %s", sunkpos_path);
+        return GS_E_IO;
+    }
+    FILE *out = out_path ? fopen(out_path, "wb") : stdout;
+    if (!out) {
+        set_error("cannot open the file %s for writing", out_path);
+        return GS_E_IO;
+    }
+    std::vector<char> obuf(1 << 20);
+    if (out_path) setvbuf(out, obuf.data(), _IOFBF, obuf.size());
+    std::string prev = "string", cur, name;
+    uint64_t rows = 0;
+    while (rd.next(line)) {
+        if (line.empty()) continue;
+        const size_t t1 = line.find('\t');
+        name.assign(line, 0, t1 == std::string::npos ? line.size() : t1);
+        if (name != prev) {
+            auto it = best.find(name);
+            cur = it == best.end() ? std::string() : it->second;
+            prev = name;
+        }
+        if (t1 == std::string::npos) continue;
+        const size_t t2 = line.find('\t', t1 + 1);
+        if (t2 == std::string::npos) continue;  // fewer than three fields
+        size_t t3 = line.find('\t', t2 + 1);
+        if (t3 == std::string::npos) t3 = line.size();
+        if (line.compare(t2 + 1, t3 - t2 - 1, cur) == 0) {
+            fwrite(line.data(), 1, line.size(), out);
+            fputc('\n', out);
+            rows++;
+        }
+    }
+    if (out_path)
+        fclose(out);
+    else
+        fflush(out);
+    if (rows_out) *rows_out = rows;
+    return GS_OK;
+}
+
+}  // extern "C"
+
 // ------------------------------------------------------------------------------------- sunkpos
 extern "C" {
 

@@ -266,6 +266,11 @@ int gs_gather_view(gs_comm *c, const gs_hit **out, uint64_t *n_out);
  * whenever the name changes (diag_filter_v3.nim:64), so a name that comes back later is a new read. */
 typedef struct gs_sunkpos gs_sunkpos;
 int gs_sunkpos_load(const char *path, gs_sunkpos **out);
+/* `diag_filter_step2 <sunkpos> <diag>` as the reference program does it on files (diag_filter_step2.nim:16-64; rule
+ * diag_filter_final, tagONT.smk:110): the `.sunkpos` rows whose contig is the best contig the diag file records for their
+ * read, written to out_path (NULL: stdout).  Both inputs plain or gzip; no GPU involved (a text join; inside one process
+ * gs_diag_filter's keep[] is the same mask).  *rows_out = rows written. */
+int gs_diag_filter_step2_files(const char *sunkpos_path, const char *diag_path, const char *out_path, uint64_t *rows_out);
 void gs_sunkpos_free(gs_sunkpos *s);
 uint64_t gs_sunkpos_n_rows(const gs_sunkpos *s);
 uint32_t gs_sunkpos_n_segs(const gs_sunkpos *s);

@@ -198,3 +198,46 @@ def test_text_blocks_cut_at_record_boundaries(tmp_path):
     empty = tmp_path / "e"
     empty.write_bytes(b"")
     assert list(engine.text_blocks(str(empty))) == []
+
+
+from conftest import DIAG_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", DIAG_CASES)
+def test_native_diag_filter_step2_equals_the_reference_binary(golden, name, tmp_path, capfd):
+    """gs_diag_filter_step2_files (the library's own text join, like the reference's compiled program) on the reference
+    binaries' own inputs and outputs (tests/golden: `diag_filter_v3` output in, `diag_filter_step2` output expected), to a
+    file, through the command-line stub's file-object form, plain and gzipped inputs."""
+    import ctypes as C
+    import gzip
+    import io
+
+    from gavisunk_amd import _lib, diag_filter_step2
+
+    c = golden(name)
+    for run in c.meta["diag"]:
+        sp, dg, exp = c.path(run["sunkpos"]), c.path(run["out"]), c.text(run["out2"])
+        out = tmp_path / "o"
+        rows = C.c_uint64(0)
+        _lib.check(_lib.lib().gs_diag_filter_step2_files(sp.encode(), dg.encode(), str(out).encode(), C.byref(rows)))
+        assert out.read_text() == exp and rows.value == exp.count("\n")
+        buf = io.StringIO()
+        assert diag_filter_step2.run(sp, dg, out=buf) == 0 and buf.getvalue() == exp
+        gz = tmp_path / "s.gz"
+        gz.write_bytes(gzip.compress(open(sp, "rb").read()))
+        buf = io.StringIO()
+        assert diag_filter_step2.run(str(gz), dg, out=buf) == 0 and buf.getvalue() == exp
+    with pytest.raises(_lib.GsError):
+        diag_filter_step2.run(str(tmp_path / "missing"), dg, out=io.StringIO())
+
+
+def test_diag_filter_step2_command_line_writes_stdout(golden):
+    import subprocess
+    import sys
+
+    c = golden("kat3")
+    run = c.meta["diag"][0]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "gavisunk_amd.diag_filter_step2", c.path(run["sunkpos"]), c.path(run["out"])],
+                       cwd=root, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout == c.text(run["out2"])
