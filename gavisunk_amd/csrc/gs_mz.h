@@ -210,6 +210,12 @@ __device__ __forceinline__ MzCand mz_candidates(uint64_t F, uint32_t fp) {
     c.m1 = mz_byte_eq((uint32_t)(F >> 32), T);
     return c;
 }
+__device__ __forceinline__ MzCand mz_candidates_T(uint64_t F, uint32_t T) {  // T: the fingerprint in all four bytes
+    MzCand c;
+    c.m0 = mz_byte_eq((uint32_t)F, T) & 0x80808000u;
+    c.m1 = mz_byte_eq((uint32_t)(F >> 32), T);
+    return c;
+}
 // some key of this region lives in the generic table only (the count byte says "more than kMzSlots")
 __device__ __forceinline__ bool mz_region_overflowed(uint64_t F) { return ((uint32_t)F & 0xFFu) == 0xFFu - (uint32_t)(kMzSlots + 1); }
 
@@ -651,9 +657,9 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
     const uint32_t nsteps = min((td.nwin_left + 63u) / 64u, 32u);
     const uint32_t list_a = lds_addr(&L.list[0]), defer_a = lds_addr(&L.defer[0]), words_a = lds_addr(&L.words[0]);
 
-    // per in-flight step (slot = step % kMzStages): fingerprint | run << 8 | valid << 14, the tag to look for, lane r = region
-    // of run r, and the run count
-    uint32_t meta[kMzStages], runreg[kMzStages], nruns[kMzStages];
+    // per in-flight step (slot = step % kMzStages): the fingerprint to look for, where the lane's region is in the cache slot,
+    // the key / tag to look for, lane r = region of run r, and the run count
+    uint32_t fpT[kMzStages], regoff[kMzStages], runreg[kMzStages], nruns[kMzStages];  // fpT: fingerprint in all four bytes, bit 31 of regoff: invalid lane
     uint64_t want[kMzStages];
     MzWin cur = mz_window_lds(words_a, 0, lane, k, m, kmask, mmask);
     MzSlide<NT> slide;
@@ -690,7 +696,8 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
         const unsigned long long lb = __ballot(leader);
         const uint32_t R = (uint32_t)__popcll(lb);  // >= 1: lane 0 of an existing step is valid
         const uint32_t myrun = (uint32_t)__popcll(lb & (lt | (1ULL << lane))) - 1u;
-        meta[slot] = key.fp | (myrun << 8) | ((valid ? 1u : 0u) << 14);
+        fpT[slot] = key.fp * 0x01010101u;
+        regoff[slot] = myrun * (uint32_t)(kMzWords * 8) | (valid ? 0u : 0x80000000u);  // byte offset of the run's region in the cache slot
         want[slot] = key.tag << locbits;
         nruns[slot] = R;
         // lane r <- region of run r (leaders push; the others push to lane 63, which holds a run only when all 64 lanes lead)
@@ -703,15 +710,15 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
     // BIG (compile-time): the step has more runs than a cache slot holds and is looked up in two halves
     auto lookups = [&](uint32_t s, int u, uint32_t r0, auto full_tile, auto big_step) {
         constexpr bool FULL = decltype(full_tile)::value, BIG = decltype(big_step)::value;
-        const uint32_t fp = meta[u] & 0xFFu, myrun = (meta[u] >> 8) & 63u;
-        const bool mine = (FULL || ((meta[u] >> 14) & 1u)) && (!BIG || (myrun >= r0 && myrun < r0 + (uint32_t)kMzRunCap));
-        const uint32_t reg_a = lds_addr(&L.cache[u][0]) + (myrun - r0) * (uint32_t)(kMzWords * 8);
+        const uint32_t off = regoff[u] & 0x7FFFFFFFu, myrun = off / (uint32_t)(kMzWords * 8);
+        const bool mine = (FULL || !(regoff[u] >> 31)) && (!BIG || (myrun >= r0 && myrun < r0 + (uint32_t)kMzRunCap));
+        const uint32_t reg_a = lds_addr(&L.cache[u][0]) + (FULL ? regoff[u] : off) - r0 * (uint32_t)(kMzWords * 8);
         uint64_t F = ~0ULL;
         if (FULL && !BIG)
             F = lds_read_b64(reg_a);
         else if (mine)
             F = lds_read_b64(reg_a);
-        MzCand cd = mz_candidates(F, fp);
+        MzCand cd = mz_candidates_T(F, fpT[u]);
         // the first slot whose fingerprint matches: the hit, nearly always (a second candidate needs a fingerprint collision)
         bool hit = false;
         uint64_t e = 0;
