@@ -63,9 +63,14 @@ def kernel_names(layout: str) -> str:
 
 
 def source_hash() -> str:
+    """Hash of the kernel sources as the compiler sees them: `//` comments and blank lines do not count (so that a comment
+    edit does not orphan the measured traffic figure; any code edit does)."""
     h = hashlib.sha256()
     for f in ("gs_device.hip", "gs_mz.h"):
-        h.update(open(os.path.join(ROOT, "gavisunk_amd", "csrc", f), "rb").read())
+        for ln in open(os.path.join(ROOT, "gavisunk_amd", "csrc", f), "r"):
+            code = ln.split("//", 1)[0].rstrip()
+            if code:
+                h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 

@@ -34,14 +34,15 @@
 //             byte i      fingerprint of slot i (i = 1..7), 0xFF = empty
 //             word i      tag << locbits | loc            (all ones = empty; the all-ones loc is never stored)
 //
-// (fp, tag) determine l and with it the key -- 0xFE stands for both 0xFE and 0xFF, which differ in bit 24 of l, and that
-// bit is in the tag too -- so a slot whose fingerprint and tag match is an exact hit, wherever the region came from.
-// A lookup reads the fingerprint word, compares its bytes all at once, and reads only the slots whose fingerprint matches
-// (one for a hit, none for 97 % of the misses).  Keys fill a region's slots in arrival order; a key whose region is full
-// stays in the generic 16-byte-slot table, and a lookup without a match in a FULL region asks that table.
-// m >= k - 7 (a minimiser owns at most w = 8 adjacent k-mers of one place) and grows with the key count (about log4 of
-// it: each minimiser value should own <= ~1 place of the assembly): human-genome-scale tables of 20-mers get m = 16, runs
-// of ~3 windows.  m-mers longer than 16 bases (k > 23) are hashed down to 32 bits.
+// HASHED slots: (fp, tag) determine l and with it the key -- 0xFE stands for both 0xFE and 0xFF, which differ in bit 24 of
+// l, and that bit is in the tag too; RAW slots hold the key itself -- either way a slot whose fingerprint and key / tag match
+// is an exact hit, wherever the region came from.  A lookup reads the fingerprint word, compares its bytes all at once, and
+// reads only the slots whose fingerprint matches (one for a hit, none for 97 % of the misses).  The build is a stable sort by
+// region: a region's keys take its slots in key order; the keys an overflowed region cannot hold stay in the generic
+// 16-byte-slot table, and a lookup without a match there asks that table unless the region's filter word rules the key out.
+// m >= k - 7 (a minimiser owns at most w = 8 adjacent k-mers of one place), starts at k - 4 and grows with the key count (each
+// minimiser value should own <= ~1 place of the assembly): 20-mer tables get m = 16 up to ~2.6e8 keys, m = 17 at human-genome
+// scale (1.5e9 keys), runs of ~3 windows.  m-mers longer than 16 bases are hashed down to 32 bits.
 //
 // Payloads (the loc row a hit reports) are not in the slots: only the emitted rows (1e-4 .. 1e-3 of the windows) need one.
 // They sit in a parallel array, one 32-bit word per slot, that only k_emit reads.
@@ -58,8 +59,8 @@ constexpr uint64_t kMzEmpty = ~0ULL;
 constexpr int kMzWords = 8;        // 64-bit words per region (64 bytes): word 0 = fingerprint bytes, words 1..7 = slots
 constexpr int kMzPieces = kMzWords / 2;  // 16-byte pieces per region (what one lane fetches)
 constexpr int kMzSlots = kMzWords - 1;   // keys per region
-constexpr int kMzCandLds = 128;    // candidates of a tile kept in LDS; tiles with more are walked a second time
-constexpr int kMzU = 4;            // wave-steps (64 windows each) whose table loads are in flight together
+constexpr int kMzCandLds = 128;    // candidates of a tile kept in LDS; tiles with more are walked a second time (exact form) / done over by it (fast form)
+constexpr int kMzU = 4;            // exact form: wave-steps (64 windows each) whose table loads are in flight together
 
 // two different bijections on 32-bit values
 __host__ __device__ __forceinline__ uint32_t mz_mix_a(uint32_t x) {

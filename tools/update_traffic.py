@@ -2,7 +2,7 @@
 """usage: python tools/update_traffic.py <tag>   -- after tools/final_profile_r02.sh <tag> has run on the GPU box.
 Copies gpurun_out/r02/<tag>_{bench.json,bench_under_rocprof.json,kernel_stats.csv,pmc.txt} into profiles/r02/ and rewrites
 profiles/r02/traffic.json (HBM bytes per launch of the headline kernel) from the PMC summary, keyed by the workload and by the
-hash of the kernel sources it was measured on (bench.py quotes the figure only while both still match)."""
+hash of the kernel sources it was measured on (code only: comments and blank lines do not count) (bench.py quotes the figure only while both still match)."""
 import json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
