@@ -452,8 +452,8 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 //            hit does.  A step with more than kMzRunCap runs (rare) is consumed in two halves, the second fetched on the spot.
 //   flush    when the hit list or the deferred queue might not hold one more step, and after the last step: the deferred
 //            lookups go to the generic table 64 at a time (their latencies overlap), then one ordered pass over the dense hit
-//            list does the bookkeeping exactly as mz_tile does, and the list starts over (the small list is what lets 20
-//            waves share a CU's LDS).
+//            list does the bookkeeping exactly as mz_tile does, and the list starts over (the small list is what lets 24
+//            waves share a CU's LDS: 6.5 KB each, 79 VGPRs).
 //
 // A tile with more candidates (location changes) than the LDS buffer holds (kMzCandLds) is done over by mz_tile_exact:
 // exactness never depends on the budgets.
@@ -461,8 +461,10 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 constexpr int kMzRunCap = 32;                  // runs of a step whose regions fit the LDS cache slot (2 KiB)
 constexpr int kMzDma = kMzRunCap * kMzPieces / 64;  // LDS-DMA wave-instructions per step
 constexpr int kMzStages = 2;                   // steps whose region fetches are in flight together
-constexpr int kMzListCap = 512;                // maybe-hits held before the list is flushed (a step adds up to 64)
-constexpr int kMzDeferCap = 128;               // deferred generic-table lookups held before a flush
+constexpr int kMzListCap = 320;                // maybe-hits held before the list is flushed (a step adds up to 64)
+constexpr int kMzDeferCap = 96;  
+constexpr int kMzFastCand = 64;                // candidates (location changes) of a tile before it is handed to the exact form
+static_assert(kMzListCap >= kMzCandLds, "the exact form borrows the hit list as its candidate buffer");              // deferred generic-table lookups held before a flush
 constexpr int kMzWaves = 2;                    // waves per workgroup
 constexpr int kMzListLocBits = 21;             // a list entry = window offset in the tile << 21 | loc + 1 (0 = no hit after all)
 constexpr uint32_t kMzListLocMask = (1u << kMzListLocBits) - 1u;
@@ -473,7 +475,7 @@ struct MzWaveLds {
     uint4 cache[kMzStages][kMzRunCap * kMzPieces];
     uint32_t list[kMzListCap];
     uint32_t defer[kMzDeferCap];
-    uint32_t cand[kMzCandLds];              // the tile's candidates (a tile with more is done over by the exact form)
+    uint32_t cand[kMzFastCand];             // the tile's candidates (a tile with more is done over by the exact form)
     uint64_t words[kTileWords + 2];         // the tile's packed bases
 };
 
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(64) void k_mz_rule_check(int k_rt, int m_rt, const 
 
 // KT / MT: k and m as compile-time constants (0 = take them from the table)
 template <int KT, int MT>
-__global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView tab, const uint64_t *__restrict__ words,
+__global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableView tab, const uint64_t *__restrict__ words,
                                                            const TileDesc *__restrict__ tdesc, uint32_t n_tiles, TileArrays ta,
                                                            uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
                                                            uint32_t *g_fallback_tiles) {
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
             const bool chg = hit && loc != prev;
             const unsigned long long cb = __ballot(chg);
             const uint32_t ci = n_cand + (uint32_t)__popcll(cb & lt);
-            if (chg && ci < (uint32_t)kMzCandLds) L.cand[ci] = ((n_raw + (uint32_t)__popcll(below)) << 16) | woff;
+            if (chg && ci < (uint32_t)kMzFastCand) L.cand[ci] = ((n_raw + (uint32_t)__popcll(below)) << 16) | woff;
             n_cand += (uint32_t)__popcll(cb);
             if (first_loc == GS_NONE) first_loc = lane_value(loc, __ffsll((unsigned long long)hb) - 1);
             carry = lane_value(loc, 63 - __clzll((long long)hb));
@@ -856,9 +858,9 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_probe_mz(MzView mz, TableView
         steps(std::false_type{});
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     flush();
-    if (n_cand > (uint32_t)kMzCandLds) {  // (wave-uniform, rare) more location changes than the candidate buffer holds
+    if (n_cand > (uint32_t)kMzFastCand) {  // (wave-uniform, rare) more location changes than the candidate buffer holds
         if (lane == 0) atomicAdd(g_fallback_tiles, 1u);
-        mz_tile_exact(mz, tab, words, td, tile, n_tiles, ta, cand, cand_cap, g_cand_count, L.cand);
+        mz_tile_exact(mz, tab, words, td, tile, n_tiles, ta, cand, cand_cap, g_cand_count, L.list);
         return;
     }
     const uint32_t *cbuf = L.cand;
