@@ -381,7 +381,11 @@ def main():
         summ = comm.exchange_summaries(has.value, last.value)
         _lib.check(L.gs_tag_phase2(table._h, dev_reads._h, gdist.resolve_carry(summ, rank)))
         _lib.check(L.gs_tag_finish(table._h, dev_reads._h, None, 0, C.byref(n_hits), C.byref(carry), C.byref(ctr)))
-        return comm.gather_hits(table, dev_reads, n_hits.value, read_lo)
+        # every rank's rows are on its own host now (gs_tag_finish, as at N = 1); the concatenated list is gathered into the
+        # root's device memory over xGMI (north_star's "hit buffers concatenated via an RCCL gather") and stays there
+        return comm.gather_hits(table, dev_reads, n_hits.value, read_lo, to_host=gather_to_host)
+
+    gather_to_host = False
 
     def sync():
         if world > 1:
@@ -407,6 +411,19 @@ def main():
     else:
         total_bases = n_bases
     log(f"{a.steps} steps: {total_bases * a.steps / dt / 1e9:.1f} Gbase/s")
+    gather_check = None
+    if world > 1:  # once, outside the timed region: the gathered list on the root's host = every rank's rows, rank 0's first
+        gather_to_host = True
+        g = step()
+        gather_to_host = False
+        tot = int(comm.all_sum(int(n_hits.value)))
+        if rank == 0:
+            vp = C.c_void_p()
+            _lib.check(L.gs_tag_hits_view(table._h, dev_reads._h, C.byref(vp), None))
+            own = engine._view(vp.value, n_hits.value, engine.HIT_DTYPE)
+            gather_check = bool(g is not None and len(g) == tot and np.array_equal(g[: len(own)], own)
+                                and (len(g) == len(own) or int(g["read"][len(own)]) >= a.reads))
+            log(f"gathered list: {len(g) if g is not None else None} rows of {tot}, head = rank 0's rows: {gather_check}")
     c_main = ctr.as_dict()  # counters of the timed passes (the strong-scaling leg below runs more)
     # strong scaling beside the weak headline (N > 1): the SAME total read count as one GPU tags, cut over the ranks
     strong = None
@@ -463,6 +480,7 @@ def main():
                        "h_raw": round(h_raw, 5), "h_emit": round(h_emit, 7), "tiles": c["tiles"],
                        "fallback_tiles": c["fallback_tiles"], "table_GiB": round(table.nbytes / 2**30, 2), "table_layout": table.layout,
                        "parallelism": f"read-sharded x{world}, table replicated", "data_plane": data_plane,
+                       "gathered_list_checked": gather_check,
                        "env_knobs": knobs},
             "roofline": {"bound": "hbm", "kernel": kernel_names(table.layout), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": tnote,

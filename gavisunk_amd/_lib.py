@@ -103,6 +103,7 @@ SIGNATURES = {
     "gs_comm_destroy": (None, [P]),
     "gs_table_broadcast": (I, [P, I, P, C.POINTER(P)]),
     "gs_gather_hits": (I, [P, I, P, P, U32, P, U64, C.POINTER(U64)]),
+    "gs_gather_device": (I, [P, C.POINTER(P), C.POINTER(U64)]),
     "gs_gather_view": (I, [P, C.POINTER(P), C.POINTER(U64)]),
     "gs_diag_filter_step2_files": (I, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(U64)]),
     "gs_sunkpos_load": (I, [C.c_char_p, C.POINTER(P)]),

@@ -26,6 +26,8 @@ struct gs_comm {
     gs_hit *d_gather = nullptr;            // root: all ranks' rows
     gs_hit *h_gather = nullptr;            // root: pinned host copy of them (gs_gather_view)
     uint64_t gather_cap = 0, gather_n = 0;
+    uint64_t host_cap = 0;    // rows h_gather holds
+    bool host_valid = false;  // h_gather holds the rows of the last gather
 };
 
 namespace {
@@ -293,18 +295,16 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
             set_error("%llu hits do not fit in cap = %llu", (unsigned long long)total, (unsigned long long)cap);
             // the other ranks are about to send: take part in the exchange below with a scratch buffer, then report
         }
-        if (c->gather_cap < total) {  // grown once; later passes reuse both buffers
+        if (c->gather_cap < total) {  // grown once; later passes reuse the buffer
             (void)hipFree(c->d_gather);
-            if (c->h_gather) (void)hipHostFree(c->h_gather);
             c->d_gather = nullptr;
-            c->h_gather = nullptr;
             c->gather_cap = 0;
             const uint64_t want = total + (total >> 3) + 1024;
             if ((rc = dev_alloc(&c->d_gather, want))) return rc;
-            HIP_TRY(hipHostMalloc((void **)&c->h_gather, (size_t)want * sizeof(gs_hit), hipHostMallocDefault));
             c->gather_cap = want;
         }
         c->gather_n = total;
+        c->host_valid = false;
     }
     // rows: every rank sends exactly what it has; the root receives them back to back in rank order
     if (n > 1) NCCL_TRY(R->GroupStart());
@@ -332,14 +332,13 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
                                    (uint32_t)meta[2 * i + 1]);
             at += cnt;
         }
-        if (total) {  // one copy into pinned host memory (gs_gather_view), from there into `out` if the caller wants its own
-            HIP_TRY(hipMemcpyAsync(c->h_gather, c->d_gather, total * sizeof(gs_hit), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (out && total <= cap) memcpy(out, c->h_gather, total * sizeof(gs_hit));
-        }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
+    // the concatenated rows now are in the root's device memory (gs_gather_device); they cross PCIe only when asked for: into
+    // `out` here, or into pinned host memory by gs_gather_view (every rank's own rows already are on its own host after
+    // gs_tag_finish -- eight PCIe links in parallel -- so a pipeline that writes per-shard output never needs this copy)
+    if (is_root && out && total && total <= cap) HIP_TRY(hipMemcpy(out, c->d_gather, total * sizeof(gs_hit), hipMemcpyDeviceToHost));
     if (is_root && out && total > cap) return GS_E_CAPACITY;
     return GS_OK;
 }
@@ -349,7 +348,36 @@ int gs_gather_view(gs_comm *c, const gs_hit **out, uint64_t *n_out) {
         set_error("gs_gather_view: bad argument");
         return GS_E_ARG;
     }
-    if (out) *out = c->h_gather;
+    if (n_out) *n_out = c->gather_n;
+    if (out) {
+        *out = nullptr;
+        if (c->gather_n) {
+            HIP_TRY(hipSetDevice(c->device));
+            if (c->host_cap < c->gather_n) {
+                if (c->h_gather) (void)hipHostFree(c->h_gather);
+                c->h_gather = nullptr;
+                c->host_cap = 0;
+                const uint64_t want = c->gather_n + (c->gather_n >> 3) + 1024;
+                HIP_TRY(hipHostMalloc((void **)&c->h_gather, (size_t)want * sizeof(gs_hit), hipHostMallocDefault));
+                c->host_cap = want;
+                c->host_valid = false;
+            }
+            if (!c->host_valid) {
+                HIP_TRY(hipMemcpy(c->h_gather, c->d_gather, c->gather_n * sizeof(gs_hit), hipMemcpyDeviceToHost));
+                c->host_valid = true;
+            }
+            *out = c->h_gather;
+        }
+    }
+    return GS_OK;
+}
+
+int gs_gather_device(gs_comm *c, const void **d_out, uint64_t *n_out) {
+    if (!c) {
+        set_error("gs_gather_device: bad argument");
+        return GS_E_ARG;
+    }
+    if (d_out) *d_out = c->d_gather;
     if (n_out) *n_out = c->gather_n;
     return GS_OK;
 }

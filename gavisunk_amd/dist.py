@@ -159,13 +159,15 @@ class Comm:
         return t.numpy().tobytes()
 
     # ---- data plane ----------------------------------------------------------------------------------------
-    def gather_hits(self, table, reads, n_local: int, read_offset: int, dst: int = 0):
-        """Per-rank hit lists of the last pass concatenated on rank `dst` in shard order (numpy HIT_DTYPE), None elsewhere."""
+    def gather_hits(self, table, reads, n_local: int, read_offset: int, dst: int = 0, to_host: bool = True):
+        """Per-rank hit lists of the last pass concatenated on rank `dst` in shard order (numpy HIT_DTYPE), None elsewhere.
+        to_host=False (RCCL data plane only): the concatenated rows stay in dst's device memory (every rank's own rows already
+        are on its own host)."""
         from . import engine
 
-        counts = [r[0] for r in self._all_gather_i64([n_local])]
         if self.rccl is not None:
-            return self.rccl.gather_hits(table, reads, counts, read_offset, dst)
+            return self.rccl.gather_hits(table, reads, None, read_offset, dst, to_host=to_host)
+        counts = [r[0] for r in self._all_gather_i64([n_local])]
         import torch
 
         from ._lib import check, lib

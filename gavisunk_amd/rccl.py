@@ -35,11 +35,13 @@ class RcclComm:
         t.k = t.n = None
         return t
 
-    def gather_hits(self, table, reads, counts, read_offset: int, dst: int = 0):
-        """All ranks' hit lists of the last pass on rank dst (numpy HIT_DTYPE), None elsewhere."""
+    def gather_hits(self, table, reads, counts, read_offset: int, dst: int = 0, to_host: bool = True):
+        """All ranks' hit lists of the last pass concatenated on rank dst: in its device memory, and (to_host) as a numpy
+        HIT_DTYPE view of pinned host memory; None on the other ranks and when the rows are left on the device."""
         n = C.c_uint64(0)
         check(lib().gs_gather_hits(self._h, dst, table._h, reads._h, read_offset, None, 0, C.byref(n)))
-        if self.rank != dst:
+        self.gathered_rows = n.value
+        if self.rank != dst or not to_host:
             return None
         vp = C.c_void_p()
         check(lib().gs_gather_view(self._h, C.byref(vp), None))  # pinned host memory of the library: no further copy

@@ -249,11 +249,16 @@ void gs_comm_destroy(gs_comm *c);
 /* The root's BUILT table, device array by device array, to every other rank (ncclBroadcast): nobody else parses or builds.
  * The root passes its table and gets it back in *out; the others pass NULL and own the table they receive. */
 int gs_table_broadcast(gs_comm *c, int root, gs_table *mine, gs_table **out);
-/* After a finished pass on every rank: all ranks' emitted hits on the root, in rank order, `read` shifted by the rank's
- * read_offset.  Counts and offsets travel by ncclAllGather, the rows by grouped ncclSend / ncclRecv of exactly their size.
- * Root: `out` (host, `cap` rows; may be NULL to count) and *n_out = total rows; other ranks pass out = NULL. */
+/* After a finished pass on every rank: all ranks' emitted hits concatenated in the ROOT'S DEVICE MEMORY, in rank order, `read`
+ * shifted by the rank's read_offset.  Counts and offsets travel by ncclAllGather, the rows by grouped ncclSend / ncclRecv of
+ * exactly their size.  Root: *n_out = total rows; `out` (host, `cap` rows) may be NULL: the rows then stay on the device
+ * (gs_gather_device) and cross PCIe only if gs_gather_view is called -- every rank's own rows already are on its own host
+ * after gs_tag_finish.  Other ranks pass out = NULL. */
 int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read_offset, gs_hit *out, uint64_t cap, uint64_t *n_out);
-/* Root, after gs_gather_hits: the gathered rows where the library left them -- pinned host memory, valid until the next gather. */
+/* Root, after gs_gather_hits: the gathered rows in device memory, valid until the next gather. */
+int gs_gather_device(gs_comm *c, const void **d_out, uint64_t *n_out);
+/* Root, after gs_gather_hits: the gathered rows in pinned host memory of the library (copied there on the first call after a
+ * gather), valid until the next gather. */
 int gs_gather_view(gs_comm *c, const gs_hit **out, uint64_t *n_out);
 
 
