@@ -9,7 +9,8 @@ real CHM13 / ONT data do not exist offline.  At N > 1 every rank tags its own sh
 scaling) with the table replicated.
 
 A step = one full tagging pass over the rank's resident reads (inputs already in HBM): probe kernel, tile scans, emit
-kernel, hit list to the host; at N > 1 also the carry exchange (all_gather) and the RCCL gather of the hit buffers.
+kernel, hit list to the rank's host; at N > 1 also the carry exchange (all_gather) and the RCCL gather of the hit buffers
+into the root's device memory.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -18,7 +19,8 @@ Prints ONE JSON line on rank 0: the driver contract's keys, `roofline` (probe ke
 against 8 TB/s HBM), `cpu_baseline` (the oracle's C restatement of the reference tagger on this box's host cores, on a
 bounded sample), `parity` (GPU vs oracle on the first reads of the stream), `engine_bases_per_s` (host-packed words ->
 hits on host, upload included, on a sample), and `config2` (the same measurements on BASELINE.json configs[1], every row
-compared with the reference binary's golden output; `--no-config2` skips it).  `--genome-mb / --reads` shrink the workload
+compared with the reference binary's golden output, plus `cli`: wall time of the command-line drop-in `.fa -> .sunkpos` on
+the same files; `--no-config2` / `--no-cli` skip them).  `--genome-mb / --reads` shrink the workload
 for rehearsals (the line then says so in `config.workload`).
 """
 from __future__ import annotations
@@ -294,8 +296,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity + CPU baseline)")
     ap.add_argument("--no-config2", action="store_true", help="skip the config-2 extra key")
-    ap.add_argument("--cli", action="store_true", help="config-2 leg: also time the command-line drop-in (.fa -> .sunkpos)")
+    ap.add_argument("--cli", action="store_true", help="(default now) config-2 leg: also time the command-line drop-in (.fa -> .sunkpos)")
+    ap.add_argument("--no-cli", action="store_true", help="config-2 leg without the command-line timing")
     a = ap.parse_args()
+    a.cli = not a.no_cli
 
     # stdout carries exactly ONE line, the JSON: everything else any library prints there (gloo announces its connections on
     # stdout from C++) goes to stderr -- fd 1 is pointed at fd 2 until the line is written to the real stdout at the end

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 tag=$1
 mkdir -p gpurun_out/r02
-python3 bench.py --cli > gpurun_out/r02/${tag}_bench.json 2> gpurun_out/r02/${tag}_bench.log || { tail -5 gpurun_out/r02/${tag}_bench.log; exit 1; }
+python3 bench.py > gpurun_out/r02/${tag}_bench.json 2> gpurun_out/r02/${tag}_bench.log || { tail -5 gpurun_out/r02/${tag}_bench.log; exit 1; }
 tail -4 gpurun_out/r02/${tag}_bench.log
 rocprofv3 --kernel-trace --stats -d gpurun_out/r02/prof_$tag -o x --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-config2 > gpurun_out/r02/${tag}_bench_under_rocprof.json 2> gpurun_out/r02/prof_$tag.log || { tail -5 gpurun_out/r02/prof_$tag.log; exit 1; }
 f=$(ls gpurun_out/r02/prof_$tag/*/x_kernel_stats.csv gpurun_out/r02/prof_$tag/x_kernel_stats.csv 2>/dev/null | head -1)
