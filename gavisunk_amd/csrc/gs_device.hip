@@ -2441,19 +2441,26 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
     };
     int lg_full;
     const uint64_t cap_full = pow2_cap(2 * n, lg_full);
-    // Layout (GAVISUNK_TABLE forces one; read once per table).  Exact compact copy first, when it applies: small tables
-    // are probed from LDS / the L2s; tables that only fit HBM take the minimiser-addressed layout (the one-bucket-load
-    // "compact-hbm" layout stays available, forced).  The generic 16-byte-slot table holds what those could not take,
-    // or everything.
+    // Layout (GAVISUNK_TABLE forces one; read once per table).  The minimiser-addressed layout whenever it applies (k >= 16, the
+    // slot fits 64 bits): since round 2 its kernel is the fastest on every table size -- cache-resident tables included (config
+    // 2: 188 Gbase/s against 175 of the LDS join).  Otherwise, and when forced ("compact-lds": what small tables got by default
+    // before), an exact compact copy probed from LDS / the L2s, or one bucket load per window from HBM ("compact-hbm").  The
+    // generic 16-byte-slot table holds what those could not take, or everything.
     const char *env = getenv("GAVISUNK_TABLE");
+    if (env && !strcmp(env, "auto")) env = nullptr;
     const bool force_mz = env && (!strcmp(env, "minimizer") || !strcmp(env, "minimizer-exact"));
-    t->compact = force_mz ? 0 : choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, env, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
-    if (force_mz || ((t->compact == 2 || t->compact == 3) && !(env && !strcmp(env, "compact-hbm")))) {
-        if (mz_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_n_regions, t->mz_locbits)) {
-            t->mz = env && !strcmp(env, "minimizer-exact") ? 2 : 1;
+    const bool old_auto = env && !strcmp(env, "compact-lds");  // the compact layouts as they were chosen before
+    if ((force_mz || !env) && mz_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_n_regions, t->mz_locbits)) {
+        t->mz = force_mz && !strcmp(env, "minimizer-exact") ? 2 : 1;
+        t->compact = 0;
+    } else {
+        const char *cenv = force_mz || old_auto ? nullptr : env;
+        t->compact = choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, cenv, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
+        // a small-table layout forced on a table it does not apply to: the default layout
+        if ((t->compact == 2 || t->compact == 3) && (old_auto || (env && !strcmp(env, "compact-l2"))) &&
+            mz_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_n_regions, t->mz_locbits)) {
+            t->mz = 1;
             t->compact = 0;
-        } else if (force_mz) {
-            t->compact = choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, nullptr, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
         }
     }
     uint64_t n_generic = n;

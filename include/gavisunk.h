@@ -128,10 +128,11 @@ int gs_table_create_device(int device, int k, uint64_t n, const void *d_keys, co
                            gs_table **out);
 void gs_table_destroy(gs_table *t);
 uint64_t gs_table_bytes(const gs_table *t);
-/* Human-readable description of the layout chosen for this table: "compact-lds" / "compact-l2" (small tables: an exact
- * compact copy probed from LDS / the XCD-partitioned L2s), "minimizer-hbm" (tables that only fit HBM: 64-byte regions
- * addressed by a mod-minimiser of the k-mer, so that consecutive windows share one memory request), "compact-hbm", "generic".
- * GAVISUNK_TABLE=generic|compact-l2|compact-hbm|minimizer (read once, when the table is created) forces one. */
+/* Human-readable description of the layout chosen for this table: "minimizer-hbm" (the default for k >= 16: 64-byte regions
+ * addressed by a mod-minimiser of the k-mer, so that consecutive windows share one memory request -- the fastest layout on
+ * every table size), "compact-lds" / "compact-l2" (small tables: an exact compact copy probed from LDS / the
+ * XCD-partitioned L2s), "compact-hbm", "generic" (k < 16, db k-mers without loc row).
+ * GAVISUNK_TABLE=generic|compact-lds|compact-l2|compact-hbm|minimizer (read once, when the table is created) forces one. */
 const char *gs_table_layout(const gs_table *t);
 
 /* Device-resident batch of packed reads (+ the per-tile index the kernels need). */

@@ -64,7 +64,7 @@ def _tag(monkeypatch, layout, keys, loc, batches, carry=_lib.GS_NONE):
 def test_config2_full_size_properties(config2, monkeypatch):
     keys, loc, seqs = config2
     whole, carry, ctrs, name = _tag(monkeypatch, "auto", keys, loc, [seqs])
-    assert name == "compact-lds"
+    assert name == "minimizer-hbm"  # (since round 2 the default for every k >= 16 table, this small one included)
     c = ctrs[0]
     nwin = np.array([max(len(s) - K + 1, 1) for s in seqs], dtype=np.int64)
     assert c["windows"] == int(nwin.sum()) > 240_000_000 and len(whole) == c["emitted"] <= c["raw_hits"]
@@ -91,7 +91,7 @@ def test_config2_full_size_properties(config2, monkeypatch):
     assert carry != _lib.GS_NONE and carry <= loc.max()
 
     # the other probe paths agree bit for bit
-    for layout, want in (("compact-l2", "compact-l2"), ("compact-hbm", "compact-hbm")):
+    for layout, want in (("compact-lds", "compact-lds"), ("compact-l2", "compact-l2"), ("compact-hbm", "compact-hbm")):
         other, carry2, ctrs2, name2 = _tag(monkeypatch, layout, keys, loc, [seqs])
         assert name2 == want
         assert np.array_equal(other, whole) and carry2 == carry and ctrs2[0]["raw_hits"] == c["raw_hits"]

@@ -12,13 +12,14 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "compact-l2", "compact-hbm", "minimizer", "minimizer-exact", "generic"], autouse=True)
+@pytest.fixture(params=["auto", "compact-lds", "compact-l2", "compact-hbm", "minimizer", "minimizer-exact", "generic"], autouse=True)
 def table_layout(request, monkeypatch):
-    """Every test runs five times: with the layout the library picks (small k <= 20 tables get the exact compact
-    copy: at k = 20 the radix join probes its slices from LDS, at other k it is probed out of the XCD-partitioned
-    L2), with the L2 path forced, with the compact table treated as HBM-resident (one bucket load per window), with
-    the minimiser-addressed layout that genome-scale tables get (lane = window, k >= 16; "minimizer-exact" runs every
-    tile through the per-lane form that is the fast kernel's fallback), and with the generic 16-byte-slot table forced."""
+    """Every test runs seven times: with the layout the library picks (the minimiser-addressed table for k >= 16, whatever
+    the size; the generic table below), with the small-table layouts that were the default before (compact-lds: at k = 20
+    the radix join probes its slices from LDS, at other k <= 20 the exact compact copy is probed out of the XCD-partitioned
+    L2), with the L2 path forced, with the compact table treated as HBM-resident (one bucket load per window), with the
+    minimiser-addressed layout forced (lane = window; "minimizer-exact" runs every tile through the per-lane form that
+    is the fast kernel's fallback), and with the generic 16-byte-slot table forced."""
     monkeypatch.setenv("GAVISUNK_TABLE", request.param)
     return request.param
 
@@ -184,12 +185,12 @@ def test_empty_and_tiny_batches():
 def test_layout_selection(table_layout):
     keys, loc, _ = _random_case(3, 20)
     tab = engine.DeviceTable(20, keys, loc, np.arange(len(keys), dtype=np.uint32))
-    assert tab.layout.startswith({"auto": "compact-lds", "compact-l2": "compact-l2", "compact-hbm": "compact-hbm",
+    assert tab.layout.startswith({"auto": "minimizer-hbm", "compact-lds": "compact-lds", "compact-l2": "compact-l2", "compact-hbm": "compact-hbm",
                                   "minimizer": "minimizer-hbm", "minimizer-exact": "minimizer-hbm", "generic": "generic"}[table_layout])
     tab.close()
     keys, loc, _ = _random_case(3, 18)
     tab = engine.DeviceTable(18, keys, loc, np.arange(len(keys), dtype=np.uint32))
-    assert tab.layout.startswith({"auto": "compact-l2", "compact-l2": "compact-l2", "compact-hbm": "compact-hbm",
+    assert tab.layout.startswith({"auto": "minimizer-hbm", "compact-lds": "compact-l2", "compact-l2": "compact-l2", "compact-hbm": "compact-hbm",
                                   "minimizer": "minimizer-hbm", "minimizer-exact": "minimizer-hbm", "generic": "generic"}[table_layout])
     tab.close()
     keys, loc, _ = _random_case(3, 25)
@@ -198,7 +199,7 @@ def test_layout_selection(table_layout):
     # minimiser-addressed layout is the default; forced, the one-bucket-load layout takes 64-bit slots
     if table_layout == "generic":
         assert tab.layout.startswith("generic")
-    elif table_layout in ("auto", "minimizer", "minimizer-exact", "compact-l2"):
+    elif table_layout in ("auto", "minimizer", "minimizer-exact", "compact-l2", "compact-lds"):
         assert tab.layout.startswith("minimizer-hbm") and "50-bit key" in tab.layout and "mod-minimiser of length 21 " in tab.layout
     else:
         assert "compact-hbm" in tab.layout and "x u64" in tab.layout
@@ -258,7 +259,7 @@ def test_low_complexity_reads_overflow_one_partition():
 def test_undersized_compact_table_uses_every_overflow_path(qb, monkeypatch, table_layout):
     """With far too few buckets most keys live in their second-chance bucket or only in the generic side table:
     deferred lookups, their flushes and the generic fallback carry the load, and the answer must not change."""
-    if table_layout in ("generic", "minimizer", "minimizer-exact"):
+    if table_layout in ("generic", "auto", "minimizer", "minimizer-exact"):
         pytest.skip("needs a compact layout")
     monkeypatch.setenv("GAVISUNK_COMPACT_QB", qb)
     k = 20
@@ -313,7 +314,7 @@ def test_slots_without_a_spare_bit(k, qb, monkeypatch, table_layout):
         monkeypatch.setenv("GAVISUNK_COMPACT_QB", qb)
     keys, loc, seqs = _random_case(91, k, n_reads=60, glen=8000, median=2000)
     loc = np.zeros_like(loc)
-    if table_layout not in ("generic", "minimizer", "minimizer-exact"):
+    if table_layout not in ("generic", "auto", "minimizer", "minimizer-exact"):
         tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
         assert "31-bit remainder, 1-bit loc" in tab.layout
         tab.close()
@@ -396,7 +397,7 @@ def test_join_overflow_lists_longer_than_lds_are_searched_in_hbm(monkeypatch, ta
     """32 buckets per partition for a quarter of a million keys: nearly every key overflows, ~900 per table slice -- more
     than the 512 the LDS join keeps in LDS, so its probe kernel binary-searches the slice's sorted overflow list in HBM.
     (A 31-bit remainder leaves one loc bit: one location group, so the raw-hit count is what is compared.)"""
-    if table_layout != "auto":
+    if table_layout != "compact-lds":
         pytest.skip("LDS join only")
     monkeypatch.setenv("GAVISUNK_COMPACT_QB", "5")
     k = 20
@@ -418,7 +419,7 @@ def test_table_build_is_deterministic(table_layout, monkeypatch):
     scheduling did.  (An undersized compact table makes sure there are many of them.)"""
     if table_layout in ("generic", "minimizer-exact"):
         pytest.skip("nothing to overflow")
-    if table_layout != "minimizer":
+    if table_layout not in ("minimizer", "auto"):
         monkeypatch.setenv("GAVISUNK_COMPACT_QB", "9")
     keys, loc, seqs = _random_case(57, 20, n_reads=30, glen=300000, median=3000)
     loc = (loc % 7).astype(np.uint32)

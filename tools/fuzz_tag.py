@@ -17,7 +17,7 @@ from gavisunk_amd import _lib, engine, synth  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 K = 20  # k of the current round (most rounds: GAVISUNK's default 20)
-LAYOUTS = ["auto", "compact-l2", "compact-hbm", "minimizer", "generic"]
+LAYOUTS = ["auto", "compact-lds", "compact-l2", "compact-hbm", "minimizer", "generic"]
 
 
 def draw(seed):
