@@ -96,6 +96,17 @@ SIGNATURES = {
     "gs_tag_phase2": (I, [P, P, U32]),
     "gs_tag_hits_to_host": (I, [P, P, P, U64, C.POINTER(U64)]),
     "gs_tag_hits_to_device": (I, [P, P, P, U64, C.POINTER(U64)]),
+    "gs_tag_launch_after": (I, [P, P, P]),
+    "gs_stream_create": (I, [P, U64, U32, I, U32, C.POINTER(P)]),
+    "gs_stream_destroy": (None, [P]),
+    "gs_stream_submit": (I, [P, P, U64, P, P, U32]),
+    "gs_stream_submit_reads": (I, [P, P]),
+    "gs_stream_next": (I, [P, C.POINTER(P), C.POINTER(U64), C.POINTER(U32), C.POINTER(GsCounters)]),
+    "gs_stream_release": (None, [P]),
+    "gs_stream_in_flight": (I, [P]),
+    "gs_stream_carry": (U32, [P]),
+    "gs_host_alloc": (I, [U64, C.POINTER(P)]),
+    "gs_host_free": (None, [P]),
     "gs_tag_hits_view": (I, [P, P, C.POINTER(P), C.POINTER(U64)]),
     "gs_counters_reset": (None, [P]),
     "gs_comm_unique_id": (I, [P]),

@@ -271,7 +271,7 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
     }
     if ((rc = check_pair(t, r, "gs_gather_hits"))) return rc;
     if ((rc = settle(t, r))) return rc;
-    if (t->res_keyerr) {
+    if (r->ps.res_keyerr) {
         set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
         return GS_E_KEYERROR;
     }
@@ -281,7 +281,7 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
     const bool is_root = c->rank == root;
     const int n = c->nranks;
     // (count, read offset) of every rank
-    const unsigned long long mine[2] = {t->res_n, read_offset};
+    const unsigned long long mine[2] = {r->ps.res_n, read_offset};
     HIP_TRY(hipMemcpyAsync(c->d_meta + 2 * c->rank, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
     if (n > 1) NCCL_TRY(R->AllGather(c->d_meta + 2 * c->rank, c->d_meta, 2, ncclUint64, c->comm, c->stream));
     std::vector<unsigned long long> meta((size_t)2 * n);
@@ -319,8 +319,8 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
             }
             at += cnt;
         }
-    } else if (t->res_n) {
-        NCCL_TRY(R->Send(r->hits, (size_t)t->res_n * sizeof(gs_hit), ncclUint8, root, c->comm, c->stream));
+    } else if (r->ps.res_n) {
+        NCCL_TRY(R->Send(r->hits, (size_t)r->ps.res_n * sizeof(gs_hit), ncclUint8, root, c->comm, c->stream));
     }
     if (n > 1) NCCL_TRY(R->GroupEnd());
     if (is_root) {

@@ -88,6 +88,7 @@ struct TileArrays {
     uint32_t *seg_carry;
 };
 constexpr uint32_t kNoSeed = 0xFFFFFFFDu;
+constexpr uint64_t kReadSlackWords = 66;  // zero words after the last read of a batch (a tile loads 64 + 2 words whatever its length)
 
 __device__ __forceinline__ uint64_t revpairs(uint64_t x) {
     x = __brevll(x);
@@ -1991,22 +1992,31 @@ struct gs_table {
     uint64_t *j_ovf_code = nullptr;
     uint32_t *j_ovf_loc = nullptr;
     uint32_t *j_ovf_start = nullptr;  // [kJoinSlices + 1] first overflow key of every slice
-    uint32_t *d_complex_n = nullptr;
+    hipStream_t stream = nullptr;       // every pass over this table runs here, in launch order
+    hipStream_t copy_stream = nullptr;  // hit lists to the host: overlaps the next pass
+    gs_counters ctr{};
+};
+
+// State of ONE tagging pass.  It belongs to the read batch, not to the table: several batches can be in flight against one
+// table (launched back to back on the table's stream, `prevLoc` handed from pass to pass in device memory), and each is
+// settled on its own.
+struct PassState {
     PassStatus *d_status = nullptr;       // the five scalars below live in this one block
     PassStatus *h_status = nullptr;       // pinned: filled by an async copy at the end of a pass
     PassStatus *h_init = nullptr;         // pinned: template the block is reset from
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // pass start, probe done, emit done, status on the host
     // scalars on device
     uint32_t *d_cand_count = nullptr;
     unsigned long long *d_err_pos = nullptr;
     uint32_t *d_carry_in = nullptr;
     Agg *d_totals = nullptr;  // [0] scan A grand total, [1] scan B grand total
-    gs_counters ctr{};
+    uint32_t *d_complex_n = nullptr;
     bool pass_pending = false;
+    const gs_table *table = nullptr;      // of the pending / settled pass
+    const struct gs_reads *after = nullptr;  // the batch whose pass hands its carry to this one on the device (or NULL)
     uint32_t last_carry_in = GS_NONE;
+    bool settled = false;
     // outcome of the last settled pass
-    const struct gs_reads *settled_reads = nullptr;
     uint64_t res_n = 0;
     uint32_t res_carry = GS_NONE;
     bool res_keyerr = false;
@@ -2036,6 +2046,7 @@ struct gs_reads {
     PartRec *part_recs = nullptr;      // [n_tiles * kNPart], fast path only
     uint32_t *complex_list = nullptr;  // [n_tiles]
     JoinQ jq{};                        // LDS join queues for min(batches, kJoinChunk) batches
+    PassState ps;
 };
 
 namespace {
@@ -2093,37 +2104,39 @@ int launch_phase1(gs_table *t, gs_reads *r) {
         if ((rc = dev_alloc(&r->part_recs, (uint64_t)r->n_tiles * kNPart))) return rc;
         if (!r->complex_list && (rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
     }
-    memset(t->h_init, 0, sizeof(PassStatus));
-    t->h_init->err_pos = ~0ULL;
-    t->h_init->totals[0].loc = t->h_init->totals[1].loc = GS_NONE;
-    t->h_init->carry_in = GS_NONE;
-    HIP_TRY(hipMemcpyAsync(t->d_status, t->h_init, sizeof(PassStatus), hipMemcpyHostToDevice, t->stream));
-    HIP_TRY(hipEventRecord(t->ev[0], t->stream));
+    memset(r->ps.h_init, 0, sizeof(PassStatus));
+    r->ps.h_init->err_pos = ~0ULL;
+    r->ps.h_init->totals[0].loc = r->ps.h_init->totals[1].loc = GS_NONE;
+    r->ps.h_init->carry_in = GS_NONE;
+    HIP_TRY(hipMemcpyAsync(r->ps.d_status, r->ps.h_init, sizeof(PassStatus), hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipEventRecord(r->ps.ev[0], t->stream));
     if (r->n_tiles) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
-        // GAVISUNK_TABLE=minimizer-exact: every tile by the per-lane form (the fast form's fallback); also tables whose loc ids
-        // are longer than a hit-list entry of the fast form holds (more than 2^20 location groups)
-        if (t->mz && (t->mz == 2 || t->mz_locbits > kMzFastLocBits)) {
+        // GAVISUNK_TABLE=minimizer-exact: every tile by the per-lane form (the fast form's fallback)
+        if (t->mz == 2) {
             hipLaunchKernelGGL(k_probe_mz_exact, dim3(blocks), dim3(256), 0, t->stream, mz_view(t), view(t), (const uint64_t *)r->words,
-                               (const TileDesc *)r->tile_desc, r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count);
+                               (const TileDesc *)r->tile_desc, r->n_tiles, r->ta, r->cand, r->cand_cap, r->ps.d_cand_count);
         } else if (t->mz) {
-#define GS_LAUNCH_MZ(KT, MT)                                                                                                  \
-    hipLaunchKernelGGL((k_probe_mz<KT, MT>), dim3((r->n_tiles + kMzWaves - 1) / kMzWaves), dim3(64 * kMzWaves), 0, t->stream,  \
-                       mz_view(t), view(t), (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->ta,     \
-                       r->cand, r->cand_cap, t->d_cand_count, t->d_complex_n)
-            if (t->k == 20 && t->mz_m == 16)
-                GS_LAUNCH_MZ(20, 16);  // GAVISUNK's default SUNK length and the minimiser lengths its tables get: constants
-            else if (t->k == 20 && t->mz_m == 17)
-                GS_LAUNCH_MZ(20, 17);
-            else if (t->k == 20 && t->mz_m == 18)
-                GS_LAUNCH_MZ(20, 18);
-            else if (t->k == 21 && t->mz_m == 17)
-                GS_LAUNCH_MZ(21, 17);  // BASELINE.json configs[4]: k = 21 and 25 (tables up to ~10^9 keys)
+#define GS_LAUNCH_MZ(KT, MT, FMT)                                                                                                  \
+    hipLaunchKernelGGL((k_probe_mz<KT, MT, FMT>), dim3((r->n_tiles + kMzWaves - 1) / kMzWaves), dim3(64 * kMzWaves), 0, t->stream,  \
+                       mz_view(t), view(t), (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->ta,          \
+                       r->cand, r->cand_cap, r->ps.d_cand_count, r->ps.d_complex_n)
+            // GAVISUNK's default SUNK length and the minimiser lengths its tables get, the slot format that goes with them
+            // (k = 20: the key itself up to 2^24 location groups), and BASELINE.json configs[4] (k = 21 and 25): constants
+            const bool raw = mz_raw(t->k, t->mz_locbits);
+            if (t->k == 20 && t->mz_m == 16 && raw)
+                GS_LAUNCH_MZ(20, 16, 1);
+            else if (t->k == 20 && t->mz_m == 17 && raw)
+                GS_LAUNCH_MZ(20, 17, 1);
+            else if (t->k == 20 && t->mz_m == 18 && raw)
+                GS_LAUNCH_MZ(20, 18, 1);
+            else if (t->k == 21 && t->mz_m == 17 && raw)
+                GS_LAUNCH_MZ(21, 17, 1);
             else if (t->k == 25 && t->mz_m == 21)
-                GS_LAUNCH_MZ(25, 21);
+                GS_LAUNCH_MZ(25, 21, -1);
             else
-                GS_LAUNCH_MZ(0, 0);
+                GS_LAUNCH_MZ(0, 0, -1);
 #undef GS_LAUNCH_MZ
         } else if (t->compact == 1 && t->join) {
             const uint32_t n_batches = (r->n_tiles + kJoinTiles - 1) / kJoinTiles;
@@ -2171,13 +2184,13 @@ int launch_phase1(gs_table *t, gs_reads *r) {
 #undef GS_LAUNCH_JOIN_PROBE
 #undef GS_LAUNCH_JOIN_PROBE_DBG
                 hipLaunchKernelGGL(k_join_merge, dim3((nb + kJoinMergeBatches - 1) / kJoinMergeBatches), dim3(1024), 0, t->stream,
-                                   r->jq, b0, nb, r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list,
-                                   t->d_complex_n);
+                                   r->jq, b0, nb, r->n_tiles, r->ta, r->cand, r->cand_cap, r->ps.d_cand_count, r->complex_list,
+                                   r->ps.d_complex_n);
             }
             // tiles of degenerate groups (none on ordinary reads): generic exact probe, grid-stride over the list
             hipLaunchKernelGGL(k_probe<true>, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), cv,
-                               view(r), r->ta, r->cand, r->cand_cap, t->d_cand_count, t->d_err_pos,
-                               (const uint32_t *)r->complex_list, (const uint32_t *)t->d_complex_n);
+                               view(r), r->ta, r->cand, r->cand_cap, r->ps.d_cand_count, r->ps.d_err_pos,
+                               (const uint32_t *)r->complex_list, (const uint32_t *)r->ps.d_complex_n);
         } else if (t->compact == 1) {
             constexpr int nt = 4;
             const uint32_t pblocks = ((r->n_tiles + nt - 1) / nt + 3) / 4 * kNPart;
@@ -2214,62 +2227,76 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             }
 #undef GS_LAUNCH_PART
             hipLaunchKernelGGL(k_merge_part, dim3((r->n_tiles + 15) / 16), dim3(256), 0, t->stream, (const PartRec *)r->part_recs,
-                               r->n_tiles, r->ta, r->cand, r->cand_cap, t->d_cand_count, r->complex_list, t->d_complex_n);
+                               r->n_tiles, r->ta, r->cand, r->cand_cap, r->ps.d_cand_count, r->complex_list, r->ps.d_complex_n);
             // tiles whose partition summaries cannot be merged exactly: generic probe, grid-stride over the list
             hipLaunchKernelGGL(k_probe<true>, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), cv,
-                               view(r), r->ta, r->cand, r->cand_cap, t->d_cand_count, t->d_err_pos,
-                               (const uint32_t *)r->complex_list, (const uint32_t *)t->d_complex_n);
+                               view(r), r->ta, r->cand, r->cand_cap, r->ps.d_cand_count, r->ps.d_err_pos,
+                               (const uint32_t *)r->complex_list, (const uint32_t *)r->ps.d_complex_n);
         } else if (t->compact == 2) {
             hipLaunchKernelGGL(k_probe<true>, dim3(blocks), dim3(256), 0, t->stream, view(t), cv, view(r), r->ta, r->cand,
-                               r->cand_cap, t->d_cand_count, t->d_err_pos, (const uint32_t *)nullptr,
+                               r->cand_cap, r->ps.d_cand_count, r->ps.d_err_pos, (const uint32_t *)nullptr,
                                (const uint32_t *)nullptr);
         } else {
             hipLaunchKernelGGL(k_probe<false>, dim3(blocks), dim3(256), 0, t->stream, view(t), cv, view(r), r->ta, r->cand,
-                               r->cand_cap, t->d_cand_count, t->d_err_pos, (const uint32_t *)nullptr,
+                               r->cand_cap, r->ps.d_cand_count, r->ps.d_err_pos, (const uint32_t *)nullptr,
                                (const uint32_t *)nullptr);
         }
     }
-    HIP_TRY(hipEventRecord(t->ev[1], t->stream));
+    HIP_TRY(hipEventRecord(r->ps.ev[1], t->stream));
     HIP_TRY(hipGetLastError());
     return GS_OK;
 }
 
+// a batch without tiles: its totals are "nothing", or what it was handed
+__global__ void k_empty_totals(const uint32_t *carry_in, Agg *total, int mode) {
+    Agg z{0, GS_NONE, 0};
+    if (mode == 0 && *carry_in != GS_NONE) {
+        z.loc = *carry_in;
+        z.has = 1;
+    }
+    *total = z;
+}
+// prevLoc handed from one pass to the next in device memory (kmerpos_annot3.nim:82-84: the state crosses reads, and batches)
+__global__ void k_chain_carry(const Agg *prev_total, uint32_t *carry_in) { *carry_in = (prev_total->has & 1u) ? prev_total->loc : GS_NONE; }
+
 int launch_scan(gs_table *t, gs_reads *r, int mode) {
     const uint32_t nb = r->n_scan_blocks;
     if (!r->n_tiles) {
-        Agg z{0, GS_NONE, 0};
-        if (mode == 0 && t->last_carry_in != GS_NONE) {
-            z.loc = t->last_carry_in;
-            z.has = 1;
-        }
-        HIP_TRY(hipMemcpyAsync(t->d_totals + mode, &z, sizeof z, hipMemcpyHostToDevice, t->stream));
+        hipLaunchKernelGGL(k_empty_totals, dim3(1), dim3(1), 0, t->stream, (const uint32_t *)r->ps.d_carry_in, r->ps.d_totals + mode, mode);
         return GS_OK;
     }
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanThreads), 0, t->stream, r->ta, r->n_tiles, mode, r->block_agg);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanThreads), 0, t->stream, r->block_agg, nb,
-                       mode == 0 ? t->d_carry_in : (const uint32_t *)nullptr, t->d_totals + mode);
+                       mode == 0 ? r->ps.d_carry_in : (const uint32_t *)nullptr, r->ps.d_totals + mode);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanThreads), 0, t->stream, r->ta, r->n_tiles, mode, r->block_agg);
     HIP_TRY(hipGetLastError());
     return GS_OK;
 }
 
-int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {
+// `after` != NULL: the carry is what the pass of that batch (launched before this one on the same table) carries out
+int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in, const gs_reads *after = nullptr) {
     HIP_TRY(hipSetDevice(t->device));
-    t->last_carry_in = carry_in;
-    HIP_TRY(hipMemcpyAsync(t->d_carry_in, &t->last_carry_in, sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+    r->ps.last_carry_in = carry_in;
+    r->ps.after = after;
+    if (after)
+        hipLaunchKernelGGL(k_chain_carry, dim3(1), dim3(1), 0, t->stream, (const Agg *)after->ps.d_totals, r->ps.d_carry_in);
+    else
+        HIP_TRY(hipMemcpyAsync(r->ps.d_carry_in, &r->ps.last_carry_in, sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
     int rc;
     if ((rc = launch_scan(t, r, 0))) return rc;
     if ((rc = launch_scan(t, r, 1))) return rc;
     if (r->n_tiles) {
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
         hipLaunchKernelGGL(k_emit, dim3((r->n_tiles + 255) / 256), dim3(256), 0, t->stream, view(t), cv, mz_view(t), t->mz ? 4 : t->compact, view(r), r->ta,
-                           r->cand, r->cand_cap, r->hits, r->hits_host, r->hit_cap, (const Agg *)(t->d_totals + 1));
+                           r->cand, r->cand_cap, r->hits, r->hits_host, r->hit_cap, (const Agg *)(r->ps.d_totals + 1));
     }
-    HIP_TRY(hipEventRecord(t->ev[2], t->stream));
-    HIP_TRY(hipMemcpyAsync(t->h_status, t->d_status, sizeof(PassStatus), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipEventRecord(r->ps.ev[2], t->stream));
+    HIP_TRY(hipMemcpyAsync(r->ps.h_status, r->ps.d_status, sizeof(PassStatus), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipEventRecord(r->ps.ev[3], t->stream));
     HIP_TRY(hipGetLastError());
-    t->pass_pending = true;
-    t->settled_reads = nullptr;
+    r->ps.pass_pending = true;
+    r->ps.settled = false;
+    r->ps.table = t;
     return GS_OK;
 }
 
@@ -2402,18 +2429,32 @@ int table_init(gs_table *t, int device, int k, uint64_t n) {
     t->device = device;
     t->k = k;
     t->n = n;
-    int rc;
     HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
-    for (auto &e : t->ev) HIP_TRY(hipEventCreate(&e));
-    if ((rc = dev_alloc(&t->d_status, 1))) return rc;
-    HIP_TRY(hipHostMalloc((void **)&t->h_status, sizeof(PassStatus), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&t->h_init, sizeof(PassStatus), hipHostMallocDefault));
-    t->d_err_pos = &t->d_status->err_pos;
-    t->d_totals = t->d_status->totals;
-    t->d_cand_count = &t->d_status->cand_count;
-    t->d_complex_n = &t->d_status->complex_n;
-    t->d_carry_in = &t->d_status->carry_in;
+    HIP_TRY(hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking));
     return GS_OK;
+}
+
+int pass_state_init(PassState &ps) {
+    int rc;
+    for (auto &e : ps.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDefault));
+    if ((rc = dev_alloc(&ps.d_status, 1))) return rc;
+    HIP_TRY(hipHostMalloc((void **)&ps.h_status, sizeof(PassStatus), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&ps.h_init, sizeof(PassStatus), hipHostMallocDefault));
+    ps.d_err_pos = &ps.d_status->err_pos;
+    ps.d_totals = ps.d_status->totals;
+    ps.d_cand_count = &ps.d_status->cand_count;
+    ps.d_complex_n = &ps.d_status->complex_n;
+    ps.d_carry_in = &ps.d_status->carry_in;
+    return GS_OK;
+}
+
+void pass_state_free(PassState &ps) {
+    (void)hipFree(ps.d_status);
+    if (ps.h_status) (void)hipHostFree(ps.h_status);
+    if (ps.h_init) (void)hipHostFree(ps.h_init);
+    for (auto &e : ps.ev)
+        if (e) (void)hipEventDestroy(e);
+    ps = PassState{};
 }
 
 // Builds the device tables from key / loc / payload arrays that already are in device memory (not owned).
@@ -2464,12 +2505,17 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
         }
     }
     uint64_t n_generic = n;
-    if (t->mz) {
+    // A minimiser length whose regions cannot hold the keys (more than an eighth of them overflow: clustered minimisers, a
+    // repeat-rich assembly) is no reason to fail: the next length is tried (shorter runs, emptier regions), and when none
+    // does, the layouts below take the table -- only a FORCED layout reports the misfit.
+    while (t->mz) {
         const uint64_t nslots = (uint64_t)t->mz_n_regions * kMzWords;
-        const uint64_t ocap = std::max<uint64_t>(getenv("GAVISUNK_MZ_M") || getenv("GAVISUNK_MZ_LOAD") ? n : n / 8, 1u << 16);
+        const bool knob = getenv("GAVISUNK_MZ_M") || getenv("GAVISUNK_MZ_LOAD");
+        const uint64_t ocap = std::max<uint64_t>(knob && force_mz ? n : n / 8, 1u << 16);
         unsigned long long *dov = nullptr;
+        DevBufs ot;
         if ((rc = dev_alloc((unsigned long long **)&t->mz_regions, nslots)) || (rc = dev_alloc(&t->mz_pay, nslots)) ||
-            (rc = tmp.get(&dov, 1)) || (rc = tmp.get(&dlist, ocap)))
+            (rc = ot.get(&dov, 1)) || (rc = ot.get(&dlist, ocap)))
             return rc;
         HIP_TRY(hipMemsetAsync(t->mz_regions, 0xFF, nslots * sizeof(unsigned long long), t->stream));
         HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
@@ -2490,13 +2536,31 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
         HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         HIP_TRY(hipGetLastError());
-        if (ov > ocap) {
+        if (ov <= ocap) {
+            t->mz_overflow = ov;
+            n_generic = ov;
+            tmp.p.insert(tmp.p.end(), ot.p.begin(), ot.p.end());  // (the overflow list is read once more below)
+            ot.p.clear();
+            break;
+        }
+        if (force_mz) {
             set_error("gs_table_create: %llu of %llu keys do not fit their minimiser regions (m = %d); force another layout with GAVISUNK_TABLE",
                       ov, (unsigned long long)n, t->mz_m);
             return GS_E_NOMEM;
         }
-        t->mz_overflow = ov;
-        n_generic = ov;
+        (void)hipFree(t->mz_regions);
+        (void)hipFree(t->mz_pay);
+        t->mz_regions = nullptr;
+        t->mz_pay = nullptr;
+        dlist = nullptr;
+        if (!getenv("GAVISUNK_MZ_M") && t->mz_m < std::min(31, k - 1) && t->mz_m < k - 2) {
+            t->mz_m++;
+            continue;
+        }
+        t->mz = 0;
+        t->compact = choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, nullptr, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
+    }
+    if (t->mz) {
     } else if (t->compact) {
         t->c_w64 = t->compact == 3;
         if (t->compact == 3) t->compact = 2;  // same probe kernel; the view says which slot width
@@ -2789,12 +2853,8 @@ void gs_table_destroy(gs_table *t) {
     (void)hipFree(t->j_ovf_code);
     (void)hipFree(t->j_ovf_loc);
     (void)hipFree(t->j_ovf_start);
-    (void)hipFree(t->d_status);
-    if (t->h_status) (void)hipHostFree(t->h_status);
-    if (t->h_init) (void)hipHostFree(t->h_init);
-    for (auto &e : t->ev)
-        if (e) (void)hipEventDestroy(e);
     if (t->stream) (void)hipStreamDestroy(t->stream);
+    if (t->copy_stream) (void)hipStreamDestroy(t->copy_stream);
     delete t;
 }
 
@@ -2804,31 +2864,16 @@ uint64_t gs_table_bytes(const gs_table *t) {
     return t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)((t->c_w64 ? 48 : 32) * kNPart) << t->c_qb) : 0);  // slots + payloads
 }
 
-// index building + allocations shared by the two upload entry points; the packed words are zeroed, not filled
-// `order` (may be NULL = identity): the batch reads in the order they are tagged; n_reads = its length
-static int reads_setup(int device, uint64_t n_words, const uint64_t *word_off, const uint32_t *len, uint32_t n_reads, int k,
-                       gs_reads **out, const uint32_t *order = nullptr, uint32_t n_batch_reads = 0) {
-    if (!out || k < 1 || k > 32 || (n_reads && (!word_off || !len))) {
-        set_error("gs_reads_upload: bad argument");
-        return GS_E_ARG;
-    }
-    *out = nullptr;
-    if (gs_device_count() <= device || device < 0) {
-        set_error("gs_reads_upload: HIP device %d not available -- there is no CPU fallback", device);
-        return GS_E_NODEVICE;
-    }
-    HIP_TRY(hipSetDevice(device));
-    auto *r = new gs_reads();
-    std::unique_ptr<gs_reads, void (*)(gs_reads *)> guard(r, gs_reads_destroy);
-    r->device = device;
-    r->k = k;
-    r->n_reads = n_reads;
-    r->n_words = n_words;
-    std::vector<uint32_t> nwin(n_reads), tile0(n_reads);
-    std::vector<uint32_t> tile_read;
-    std::vector<TileDesc> tdesc;
-    uint64_t tiles = 0;
-    std::vector<uint64_t> start((size_t)n_reads + 1, 0);
+// ---- a read batch on the device: host-side index (per read: first word, window count, first tile), device arrays at a given
+// capacity, tile descriptors built by a kernel.  Shared by the one-shot upload entry points and the streaming engine's slots.
+struct ReadIndexTotals {
+    uint64_t tiles = 0, n_bases = 0, n_windows = 0;
+};
+// `order` (may be NULL = identity): the batch reads in the order they are tagged; n_reads = its length.  start / nwin / tile0
+// receive n_reads (+ 1 for start) entries.
+static int read_index_host(int k, const uint64_t *word_off, const uint32_t *len, uint32_t n_reads, const uint32_t *order,
+                           uint32_t n_batch_reads, uint64_t *start, uint32_t *nwin, uint32_t *tile0, ReadIndexTotals &tot) {
+    tot = ReadIndexTotals{};
     for (uint32_t i = 0; i < n_reads; i++) {
         const uint32_t src = order ? order[i] : i;
         if (order && src >= n_batch_reads) {
@@ -2845,48 +2890,109 @@ static int reads_setup(int device, uint64_t n_words, const uint64_t *word_off, c
             return GS_E_ARG;
         }
         nwin[i] = l >= (uint32_t)k ? l - (uint32_t)k + 1 : 1u;  // Q6: a short read still yields one window
-        tile0[i] = (uint32_t)tiles;
-        const uint32_t nt = (nwin[i] + kTileWindows - 1) / kTileWindows;
-        tiles += nt;
-        if (tiles > 0x20000000ull) {
-            set_error("gs_reads_upload: batch too large (%llu tiles); split it", (unsigned long long)tiles);
+        tile0[i] = (uint32_t)tot.tiles;
+        tot.tiles += (nwin[i] + kTileWindows - 1) / kTileWindows;
+        if (tot.tiles > 0x20000000ull) {
+            set_error("gs_reads_upload: batch too large (%llu tiles); split it", (unsigned long long)tot.tiles);
             return GS_E_ARG;
         }
-        tile_read.insert(tile_read.end(), nt, i);
-        for (uint32_t q = 0; q < nt; q++)
-            tdesc.push_back(TileDesc{start[i] + (uint64_t)q * kTileWords, nwin[i] - q * kTileWindows, i});
-        r->n_bases += l;
-        r->n_windows += nwin[i];
+        tot.n_bases += l;
+        tot.n_windows += nwin[i];
     }
-    r->n_tiles = (uint32_t)tiles;
-    r->read_tile0_host = tile0;
+    start[n_reads] = 0;
+    return GS_OK;
+}
+
+// tile t of the batch: its read (the last one whose first tile is <= t), its words, the windows left in the read
+__global__ void k_tile_index(const uint64_t *__restrict__ read_word_off, const uint32_t *__restrict__ read_nwin,
+                             const uint32_t *__restrict__ read_tile0, uint32_t n_reads, uint32_t n_tiles, uint32_t *tile_read,
+                             TileDesc *tdesc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    uint32_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (read_tile0[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t q = t - read_tile0[lo];
+    tile_read[t] = lo;
+    tdesc[t] = TileDesc{read_word_off[lo] + (uint64_t)q * kTileWords, read_nwin[lo] - q * kTileWindows, lo};
+}
+
+// every device array of a batch, for up to cap_words packed words, cap_reads reads, cap_tiles tiles
+static int reads_alloc(int device, int k, uint64_t cap_words, uint32_t cap_reads, uint64_t cap_tiles, uint64_t cand_rows, gs_reads **out) {
+    HIP_TRY(hipSetDevice(device));
+    auto *r = new gs_reads();
+    std::unique_ptr<gs_reads, void (*)(gs_reads *)> guard(r, gs_reads_destroy);
+    r->device = device;
+    r->k = k;
     int rc;
+    if ((rc = pass_state_init(r->ps))) return rc;
     // zero slack after the last read: every lane of a tile loads words [l, l+1] unconditionally
-    const uint64_t slack = kTileWords + 2;
-    if ((rc = dev_alloc(&r->words, n_words + slack))) return rc;
-    HIP_TRY(hipMemset(r->words, 0, (n_words + slack) * sizeof(uint64_t)));
-    if ((rc = dev_alloc(&r->read_word_off, (uint64_t)n_reads + 1))) return rc;
-    if ((rc = dev_alloc(&r->read_nwin, n_reads)) || (rc = dev_alloc(&r->read_tile0, n_reads)) ||
-        (rc = dev_alloc(&r->tile_read, tiles)))
+    if ((rc = dev_alloc(&r->words, cap_words + kReadSlackWords))) return rc;
+    if ((rc = dev_alloc(&r->read_word_off, (uint64_t)cap_reads + 1))) return rc;
+    if ((rc = dev_alloc(&r->read_nwin, cap_reads)) || (rc = dev_alloc(&r->read_tile0, cap_reads)) ||
+        (rc = dev_alloc(&r->tile_read, cap_tiles)) || (rc = dev_alloc(&r->tile_desc, cap_tiles)))
         return rc;
-    if (n_reads) {
-        HIP_TRY(hipMemcpy(r->read_word_off, start.data(), ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(r->read_nwin, nwin.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(r->read_tile0, tile0.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
-    if (tiles) HIP_TRY(hipMemcpy(r->tile_read, tile_read.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if ((rc = dev_alloc(&r->tile_desc, tiles))) return rc;
-    if (tiles) HIP_TRY(hipMemcpy(r->tile_desc, tdesc.data(), tiles * sizeof(TileDesc), hipMemcpyHostToDevice));
     TileArrays &ta = r->ta;
-    if ((rc = dev_alloc(&ta.n_raw, tiles)) || (rc = dev_alloc(&ta.n_cand, tiles)) || (rc = dev_alloc(&ta.first_loc, tiles)) ||
-        (rc = dev_alloc(&ta.last_loc, tiles)) || (rc = dev_alloc(&ta.cand_off, tiles)) || (rc = dev_alloc(&ta.n_emit, tiles)) ||
-        (rc = dev_alloc(&ta.carry_loc, tiles)) || (rc = dev_alloc(&ta.raw_prefix, tiles)) ||
-        (rc = dev_alloc(&ta.emit_prefix, tiles)))
+    if ((rc = dev_alloc(&ta.n_raw, cap_tiles)) || (rc = dev_alloc(&ta.n_cand, cap_tiles)) || (rc = dev_alloc(&ta.first_loc, cap_tiles)) ||
+        (rc = dev_alloc(&ta.last_loc, cap_tiles)) || (rc = dev_alloc(&ta.cand_off, cap_tiles)) || (rc = dev_alloc(&ta.n_emit, cap_tiles)) ||
+        (rc = dev_alloc(&ta.carry_loc, cap_tiles)) || (rc = dev_alloc(&ta.raw_prefix, cap_tiles)) ||
+        (rc = dev_alloc(&ta.emit_prefix, cap_tiles)))
         return rc;
-    r->n_scan_blocks = (uint32_t)((tiles + kScanBlock - 1) / kScanBlock);
-    if ((rc = dev_alloc(&r->block_agg, r->n_scan_blocks))) return rc;
-    const uint64_t want = std::min<uint64_t>((kDirectCand + 2) * tiles + 65536, 0xFFFFFFFFull);
-    if ((rc = ensure_out_buffers(r, (uint32_t)want))) return rc;
+    if ((rc = dev_alloc(&r->block_agg, (cap_tiles + kScanBlock - 1) / kScanBlock))) return rc;
+    if ((rc = ensure_out_buffers(r, (uint32_t)std::min<uint64_t>(cand_rows, 0xFFFFFFFFull)))) return rc;
+    *out = guard.release();
+    return GS_OK;
+}
+
+// the per-read index to the device and the tile descriptors built there, on `st` (the host arrays must outlive the copies:
+// pinned staging for the streaming engine, a synchronised stream for the one-shot path)
+static int reads_index_upload(gs_reads *r, const uint64_t *start, const uint32_t *nwin, const uint32_t *tile0, uint32_t n_reads,
+                              const ReadIndexTotals &tot, hipStream_t st) {
+    r->n_reads = n_reads;
+    r->n_tiles = (uint32_t)tot.tiles;
+    r->n_bases = tot.n_bases;
+    r->n_windows = tot.n_windows;
+    r->n_scan_blocks = (uint32_t)((tot.tiles + kScanBlock - 1) / kScanBlock);
+    if (n_reads) {
+        HIP_TRY(hipMemcpyAsync(r->read_word_off, start, ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(r->read_nwin, nwin, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(r->read_tile0, tile0, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    if (tot.tiles)
+        hipLaunchKernelGGL(k_tile_index, dim3((unsigned)((tot.tiles + 255) / 256)), dim3(256), 0, st, (const uint64_t *)r->read_word_off,
+                           (const uint32_t *)r->read_nwin, (const uint32_t *)r->read_tile0, n_reads, r->n_tiles, r->tile_read, r->tile_desc);
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+// index building + allocations shared by the upload entry points; the packed words are zeroed, not filled
+static int reads_setup(int device, uint64_t n_words, const uint64_t *word_off, const uint32_t *len, uint32_t n_reads, int k,
+                       gs_reads **out, const uint32_t *order = nullptr, uint32_t n_batch_reads = 0) {
+    if (!out || k < 1 || k > 32 || (n_reads && (!word_off || !len))) {
+        set_error("gs_reads_upload: bad argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_reads_upload: HIP device %d not available -- there is no CPU fallback", device);
+        return GS_E_NODEVICE;
+    }
+    std::vector<uint32_t> nwin(n_reads), tile0(n_reads);
+    std::vector<uint64_t> start((size_t)n_reads + 1, 0);
+    ReadIndexTotals tot;
+    int rc;
+    if ((rc = read_index_host(k, word_off, len, n_reads, order, n_batch_reads, start.data(), nwin.data(), tile0.data(), tot))) return rc;
+    gs_reads *r = nullptr;
+    if ((rc = reads_alloc(device, k, n_words, n_reads, tot.tiles, (kDirectCand + 2) * tot.tiles + 65536, &r))) return rc;
+    std::unique_ptr<gs_reads, void (*)(gs_reads *)> guard(r, gs_reads_destroy);
+    r->n_words = n_words;
+    r->read_tile0_host = tile0;
+    HIP_TRY(hipMemsetAsync(r->words, 0, (n_words + kReadSlackWords) * sizeof(uint64_t), nullptr));
+    if ((rc = reads_index_upload(r, start.data(), nwin.data(), tile0.data(), n_reads, tot, nullptr))) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
     *out = guard.release();
     return GS_OK;
 }
@@ -3087,6 +3193,7 @@ void gs_reads_destroy(gs_reads *r) {
     (void)hipFree(r->jq.late);
     (void)hipFree(r->jq.nlate);
     (void)hipFree(r->complex_list);
+    pass_state_free(r->ps);
     delete r;
 }
 
@@ -3113,18 +3220,30 @@ int gs_tag_launch(gs_table *t, gs_reads *r, uint32_t carry_in) {
     return launch_phase2(t, r, carry_in);
 }
 
+int gs_tag_launch_after(gs_table *t, gs_reads *r, const gs_reads *prev) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_launch_after"))) return rc;
+    if (!prev || prev == r || prev->ps.table != t || !(prev->ps.pass_pending || prev->ps.settled)) {
+        set_error("gs_tag_launch_after: `prev` must be another batch whose pass was launched on this table");
+        return GS_E_ARG;
+    }
+    if ((rc = launch_phase1(t, r))) return rc;
+    return launch_phase2(t, r, GS_NONE, prev);
+}
+
 static hipError_t wait_stream(hipStream_t st);
+static hipError_t wait_event(hipEvent_t ev);
 
 int gs_tag_phase1(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_loc) {
     int rc;
     if ((rc = check_pair(t, r, "gs_tag_phase1"))) return rc;
     if ((rc = launch_phase1(t, r))) return rc;
     // summary = scan A with no carry-in; cheap, and phase 2 redoes it with the true carry
-    t->last_carry_in = GS_NONE;
-    HIP_TRY(hipMemcpyAsync(t->d_carry_in, &t->last_carry_in, sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+    r->ps.last_carry_in = GS_NONE;
+    HIP_TRY(hipMemcpyAsync(r->ps.d_carry_in, &r->ps.last_carry_in, sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
     if ((rc = launch_scan(t, r, 0))) return rc;
     Agg tot;
-    HIP_TRY(hipMemcpyAsync(&tot, t->d_totals, sizeof tot, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(&tot, r->ps.d_totals, sizeof tot, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(wait_stream(t->stream));
     if (has_raw) *has_raw = tot.has & 1u;
     if (last_loc) *last_loc = (tot.has & 1u) ? tot.loc : GS_NONE;
@@ -3146,43 +3265,58 @@ static hipError_t wait_stream(hipStream_t st) {
         if (std::chrono::steady_clock::now() - t_poll > std::chrono::milliseconds(20)) break;
     return q == hipErrorNotReady ? hipStreamSynchronize(st) : q;
 }
+static hipError_t wait_event(hipEvent_t ev) {
+    hipError_t q = hipErrorNotReady;
+    const auto t_poll = std::chrono::steady_clock::now();
+    while ((q = hipEventQuery(ev)) == hipErrorNotReady)
+        if (std::chrono::steady_clock::now() - t_poll > std::chrono::milliseconds(20)) break;
+    return q == hipErrorNotReady ? hipEventSynchronize(ev) : q;
+}
 
-// Waits for the pass and caches its outcome in the table handle (idempotent until the next launch).
-// A candidate-buffer overflow (more location changes than budgeted) grows the buffer and re-runs.
+// Waits for the pass of THIS batch (later passes on the same table keep running) and caches its outcome in the batch handle
+// (idempotent until the next launch).  A candidate-buffer overflow (more location changes than budgeted) grows the buffer and
+// re-runs.
 static int settle(gs_table *t, gs_reads *r) {
-    if (!t->pass_pending) {
-        if (t->settled_reads == r) return GS_OK;
+    PassState &ps = r->ps;
+    if (!ps.pass_pending) {
+        if (ps.settled && ps.table == t) return GS_OK;
         set_error("no tagging pass was launched for this (table, reads) pair");
+        return GS_E_ARG;
+    }
+    if (ps.table != t) {
+        set_error("the pending pass of these reads was launched on another table");
         return GS_E_ARG;
     }
     HIP_TRY(hipSetDevice(t->device));
     for (int attempt = 0; attempt < 8; attempt++) {
-        HIP_TRY(wait_stream(t->stream));
-        const uint32_t ncand = t->h_status->cand_count;
-        const unsigned long long err = t->h_status->err_pos;
-        const Agg tot[2] = {t->h_status->totals[0], t->h_status->totals[1]};
+        HIP_TRY(wait_event(ps.ev[3]));
+        const uint32_t ncand = ps.h_status->cand_count;
+        const unsigned long long err = ps.h_status->err_pos;
+        const Agg tot[2] = {ps.h_status->totals[0], ps.h_status->totals[1]};
         if ((uint64_t)r->n_tiles * kDirectCand + ncand > r->cand_cap) {
             int rc;
+            const uint32_t carry_in = ps.h_status->carry_in;  // (what the pass was handed, by the host or by its predecessor)
+            HIP_TRY(hipStreamSynchronize(t->stream));  // nothing may still read the buffers that are about to be replaced
             if ((rc = ensure_out_buffers(r, (uint32_t)std::min<uint64_t>((uint64_t)r->n_tiles * kDirectCand + ncand + 65536, 0xFFFFFFFFull)))) return rc;
             if ((rc = launch_phase1(t, r))) return rc;
-            if ((rc = launch_phase2(t, r, t->last_carry_in))) return rc;
+            if ((rc = launch_phase2(t, r, carry_in))) return rc;
             continue;
         }
         float ms01 = 0, ms02 = 0;
-        HIP_TRY(hipEventElapsedTime(&ms01, t->ev[0], t->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&ms02, t->ev[0], t->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&ms01, ps.ev[0], ps.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms02, ps.ev[0], ps.ev[2]));
         t->ctr.probe_ms += ms01;
         t->ctr.total_ms += ms02;
         t->ctr.launches += 1;
         t->ctr.windows = r->n_windows;
         t->ctr.tiles = r->n_tiles;
-        t->ctr.fallback_tiles = t->h_status->complex_n;
+        t->ctr.fallback_tiles = ps.h_status->complex_n;
         t->ctr.raw_hits = tot[0].sum;
         t->ctr.emitted = tot[1].sum;
-        t->res_n = tot[1].sum;
-        t->res_carry = (tot[0].has & 1u) ? tot[0].loc : GS_NONE;
-        t->res_keyerr = err != ~0ULL;
-        if (t->res_keyerr) {
+        ps.res_n = tot[1].sum;
+        ps.res_carry = (tot[0].has & 1u) ? tot[0].loc : GS_NONE;
+        ps.res_keyerr = err != ~0ULL;
+        if (ps.res_keyerr) {
             // hits emitted before the offending window = emit_prefix of its tile + its earlier candidates
             const uint32_t tile = (uint32_t)(err >> 32), woff = (uint32_t)err;
             uint64_t ep = 0;
@@ -3196,12 +3330,16 @@ static int settle(gs_table *t, gs_reads *r) {
             uint64_t before = 0;
             for (uint32_t j = nc - ne; j < nc; j++)
                 if ((cv[j] & 0xFFFFu) < woff) before++;
-            t->res_n = ep + before;
+            ps.res_n = ep + before;
         }
-        if (t->res_n > kMirrorRows)  // long list: one bulk copy into the pinned mirror
-            HIP_TRY(hipMemcpy(r->hits_host, r->hits, std::min<uint64_t>(t->res_n, r->hit_cap) * sizeof(gs_hit), hipMemcpyDeviceToHost));
-        t->pass_pending = false;
-        t->settled_reads = r;
+        // long list (k_emit mirrors only lists up to kMirrorRows to the host itself -- it decides by the same total): one bulk
+        // copy into the pinned mirror, on the copy stream: the next pass on this table keeps the kernels' stream busy meanwhile
+        if (tot[1].sum > kMirrorRows && ps.res_n) {
+            HIP_TRY(hipMemcpyAsync(r->hits_host, r->hits, std::min<uint64_t>(ps.res_n, r->hit_cap) * sizeof(gs_hit), hipMemcpyDeviceToHost, t->copy_stream));
+            HIP_TRY(hipStreamSynchronize(t->copy_stream));
+        }
+        ps.pass_pending = false;
+        ps.settled = true;
         return GS_OK;
     }
     set_error("gs_tag: candidate buffer kept overflowing");
@@ -3211,18 +3349,18 @@ static int settle(gs_table *t, gs_reads *r) {
 static int copy_hits(gs_table *t, gs_reads *r, void *out, uint64_t cap, uint64_t *n_out, hipMemcpyKind kind) {
     int rc;
     if ((rc = settle(t, r))) return rc;
-    if (n_out) *n_out = t->res_n;
+    if (n_out) *n_out = r->ps.res_n;
     if (out) {
-        if (t->res_n > cap) {
-            set_error("%llu hits do not fit in cap = %llu", (unsigned long long)t->res_n, (unsigned long long)cap);
+        if (r->ps.res_n > cap) {
+            set_error("%llu hits do not fit in cap = %llu", (unsigned long long)r->ps.res_n, (unsigned long long)cap);
             return GS_E_CAPACITY;
         }
-        if (t->res_n) {
-            if (kind == hipMemcpyDeviceToHost) memcpy(out, r->hits_host, t->res_n * sizeof(gs_hit));  // k_emit wrote them there too
-            else HIP_TRY(hipMemcpy(out, r->hits, t->res_n * sizeof(gs_hit), kind));
+        if (r->ps.res_n) {
+            if (kind == hipMemcpyDeviceToHost) memcpy(out, r->hits_host, r->ps.res_n * sizeof(gs_hit));  // k_emit wrote them there too
+            else HIP_TRY(hipMemcpy(out, r->hits, r->ps.res_n * sizeof(gs_hit), kind));
         }
     }
-    if (t->res_keyerr) {
+    if (r->ps.res_keyerr) {
         set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
         return GS_E_KEYERROR;
     }
@@ -3234,7 +3372,7 @@ int gs_tag_finish(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uint64_t 
     int rc;
     if ((rc = check_pair(t, r, "gs_tag_finish"))) return rc;
     if ((rc = settle(t, r))) return rc;
-    if (carry_out) *carry_out = t->res_carry;
+    if (carry_out) *carry_out = r->ps.res_carry;
     if (ctr) *ctr = t->ctr;
     return copy_hits(t, r, out, cap, n_out, hipMemcpyDeviceToHost);
 }
@@ -3266,8 +3404,8 @@ int gs_tag_hits_view(gs_table *t, gs_reads *r, const gs_hit **out, uint64_t *n_o
     if ((rc = check_pair(t, r, "gs_tag_hits_view"))) return rc;
     if ((rc = settle(t, r))) return rc;
     if (out) *out = r->hits_host;
-    if (n_out) *n_out = t->res_n;
-    if (t->res_keyerr) {
+    if (n_out) *n_out = r->ps.res_n;
+    if (r->ps.res_keyerr) {
         set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
         return GS_E_KEYERROR;
     }
@@ -3286,4 +3424,5 @@ void gs_counters_reset(gs_table *t) {
 
 }  // extern "C"
 
+#include "gs_stream.h"
 #include "gs_comm.h"

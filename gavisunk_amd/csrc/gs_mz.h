@@ -52,7 +52,7 @@ struct MzView {
     const uint4 *regions;  // [n_regions][8] pieces of two 64-bit slots
     uint32_t n_regions;
     int k, m, locbits;
-    const uint32_t *pay;  // [n_regions][16]: payload of the key in slot i (words 0 and 1 of a region are unused)
+    const uint32_t *pay;  // [n_regions][8]: payload of the key in slot i (word 0 of a region is unused)
 };
 
 constexpr uint64_t kMzEmpty = ~0ULL;
@@ -98,6 +98,25 @@ __host__ __device__ __forceinline__ MzKey mz_key(uint64_t c, int k, int locbits)
     o.fp = min(l >> 24, 0xFEu);
     o.tag = ((uint64_t)(l & 0x1FFFFFFFu) << (2 * k - 32)) | (uint64_t)hi;  // k = 16: hi = 0, no shift
     return o;
+}
+// FMT: 1 = RAW, 0 = HASHED (compile-time: the specialised kernels), -1 = decided from (k, locbits) at run time
+template <int FMT>
+__device__ __forceinline__ MzKey mz_key_fmt(uint64_t c, int k, int locbits) {
+    if constexpr (FMT == 1) {
+        MzKey o;
+        o.fp = min(((uint32_t)c * 0x9E3779B1u) >> 24, 0xFEu);
+        o.tag = c;
+        return o;
+    } else if constexpr (FMT == 0) {
+        const uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
+        const uint32_t l = mz_mix_a(lo) ^ mz_mix_b(hi + 0x632BE5ABu);
+        MzKey o;
+        o.fp = min(l >> 24, 0xFEu);
+        o.tag = ((uint64_t)(l & 0x1FFFFFFFu) << (2 * k - 32)) | (uint64_t)hi;
+        return o;
+    } else {
+        return mz_key(c, k, locbits);
+    }
 }
 // the two bits of a key in the 64-bit filter word of an overflowed region (from its tag: both slot formats have it at hand)
 __host__ __device__ __forceinline__ unsigned long long mz_filter_bits(uint64_t tag) {
@@ -461,22 +480,24 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 constexpr int kMzRunCap = 32;                  // runs of a step whose regions fit the LDS cache slot (2 KiB)
 constexpr int kMzDma = kMzRunCap * kMzPieces / 64;  // LDS-DMA wave-instructions per step
 constexpr int kMzStages = 2;                   // steps whose region fetches are in flight together
-constexpr int kMzListCap = 320;                // maybe-hits held before the list is flushed (a step adds up to 64)
-constexpr int kMzDeferCap = 96;  
+constexpr int kMzListCap = 240;                // maybe-hits held before the list is flushed (a step adds up to 64)
+constexpr int kMzDeferCap = 96;                // deferred generic-table lookups held before a flush
 constexpr int kMzFastCand = 64;                // candidates (location changes) of a tile before it is handed to the exact form
-static_assert(kMzListCap >= kMzCandLds, "the exact form borrows the hit list as its candidate buffer");              // deferred generic-table lookups held before a flush
+static_assert(kMzListCap >= kMzCandLds, "the exact form borrows the hit list as its candidate buffer");
 constexpr int kMzWaves = 2;                    // waves per workgroup
-constexpr int kMzListLocBits = 21;             // a list entry = window offset in the tile << 21 | loc + 1 (0 = no hit after all)
-constexpr uint32_t kMzListLocMask = (1u << kMzListLocBits) - 1u;
-constexpr uint32_t kMzPending = kMzListLocMask;  // loc field of an entry whose generic-table lookup is still to come
-constexpr int kMzFastLocBits = kMzListLocBits - 1;  // tables with longer loc ids take the exact kernel
+// a list entry = (window offset in the tile: 16 bits, loc + 1: 32 bits, 0 = no hit after all) in two parallel arrays, so that
+// tables with any number of location groups the slot format holds (2^27 for k = 20) take this kernel -- a human assembly has
+// millions of groups (one per stretch of SUNKs with gaps <= k), a diploid one (BASELINE.json configs[3]) one per SNP
+constexpr uint32_t kMzPending = 0xFFFFFFFFu;   // loc of an entry whose generic-table lookup is still to come
 
 struct MzWaveLds {
     uint4 cache[kMzStages][kMzRunCap * kMzPieces];
-    uint32_t list[kMzListCap];
+    uint32_t list[kMzListCap];              // loc + 1 of every maybe-hit (the exact form borrows this as its candidate buffer)
     uint32_t defer[kMzDeferCap];
     uint32_t cand[kMzFastCand];             // the tile's candidates (a tile with more is done over by the exact form)
-    uint64_t words[kTileWords + 2];         // the tile's packed bases
+    uint64_t words[kTileWords + 3];         // the tile's packed bases (+ 2 words a window of the last step reaches into, + 1 that
+                                            // step's look-ahead read touches and never uses)
+    uint16_t list_w[kMzListCap];            // window offset of every maybe-hit
 };
 
 // LDS accesses of the main loop are written as asm: while an LDS-DMA is in flight hipcc puts `s_waitcnt vmcnt(0)` in
@@ -497,6 +518,9 @@ __device__ __forceinline__ uint64_t lds_read_b64(uint32_t addr) {
 }
 __device__ __forceinline__ void lds_write_b32(uint32_t addr, uint32_t v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write_b16(uint32_t addr, uint32_t v) {
+    asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 // the window that starts at this lane's base in step s, from the tile's 66 words staged in LDS (two 8-byte reads, one
@@ -631,8 +655,8 @@ __global__ __launch_bounds__(64) void k_mz_rule_check(int k_rt, int m_rt, const 
     }
 }
 
-// KT / MT: k and m as compile-time constants (0 = take them from the table)
-template <int KT, int MT>
+// KT / MT: k and m as compile-time constants (0 = take them from the table); FMT: slot format (mz_key_fmt)
+template <int KT, int MT, int FMT>
 __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableView tab, const uint64_t *__restrict__ words,
                                                            const TileDesc *__restrict__ tdesc, uint32_t n_tiles, TileArrays ta,
                                                            uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
@@ -654,11 +678,11 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     // the tile's 64 words + the two after them (the buffer carries that much slack after the last read), staged in LDS
     L.words[lane] = __builtin_nontemporal_load(words + td.wbase + lane);
-    if (lane < 2) L.words[64 + lane] = __builtin_nontemporal_load(words + td.wbase + 64 + lane);
+    if (lane < 3) L.words[64 + lane] = lane < 2 ? __builtin_nontemporal_load(words + td.wbase + 64 + lane) : 0ULL;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint32_t nsteps = min((td.nwin_left + 63u) / 64u, 32u);
-    const uint32_t list_a = lds_addr(&L.list[0]), defer_a = lds_addr(&L.defer[0]), words_a = lds_addr(&L.words[0]);
+    const uint32_t list_a = lds_addr(&L.list[0]), listw_a = lds_addr(&L.list_w[0]), defer_a = lds_addr(&L.defer[0]), words_a = lds_addr(&L.words[0]);
 
     // per in-flight step (slot = step % kMzStages): the fingerprint to look for, where the lane's region is in the cache slot,
     // the key / tag to look for, lane r = region of run r, and the run count
@@ -669,7 +693,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     slide.reset();
     uint32_t e_cur = slide.advance(mz_pk_of(cur.o, lane), lane, nt);  // E of the step `cur` is the window of
 
-    // LDS-DMA wave-instructions that fetch the regions of (the first kMzRunCap of) R runs: 8 runs each
+    // LDS-DMA wave-instructions that fetch the regions of (the first kMzRunCap of) R runs: 16 runs each
     constexpr uint32_t kRunsPerDma = 64 / kMzPieces;
     auto dma_count = [](uint32_t R) { return min((R + kRunsPerDma - 1u) / kRunsPerDma, (uint32_t)kMzDma); };
     // the regions of runs [r0, r0 + kMzRunCap) of a step into cache slot `slot`
@@ -692,7 +716,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
         const uint32_t H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
         const uint64_t c = rc_strand ? cur.r : cur.f;
         cur = nxt;
-        const MzKey key = mz_key(c, k, KT && 2 * KT + kMzFastLocBits <= 64 ? kMzFastLocBits : locbits);
+        const MzKey key = mz_key_fmt<FMT>(c, k, locbits);
         const uint32_t reg = mz_region(H, mz.n_regions);
         const bool valid = FULL || s * 64u + (uint32_t)lane < td.nwin_left;
         const bool leader = valid && (lane == 0 || reg != mz_shift_up(reg, ~reg));
@@ -758,7 +782,10 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
         if (mb) {
             // (a big step calls this twice, lower lanes first: its entries still land in lane order)
             const uint32_t idx = lcount + (uint32_t)__popcll(mb & lt);
-            if (mb_mine) lds_write_b32(list_a + idx * 4u, ((s * 64u + (uint32_t)lane) << kMzListLocBits) | (hit ? (uint32_t)e + 1u : kMzPending));
+            if (mb_mine) {
+                lds_write_b32(list_a + idx * 4u, hit ? (uint32_t)e + 1u : kMzPending);
+                lds_write_b16(listw_a + idx * 2u, s * 64u + (uint32_t)lane);
+            }
             if (defer) lds_write_b32(defer_a + (dcount + (uint32_t)__popcll(db & lt)) * 4u, (s * 64u + (uint32_t)lane) | (idx << 16));
             lcount += (uint32_t)__popcll(mb);
             dcount += (uint32_t)__popcll(db);
@@ -785,14 +812,14 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
                     hh = (hh + 1) & tab.mask;
                     sl = load_slot(tab.slots + hh);
                 }
-                L.list[ent >> 16] = (wi << kMzListLocBits) | (sl.key == c ? sl.loc + 1u : 0u);
+                L.list[ent >> 16] = sl.key == c ? sl.loc + 1u : 0u;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (uint32_t i0 = 0; i0 < lcount; i0 += 64u) {
-            const uint32_t v = i0 + (uint32_t)lane < lcount ? L.list[i0 + (uint32_t)lane] : 0u;
-            const uint32_t lv = v & kMzListLocMask, woff = v >> kMzListLocBits;
+            const bool have = i0 + (uint32_t)lane < lcount;
+            const uint32_t lv = have ? L.list[i0 + (uint32_t)lane] : 0u, woff = have ? (uint32_t)L.list_w[i0 + (uint32_t)lane] : 0u;
             const bool hit = lv != 0u;
             const uint32_t loc = lv - 1u;
             const unsigned long long hb = __ballot(hit);

@@ -3,14 +3,16 @@
 // -- the canonical k-mers that occur exactly once over hap1+hap2, their positions, and the merged
 // overlapping/book-ended [start, start+k) intervals (group id = start of the merged interval).
 //
-//   k_window_codes   canonical code of every window (windows with a non-ACGT byte are not k-mers)
+//   k_window_codes   canonical code of every window (windows with a non-ACGT byte are not k-mers), in P passes over the
+//                    code space so that hap1 + hap2 of a human genome (6e9 windows) fit the sorts: count, scan, emit
 //   radix sort       (code, contig<<32|pos) by code           (rocPRIM: plain device-wide primitive)
 //   k_mark_unique    code differs from both neighbours
-//   select           -> the singly-unique ones
+//   select           -> the singly-unique ones (of this pass; the passes' survivors are concatenated)
 //   radix sort       by (contig, pos)  = kmer.loc order
 //   k_group_flags / inclusive sum-scan / k_group_loc   group = start of the run with gaps <= k, loc = dense id of the run
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <memory>
@@ -53,10 +55,17 @@ __device__ __forceinline__ int base_code(uint8_t c) {  // -1: not a nucleotide j
     }
 }
 
-// one thread per 64 consecutive windows of a contig
+// one thread per 64 consecutive windows of a contig.  The definition runs in P passes over the code space (P a power of two;
+// a pass takes the windows whose canonical code falls into its partition: uniform by a multiplicative hash), so that an
+// assembly of any size -- hap1 + hap2 of a human genome is 6e9 windows -- is counted with sorts that fit device memory:
+//   EMIT = false   per chunk, the number of k-mers (windows without a non-ACGT byte) of partition `part`
+//   EMIT = true    those k-mers' (canonical code, contig << 32 | window), compacted, at chunk_base[chunk] ..
 constexpr int kChunk = 64;
-__global__ void k_window_codes(const uint8_t *seq, const uint64_t *coff, const uint64_t *chunk_off, uint32_t n_contigs,
-                               int k, uint64_t invalid_key, uint64_t *keys, uint64_t *vals) {
+__device__ __forceinline__ uint32_t code_partition(uint64_t c, uint32_t pmask) { return (uint32_t)((c * 0x9E3779B97F4A7C15ULL) >> 56) & pmask; }
+template <bool EMIT>
+__global__ void k_window_codes(const uint8_t *seq, const uint64_t *coff, const uint64_t *chunk_off, uint32_t n_contigs, int k,
+                               uint32_t pmask, uint32_t part, uint64_t *chunk_count, const uint64_t *chunk_base, uint64_t *keys,
+                               uint64_t *vals) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= chunk_off[n_contigs]) return;
     // contig of this chunk: binary search over the chunk prefix
@@ -76,6 +85,7 @@ __global__ void k_window_codes(const uint8_t *seq, const uint64_t *coff, const u
     uint64_t fwd = 0, rev = 0;
     int good = 0;  // consecutive valid bases ending here
     const uint64_t wend = min(w0 + (uint64_t)kChunk, nwin);
+    uint64_t o = EMIT ? chunk_base[t] : 0;
     for (uint64_t e = w0; e < wend + k - 1; e++) {
         const int b = base_code(s[e]);
         if (b < 0) {
@@ -86,33 +96,25 @@ __global__ void k_window_codes(const uint8_t *seq, const uint64_t *coff, const u
             fwd = ((fwd << 2) | (uint64_t)b) & kmask;
             rev = (rev >> 2) | ((uint64_t)(3 - b) << rshift);
         }
-        if (e + 1 >= w0 + (uint64_t)k) {
-            const uint64_t w = e + 1 - k;
-            const uint64_t g = coff[c] + w;  // global slot of the window
-            keys[g] = good >= k ? (fwd < rev ? fwd : rev) : invalid_key;
-            vals[g] = ((uint64_t)c << 32) | w;
+        if (e + 1 >= w0 + (uint64_t)k && good >= k) {
+            const uint64_t code = fwd < rev ? fwd : rev;
+            if (code_partition(code, pmask) == part) {
+                if (EMIT) {
+                    keys[o] = code;
+                    vals[o] = ((uint64_t)c << 32) | (e + 1 - k);
+                }
+                o++;
+            }
         }
     }
+    if (!EMIT) chunk_count[t] = o;
 }
 
-__global__ void k_fill_invalid(uint64_t *keys, uint64_t *vals, const uint64_t *coff, uint32_t n_contigs, int k,
-                               uint64_t invalid_key) {
-    // the last k-1 slots of every contig hold no window
-    const uint32_t c = blockIdx.x;
-    const uint64_t len = coff[c + 1] - coff[c];
-    const uint64_t nwin = len >= (uint64_t)k ? len - k + 1 : 0;
-    for (uint64_t i = nwin + threadIdx.x; i < len; i += blockDim.x) {
-        keys[coff[c] + i] = invalid_key;
-        vals[coff[c] + i] = 0;
-    }
-}
-
-__global__ void k_mark_unique(const uint64_t *keys, uint64_t n, uint64_t invalid_key, uint8_t *flag) {
+__global__ void k_mark_unique(const uint64_t *keys, uint64_t n, uint8_t *flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t x = keys[i];
-    const bool u = x != invalid_key && (i == 0 || keys[i - 1] != x) && (i + 1 == n || keys[i + 1] != x);
-    flag[i] = u ? 1 : 0;
+    flag[i] = ((i == 0 || keys[i - 1] != x) && (i + 1 == n || keys[i + 1] != x)) ? 1 : 0;
 }
 
 struct Bufs {
@@ -186,65 +188,146 @@ int sunks_define_core(int device, int k, uint32_t n_contigs, const uint8_t *d_se
     res->k = k;
     const uint64_t n = n_contigs ? off[n_contigs] : 0;
     if (n == 0) return GS_OK;
-    if (n > 0xFFFFFFF0ull) {
-        set_error("gs_sunks_define: more than 2^32 bases; split the assembly");
-        return GS_E_ARG;
-    }
     for (uint32_t c = 0; c < n_contigs; c++)
         if (off[c + 1] - off[c] > 0xFFFFFFFFull) {
             set_error("gs_sunks_define: contig %u is longer than 2^32 bases", c);
             return GS_E_ARG;
         }
     std::vector<uint64_t> chunk_off(n_contigs + 1, 0);
+    uint64_t n_windows = 0;
     for (uint32_t c = 0; c < n_contigs; c++) {
         const uint64_t len = off[c + 1] - off[c];
         const uint64_t nwin = len >= (uint64_t)k ? len - k + 1 : 0;
         chunk_off[c + 1] = chunk_off[c] + (nwin + kChunk - 1) / kChunk;
+        n_windows += nwin;
     }
+    const uint64_t n_chunks = chunk_off[n_contigs];
     uint64_t m = 0;
     uint64_t *d_code = nullptr, *d_pos = nullptr;  // survivors of the first stage
-    {
-        Bufs b;  // stage 1: window codes, sort by code, keep the singly-unique ones
+    if (n_chunks) {
+        // stage 1: window codes, sorted by code, the singly-unique ones kept -- in P passes over the code space, P = the
+        // smallest power of two whose per-pass buffers (4 x 8 B + 1 B per window, + the sort's own) fit the free device memory
+        // and whose windows stay below 2^32 (GAVISUNK_DEFINE_PASSES forces more: test knob)
+        Bufs b;
         int rc;
-        uint8_t *d_flag;
-        uint64_t *d_coff, *d_chunk, *d_k0, *d_v0, *d_k1, *d_v1, *d_cnt;
+        uint64_t *d_coff, *d_chunk, *d_count, *d_base, *d_cnt;
         if ((rc = b.get(&d_coff, (uint64_t)n_contigs + 1)) || (rc = b.get(&d_chunk, (uint64_t)n_contigs + 1)) ||
-            (rc = b.get(&d_k0, n)) || (rc = b.get(&d_v0, n)) || (rc = b.get(&d_k1, n)) || (rc = b.get(&d_v1, n)) ||
-            (rc = b.get(&d_flag, n)) || (rc = b.get(&d_cnt, 1)))
+            (rc = b.get(&d_count, n_chunks + 1)) || (rc = b.get(&d_base, n_chunks + 1)) || (rc = b.get(&d_cnt, 1)))
             return rc;
         HIP_TRY(hipMemcpy(d_coff, off, ((uint64_t)n_contigs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_chunk, chunk_off.data(), chunk_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-        const uint64_t invalid_key = k == 32 ? ~0ULL : (1ULL << (2 * k));  // sorts after every real code (k = 32: poly-T is never canonical)
-        const int end_bit = k == 32 ? 64 : 2 * k + 1;
-        hipLaunchKernelGGL(k_fill_invalid, dim3(n_contigs), dim3(64), 0, 0, d_k0, d_v0, d_coff, n_contigs, k, invalid_key);
-        if (chunk_off[n_contigs])
-            hipLaunchKernelGGL(k_window_codes, dim3((unsigned)((chunk_off[n_contigs] + 127) / 128)), dim3(128), 0, 0, d_seq, d_coff,
-                               d_chunk, n_contigs, k, invalid_key, d_k0, d_v0);
-        HIP_TRY(hipGetLastError());
-        size_t tmp_bytes = 0, tb2 = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, n, 0u, (unsigned)end_bit));
-        HIP_TRY(rocprim::select(nullptr, tb2, d_v1, d_flag, d_v0, d_cnt, n));
-        tmp_bytes = std::max(tmp_bytes, tb2);
-        void *d_tmp;
-        if ((rc = b.get((uint8_t **)&d_tmp, tmp_bytes))) return rc;
-        size_t tbb = tmp_bytes;
-        HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tbb, d_k0, d_k1, d_v0, d_v1, n, 0u, (unsigned)end_bit));
-        hipLaunchKernelGGL(k_mark_unique, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_k1, n, invalid_key, d_flag);
-        // singly-unique: positions -> v0, codes -> k0
-        tbb = tmp_bytes;
-        HIP_TRY(rocprim::select(d_tmp, tbb, d_v1, d_flag, d_v0, d_cnt, n));
-        tbb = tmp_bytes;
-        HIP_TRY(rocprim::select(d_tmp, tbb, d_k1, d_flag, d_k0, d_cnt, n));
-        HIP_TRY(hipMemcpy(&m, d_cnt, sizeof m, hipMemcpyDeviceToHost));
-        if (m) {  // compact copies: the big buffers go away before the second stage
-            HIP_TRY(hipMalloc((void **)&d_code, m * sizeof(uint64_t)));
-            if (hipMalloc((void **)&d_pos, m * sizeof(uint64_t)) != hipSuccess) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        uint32_t P = 1;
+        while (P < 256 && ((double)n_windows / P * 1.05 > 4.0e9 || (double)n_windows / P * 36.0 * 1.05 > 0.80 * (double)free_b)) P *= 2;
+        if (const char *e = getenv("GAVISUNK_DEFINE_PASSES")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 256 && (v & (v - 1)) == 0) P = std::max<uint32_t>(P, (uint32_t)v);
+        }
+        const int end_bit = k == 32 ? 64 : 2 * k;
+        const unsigned cblocks = (unsigned)((n_chunks + 127) / 128);
+        size_t scan_tmp_bytes = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tmp_bytes, d_count, d_base, (uint64_t)0, n_chunks + 1, rocprim::plus<uint64_t>()));
+        void *d_scan_tmp;
+        if ((rc = b.get((uint8_t **)&d_scan_tmp, scan_tmp_bytes))) return rc;
+        HIP_TRY(hipMemset(d_count + n_chunks, 0, sizeof(uint64_t)));  // (the scan's last output = the pass's window count)
+        std::vector<std::pair<uint64_t *, uint64_t *>> parts;  // per pass: codes, positions of its singly-unique k-mers
+        std::vector<uint64_t> part_n;
+        auto drop_parts = [&]() {
+            for (auto &pp : parts) {
+                (void)hipFree(pp.first);
+                (void)hipFree(pp.second);
+            }
+        };
+        for (uint32_t part = 0; part < P; part++) {
+            hipLaunchKernelGGL((k_window_codes<false>), dim3(cblocks), dim3(128), 0, 0, d_seq, d_coff, d_chunk, n_contigs, k, P - 1u, part,
+                               d_count, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr);
+            size_t stb = scan_tmp_bytes;
+            hipError_t e = rocprim::exclusive_scan(d_scan_tmp, stb, d_count, d_base, (uint64_t)0, n_chunks + 1, rocprim::plus<uint64_t>());
+            uint64_t np = 0;
+            if (e == hipSuccess) e = hipMemcpy(&np, d_base + n_chunks, sizeof np, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                drop_parts();
+                set_error("gs_sunks_define: counting pass failed: %s", hipGetErrorString(e));
+                return GS_E_NODEVICE;
+            }
+            if (!np) continue;
+            Bufs pb;  // this pass's buffers
+            uint8_t *d_flag;
+            uint64_t *d_k0, *d_v0, *d_k1, *d_v1;
+            if ((rc = pb.get(&d_k0, np)) || (rc = pb.get(&d_v0, np)) || (rc = pb.get(&d_k1, np)) || (rc = pb.get(&d_v1, np)) ||
+                (rc = pb.get(&d_flag, np))) {
+                drop_parts();
+                return rc;
+            }
+            hipLaunchKernelGGL((k_window_codes<true>), dim3(cblocks), dim3(128), 0, 0, d_seq, d_coff, d_chunk, n_contigs, k, P - 1u, part,
+                               (uint64_t *)nullptr, (const uint64_t *)d_base, d_k0, d_v0);
+            size_t tmp_bytes = 0, tb2 = 0;
+            e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, np, 0u, (unsigned)end_bit);
+            if (e == hipSuccess) e = rocprim::select(nullptr, tb2, d_v1, d_flag, d_v0, d_cnt, np);
+            tmp_bytes = std::max(tmp_bytes, tb2);
+            void *d_tmp = nullptr;
+            if (e == hipSuccess && (rc = pb.get((uint8_t **)&d_tmp, tmp_bytes))) {
+                drop_parts();
+                return rc;
+            }
+            size_t tbb = tmp_bytes;
+            if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tbb, d_k0, d_k1, d_v0, d_v1, np, 0u, (unsigned)end_bit);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_mark_unique, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, 0, d_k1, np, d_flag);
+                tbb = tmp_bytes;  // singly-unique: positions -> v0, codes -> k0
+                e = rocprim::select(d_tmp, tbb, d_v1, d_flag, d_v0, d_cnt, np);
+            }
+            tbb = tmp_bytes;
+            if (e == hipSuccess) e = rocprim::select(d_tmp, tbb, d_k1, d_flag, d_k0, d_cnt, np);
+            uint64_t mp = 0;
+            if (e == hipSuccess) e = hipMemcpy(&mp, d_cnt, sizeof mp, hipMemcpyDeviceToHost);
+            uint64_t *pc = nullptr, *pp = nullptr;
+            if (e == hipSuccess && mp) {
+                e = hipMalloc((void **)&pc, mp * sizeof(uint64_t));
+                if (e == hipSuccess) e = hipMalloc((void **)&pp, mp * sizeof(uint64_t));
+                if (e == hipSuccess) e = hipMemcpy(pc, d_k0, mp * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+                if (e == hipSuccess) e = hipMemcpy(pp, d_v0, mp * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+                if (e != hipSuccess) {
+                    (void)hipFree(pc);
+                    (void)hipFree(pp);
+                }
+            }
+            if (e != hipSuccess) {
+                drop_parts();
+                set_error("gs_sunks_define: pass %u of %u failed: %s", part + 1, P, hipGetErrorString(e));
+                return e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_NODEVICE;
+            }
+            if (mp) {
+                parts.push_back({pc, pp});
+                part_n.push_back(mp);
+                m += mp;
+            }
+        }
+        if (m > 0xFFFFFFF0ull) {
+            drop_parts();
+            set_error("gs_sunks_define: %llu singly-unique k-mers (the table and kmer.loc rows are indexed with 32 bits)", (unsigned long long)m);
+            return GS_E_ARG;
+        }
+        if (parts.size() == 1) {
+            d_code = parts[0].first;
+            d_pos = parts[0].second;
+        } else if (m) {
+            hipError_t e = hipMalloc((void **)&d_code, m * sizeof(uint64_t));
+            if (e == hipSuccess) e = hipMalloc((void **)&d_pos, m * sizeof(uint64_t));
+            uint64_t at = 0;
+            for (size_t i = 0; i < parts.size() && e == hipSuccess; i++) {
+                e = hipMemcpy(d_code + at, parts[i].first, part_n[i] * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+                if (e == hipSuccess) e = hipMemcpy(d_pos + at, parts[i].second, part_n[i] * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+                at += part_n[i];
+            }
+            drop_parts();
+            if (e != hipSuccess) {
                 (void)hipFree(d_code);
+                (void)hipFree(d_pos);
                 set_error("gs_sunks_define: out of device memory");
                 return GS_E_NOMEM;
             }
-            HIP_TRY(hipMemcpy(d_code, d_k0, m * sizeof(uint64_t), hipMemcpyDeviceToDevice));
-            HIP_TRY(hipMemcpy(d_pos, d_v0, m * sizeof(uint64_t), hipMemcpyDeviceToDevice));
         }
     }
     res->n = m;

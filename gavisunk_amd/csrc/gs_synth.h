@@ -13,6 +13,11 @@ void gs_synth_free(int device, void *d);
 /* ASCII assembly of n_bases: uniform ACGT, slots of family_len bases are repeat-family copies with probability repeat_fraction */
 int gs_synth_genome(int device, uint64_t seed, uint64_t n_bases, double repeat_fraction, uint32_t n_families, uint32_t family_len,
                     void **d_ascii_out);
+/* diploid assembly (BASELINE.json configs[3]): hap 1 then hap 2, n_bases_per_hap each, both descended from the assembly
+ * gs_synth_genome makes from the same arguments; the haplotypes differ at a fraction `snp` of the sites, and a fraction `spec`
+ * of each haplotype's slots of spec_len bases is sequence found nowhere else */
+int gs_synth_diploid(int device, uint64_t seed, uint64_t n_bases_per_hap, double repeat_fraction, uint32_t n_families,
+                     uint32_t family_len, double snp, double spec, uint32_t spec_len, void **d_ascii_out);
 /* reads cut from [src_start, src_start + src_len) of the assembly (reverse-complemented where rev), with per-base
  * substitution / deletion / insertion; off_out[n_reads + 1] (host) receives the offsets of the reads in *d_ascii_out */
 int gs_synth_reads(int device, uint64_t seed, const void *d_genome_ascii, uint32_t n_reads, const uint64_t *src_start,

@@ -43,18 +43,44 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 __device__ __forceinline__ uint8_t ascii_of(uint32_t c) { return (uint8_t)("ACGT"[c & 3u]); }
 __device__ __forceinline__ uint8_t complement(uint8_t b) { return b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : 'A'; }
 
+// base i of the (ancestral) assembly: a pure function of (seed, i)
+__device__ __forceinline__ uint32_t ancestor_base(uint64_t i, uint64_t seed, uint32_t family_len, uint32_t n_families, uint32_t repeat_thr) {
+    const uint64_t slot = i / family_len;
+    const uint64_t hs = mix64(seed ^ (slot * 0xD1B54A32D192ED03ULL) ^ 0xABCDEF);
+    uint64_t h;
+    if ((uint32_t)hs < repeat_thr) {  // a repeat slot: base (i mod family_len) of family (hs >> 32) mod n_families
+        const uint64_t fam = (hs >> 32) % n_families;
+        h = mix64(seed ^ 0x5EED0FFA ^ ((fam << 32) | (i % family_len)));
+    } else {
+        h = mix64(seed ^ (i * 0x9E3779B97F4A7C15ULL));
+    }
+    return (uint32_t)(h >> 13) & 3u;
+}
+
 __global__ void k_genome(uint8_t *out, uint64_t n, uint64_t seed, uint32_t family_len, uint32_t n_families, uint32_t repeat_thr) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = ascii_of(ancestor_base(i, seed, family_len, n_families, repeat_thr));
+}
+
+// BASELINE.json configs[3] (cfg 4): haplotype `hap` (0 / 1) of a diploid assembly -- both descend from
+// the ancestor above; a site is a SNP with probability snp (hap 1 then carries another base than the ancestor, hap 0 keeps
+// it: the haplotypes DIFFER at that rate), and a slot of spec_len bases is, per haplotype and independently, replaced by
+// sequence that exists nowhere else with probability spec ("5 % hap-specific sequence"; same length in both haplotypes).
+__global__ void k_haplotype(uint8_t *out, uint64_t n, uint64_t seed, uint32_t family_len, uint32_t n_families, uint32_t repeat_thr,
+                            uint32_t hap, uint32_t snp_thr, uint32_t spec_thr, uint32_t spec_len) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t slot = i / family_len;
-        const uint64_t hs = mix64(seed ^ (slot * 0xD1B54A32D192ED03ULL) ^ 0xABCDEF);
-        uint64_t h;
-        if ((uint32_t)hs < repeat_thr) {  // a repeat slot: base (i mod family_len) of family (hs >> 32) mod n_families
-            const uint64_t fam = (hs >> 32) % n_families;
-            h = mix64(seed ^ 0x5EED0FFA ^ ((fam << 32) | (i % family_len)));
+        const uint64_t hs = mix64(seed ^ ((i / spec_len) * 0xA24BAED4963EE407ULL) ^ (0x51ED27 + hap));
+        uint32_t b;
+        if ((uint32_t)hs < spec_thr) {
+            b = (uint32_t)(mix64(seed ^ 0x4A9C0DE ^ ((uint64_t)(hap + 1) << 60) ^ (i * 0x9E3779B97F4A7C15ULL)) >> 13) & 3u;
         } else {
-            h = mix64(seed ^ (i * 0x9E3779B97F4A7C15ULL));
+            b = ancestor_base(i, seed, family_len, n_families, repeat_thr);
+            if (hap) {
+                const uint64_t h2 = mix64(seed ^ 0x5A9 ^ (i * 0xC2B2AE3D27D4EB4FULL));
+                if ((uint32_t)h2 < snp_thr) b = (b + 1u + (uint32_t)((h2 >> 40) % 3u)) & 3u;
+            }
         }
-        out[i] = ascii_of((uint32_t)(h >> 13));
+        out[i] = ascii_of(b);
     }
 }
 
@@ -150,6 +176,26 @@ int gs_synth_genome(int device, uint64_t seed, uint64_t n_bases, double repeat_f
     SY_TRY(hipMalloc((void **)&d, n_bases + 64));
     const uint32_t thr = (uint32_t)(repeat_fraction * 4294967295.0);
     hipLaunchKernelGGL(k_genome, dim3(8192), dim3(256), 0, 0, d, n_bases, seed, family_len, n_families, thr);
+    SY_TRY(hipGetLastError());
+    SY_TRY(hipDeviceSynchronize());
+    *d_ascii_out = d;
+    return 0;
+}
+
+int gs_synth_diploid(int device, uint64_t seed, uint64_t n_bases_per_hap, double repeat_fraction, uint32_t n_families,
+                     uint32_t family_len, double snp, double spec, uint32_t spec_len, void **d_ascii_out) {
+    if (!d_ascii_out || !n_bases_per_hap || !n_families || !family_len || !spec_len || repeat_fraction < 0 || repeat_fraction > 1 ||
+        snp < 0 || snp > 1 || spec < 0 || spec > 1) {
+        snprintf(g_err, sizeof g_err, "gs_synth_diploid: bad argument");
+        return -1;
+    }
+    SY_TRY(hipSetDevice(device));
+    uint8_t *d = nullptr;
+    SY_TRY(hipMalloc((void **)&d, 2 * n_bases_per_hap + 64));
+    const uint32_t thr = (uint32_t)(repeat_fraction * 4294967295.0);
+    for (uint32_t hap = 0; hap < 2; hap++)
+        hipLaunchKernelGGL(k_haplotype, dim3(8192), dim3(256), 0, 0, d + (uint64_t)hap * n_bases_per_hap, n_bases_per_hap, seed,
+                           family_len, n_families, thr, hap, (uint32_t)(snp * 4294967295.0), (uint32_t)(spec * 4294967295.0), spec_len);
     SY_TRY(hipGetLastError());
     SY_TRY(hipDeviceSynchronize());
     *d_ascii_out = d;

@@ -320,6 +320,80 @@ def tag(table: DeviceTable, reads: DeviceReads, carry_in: int = GS_NONE):
     return st, out, carry.value, ctr.as_dict()
 
 
+class PinnedWords:
+    """Pinned host memory for packed read words (gs_host_alloc): what Stream.submit hands to the DMA engine without a copy."""
+
+    def __init__(self, n_words: int):
+        p = C.c_void_p()
+        check(lib().gs_host_alloc(max(n_words, 1) * 8, C.byref(p)))
+        self._p, self.n_words = p, n_words
+        self.words = _view(p.value, n_words, np.uint64)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.words = None
+            lib().gs_host_free(self._p)
+            self._p = None
+
+    __del__ = close
+
+
+class Stream:
+    """Streaming engine (gs_stream_*): the main loop kmerpos_annot3.nim:85-96 as a pipeline of read batches against one table.
+    `submit` queues a host batch (upload overlapped with the previous batch's pass, `prevLoc` handed on in device memory),
+    `next` returns the oldest batch's rows; at most `depth` batches are between the two."""
+
+    def __init__(self, table: DeviceTable, max_words: int, max_reads: int, depth: int = 3, carry_in: int = GS_NONE):
+        h = C.c_void_p()
+        check(lib().gs_stream_create(table._h, max_words, max_reads, depth, carry_in, C.byref(h)))
+        self._h, self.table, self.depth = h, table, depth
+        self._cap_words, self._cap_reads = max_words, max_reads
+        self._keep = []  # host arrays of batches in flight (the DMA engine reads pinned words where they lie)
+
+    def submit(self, words: np.ndarray, word_off: np.ndarray, length: np.ndarray) -> None:
+        """A host batch in the ReadBatch layout (words u64, word_off u64[n + 1], len u32[n])."""
+        n = len(length)
+        check(lib().gs_stream_submit(self._h, words.ctypes.data if len(words) else None, len(words), word_off.ctypes.data,
+                                     length.ctypes.data if n else None, n))
+        self._keep.append((words, word_off, length))
+
+    def submit_batch(self, batch: ReadBatch) -> None:
+        self.submit(batch.words, batch.word_off, batch.len)
+        self._keep[-1] = batch
+
+    def submit_reads(self, reads: DeviceReads) -> None:
+        """A batch that already is device-resident."""
+        check(lib().gs_stream_submit_reads(self._h, reads._h))
+        self._keep.append(reads)
+
+    @property
+    def in_flight(self) -> int:
+        return lib().gs_stream_in_flight(self._h)
+
+    @property
+    def carry(self) -> int:
+        return lib().gs_stream_carry(self._h)
+
+    def next(self, copy: bool = True):
+        """-> (status, hits, n_reads, counters) of the oldest batch in flight; hits is a view of pinned memory that the next
+        call invalidates unless copy=True.  status is GS_OK or GS_E_KEYERROR (hits = the rows before the offending window)."""
+        hp, n, nr, ctr = C.c_void_p(), C.c_uint64(0), C.c_uint32(0), GsCounters()
+        st = lib().gs_stream_next(self._h, C.byref(hp), C.byref(n), C.byref(nr), C.byref(ctr))
+        if st not in (_lib.GS_OK, _lib.GS_E_KEYERROR):
+            check(st)
+        self._keep.pop(0)
+        hits = _view(hp.value, n.value, HIT_DTYPE)
+        return st, (hits.copy() if copy else hits), nr.value, ctr.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_stream_destroy(self._h)
+            self._h = None
+            self._keep = []
+
+    __del__ = close
+
+
 def format_sunkpos(hits: np.ndarray, names: Sequence[str], db: SunkDB) -> str:
     """Rows of the reference's output file: name, i, chrom, start, group (kmerpos_annot3.nim:93)."""
     rows = hits["payload"]

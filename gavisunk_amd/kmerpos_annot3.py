@@ -105,6 +105,71 @@ def _tag_text_blocks(blocks, db, table, ofile: str, device: int):
     return 0
 
 
+def _tag_host_batches(batches, db, table, ofile: str, batch_bases: int) -> int:
+    """Batches parsed and packed by the host reader.  A file that is one batch is tagged in one call; a longer one goes through
+    the streaming engine (gs_stream_*): batch i + 1 is uploaded while batch i is tagged, the rows of batch i are formatted and
+    written while batch i + 1 is tagged, and `prevLoc` goes from pass to pass on the device."""
+    it = iter(batches)
+    first = next(it, None)
+    second = next(it, None) if first is not None else None
+    with open(ofile, "w") as out:
+        if first is None:
+            return 0
+        if second is None:
+            dev = engine.DeviceReads(first, db.k, table.device)
+            st, hits, _, _ = engine.tag(table, dev)
+            out.write(engine.format_sunkpos(hits, first.names, db))
+            dev.close()
+            first.close()
+            if st == _lib.GS_E_KEYERROR:
+                sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
+                return 1
+            return 0
+        cap_reads = 1 << 22  # the reader's own limits: a batch has at most 2^22 reads and batch_bases bases (+ 2 words per read)
+        cap_words = batch_bases // 32 + 2 * cap_reads + 64
+        stream = engine.Stream(table, cap_words, cap_reads, depth=3)
+        pending = []  # batches in flight (names are needed when the rows come back), with the device copy of an outsized one
+
+        def drain(upto: int) -> int:
+            while len(pending) > upto:
+                st, hits, _, _ = stream.next(copy=False)
+                b, dev = pending.pop(0)
+                out.write(engine.format_sunkpos(hits, b.names, db))
+                if dev is not None:
+                    dev.close()
+                b.close()
+                if st == _lib.GS_E_KEYERROR:
+                    sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
+                    return 1
+            return 0
+
+        rc = 0
+        try:
+            import itertools
+
+            for batch in itertools.chain((first, second), it):
+                rc = drain(1)  # at most two in flight: one being tagged, one being uploaded
+                if rc:
+                    batch.close()
+                    break
+                if batch.n_words > cap_words or batch.n_reads > cap_reads:  # (one read longer than a batch: its own device copy)
+                    dev = engine.DeviceReads(batch, db.k, table.device)
+                    stream.submit_reads(dev)
+                    pending.append((batch, dev))
+                else:
+                    stream.submit_batch(batch)
+                    pending.append((batch, None))
+            if not rc:
+                rc = drain(0)
+        finally:
+            for b, dev in pending:
+                if dev is not None:
+                    dev.close()
+                b.close()
+            stream.close()
+        return rc
+
+
 def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_bases: int = 1 << 31) -> int:
     host_parse = os.environ.get("GAVISUNK_PARSE", "device") == "host"
     batches = _Prefetch(reads, batch_bases) if host_parse else None
@@ -131,19 +196,7 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
         if rc is None:
             batches = _Prefetch(reads, batch_bases)
     if rc is None:
-        carry = _lib.GS_NONE
-        rc = 0
-        with open(ofile, "w") as out:
-            for batch in batches:
-                dev = engine.DeviceReads(batch, db.k, device)
-                st, hits, carry, _ = engine.tag(table, dev, carry)
-                out.write(engine.format_sunkpos(hits, batch.names, db))
-                dev.close()
-                batch.close()
-                if st == _lib.GS_E_KEYERROR:
-                    sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
-                    rc = 1
-                    break
+        rc = _tag_host_batches(batches, db, table, ofile, batch_bases)
     if batches is not None:
         batches.close()
     table.close()

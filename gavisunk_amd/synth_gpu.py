@@ -33,6 +33,7 @@ def lib() -> C.CDLL:
         L.gs_synth_free.argtypes = [I, P]
         L.gs_synth_free.restype = None
         L.gs_synth_genome.argtypes = [I, U64, U64, D, U32, U32, C.POINTER(P)]
+        L.gs_synth_diploid.argtypes = [I, U64, U64, D, U32, U32, D, D, U32, C.POINTER(P)]
         L.gs_synth_reads.argtypes = [I, U64, P, U32, P, P, P, D, D, D, C.POINTER(P), P]
         L.gs_synth_select_rows.argtypes = [I, P, U64, P, U64, P, U64, C.POINTER(U64)]
         L.gs_synth_gather.argtypes = [I, P, I, P, U64, P]
@@ -83,6 +84,29 @@ class Genome:
             self.ptr = None
 
     __del__ = close
+
+
+class DiploidGenome(Genome):
+    """BASELINE.json configs[3] (SURVEY.md section 8d cfg 4): two haplotypes of `bases_per_hap` that descend from one ancestor
+    (the assembly `Genome` makes from the same arguments) and differ by `snp` = 0.1 % SNPs plus `spec` = 5 % haplotype-specific
+    sequence (slots of `spec_len` bases replaced, per haplotype, by sequence found nowhere else).  Hap 1's contigs, then hap
+    2's, back to back in one device buffer -- what `combine_asm_haps` (workflow/rules/defineSUNKs.smk:1-20) hands the SUNK
+    definition; a k-mer is a SUNK when it is singly unique over BOTH haplotypes."""
+
+    def __init__(self, bases_per_hap: int, n_contigs: int = 24, repeat_fraction: float = 0.5, n_families: int = 64,
+                 family_len: int = 6000, snp: float = 0.001, spec: float = 0.05, spec_len: int = 20000, seed: int = 40,
+                 device: int = 0):
+        wts = np.linspace(2.0, 0.5, n_contigs)
+        lens = np.maximum((wts / wts.sum() * bases_per_hap).astype(np.int64), 1000)
+        per_hap = int(lens.sum())
+        self.off = np.zeros(2 * n_contigs + 1, dtype=np.uint64)
+        self.off[1:] = np.cumsum(np.concatenate([lens, lens]))
+        self.names = [f"hap{h}_ctg{i + 1}" for h in (1, 2) for i in range(n_contigs)]
+        self.device = device
+        self.bases_per_hap = per_hap
+        p = P()
+        _check(lib().gs_synth_diploid(device, seed, per_hap, repeat_fraction, n_families, family_len, snp, spec, spec_len, C.byref(p)))
+        self.ptr = p.value
 
 
 def lognormal_lengths(rng: np.random.Generator, n: int, median: float, sigma: float = 0.7, lo: int = 1000,
@@ -153,3 +177,36 @@ def gather(device: int, d_src: int, dtype, rows: np.ndarray) -> np.ndarray:
 def n50(lengths: np.ndarray) -> int:
     s = np.sort(np.asarray(lengths, dtype=np.int64))[::-1]
     return int(s[np.searchsorted(np.cumsum(s), s.sum() / 2)])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The BASELINE.json workloads, defined ONCE for bench.py and the full-size GPU tests
+# ------------------------------------------------------------------------------------------------------------------
+WORKLOADS = {
+    # configs[2] ("config 3"): CHM13-scale haplotype, 1 000 000 reads N50 ~ 50 kb, k = 20
+    "config3": dict(kind="haploid", genome_mb=3100.0, repeat_fraction=0.5, reads=1_000_000, median=32000.0, max_len=400_000, seed=30,
+                    title="config 3 (BASELINE.json configs[2]): CHM13-scale haplotype surrogate"),
+    # configs[3] ("config 4"): diploid assembly (both haplotypes), ~40x ONT = 1.2e11 bases read-sharded over 8 GPUs: ONE shard
+    "diploid": dict(kind="diploid", genome_mb=3000.0, repeat_fraction=0.5, snp=0.001, spec=0.05, spec_len=20000, reads=367_000,
+                    median=32000.0, max_len=400_000, seed=40,
+                    title="config 4 (BASELINE.json configs[3]): diploid assembly surrogate (2 x 3.0 Gb, 0.1 % SNPs + 5 % hap-specific), "
+                          "one GPU's shard (1/8) of ~40x ONT"),
+    # configs[4] ("config 5"): T2T primate assembly, 60 % repeats, ultra-long reads N50 = 100 kb, k = 21 and k = 25
+    "config5": dict(kind="haploid", genome_mb=3000.0, repeat_fraction=0.6, reads=500_000, median=61300.0, max_len=1_000_000, seed=50,
+                    title="config 5 (BASELINE.json configs[4]): T2T primate assembly surrogate (60 % repeats), ultra-long ONT"),
+}
+
+
+def make_genome(w: dict, genome_mb: float | None = None, device: int = 0) -> Genome:
+    mb = w["genome_mb"] if genome_mb is None else genome_mb
+    if w["kind"] == "diploid":
+        return DiploidGenome(int(mb * 1e6), n_contigs=24, repeat_fraction=w["repeat_fraction"], snp=w["snp"], spec=w["spec"],
+                             spec_len=w["spec_len"], seed=w["seed"], device=device)
+    return Genome(int(mb * 1e6), n_contigs=24, repeat_fraction=w["repeat_fraction"], seed=w["seed"], device=device)
+
+
+def make_reads(w: dict, gen: Genome, n_reads: int | None = None, shard: int = 0) -> ReadSet:
+    """Shard `shard` of the workload's read set (every shard its own seeded draw: at N GPUs rank r tags shard r)."""
+    n = w["reads"] if n_reads is None else n_reads
+    rng = np.random.default_rng([w["seed"], shard])
+    return ReadSet(gen, lognormal_lengths(rng, n, median=w["median"], hi=w["max_len"]), seed=w["seed"] * 1000 + shard)

@@ -227,6 +227,39 @@ int gs_tag_hits_to_host(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uin
  * at those *n_out rows.  Valid until the next pass over `r` or its destruction. */
 int gs_tag_hits_view(gs_table *t, gs_reads *r, const gs_hit **out, uint64_t *n_out);
 int gs_tag_hits_to_device(gs_table *t, gs_reads *r, void *dst_device, uint64_t cap, uint64_t *n_out);
+/* Several batches in flight against one table: the pass of `r` is queued behind the pass of `prev` (launched before, on the
+ * same table) and takes its `prevLoc` from it ON THE DEVICE -- kmerpos_annot3.nim:82-84: the state crosses reads, and
+ * therefore batches -- so no host round trip separates them.  Every batch is finished on its own (gs_tag_finish /
+ * gs_tag_hits_view), in any order; a batch's pass state lives in its gs_reads handle. */
+int gs_tag_launch_after(gs_table *t, gs_reads *r, const gs_reads *prev);
+
+/* ---- streaming engine: `for rec in readfq(reads)` + the main loop (kmerpos_annot3.nim:85-96) as a pipeline of batches ----
+ * gs_stream_create   `depth` slots sized once for batches of up to max_words packed words / max_reads reads (max_words = 0:
+ *                    no slots, a stream of caller-owned device batches only); carry_in = `prevLoc` before the first batch.
+ * gs_stream_submit   a host batch in the gs_reads_upload layout.  Returns as soon as the copies and kernels are queued: the
+ *                    upload of this batch overlaps the pass of the one before it, `prevLoc` goes from pass to pass in device
+ *                    memory.  `words` in pinned memory (gs_host_alloc) are read by DMA where they lie and must stay untouched
+ *                    until the batch comes back from gs_stream_next; pageable words are copied before the call returns.
+ *                    GS_E_CAPACITY: every slot is in flight or held -- call gs_stream_next / gs_stream_release first.
+ * gs_stream_submit_reads   the same for a batch that already is device-resident (a gs_reads handle the caller keeps).
+ * gs_stream_next     the OLDEST batch in flight: waits for ITS pass (later ones keep running), returns its rows in pinned host
+ *                    memory (*hits, valid until the next gs_stream_next or gs_stream_release), its read count and counters.
+ *                    GS_E_KEYERROR hands out the rows before the offending window and stops the stream (the reference exits
+ *                    there: kmerpos_annot3.nim:90).
+ * gs_stream_carry    `prevLoc` after the last batch gs_stream_next returned. */
+typedef struct gs_stream gs_stream;
+int gs_stream_create(gs_table *t, uint64_t max_words, uint32_t max_reads, int depth, uint32_t carry_in, gs_stream **out);
+void gs_stream_destroy(gs_stream *s);
+int gs_stream_submit(gs_stream *s, const uint64_t *words, uint64_t n_words, const uint64_t *word_off, const uint32_t *len,
+                     uint32_t n_reads);
+int gs_stream_submit_reads(gs_stream *s, gs_reads *r);
+int gs_stream_next(gs_stream *s, const gs_hit **hits, uint64_t *n_hits, uint32_t *n_reads, gs_counters *ctr);
+void gs_stream_release(gs_stream *s);
+int gs_stream_in_flight(const gs_stream *s);
+uint32_t gs_stream_carry(const gs_stream *s);
+/* pinned host memory for batches handed to gs_stream_submit (any host memory works; this kind is not copied a second time) */
+int gs_host_alloc(uint64_t bytes, void **out);
+void gs_host_free(void *p);
 void gs_counters_reset(gs_table *t);
 
 

@@ -1,0 +1,106 @@
+"""Shared checks of the full-size GPU tests (BASELINE.json configs[2], [3], [4]: tests/test_config3_gpu.py,
+test_config_diploid_gpu.py, test_config4_gpu.py).
+
+A genome-scale run cannot be walked by the oracle as a whole (a 1e9-key table, 1e10 .. 4e10 bases), so it is checked through
+* slices of the stream against the oracle (the head of the stream, slices in its middle started from the carry the GPU itself
+  reports for everything before them, the tail), the oracle's table holding exactly the SUNKs that occur in the slice (found
+  by a plain set-membership kernel of the bench-support library: independent of the product's tables);
+* properties that do not depend on size: counters add up, the emitted list is in stream order and inside every read, no row
+  repeats the location group of its predecessor (kmerpos_annot3.nim:82-96) across read boundaries too, two passes give
+  identical bytes, and cutting the read set into device batches with `prevLoc` threaded through changes nothing.
+"""
+import ctypes as C
+import hashlib
+
+import numpy as np
+
+from gavisunk_amd import _lib, engine, synth_gpu
+from oracle import oracle
+
+
+def one_pass(table, reads, carry=_lib.GS_NONE):
+    """One tagging pass; the hit list as a numpy copy of the pinned host mirror (the next pass overwrites it)."""
+    L = _lib.lib()
+    n, c_out, ctr = C.c_uint64(0), C.c_uint32(0), _lib.GsCounters()
+    _lib.check(L.gs_tag_launch(table._h, reads._h, carry))
+    _lib.check(L.gs_tag_finish(table._h, reads._h, None, 0, C.byref(n), C.byref(c_out), C.byref(ctr)))
+    vp = C.c_void_p()
+    _lib.check(L.gs_tag_hits_view(table._h, reads._h, C.byref(vp), None))
+    return engine._view(vp.value, n.value, engine.HIT_DTYPE).copy(), c_out.value, ctr.as_dict()
+
+
+def oracle_slice(sunks, rs, k, lo, hi, prev_loc):
+    """Oracle over reads [lo, hi) with the sub-table of SUNKs that occur in them -> (hits, global rows of the sub-table, counters)."""
+    seqs = rs.host_reads(lo, hi)
+    q = np.unique(np.concatenate([oracle.canonical_windows(s if len(s) >= k else s + b"A" * (k - len(s)), k) for s in seqs]))
+    L = _lib.lib()
+    rows = synth_gpu.select_rows(0, L.gs_sunkset_dev_code(sunks._h), sunks.n, q)
+    code = synth_gpu.gather(0, L.gs_sunkset_dev_code(sunks._h), np.uint64, rows)
+    pos = synth_gpu.gather(0, L.gs_sunkset_dev_pos(sunks._h), np.uint64, rows)
+    grp = synth_gpu.gather(0, L.gs_sunkset_dev_group(sunks._h), np.uint32, rows)
+    loc = synth_gpu.gather(0, L.gs_sunkset_dev_loc(sunks._h), np.uint32, rows)
+    t = oracle.Table(k, code, code, (pos >> np.uint64(32)).astype(np.uint32), grp.astype(np.int64))
+    prev_row = oracle.NONE
+    if prev_loc != _lib.GS_NONE:  # any row of that location group: the oracle compares (contig, group)
+        w = np.nonzero(loc == prev_loc)[0]
+        if len(w):  # (a carried group without a SUNK in this slice cannot suppress anything here)
+            prev_row = int(w[0])
+    buf, off = oracle.concat_reads(seqs)
+    rc, oh, _, octr = t.tag(buf, off, prev_row=prev_row, cap=1 << 24)
+    assert rc == 0
+    return oh, rows, octr
+
+
+def full_size_checks(table, reads, rs, sunks, k, cuts, slices, min_rows, min_slice_rows, hit_rate=(0.1, 0.4)):
+    n_reads = rs.n_reads
+    whole, carry, c = one_pass(table, reads)
+    rlen = (rs.off[1:] - rs.off[:-1]).astype(np.int64)
+    nwin = np.maximum(rlen - k + 1, 1)
+    # counters
+    assert c["windows"] == int(nwin.sum()) and len(whole) == c["emitted"] <= c["raw_hits"] <= c["windows"]
+    assert hit_rate[0] < c["raw_hits"] / c["windows"] < hit_rate[1] and len(whole) > min_rows
+    assert c["fallback_tiles"] < 0.05 * c["tiles"]  # tiles the fast kernel hands to its exact form (LDS budgets)
+    # stream order, positions inside the read (pos is deflated, so it is below the window count all the more)
+    key = whole["read"].astype(np.int64) << 32 | whole["pos"].astype(np.int64)
+    assert np.all(np.diff(key) > 0)
+    assert np.all(whole["pos"] < nwin[whole["read"]])
+    # never the location group of the previous emitted row, reads notwithstanding
+    L = _lib.lib()
+    eloc = np.concatenate([synth_gpu.gather(0, L.gs_sunkset_dev_loc(sunks._h), np.uint32, whole["payload"][a:a + (1 << 24)])
+                           for a in range(0, len(whole), 1 << 24)])
+    assert np.all(eloc[1:] != eloc[:-1])
+    assert carry != _lib.GS_NONE and carry < sunks.n_groups
+    del eloc, key
+
+    # a second pass gives the same bytes
+    again, carry2, c2 = one_pass(table, reads)
+    assert carry2 == carry and c2["raw_hits"] == c["raw_hits"]
+    assert hashlib.sha256(again.tobytes()).digest() == hashlib.sha256(whole.tobytes()).digest()
+    del again
+
+    # device batches of very different sizes, `prevLoc` threaded through
+    parts, cr, raw = [], _lib.GS_NONE, 0
+    for a, b in zip(cuts, cuts[1:]):
+        dr = engine.device_reads_from_device_ascii(rs.ptr + int(rs.off[a]), rs.off[a:b + 1] - rs.off[a], k)
+        h, cr, cc = one_pass(table, dr, cr)
+        dr.close()
+        h["read"] += np.uint32(a)
+        parts.append(h)
+        raw += cc["raw_hits"]
+    parts = np.concatenate(parts)
+    assert cuts[0] == 0 and cuts[-1] == n_reads and cr == carry and raw == c["raw_hits"] and np.array_equal(parts, whole)
+    del parts
+
+    # slices of the stream against the oracle
+    for lo, hi in slices:
+        prev = _lib.GS_NONE
+        if lo:
+            dr = engine.device_reads_from_device_ascii(rs.ptr, rs.off[: lo + 1], k)
+            _, prev, _ = one_pass(table, dr)
+            dr.close()
+        oh, rows, octr = oracle_slice(sunks, rs, k, lo, hi, prev)
+        mine = whole[(whole["read"] >= lo) & (whole["read"] < hi)]
+        assert len(mine) == len(oh) > min_slice_rows
+        assert np.array_equal(mine["read"] - lo, oh["read"]) and np.array_equal(mine["pos"], oh["pos"])
+        assert np.array_equal(mine["payload"], rows[oh["row"]])
+    return whole, carry, c

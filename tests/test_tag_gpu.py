@@ -347,6 +347,29 @@ def test_minimizer_table_walks_and_overflows(m, load, monkeypatch, table_layout)
     assert np.array_equal(gh["payload"], oh["row"]) and carry == (loc[oprev] if oprev != oracle.NONE else _lib.GS_NONE)
 
 
+def test_crowded_minimiser_regions_fall_back_instead_of_failing(monkeypatch, table_layout):
+    """The default layout must never abort a table it could have served another way: with 8 keys per 7-slot region far more
+    than an eighth of the keys overflow at every minimiser length, so the library walks m upwards and then hands the
+    table to the compact / generic layouts (a FORCED minimiser layout reports the misfit instead)."""
+    if table_layout not in ("auto", "minimizer"):
+        pytest.skip("layout choice of the default path")
+    monkeypatch.setenv("GAVISUNK_MZ_LOAD", "16")
+    k = 20
+    keys, loc, seqs = _random_case(58, k, n_reads=40, glen=200000, median=3000)
+    if table_layout == "minimizer":
+        tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))  # forced + knob: everything may overflow
+        assert tab.layout.startswith("minimizer-hbm")
+        tab.close()
+        return
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    assert not tab.layout.startswith("minimizer-hbm"), tab.layout
+    tab.close()
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] and len(gh) == len(oh) > 100
+    assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"]) and np.array_equal(gh["payload"], oh["row"])
+
+
 @pytest.mark.parametrize("k,m", [(20, 17), (20, 16), (20, 18), (21, 17), (25, 21), (20, 13), (16, 16), (32, 28), (31, 31), (24, 17)])
 def test_minimizer_rule_selftest(k, m):
     """The window -> region rule of the minimiser-addressed table has two forms: lane by lane (table build, exact kernel) and
@@ -380,9 +403,10 @@ def test_exact_reads_fill_and_flush_the_hit_list(groups_div, table_layout):
 
 @pytest.mark.parametrize("k", [20, 25])
 def test_more_than_a_million_location_groups(k, table_layout):
-    """Loc ids of 21 bits: more than an entry of the fast minimiser kernel's hit list holds -- such a table is tagged by the
-    exact per-lane kernel -- and, for k = 25, more than a 64-bit slot takes beside the key at all (the minimiser layout does
-    not apply and must not be launched: found by tools/fuzz_tag.py seed 9013)."""
+    """Loc ids of 21 bits (real assemblies have millions of location groups; the fast minimiser kernel's hit list holds 32-bit
+    locs since round 3, before that such a table fell to the exact per-lane kernel) -- and, for k = 25, more than a 64-bit
+    slot takes beside the key at all (the minimiser layout does not apply and must not be launched: found by
+    tools/fuzz_tag.py seed 9013)."""
     keys, loc, seqs = _random_case(91, k, n_reads=12, glen=1_200_000, median=3000, n_groups_div=1)
     assert int(loc.max()) >= 1 << 20
     seqs = seqs + [seqs[0][:k - 1], b""]
