@@ -130,16 +130,17 @@ def same_hits(gh, oh, rows_of_oracle=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# config 3: everything on the device
+# the genome-scale workloads (synth_gpu.WORKLOADS): everything on the device
 # ------------------------------------------------------------------------------------------------------------------
-def config3(a, device, rank, comm):
-    """-> table, packed reads, read lengths, SUNK count, group count, oracle sample, the read set (device ASCII).
-    With an RCCL communicator only rank 0 defines the SUNKs and builds the table; the others receive the built table."""
+def build_workload(a, w, device, rank, world, comm, shards):
+    """-> table, resident device batches [(DeviceReads, first read, read lengths)], SUNK count, group count, oracle sample.
+    With an RCCL communicator only rank 0 defines the SUNKs and builds the table; the others receive the built table.
+    `shards`: the read shards (synth_gpu.make_reads) this rank tags, each cut into a.batches resident device batches."""
     from gavisunk_amd import engine, synth_gpu
 
     t0 = time.perf_counter()
-    gen = synth_gpu.Genome(int(a.genome_mb * 1e6), n_contigs=24, seed=a.seed, device=device)
-    log(f"assembly surrogate: {gen.n_bases} bases in 24 contigs ({time.perf_counter() - t0:.1f} s)")
+    gen = synth_gpu.make_genome(w, a.genome_mb, device)
+    log(f"assembly surrogate: {gen.n_bases} bases in {len(gen.off) - 1} contigs ({time.perf_counter() - t0:.1f} s)")
     replicate = comm is not None and comm.rccl is not None
     sunks = table = None
     if rank == 0 or not replicate:
@@ -153,38 +154,42 @@ def config3(a, device, rank, comm):
         t0 = time.perf_counter()
         table = comm.rccl.broadcast_table(table, root=0)
         log(f"table replicated over RCCL ({time.perf_counter() - t0:.1f} s, gs_table_broadcast)")
-    t0 = time.perf_counter()
-    rng = np.random.default_rng([a.seed, rank])
-    lens = synth_gpu.lognormal_lengths(rng, a.reads, median=32000.0)
-    rs = synth_gpu.ReadSet(gen, lens, seed=a.seed * 1000 + rank)
-    rlen = (rs.off[1:] - rs.off[:-1]).astype(np.int64)
-    log(f"{a.reads} reads, {rs.n_bases} bases, N50 {synth_gpu.n50(rlen)} ({time.perf_counter() - t0:.1f} s)")
-    gen.close()
-    t0 = time.perf_counter()
-    dev_reads = engine.device_reads_from_device_ascii(rs.ptr, rs.off, K, device)
-    log(f"packed on the device: {dev_reads.n_windows} windows ({time.perf_counter() - t0:.1f} s)")
-    # ---- the sample the oracle walks: the first reads of the stream, and the SUNKs that can matter for them ----
-    sample = None
-    if rank == 0 and not a.no_cpu_baseline:
+    batches, sample, read0 = [], None, 0
+    for si, shard in enumerate(shards):
         t0 = time.perf_counter()
-        from oracle import oracle
+        rs = synth_gpu.make_reads(w, gen, a.reads, shard)
+        rlen = (rs.off[1:] - rs.off[:-1]).astype(np.int64)
+        n = rs.n_reads
+        cuts = [n * j // a.batches for j in range(a.batches + 1)]
+        for lo, hi in zip(cuts, cuts[1:]):
+            if hi > lo:
+                dr = engine.device_reads_from_device_ascii(rs.ptr + int(rs.off[lo]), rs.off[lo:hi + 1] - rs.off[lo], K, device)
+                batches.append((dr, read0 + lo, rlen[lo:hi]))
+        log(f"shard {shard}: {n} reads, {rs.n_bases} bases, N50 {synth_gpu.n50(rlen)}, packed on the device in {a.batches} batches ({time.perf_counter() - t0:.1f} s)")
+        # ---- the sample the oracle walks: the first reads of the rank-0 stream, and the SUNKs that can matter for them ----
+        if si == 0 and rank == 0 and not a.no_cpu_baseline and sunks is not None:
+            t0 = time.perf_counter()
+            from oracle import oracle
 
-        ns = min(a.check_reads, a.reads)
-        seqs = rs.host_reads(0, ns)
-        # every canonical window code of the sample (CPU, oracle library), then the rows of the SUNK set that hold one of
-        # them (a plain set-membership kernel of the bench-support library: independent of the product's tables)
-        q = np.unique(np.concatenate([oracle.canonical_windows(s if len(s) >= K else s + b"A" * (K - len(s)), K) for s in seqs]))
-        L = engine.lib()
-        rows = synth_gpu.select_rows(device, L.gs_sunkset_dev_code(sunks._h), sunks.n, q)
-        sub = {"rows": rows, "code": synth_gpu.gather(device, L.gs_sunkset_dev_code(sunks._h), np.uint64, rows),
-               "pos": synth_gpu.gather(device, L.gs_sunkset_dev_pos(sunks._h), np.uint64, rows),
-               "group": synth_gpu.gather(device, L.gs_sunkset_dev_group(sunks._h), np.uint32, rows)}
-        sample = {"seqs": seqs, "sub": sub}
-        log(f"oracle sample: {ns} reads, {len(q)} distinct windows, {len(rows)} SUNKs among them ({time.perf_counter() - t0:.1f} s)")
+            ns = min(a.check_reads, n, cuts[1])
+            seqs = rs.host_reads(0, ns)
+            # every canonical window code of the sample (CPU, oracle library), then the rows of the SUNK set that hold one of
+            # them (a plain set-membership kernel of the bench-support library: independent of the product's tables)
+            q = np.unique(np.concatenate([oracle.canonical_windows(s if len(s) >= K else s + b"A" * (K - len(s)), K) for s in seqs]))
+            L = engine.lib()
+            rows = synth_gpu.select_rows(device, L.gs_sunkset_dev_code(sunks._h), sunks.n, q)
+            sub = {"rows": rows, "code": synth_gpu.gather(device, L.gs_sunkset_dev_code(sunks._h), np.uint64, rows),
+                   "pos": synth_gpu.gather(device, L.gs_sunkset_dev_pos(sunks._h), np.uint64, rows),
+                   "group": synth_gpu.gather(device, L.gs_sunkset_dev_group(sunks._h), np.uint32, rows)}
+            sample = {"seqs": seqs, "sub": sub}
+            log(f"oracle sample: {ns} reads, {len(q)} distinct windows, {len(rows)} SUNKs among them ({time.perf_counter() - t0:.1f} s)")
+        read0 += n
+        rs.close()
+    gen.close()
     n_sunks, n_groups = (sunks.n, sunks.n_groups) if sunks is not None else (0, 0)
     if sunks is not None:
         sunks.close()
-    return table, dev_reads, rlen, n_sunks, n_groups, sample, rs
+    return table, batches, n_sunks, n_groups, sample
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -273,14 +278,71 @@ def config2_cli(sunks, names, reads, n_bases, want):
             f.write(b"".join(b"ctg5M\t%d\t%s\t%d\n" % (s, ka[i, :K].tobytes(), g)
                              for i, (s, g) in enumerate(zip(sunks.start.tolist(), sunks.group.tolist()))))
         synth.write_fasta(f"{d}/reads.fa", names, reads)
+        # what the workflow's rule really feeds the tagger (tagONT.smk:17,36): `seqtk seq -F '#'` output, gzip-compressed
+        t0 = time.perf_counter()
+        with gzip.open(f"{d}/reads.fq.gz", "wb", compresslevel=1) as f:
+            for nm, rd in zip(names, reads):
+                sq = synth.codes_to_ascii(rd)
+                f.write(b"@" + nm.encode() + b"\n" + sq + b"\n+\n" + b"#" * len(sq) + b"\n")
+        log(f"config 2 CLI inputs written ({time.perf_counter() - t0:.1f} s for the .fq.gz)")
         res = {}
-        for tag, path in (("fasta", f"{d}/reads.fa"),):
+        for tag, path in (("fasta", f"{d}/reads.fa"), ("fastq_gz", f"{d}/reads.fq.gz")):
             t0 = time.perf_counter()
             rc = kmerpos_annot3.main([path, f"{d}/db", f"{d}/loc", f"{d}/out.sunkpos"])
             dt = time.perf_counter() - t0
             ok = rc == 0 and open(f"{d}/out.sunkpos", "rb").read().split(b"\n")[:-1] == want
             res[tag] = {"seconds": round(dt, 3), "cli_bases_per_s": n_bases / dt, "bit_exact": bool(ok)}
+        res["note"] = ("`python -m gavisunk_amd.kmerpos_annot3 <reads> <db> <loc> <out>` in a warm process; fastq_gz = the format rule SUNK_annot is "
+                       "given (tagONT.smk:17,36): inflated on the host (zlib), records parsed on the GPU")
     return res
+
+
+def engine_leg(a, table, batches, device, target_bases=2.2e10):
+    """SURVEY.md section 8(d) measurement (ii): host-packed reads in PINNED host memory -> hits on the host, through the
+    streaming engine (gs_stream_*): upload of batch i + 1 overlapped with the pass of batch i, hit lists fetched on the copy
+    stream.  The packed words are the resident batches' own (copied to the host once, outside the timed region)."""
+    from gavisunk_amd import _lib, engine
+
+    L = _lib.lib()
+    host = []
+    total = 0
+    for dr, _, rlen in batches:
+        if total >= target_bases:
+            break
+        word_off = np.zeros(len(rlen) + 1, dtype=np.uint64)
+        word_off[1:] = np.cumsum((rlen + 31) // 32 + 1)
+        pw = engine.PinnedWords(int(word_off[-1]))
+        _lib.check(L.gs_reads_copy_words(dr._h, 0, int(word_off[-1]), pw.words.ctypes.data))
+        host.append((pw, word_off, rlen.astype(np.uint32)))
+        total += int(rlen.sum())
+    max_words = max(len(h[0].words) for h in host)
+    max_reads = max(len(h[2]) for h in host)
+    t0 = time.perf_counter()
+    st = engine.Stream(table, max_words, max_reads, depth=3)
+    t_create = time.perf_counter() - t0
+    rows = 0
+    for rep in range(2):  # the first round warms the slots (first touch of the arenas), the second is timed
+        rows = 0
+        flying = 0
+        _lib.check(L.gs_device_synchronize(device))
+        t0 = time.perf_counter()
+        for pw, word_off, ln in host:
+            if flying == 2:
+                rows += len(st.next(copy=False)[1])
+                flying -= 1
+            st.submit(pw.words, word_off, ln)
+            flying += 1
+        while flying:
+            rows += len(st.next(copy=False)[1])
+            flying -= 1
+        dt = time.perf_counter() - t0
+    st.close()
+    for pw, _, _ in host:
+        pw.close()
+    return {"engine_bases_per_s": total / dt,
+            "engine_note": f"{len(host)} batches, {total} bases of host-packed reads in pinned memory (gs_host_alloc) -> rows on the host through "
+                           f"gs_stream_submit / gs_stream_next (3 slots; upload, pass and hit-list download overlapped), {dt * 1e3:.1f} ms, {rows} rows; "
+                           f"one-off slot set-up {t_create * 1e3:.0f} ms not included"}
 
 
 def main():
@@ -288,15 +350,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (config 3: 1 000 000)")
-    ap.add_argument("--genome-mb", type=float, default=3100.0, help="assembly size in Mb (config 3: 3100)")
-    ap.add_argument("--seed", type=int, default=30)
-    ap.add_argument("--k", type=int, default=20, help="SUNK length (headline: 20; 21 / 25 = BASELINE.json configs[4] rehearsals)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "config3", "diploid", "config5"],
+                    help="auto = config3 (BASELINE.json configs[2]) on one GPU, diploid (configs[3]: fixed 8 shards = ~1.2e11 bases over the ranks) on several")
+    ap.add_argument("--reads", type=int, default=None, help="reads per shard (default: the workload's own)")
+    ap.add_argument("--genome-mb", type=float, default=None, help="assembly size in Mb per haplotype (default: the workload's own)")
+    ap.add_argument("--shards", type=int, default=None, help="diploid: read shards per rank (default 8 / ranks at N > 1, 1 at N = 1)")
+    ap.add_argument("--batches", type=int, default=None, help="resident device batches per shard (default 8; diploid 2)")
+    ap.add_argument("--k", type=int, default=20, help="SUNK length (headline: 20; 21 / 25 = BASELINE.json configs[4])")
     ap.add_argument("--check-reads", type=int, default=1000, help="reads of the stream the oracle walks for the parity leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity + CPU baseline)")
     ap.add_argument("--no-config2", action="store_true", help="skip the config-2 extra key")
-    ap.add_argument("--cli", action="store_true", help="(default now) config-2 leg: also time the command-line drop-in (.fa -> .sunkpos)")
+    ap.add_argument("--no-engine", action="store_true", help="skip the streaming-engine leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra workload key (N = 1: one diploid shard; N > 1: config-3 weak scaling)")
+    ap.add_argument("--cli", action="store_true", help="(default now) config-2 leg: also time the command-line drop-in")
     ap.add_argument("--no-cli", action="store_true", help="config-2 leg without the command-line timing")
     a = ap.parse_args()
     a.cli = not a.no_cli
@@ -321,7 +388,7 @@ def main():
     if knobs and not os.environ.get("GAVISUNK_BENCH_ALLOW_KNOBS"):
         sys.exit(f"bench.py: unset {knobs} (tuning knobs change the measured path); GAVISUNK_BENCH_ALLOW_KNOBS=1 for experiments")
 
-    from gavisunk_amd import _lib, engine
+    from gavisunk_amd import _lib, engine, synth_gpu
 
     L = _lib.lib()
     if L.gs_device_count() < 1:
@@ -333,8 +400,9 @@ def main():
     if world > 1:
         from gavisunk_amd import dist as gdist
 
-        # control plane: torch.distributed over gloo (rendezvous, barrier, 8-byte summaries); data plane: RCCL behind the
-        # C-ABI (gs_comm_*).  torch never touches the GPU in this process: its wheel bundles a second HIP runtime.
+        # control plane: torch.distributed over gloo (rendezvous, barrier, scalars); data plane: RCCL behind the C-ABI
+        # (gs_comm_*: table broadcast, phase-1 summaries, hit gather).  torch never touches the GPU in this process: its wheel
+        # bundles a second HIP runtime.
         want_rccl = os.environ.get("GAVISUNK_BENCH_BACKEND", "nccl") == "nccl"
         comm = gdist.Comm(device, rccl=False)
         data_plane = "gloo, host-staged (GAVISUNK_BENCH_BACKEND=gloo: rehearsal)"
@@ -353,150 +421,204 @@ def main():
                 comm.rccl = None
                 data_plane = f"gloo, host-staged (RCCL did not start on every rank: {err or 'another rank failed'})"
             else:
-                data_plane = "RCCL over xGMI (gs_table_broadcast, gs_gather_hits)"
+                data_plane = "RCCL over xGMI (gs_table_broadcast, gs_comm_allgather_u64, gs_gather_hits)"
 
-    table, dev_reads, rlen, n_sunks, n_groups, sample, rs = config3(a, device, rank, comm)
-    n_bases = int(rlen.sum())
-    from gavisunk_amd import synth_gpu
+    def run_workload(wname, shards, batches_per_shard, steps, warmup, want_sample):
+        """Builds the workload, times `steps` passes, -> dict of raw results (rank 0: everything; others: timings only)."""
+        w = dict(synth_gpu.WORKLOADS[wname])
+        a.batches = batches_per_shard
+        table, batches, n_sunks, n_groups, sample = build_workload(a, w, device, rank, world, comm, shards)
+        if not want_sample:
+            sample = None
+        n_bases = int(sum(int(b[2].sum()) for b in batches))
+        rlen_all = np.concatenate([b[2] for b in batches]) if batches else np.zeros(0, np.int64)
+        nb = len(batches)
+        last = {"rows": 0, "raw": 0, "emitted": 0, "windows": 0, "tiles": 0, "fallback": 0}
+        gathered = {"rows": None}
+        stream = engine.Stream(table, 0, 0, depth=3) if world == 1 else None
 
-    n50 = synth_gpu.n50(rlen)
-    if world > 1 and rank != 0:
-        sample = None
-
-    n_hits = C.c_uint64(0)
-    carry = C.c_uint32(0)
-    ctr = _lib.GsCounters()
-    host_hits = np.zeros(1, dtype=engine.HIT_DTYPE)
-    read_lo = rank * a.reads
-    full_reads = dev_reads
-
-    def step():
-        nonlocal host_hits
-        if world == 1:
-            # the emit kernel writes the rows to pinned host memory itself: the pass ends with the hit list on the host
-            _lib.check(L.gs_tag_launch(table._h, dev_reads._h, _lib.GS_NONE))
-            _lib.check(L.gs_tag_finish(table._h, dev_reads._h, None, 0, C.byref(n_hits), C.byref(carry), C.byref(ctr)))
-            vp = C.c_void_p()
-            _lib.check(L.gs_tag_hits_view(table._h, dev_reads._h, C.byref(vp), None))
-            host_hits = engine._view(vp.value, n_hits.value, engine.HIT_DTYPE)
+        def step(keep_head=False, gather_to_host=False):
+            """One pass over all the rank's resident reads.  N = 1: the batches pipelined through gs_stream_submit_reads (the
+            carry goes from pass to pass on the device; every batch's rows are fetched to pinned host memory on the copy stream
+            while the next batch is probed).  N > 1: phase 1 of every batch, ONE exchange of the rank summaries, phase 2 with the
+            resolved carries, then the RCCL gather of every batch's rows into the root's device memory."""
+            tot = dict.fromkeys(last, 0)
+            head = None
+            if world == 1:
+                flying = 0
+                done = 0
+                for dr, _, _ in batches:
+                    if flying == 3:
+                        st_, hits, _, c = stream.next(copy=False)
+                        if keep_head and done == 0:
+                            head = hits.copy()
+                        done += 1
+                        flying -= 1
+                        for k_, v in (("rows", len(hits)), ("raw", c["raw_hits"]), ("emitted", c["emitted"]), ("windows", c["windows"]), ("tiles", c["tiles"]), ("fallback", c["fallback_tiles"])):
+                            tot[k_] += v
+                    stream.submit_reads(dr)
+                    flying += 1
+                while flying:
+                    st_, hits, _, c = stream.next(copy=False)
+                    if keep_head and done == 0:
+                        head = hits.copy()
+                    done += 1
+                    flying -= 1
+                    for k_, v in (("rows", len(hits)), ("raw", c["raw_hits"]), ("emitted", c["emitted"]), ("windows", c["windows"]), ("tiles", c["tiles"]), ("fallback", c["fallback_tiles"])):
+                        tot[k_] += v
+                last.update(tot)
+                return head
+            summ_local = []
+            for dr, _, _ in batches:
+                has, lastloc = C.c_uint32(0), C.c_uint32(0)
+                _lib.check(L.gs_tag_phase1(table._h, dr._h, C.byref(has), C.byref(lastloc)))
+                summ_local.append((has.value, lastloc.value))
+            mine = next(((1, l) for h, l in reversed(summ_local) if h), (0, _lib.GS_NONE))
+            summ = comm.exchange_summaries(*mine)
+            carry = gdist.resolve_carry(summ, rank)
+            for (dr, _, _), (h, l) in zip(batches, summ_local):
+                _lib.check(L.gs_tag_phase2(table._h, dr._h, carry))
+                if h:
+                    carry = l
+            rows_g = []
+            ctr = _lib.GsCounters()
+            for dr, r0, _ in batches:
+                n_hits = C.c_uint64(0)
+                _lib.check(L.gs_tag_finish(table._h, dr._h, None, 0, C.byref(n_hits), None, C.byref(ctr)))
+                c = ctr.as_dict()
+                for k_, v in (("rows", n_hits.value), ("raw", c["raw_hits"]), ("emitted", c["emitted"]), ("windows", c["windows"]), ("tiles", c["tiles"]), ("fallback", c["fallback_tiles"])):
+                    tot[k_] += v
+                # every rank's rows are on its own host now (as at N = 1); the concatenated list is gathered into the root's
+                # device memory over xGMI (north_star's "hit buffers concatenated via an RCCL gather") and stays there
+                g = comm.gather_hits(table, dr, n_hits.value, read_lo + r0, to_host=gather_to_host)
+                if gather_to_host and g is not None:
+                    rows_g.append(g.copy())
+            last.update(tot)
+            if gather_to_host:
+                gathered["rows"] = rows_g
             return None
-        has, last = C.c_uint32(0), C.c_uint32(0)
-        _lib.check(L.gs_tag_phase1(table._h, dev_reads._h, C.byref(has), C.byref(last)))
-        summ = comm.exchange_summaries(has.value, last.value)
-        _lib.check(L.gs_tag_phase2(table._h, dev_reads._h, gdist.resolve_carry(summ, rank)))
-        _lib.check(L.gs_tag_finish(table._h, dev_reads._h, None, 0, C.byref(n_hits), C.byref(carry), C.byref(ctr)))
-        # every rank's rows are on its own host now (gs_tag_finish, as at N = 1); the concatenated list is gathered into the
-        # root's device memory over xGMI (north_star's "hit buffers concatenated via an RCCL gather") and stays there
-        return comm.gather_hits(table, dev_reads, n_hits.value, read_lo, to_host=gather_to_host)
 
-    gather_to_host = False
+        # global index of this rank's first read (the ranks before it hold shards of the same size)
+        read_lo = rank * sum(len(b[2]) for b in batches)
 
-    def sync():
-        if world > 1:
-            comm.barrier()
-        _lib.check(L.gs_device_synchronize(device))
+        def sync():
+            if world > 1:
+                comm.barrier()
+            _lib.check(L.gs_device_synchronize(device))
 
-    for i in range(a.warmup):
-        step()
-        log(f"warmup {i}: {n_hits.value} rows")
-    L.gs_counters_reset(table._h)
-    sync()
-    step_s = []
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        t1 = time.perf_counter()
-        step()
-        step_s.append(time.perf_counter() - t1)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        dt = comm.all_max(dt)
-        total_bases = int(comm.all_sum(n_bases))
-    else:
-        total_bases = n_bases
-    log(f"{a.steps} steps: {total_bases * a.steps / dt / 1e9:.1f} Gbase/s")
-    gather_check = None
-    if world > 1:  # once, outside the timed region: the gathered list on the root's host = every rank's rows, rank 0's first
-        gather_to_host = True
-        g = step()
-        gather_to_host = False
-        tot = int(comm.all_sum(int(n_hits.value)))
-        if rank == 0:
-            vp = C.c_void_p()
-            _lib.check(L.gs_tag_hits_view(table._h, dev_reads._h, C.byref(vp), None))
-            own = engine._view(vp.value, n_hits.value, engine.HIT_DTYPE)
-            gather_check = bool(g is not None and len(g) == tot and np.array_equal(g[: len(own)], own)
-                                and (len(g) == len(own) or int(g["read"][len(own)]) >= a.reads))
-            log(f"gathered list: {len(g) if g is not None else None} rows of {tot}, head = rank 0's rows: {gather_check}")
-    c_main = ctr.as_dict()  # counters of the timed passes (the strong-scaling leg below runs more)
-    # strong scaling beside the weak headline (N > 1): the SAME total read count as one GPU tags, cut over the ranks
-    strong = None
-    if world > 1:
-        per = max(a.reads // world, 1)
-        dev_reads = engine.device_reads_from_device_ascii(rs.ptr, rs.off[: per + 1], K, device)
-        read_lo = rank * per
-        step()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(3):
+        for i in range(warmup):
             step()
+            log(f"{wname} warmup {i}: {last['rows']} rows")
+        L.gs_counters_reset(table._h)
         sync()
-        sdt = comm.all_max(time.perf_counter() - t1)
-        sbases = int(comm.all_sum(int(rs.off[per])))
-        strong = {"total_reads": per * world, "total_bases": sbases, "steps": 3, "ms_per_step": sdt / 3 * 1e3, "value": sbases * 3 / sdt,
-                  "unit": "bases/s", "note": "fixed total work (the one-GPU read count) cut over the ranks; the headline above is weak scaling"}
-        dev_reads.close()
-        dev_reads = full_reads
-        read_lo = rank * a.reads
-    rs.close()
+        step_s = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            step()
+            step_s.append(time.perf_counter() - t1)
+        sync()
+        dt = time.perf_counter() - t0
+        ctr = _lib.GsCounters()
+        # (the table's counters accumulate probe / pass times over every launch of the timed steps)
+        n_launch = steps * nb
+        if world > 1:
+            dt = comm.all_max(dt)
+            total_bases = int(comm.all_sum(n_bases))
+        else:
+            total_bases = n_bases
+        log(f"{wname}: {steps} steps: {total_bases * steps / dt / 1e9:.1f} Gbase/s")
+        # one more pass outside the timed region: the head batch's rows for the parity leg / the gathered list on the root
+        head = step(keep_head=True, gather_to_host=world > 1)
+        gather_check = None
+        if world > 1:
+            tot_rows = int(comm.all_sum(int(last["rows"])))
+            if rank == 0:
+                g = gathered["rows"]
+                gather_check = bool(g is not None and sum(len(x) for x in g) == tot_rows)
+                log(f"gathered list: {sum(len(x) for x in g) if g is not None else None} rows of {tot_rows}: {gather_check}")
+        L.gs_table_counters(table._h, C.byref(ctr))
+        res = {"w": w, "wname": wname, "table": table, "batches": batches, "n_bases": n_bases, "total_bases": total_bases, "dt": dt,
+               "steps": steps, "step_s": step_s, "n_sunks": n_sunks, "n_groups": n_groups, "sample": sample, "head": head,
+               "last": dict(last), "rlen": rlen_all, "n_launch": n_launch, "gather_check": gather_check, "ctr": ctr.as_dict(), "stream": stream}
+        return res
 
-    if rank == 0:
-        c = c_main
-        h_raw = c["raw_hits"] / max(c["windows"], 1)
-        h_emit = c["emitted"] / max(c["windows"], 1)
-        probe_s = c["probe_ms"] / max(c["launches"], 1) / 1e3
-        pass_s = c["total_ms"] / max(c["launches"], 1) / 1e3
+    def describe(res, headline):
+        """The JSON fragment of one workload run (rank 0)."""
+        w, table, last = res["w"], res["table"], res["last"]
+        n_bases, steps = res["n_bases"], res["steps"]
+        c = res["ctr"]
+        h_raw = last["raw"] / max(last["windows"], 1)
+        h_emit = last["emitted"] / max(last["windows"], 1)
+        launches = max(c["launches"], 1)
+        probe_launch_s = c["probe_ms"] / launches / 1e3           # average duration of ONE probe-kernel launch (HIP events)
+        probe_step_s = probe_launch_s * len(res["batches"])       # all launches of one pass
+        pass_step_s = c["total_ms"] / launches / 1e3 * len(res["batches"])
         bpb = alg_bytes_per_base(h_raw, h_emit)
-        achieved = n_bases * bpb / probe_s / 1e9
-        full = a.genome_mb == 3100.0 and a.reads == 1_000_000 and K == 20
-        wkey = f"config3:{a.genome_mb:g}Mb:{a.reads}reads:seed{a.seed}"
+        achieved = n_bases * bpb / probe_step_s / 1e9
+        default_size = a.genome_mb is None and a.reads is None
+        wkey = f"{res['wname']}:k{K}:{'full' if default_size else 'reduced'}"
         traffic, tnote = traffic_for(wkey) if world == 1 else (None, None)
+        n50 = synth_gpu.n50(res["rlen"]) if len(res["rlen"]) else 0
         out = {
-            "metric": f"ONT bases/sec SUNK-tagged (k={K}), bit-exact hit list",
-            "value": total_bases * a.steps / dt,
+            "value": res["total_bases"] * steps / res["dt"],
             "unit": "bases/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3,
-            "ms_per_step_spread": {"min": min(step_s) * 1e3, "median": float(np.median(step_s)) * 1e3, "max": max(step_s) * 1e3},
-            "higher_is_better": True,
-            "scaling": "weak",
-            "strong_scaling": strong,
-            "vs_baseline": None,
-            "dtype": "u64",
-            "data": "synthetic",
-            "config": {"workload": ("config 3 (BASELINE.json configs[2]): CHM13-scale haplotype surrogate, " if full else
-                                    "REDUCED rehearsal of config 3 (not the headline workload): ") +
-                                   f"{a.genome_mb:g} Mb in 24 contigs, exact SUNK set, {a.reads} synthetic ONT reads per GPU, N50 {n50}, k={K}",
-                       "reads_per_gpu": a.reads, "bases_per_gpu": n_bases, "sunks": int(n_sunks), "sunk_groups": int(n_groups),
-                       "windows": c["windows"], "raw_hits": c["raw_hits"], "emitted_rows": c["emitted"],
-                       "h_raw": round(h_raw, 5), "h_emit": round(h_emit, 7), "tiles": c["tiles"],
-                       "fallback_tiles": c["fallback_tiles"], "table_GiB": round(table.nbytes / 2**30, 2), "table_layout": table.layout,
+            "ms_per_step": res["dt"] / steps * 1e3,
+            "ms_per_step_spread": {"min": min(res["step_s"]) * 1e3, "median": float(np.median(res["step_s"])) * 1e3, "max": max(res["step_s"]) * 1e3},
+            "config": {"workload": (w["title"] if default_size else "REDUCED rehearsal (not the headline workload) of " + w["title"]) +
+                                   f": {(a.genome_mb if a.genome_mb is not None else w['genome_mb']):g} Mb{' per haplotype' if w['kind'] == 'diploid' else ''} in 24 contigs, exact SUNK set, "
+                                   f"{len(res['rlen'])} synthetic ONT reads per GPU, N50 {n50}, k={K}",
+                       "reads_per_gpu": int(len(res["rlen"])), "bases_per_gpu": n_bases, "device_batches_per_gpu": len(res["batches"]),
+                       "sunks": int(res["n_sunks"]), "sunk_groups": int(res["n_groups"]),
+                       "windows": last["windows"], "raw_hits": last["raw"], "emitted_rows": last["emitted"],
+                       "h_raw": round(h_raw, 5), "h_emit": round(h_emit, 7), "tiles": last["tiles"],
+                       "fallback_tiles": last["fallback"], "table_GiB": round(table.nbytes / 2**30, 2), "table_layout": table.layout,
                        "parallelism": f"read-sharded x{world}, table replicated", "data_plane": data_plane,
-                       "gathered_list_checked": gather_check,
-                       "env_knobs": knobs},
+                       "gathered_list_checked": res["gather_check"], "env_knobs": knobs},
             "roofline": {"bound": "hbm", "kernel": kernel_names(table.layout), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": tnote,
-                         "basis": "algorithmic bytes (SURVEY.md 8d: 8.25 B/base + 16 B/raw hit + 12 B/emitted row) / HIP-event time of the probe kernel; `traffic` = measured HBM bytes per launch (PMC), null when not measured for this workload and source",
-                         "alg_bytes_per_launch": int(n_bases * bpb), "alg_bytes_per_base": round(bpb, 3),
-                         "kernel_ms": round(probe_s * 1e3, 4), "pass_ms": round(pass_s * 1e3, 4),
-                         "kernel_bases_per_s": n_bases / probe_s},
+                         "basis": "algorithmic bytes (SURVEY.md 8d: 8.25 B/base + 16 B/raw hit + 12 B/emitted row) of ONE launch / average HIP-event time of one probe-kernel launch "
+                                  "(a pass = `launches_per_pass` launches, one per resident device batch); `traffic` = measured HBM bytes per launch (PMC), null when not measured for this workload and source",
+                         "launches_per_pass": len(res["batches"]),
+                         "alg_bytes_per_launch": int(n_bases * bpb / len(res["batches"])), "alg_bytes_per_base": round(bpb, 3),
+                         "kernel_ms": round(probe_launch_s * 1e3, 4), "kernel_ms_per_pass": round(probe_step_s * 1e3, 4),
+                         "pass_ms": round(pass_step_s * 1e3, 4), "kernel_bases_per_s": n_bases / probe_step_s},
         }
+        return out
+
+    def release(res):
+        if res.get("stream") is not None:
+            res["stream"].close()
+        for dr, _, _ in res["batches"]:
+            dr.close()
+        res["table"].close()
+
+    wname = a.workload if a.workload != "auto" else ("config3" if world == 1 else "diploid")
+    if wname == "diploid":
+        per_rank = a.shards if a.shards else (max(8 // world, 1) if world > 1 else 1)
+        shards = list(range(rank * per_rank, (rank + 1) * per_rank))
+        bps = a.batches or 2
+    else:
+        shards = [rank]
+        bps = a.batches or 8
+    res = run_workload(wname, shards, bps, a.steps, a.warmup, want_sample=True)
+
+    out = None
+    if rank == 0:
+        d = describe(res, True)
+        out = {"metric": f"ONT bases/sec SUNK-tagged (k={K}), bit-exact hit list", "value": d["value"], "unit": "bases/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": d["ms_per_step"], "ms_per_step_spread": d["ms_per_step_spread"],
+               "higher_is_better": True,
+               # diploid at N > 1: the FIXED ~1.2e11-base read set (8 shards) cut over the ranks = strong scaling; otherwise every
+               # rank tags its own shard of the same size = weak scaling
+               "scaling": "strong" if (wname == "diploid" and world > 1 and not a.shards) else "weak",
+               "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": d["config"], "roofline": d["roofline"]}
         # ---- parity on the head of the stream + CPU baseline (outside the timed region) --------------------------
+        sample = res["sample"]
         if sample is not None:
             from oracle import oracle
 
+            table = res["table"]
             seqs, sub = sample["seqs"], sample["sub"]
             nchk = len(seqs)
             otable = oracle.Table(K, sub["code"], sub["code"], (sub["pos"] >> np.uint64(32)).astype(np.uint32), sub["group"].astype(np.int64))
@@ -507,9 +629,9 @@ def main():
             st, gh, _, gctr = engine.tag(table, chk)
             chk.close()
             ok1 = st == 0 and orc == 0 and same_hits(gh, oh, sub["rows"]) and gctr["raw_hits"] == octr["raw_hits"] and gctr["windows"] == octr["windows"]
-            # (2) ... and the head of the big launch's own hit list
-            if world == 1:
-                big = host_hits[: n_hits.value]
+            # (2) ... and the head of the big pass's own hit list (the first resident batch, fetched after the timed steps)
+            if world == 1 and res["head"] is not None:
+                big = res["head"]
                 ok2 = same_hits(big[big["read"] < nchk], oh, sub["rows"])
             else:
                 ok2 = None
@@ -523,24 +645,34 @@ def main():
             out["cpu_baseline"] = {"value": rate, "unit": "bases/s", "cores": threads, "kind": "port",
                                    "sample": f"first {n} reads of the rank-0 stream x {reps} passes ({bases} bases) as {threads} parallel chunks, {secs:.1f} s wall; "
                                              f"oracle/gs_oracle.c, one thread per chunk (Snakemake-scatter style); its hash table holds only the {len(sub['rows'])} "
-                                             f"SUNKs that occur in the sample ({len(sub['rows']) * 100.0 / max(n_sunks, 1):.2f} % of the set): cache-friendlier than the reference's full table, i.e. a CPU-favourable baseline"}
-            # engine rate: host-packed words (pageable host memory) -> hits on host, upload included
-            # (the sample four times over: a batch of a few hundred Mbase, so that the fixed cost of a new device batch -- its
-            # per-tile arrays, the first launch -- does not dominate; config 2's engine rate below is on its whole read set)
-            erep = 4
-            batch = engine.ReadBatch.from_ascii(seqs * erep)
-            t1 = time.perf_counter()
-            d2 = engine.DeviceReads(batch, K, device)
-            engine.tag(table, d2)
-            t_engine = time.perf_counter() - t1
-            d2.close()
-            batch.close()
-            out["engine_bases_per_s"] = int(off[-1]) * erep / t_engine
-            out["engine_note"] = (f"{nchk * erep} reads ({int(off[-1]) * erep} bases: the parity sample x {erep}): gs_reads_upload of host-packed words "
-                                  f"(pageable memory) + gs_tag + hits on host, one call each, first use of this batch, {t_engine * 1e3:.1f} ms")
+                                             f"SUNKs that occur in the sample ({len(sub['rows']) * 100.0 / max(res['n_sunks'], 1):.2f} % of the set): cache-friendlier than the reference's full table, i.e. a CPU-favourable baseline",
+                                   "per_core": rate / threads,
+                                   "calibration": {"reference_binary_bases_per_s_per_core": 4.79e6, "where": "workflow/scripts/kmerpos_annot3 (the reference's Nim ELF) timed in the build container on config 2, tagging phase only (SURVEY.md section 6; the binary cannot travel to the GPU box)",
+                                                   "port_over_reference_per_core": rate / threads / 4.79e6}}
+        if not a.no_engine and world == 1:
+            try:
+                out.update(engine_leg(a, res["table"], res["batches"], device))
+            except Exception as e:  # (a measurement leg must not cost the headline)
+                out["engine_note"] = f"engine leg failed: {e}"
+    release(res)
+    # ---- the other genome-scale workload as an extra key --------------------------------------------------------------
+    if not a.no_extra and a.workload == "auto" and K == 20 and a.genome_mb is None and a.reads is None:
+        if world == 1:
+            ex = run_workload("diploid", [0], 2, max(3, a.steps // 2), 1, want_sample=False)
+            if rank == 0:
+                d = describe(ex, False)
+                out["diploid_shard"] = {k_: d[k_] for k_ in ("value", "unit", "ms_per_step", "config", "roofline")}
+                out["diploid_shard"]["note"] = "BASELINE.json configs[3] on ONE GPU: the shard (1/8 of the reads) a rank of an 8-GPU run tags; the N > 1 headline lines divide this workload's 8 shards over the ranks"
+            release(ex)
+        else:
+            ex = run_workload("config3", [rank], 8, 3, 1, want_sample=False)
+            if rank == 0:
+                d = describe(ex, False)
+                out["weak_config3"] = {k_: d[k_] for k_ in ("value", "unit", "ms_per_step", "config", "roofline")}
+                out["weak_config3"]["note"] = "weak scaling of the N = 1 headline workload (config 3: every rank tags its own 1 000 000 reads, table replicated)"
+            release(ex)
+    if rank == 0:
         if not a.no_config2 and world == 1 and K == 20:
-            dev_reads.close()
-            table.close()
             out["config2"] = config2_leg(a, device)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

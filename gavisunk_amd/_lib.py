@@ -97,6 +97,8 @@ SIGNATURES = {
     "gs_tag_hits_to_host": (I, [P, P, P, U64, C.POINTER(U64)]),
     "gs_tag_hits_to_device": (I, [P, P, P, U64, C.POINTER(U64)]),
     "gs_tag_launch_after": (I, [P, P, P]),
+    "gs_table_counters": (None, [P, C.POINTER(GsCounters)]),
+    "gs_reads_copy_words": (I, [P, U64, U64, P]),
     "gs_stream_create": (I, [P, U64, U32, I, U32, C.POINTER(P)]),
     "gs_stream_destroy": (None, [P]),
     "gs_stream_submit": (I, [P, P, U64, P, P, U32]),
@@ -111,6 +113,8 @@ SIGNATURES = {
     "gs_counters_reset": (None, [P]),
     "gs_comm_unique_id": (I, [P]),
     "gs_comm_init": (I, [I, I, I, P, C.POINTER(P)]),
+    "gs_table_clone": (I, [P, C.POINTER(P)]),
+    "gs_comm_allgather_u64": (I, [P, P, U32, P]),
     "gs_comm_destroy": (None, [P]),
     "gs_table_broadcast": (I, [P, I, P, C.POINTER(P)]),
     "gs_gather_hits": (I, [P, I, P, P, U32, P, U64, C.POINTER(U64)]),

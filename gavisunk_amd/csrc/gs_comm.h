@@ -22,7 +22,7 @@ struct gs_comm {
     int device = 0, nranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
-    unsigned long long *d_meta = nullptr;  // [2 * nranks] (count, read offset) pairs
+    unsigned long long *d_meta = nullptr;  // [4 * nranks]: (count, read offset, status) triples of a gather; summaries; statuses
     gs_hit *d_gather = nullptr;            // root: all ranks' rows
     gs_hit *h_gather = nullptr;            // root: pinned host copy of them (gs_gather_view)
     uint64_t gather_cap = 0, gather_n = 0;
@@ -99,16 +99,103 @@ __global__ void k_shift_reads(gs_hit *h, uint64_t n, uint32_t delta) {
     if (i < n) h[i].read += delta;
 }
 
-// one device array: root sends, the others allocate and receive
-template <typename T>
-int bcast_array(Rccl *R, gs_comm *c, int root, T **p, uint64_t count) {
-    if (!count) return GS_OK;
+// ---- replication of a built table ------------------------------------------------------------------------------------
+// ONE piece of code moves a table to another handle, whatever carries the bytes: RCCL broadcasts between ranks
+// (gs_table_broadcast), or device-to-device copies inside one GPU (gs_table_clone: the same scalars, the same array list,
+// the same receiving-side initialisation -- runnable, and tested, on a one-GPU box).  The receiving side allocates EVERYTHING
+// first and the ranks then agree on one status, so that a rank that is out of memory fails all of them instead of leaving
+// the others inside a collective.
+TableMeta table_meta_of(const gs_table *t, uint64_t n_ovf) {
+    return TableMeta{t->k, t->shift, t->compact, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64, t->mz, t->mz_m,
+                     t->mz_locbits, t->join, t->mz_n_regions, t->join_chunk, t->n, t->cap, t->c_overflow, t->mz_overflow, n_ovf};
+}
+
+struct TableArray {  // one device array of a table: where its pointer lives in the handle, and its size in bytes
+    void **dst;
+    const void *src;  // root / clone source: the bytes; receiving rank of a broadcast: NULL
+    uint64_t bytes;
+};
+
+// the arrays a table with these scalars owns, in a fixed order (both sides derive the same list from the same meta)
+std::vector<TableArray> table_arrays(const TableMeta &hm, gs_table *dst, const gs_table *src) {
+    std::vector<TableArray> v;
+    auto add = [&](void **d, const void *s, uint64_t bytes) {
+        if (bytes) v.push_back(TableArray{d, s, bytes});
+    };
+    add((void **)&dst->slots, src ? src->slots : nullptr, hm.cap * sizeof(Slot));
+    if (hm.mz) {
+        const uint64_t nslots = (uint64_t)hm.mz_n_regions * kMzWords;
+        add((void **)&dst->mz_regions, src ? src->mz_regions : nullptr, nslots * sizeof(unsigned long long));
+        add((void **)&dst->mz_pay, src ? src->mz_pay : nullptr, nslots * sizeof(uint32_t));
+    } else if (hm.compact) {
+        const uint64_t nslots = (uint64_t)(4 * kNPart) << hm.c_qb;
+        add((void **)&dst->cbuckets, src ? src->cbuckets : nullptr, (hm.c_w64 ? 2 * nslots : nslots) * sizeof(uint32_t));
+        add((void **)&dst->cpayload, src ? src->cpayload : nullptr, nslots * sizeof(uint32_t));
+        if (hm.join) {
+            add((void **)&dst->j_ovf_start, src ? src->j_ovf_start : nullptr, ((uint64_t)kJoinSlices + 1) * sizeof(uint32_t));
+            add((void **)&dst->j_ovf_code, src ? src->j_ovf_code : nullptr, hm.n_ovf * sizeof(uint64_t));
+            add((void **)&dst->j_ovf_loc, src ? src->j_ovf_loc : nullptr, hm.n_ovf * sizeof(uint32_t));
+        }
+    }
+    return v;
+}
+
+int table_n_ovf(const gs_table *t, uint64_t *n_ovf) {
+    *n_ovf = 0;
+    if (t->join) {
+        uint32_t last = 0;
+        HIP_TRY(hipMemcpy(&last, t->j_ovf_start + kJoinSlices, sizeof last, hipMemcpyDeviceToHost));
+        *n_ovf = last;
+    }
+    return GS_OK;
+}
+
+// receiving side: a fresh handle with the root's scalars and every array allocated (status collected, not returned early)
+int table_receive_init(gs_table *t, int device, const TableMeta &hm) {
     int rc;
-    if (c->rank != root && (rc = dev_alloc(p, count))) return rc;
-    // in pieces of 1 GiB (config 3's region array is 74 GiB: no single collective of that size)
-    const size_t bytes = (size_t)count * sizeof(T), piece = (size_t)1 << 30;
-    uint8_t *b = reinterpret_cast<uint8_t *>(*p);
-    for (size_t o = 0; o < bytes; o += piece) NCCL_TRY(R->Broadcast(b + o, b + o, std::min(piece, bytes - o), ncclUint8, root, c->comm, c->stream));
+    if ((rc = table_init(t, device, hm.k, hm.n))) return rc;
+    t->shift = hm.shift;
+    t->compact = hm.compact;
+    t->c_qb = hm.c_qb;
+    t->c_rembits = hm.c_rembits;
+    t->c_locbits = hm.c_locbits;
+    t->c_has_flag = hm.c_has_flag;
+    t->c_w64 = hm.c_w64;
+    t->mz = hm.mz;
+    t->mz_m = hm.mz_m;
+    t->mz_locbits = hm.mz_locbits;
+    t->join = hm.join;
+    t->mz_n_regions = hm.mz_n_regions;
+    t->join_chunk = hm.join_chunk;
+    t->cap = hm.cap;
+    t->c_overflow = hm.c_overflow;
+    t->mz_overflow = hm.mz_overflow;
+    for (auto &a : table_arrays(hm, t, nullptr)) {
+        uint8_t *p = nullptr;
+        if ((rc = dev_alloc(&p, a.bytes))) return rc;
+        *a.dst = p;
+    }
+    // (a join table without overflow keys still owns the two arrays, one element each, like a built one)
+    if (hm.join && !hm.n_ovf && ((rc = dev_alloc(&t->j_ovf_code, 1)) || (rc = dev_alloc(&t->j_ovf_loc, 1)))) return rc;
+    return GS_OK;
+}
+
+// every rank contributes a status; all of them get the first non-zero one in rank order (0 = all fine)
+int comm_agree(Rccl *R, gs_comm *c, int mine, int *agreed) {
+    *agreed = mine;
+    if (c->nranks == 1) return GS_OK;
+    const unsigned long long v = (unsigned long long)(long long)mine;
+    HIP_TRY(hipMemcpyAsync(c->d_meta + c->rank, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+    NCCL_TRY(R->AllGather(c->d_meta + c->rank, c->d_meta, 1, ncclUint64, c->comm, c->stream));
+    std::vector<unsigned long long> all((size_t)c->nranks);
+    HIP_TRY(hipMemcpyAsync(all.data(), c->d_meta, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *agreed = 0;
+    for (int i = 0; i < c->nranks; i++)
+        if ((long long)all[i] != 0) {
+            *agreed = (int)(long long)all[i];
+            break;
+        }
     return GS_OK;
 }
 
@@ -166,7 +253,7 @@ int gs_comm_init(int device, int nranks, int rank, const void *unique_id, gs_com
     memcpy(&id, unique_id, sizeof id);
     NCCL_TRY(R->CommInitRank(&c->comm, nranks, id, rank));
     int rc;
-    if ((rc = dev_alloc(&c->d_meta, (uint64_t)2 * nranks))) return rc;
+    if ((rc = dev_alloc(&c->d_meta, (uint64_t)4 * nranks))) return rc;
     *out = guard.release();
     return GS_OK;
 }
@@ -191,20 +278,14 @@ int gs_table_broadcast(gs_comm *c, int root, gs_table *mine, gs_table **out) {
     }
     // the scalars first (through a device buffer: one collective, no second transport)
     TableMeta hm{};
-    uint64_t n_ovf = 0;
+    int rc = GS_OK;
     if (is_root) {
-        gs_table *t = mine;
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        if (t->join) {
-            uint32_t last = 0;
-            HIP_TRY(hipMemcpy(&last, t->j_ovf_start + kJoinSlices, sizeof last, hipMemcpyDeviceToHost));
-            n_ovf = last;
-        }
-        hm = TableMeta{t->k, t->shift, t->compact, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64, t->mz, t->mz_m,
-                       t->mz_locbits, t->join, t->mz_n_regions, t->join_chunk, t->n, t->cap, t->c_overflow, t->mz_overflow, n_ovf};
+        HIP_TRY(hipStreamSynchronize(mine->stream));
+        uint64_t n_ovf = 0;
+        if ((rc = table_n_ovf(mine, &n_ovf))) return rc;
+        hm = table_meta_of(mine, n_ovf);
     }
     TableMeta *dm = nullptr;
-    int rc;
     if ((rc = dev_alloc(&dm, 1))) return rc;
     DevBufs tmp;
     tmp.p.push_back(dm);
@@ -214,52 +295,78 @@ int gs_table_broadcast(gs_comm *c, int root, gs_table *mine, gs_table **out) {
     if (!is_root) HIP_TRY(hipMemcpy(&hm, dm, sizeof hm, hipMemcpyDeviceToHost));
     gs_table *t = mine;
     std::unique_ptr<gs_table, void (*)(gs_table *)> guard(nullptr, gs_table_destroy);
+    int st = GS_OK;
     if (!is_root) {
         t = new gs_table();
         guard.reset(t);
-        if ((rc = table_init(t, c->device, hm.k, hm.n))) return rc;
-        t->shift = hm.shift;
-        t->compact = hm.compact;
-        t->c_qb = hm.c_qb;
-        t->c_rembits = hm.c_rembits;
-        t->c_locbits = hm.c_locbits;
-        t->c_has_flag = hm.c_has_flag;
-        t->c_w64 = hm.c_w64;
-        t->mz = hm.mz;
-        t->mz_m = hm.mz_m;
-        t->mz_locbits = hm.mz_locbits;
-        t->join = hm.join;
-        t->mz_n_regions = hm.mz_n_regions;
-        t->join_chunk = hm.join_chunk;
-        t->cap = hm.cap;
-        t->c_overflow = hm.c_overflow;
-        t->mz_overflow = hm.mz_overflow;
+        st = table_receive_init(t, c->device, hm);  // every allocation of this rank, BEFORE any array collective
     }
-    // the arrays, one broadcast each
-    if ((rc = bcast_array(R, c, root, &t->slots, hm.cap))) return rc;
-    if (hm.mz) {
-        const uint64_t nslots = (uint64_t)hm.mz_n_regions * kMzWords;
-        if ((rc = bcast_array(R, c, root, reinterpret_cast<unsigned long long **>(&t->mz_regions), nslots)) ||
-            (rc = bcast_array(R, c, root, &t->mz_pay, nslots)))
-            return rc;
-    } else if (hm.compact) {
-        const uint64_t nslots = (uint64_t)(4 * kNPart) << hm.c_qb;
-        if ((rc = bcast_array(R, c, root, reinterpret_cast<uint32_t **>(&t->cbuckets), hm.c_w64 ? 2 * nslots : nslots)) ||
-            (rc = bcast_array(R, c, root, &t->cpayload, nslots)))
-            return rc;
-        if (hm.join) {
-            if ((rc = bcast_array(R, c, root, &t->j_ovf_start, (uint64_t)kJoinSlices + 1))) return rc;
-            if (!is_root && (rc = dev_alloc(&t->j_ovf_code, hm.n_ovf)) == GS_OK) rc = dev_alloc(&t->j_ovf_loc, hm.n_ovf);
-            if (rc) return rc;
-            if (hm.n_ovf) {  // (at most a few thousand keys per slice: small)
-                NCCL_TRY(R->Broadcast(t->j_ovf_code, t->j_ovf_code, (size_t)hm.n_ovf * sizeof(uint64_t), ncclUint8, root, c->comm, c->stream));
-                NCCL_TRY(R->Broadcast(t->j_ovf_loc, t->j_ovf_loc, (size_t)hm.n_ovf * sizeof(uint32_t), ncclUint8, root, c->comm, c->stream));
-            }
-        }
+    int agreed = 0;
+    if ((rc = comm_agree(R, c, st, &agreed))) return rc;
+    if (agreed) {
+        if (!st) set_error("gs_table_broadcast: another rank could not receive the table (status %d)", agreed);
+        return agreed;
+    }
+    // the arrays, one broadcast each, in pieces of 1 GiB (config 3's region array is 74 GiB: no single collective of that size)
+    for (auto &a : table_arrays(hm, t, is_root ? mine : nullptr)) {
+        uint8_t *b = reinterpret_cast<uint8_t *>(*a.dst);
+        const size_t piece = (size_t)1 << 30;
+        for (size_t o = 0; o < a.bytes; o += piece)
+            NCCL_TRY(R->Broadcast(b + o, b + o, std::min<size_t>(piece, a.bytes - o), ncclUint8, root, c->comm, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!is_root) guard.release();
     *out = t;
+    return GS_OK;
+}
+
+// The same replication with device-to-device copies instead of broadcasts: a second handle of the table on ITS device.  What
+// a receiving rank of gs_table_broadcast does -- scalars through TableMeta, every array allocated from them, the handle
+// initialised without a build -- runs here on one GPU.
+int gs_table_clone(const gs_table *src, gs_table **out) {
+    if (!src || !out) {
+        set_error("gs_table_clone: bad argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(src->device));
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    int rc;
+    uint64_t n_ovf = 0;
+    if ((rc = table_n_ovf(src, &n_ovf))) return rc;
+    const TableMeta sent = table_meta_of(src, n_ovf);
+    // (the scalars take the route they take between ranks: packed, through device memory, unpacked)
+    TableMeta *dm = nullptr;
+    if ((rc = dev_alloc(&dm, 1))) return rc;
+    DevBufs tmp;
+    tmp.p.push_back(dm);
+    TableMeta hm{};
+    HIP_TRY(hipMemcpy(dm, &sent, sizeof sent, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&hm, dm, sizeof hm, hipMemcpyDeviceToHost));
+    auto *t = new gs_table();
+    std::unique_ptr<gs_table, void (*)(gs_table *)> guard(t, gs_table_destroy);
+    if ((rc = table_receive_init(t, src->device, hm))) return rc;
+    for (auto &a : table_arrays(hm, t, src)) HIP_TRY(hipMemcpyAsync(*a.dst, a.src, a.bytes, hipMemcpyDeviceToDevice, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    *out = guard.release();
+    return GS_OK;
+}
+
+// ncclAllGather of n 64-bit words per rank on the library's stream (the phase-1 summaries of a read-sharded pass: SURVEY.md
+// section 8e); out[rank * n + i] on the host
+int gs_comm_allgather_u64(gs_comm *c, const uint64_t *mine, uint32_t n, uint64_t *out) {
+    if (!c || !mine || !out || !n || n > 2) {
+        set_error("gs_comm_allgather_u64: bad argument (1 or 2 words per rank)");
+        return GS_E_ARG;
+    }
+    Rccl *R = rccl();
+    if (!R) return GS_E_NODEVICE;
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long *seg = c->d_meta + (size_t)n * c->rank;
+    HIP_TRY(hipMemcpyAsync(seg, mine, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (c->nranks > 1) NCCL_TRY(R->AllGather(seg, c->d_meta, n, ncclUint64, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->d_meta, (size_t)n * c->nranks * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return GS_OK;
 }
 
@@ -269,49 +376,62 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
         set_error("gs_gather_hits: bad argument");
         return GS_E_ARG;
     }
-    if ((rc = check_pair(t, r, "gs_gather_hits"))) return rc;
-    if ((rc = settle(t, r))) return rc;
-    if (r->ps.res_keyerr) {
-        set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
-        return GS_E_KEYERROR;
-    }
     Rccl *R = rccl();
     if (!R) return GS_E_NODEVICE;
     HIP_TRY(hipSetDevice(c->device));
+    // A rank whose pass failed -- a KeyError is data-dependent: one shard meets the db k-mer without loc row, the others do not
+    // (kmerpos_annot3.nim:90) -- must not leave the others inside a collective: its status travels WITH the counts, every rank
+    // takes part in the exchange of the meta, and all of them return the same code before any row is sent.
+    int st = check_pair(t, r, "gs_gather_hits");
+    if (!st) st = settle(t, r);
+    if (!st && r->ps.res_keyerr) {
+        set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
+        st = GS_E_KEYERROR;
+    }
     const bool is_root = c->rank == root;
     const int n = c->nranks;
-    // (count, read offset) of every rank
-    const unsigned long long mine[2] = {r->ps.res_n, read_offset};
-    HIP_TRY(hipMemcpyAsync(c->d_meta + 2 * c->rank, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-    if (n > 1) NCCL_TRY(R->AllGather(c->d_meta + 2 * c->rank, c->d_meta, 2, ncclUint64, c->comm, c->stream));
-    std::vector<unsigned long long> meta((size_t)2 * n);
+    // (count, read offset, status) of every rank
+    const unsigned long long mine[3] = {st ? 0ull : (unsigned long long)r->ps.res_n, read_offset, (unsigned long long)(long long)st};
+    HIP_TRY(hipMemcpyAsync(c->d_meta + 3 * c->rank, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+    if (n > 1) NCCL_TRY(R->AllGather(c->d_meta + 3 * c->rank, c->d_meta, 3, ncclUint64, c->comm, c->stream));
+    std::vector<unsigned long long> meta((size_t)3 * n);
     HIP_TRY(hipMemcpyAsync(meta.data(), c->d_meta, meta.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     uint64_t total = 0;
-    for (int i = 0; i < n; i++) total += meta[2 * i];
-    if (n_out) *n_out = total;
-    if (is_root) {
-        if (out && total > cap) {
-            set_error("%llu hits do not fit in cap = %llu", (unsigned long long)total, (unsigned long long)cap);
-            // the other ranks are about to send: take part in the exchange below with a scratch buffer, then report
+    for (int i = 0; i < n; i++) total += meta[3 * i];
+    for (int i = 0; i < n; i++)
+        if ((long long)meta[3 * i + 2] != 0) {
+            const int code = (int)(long long)meta[3 * i + 2];
+            if (i != c->rank) set_error("gs_gather_hits: the pass of rank %d failed (status %d%s)", i, code, code == GS_E_KEYERROR ? ": KeyError" : "");
+            if (n_out) *n_out = 0;
+            return code;
         }
+    if (n_out) *n_out = total;
+    // the root's buffer, then one more agreement: the others only send when the root can receive
+    st = GS_OK;
+    if (is_root) {
         if (c->gather_cap < total) {  // grown once; later passes reuse the buffer
             (void)hipFree(c->d_gather);
             c->d_gather = nullptr;
             c->gather_cap = 0;
             const uint64_t want = total + (total >> 3) + 1024;
-            if ((rc = dev_alloc(&c->d_gather, want))) return rc;
-            c->gather_cap = want;
+            if ((st = dev_alloc(&c->d_gather, want)) == GS_OK) c->gather_cap = want;
         }
-        c->gather_n = total;
+        c->gather_n = st ? 0 : total;
         c->host_valid = false;
+    }
+    int agreed = 0;
+    if ((rc = comm_agree(R, c, st, &agreed))) return rc;
+    if (agreed) {
+        if (!st) set_error("gs_gather_hits: the root could not allocate the gather buffer (status %d)", agreed);
+        return agreed;
     }
     // rows: every rank sends exactly what it has; the root receives them back to back in rank order
     if (n > 1) NCCL_TRY(R->GroupStart());
     if (is_root) {
         uint64_t at = 0;
         for (int i = 0; i < n; i++) {
-            const uint64_t cnt = meta[2 * i];
+            const uint64_t cnt = meta[3 * i];
             if (i == root) {
                 if (cnt) HIP_TRY(hipMemcpyAsync(c->d_gather + at, r->hits, cnt * sizeof(gs_hit), hipMemcpyDeviceToDevice, c->stream));
             } else if (cnt) {
@@ -326,10 +446,10 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
     if (is_root) {
         uint64_t at = 0;
         for (int i = 0; i < n; i++) {  // shard-local read indices -> indices in the whole input
-            const uint64_t cnt = meta[2 * i];
-            if (cnt && meta[2 * i + 1])
+            const uint64_t cnt = meta[3 * i];
+            if (cnt && meta[3 * i + 1])
                 hipLaunchKernelGGL(k_shift_reads, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->d_gather + at, cnt,
-                                   (uint32_t)meta[2 * i + 1]);
+                                   (uint32_t)meta[3 * i + 1]);
             at += cnt;
         }
     }
@@ -338,8 +458,11 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
     // the concatenated rows now are in the root's device memory (gs_gather_device); they cross PCIe only when asked for: into
     // `out` here, or into pinned host memory by gs_gather_view (every rank's own rows already are on its own host after
     // gs_tag_finish -- eight PCIe links in parallel -- so a pipeline that writes per-shard output never needs this copy)
-    if (is_root && out && total && total <= cap) HIP_TRY(hipMemcpy(out, c->d_gather, total * sizeof(gs_hit), hipMemcpyDeviceToHost));
-    if (is_root && out && total > cap) return GS_E_CAPACITY;
+    if (is_root && out && total > cap) {
+        set_error("%llu hits do not fit in cap = %llu", (unsigned long long)total, (unsigned long long)cap);
+        return GS_E_CAPACITY;
+    }
+    if (is_root && out && total) HIP_TRY(hipMemcpy(out, c->d_gather, total * sizeof(gs_hit), hipMemcpyDeviceToHost));
     return GS_OK;
 }
 

@@ -3422,6 +3422,20 @@ void gs_counters_reset(gs_table *t) {
     if (t) t->ctr = gs_counters{};
 }
 
+void gs_table_counters(const gs_table *t, gs_counters *out) {
+    if (t && out) *out = t->ctr;
+}
+
+int gs_reads_copy_words(const gs_reads *r, uint64_t word_lo, uint64_t n_words, uint64_t *dst) {
+    if (!r || (n_words && !dst) || word_lo + n_words > r->n_words) {
+        set_error("gs_reads_copy_words: bad argument (the batch has %llu words)", (unsigned long long)(r ? r->n_words : 0));
+        return GS_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(r->device));
+    if (n_words) HIP_TRY(hipMemcpy(dst, r->words + word_lo, n_words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
 }  // extern "C"
 
 #include "gs_stream.h"

@@ -11,14 +11,14 @@ reads; so the path has exactly one exchange step:
   exchange all_gather of that 2-word summary (8 bytes per rank: latency-bound, not link-bound)
   phase 2  every rank resolves its carry-in = last loc of the nearest earlier shard that has a
            raw hit, and finishes its pass
-  gather   per-rank hit buffers (12 B per output row) are concatenated on rank 0 in shard order:
-           counts first, then one padded all_gather-free `gather`.
+  gather   per-rank hit buffers (12 B per output row) are concatenated on rank 0 in shard order (gs_gather_hits: counts and
+           statuses by ncclAllGather, rows by grouped send / receive of exactly their size).
 
 Nothing here computes on the CPU: the tagging itself is engine.DeviceTable / engine.DeviceReads.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import numpy as np
 
@@ -40,68 +40,6 @@ def resolve_carry(summaries: Sequence[Tuple[int, int]], rank: int, carry0: int =
         if has:
             return int(loc)
     return int(carry0)
-
-
-def exchange_summaries(has_raw: int, last_loc: int, device=None) -> List[Tuple[int, int]]:
-    """all_gather of the per-shard phase-1 summary (one collective, one device-to-host copy)."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size()
-    mine = torch.tensor([int(has_raw), int(last_loc)], dtype=torch.int64, device=device)
-    out = torch.empty((world, 2), dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(out, mine.reshape(1, 2))
-    rows = out.cpu().tolist()
-    return [(int(h), int(l)) for h, l in rows]
-
-
-def gather_hits(local_hits, read_offset: int, dst: int = 0):
-    """Concatenate per-rank hit buffers on rank `dst` in shard order.
-
-    local_hits: int32/uint32-viewable torch tensor of shape [n, 3] (read, pos, payload) on the
-    rank's device; read indices are local to the shard and are shifted by `read_offset`.
-    Returns the [N, 3] tensor on rank dst, None elsewhere.  Two collectives: the counts
-    (all_gather, 8 B per rank), then one gather padded to the largest count."""
-    import torch
-    import torch.distributed as dist
-
-    world, rank = dist.get_world_size(), dist.get_rank()
-    dev = local_hits.device
-    n = int(local_hits.shape[0])
-    n_local = torch.tensor([[n]], dtype=torch.int64, device=dev)
-    counts_t = torch.empty((world, 1), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts_t, n_local)
-    counts = [int(c[0]) for c in counts_t.cpu().tolist()]
-    width = max(max(counts), 1)
-    padded = torch.zeros((width, 3), dtype=torch.int32, device=dev)
-    if n:
-        padded[:n] = local_hits.to(torch.int32)
-        padded[:n, 0] += int(read_offset)
-    if rank == dst:
-        bufs = [torch.empty_like(padded) for _ in range(world)]
-        dist.gather(padded, bufs, dst=dst)
-        return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
-    dist.gather(padded, None, dst=dst)
-    return None
-
-
-def broadcast_array(arr: Optional[np.ndarray], dtype, device=None, src: int = 0) -> np.ndarray:
-    """Replicate a host array from rank `src` through the collective backend (the SUNK table's key /
-    loc / payload arrays: built once, broadcast, every rank then builds its own device table)."""
-    import torch
-    import torch.distributed as dist
-
-    rank = dist.get_rank()
-    n = torch.tensor([len(arr) if rank == src else 0], dtype=torch.int64, device=device)
-    dist.broadcast(n, src=src)
-    nbytes = int(n.item()) * np.dtype(dtype).itemsize
-    if rank == src:
-        raw = np.ascontiguousarray(arr, dtype=dtype).view(np.uint8)
-        t = torch.from_numpy(raw.copy()).to(device) if device is not None else torch.from_numpy(raw.copy())
-    else:
-        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    dist.broadcast(t, src=src)
-    return t.cpu().numpy().view(dtype)
 
 
 class Comm:
@@ -137,6 +75,10 @@ class Comm:
         return out.tolist()
 
     def exchange_summaries(self, has_raw: int, last_loc: int):
+        """{has a raw hit, loc of the last one} of every rank: ncclAllGather on the library's stream when the data plane is
+        RCCL, the gloo control plane otherwise."""
+        if self.rccl is not None:
+            return self.rccl.allgather_pairs(has_raw, last_loc)
         return [(int(h), int(l)) for h, l in self._all_gather_i64([has_raw, last_loc])]
 
     def all_max(self, x: float) -> float:
@@ -167,14 +109,21 @@ class Comm:
 
         if self.rccl is not None:
             return self.rccl.gather_hits(table, reads, None, read_offset, dst, to_host=to_host)
-        counts = [r[0] for r in self._all_gather_i64([n_local])]
         import torch
 
-        from ._lib import check, lib
+        from ._lib import GS_OK, GsError, lib
 
+        # every rank takes part in the exchange of the counts, which carries its status (a KeyError is data-dependent: one shard
+        # meets it, kmerpos_annot3.nim:90): all ranks then raise the same error instead of waiting for each other
         mine = np.zeros(max(n_local, 1), dtype=engine.HIT_DTYPE)
+        st = lib().gs_tag_hits_to_host(table._h, reads._h, mine.ctypes.data, len(mine), None) if n_local else \
+            lib().gs_tag_hits_to_host(table._h, reads._h, None, 0, None)
+        meta = self._all_gather_i64([n_local if st == GS_OK else 0, st])
+        for r, (_, code) in enumerate(meta):
+            if code != GS_OK:
+                raise GsError(int(code), f"the pass of rank {r} failed" + (": key not found [KeyError]" if code == -2 else ""))
+        counts = [m[0] for m in meta]
         if n_local:
-            check(lib().gs_tag_hits_to_host(table._h, reads._h, mine.ctypes.data, n_local, None))
             mine["read"][:n_local] += np.uint32(read_offset)
         width = max(max(counts), 1)
         padded = torch.zeros((width, 3), dtype=torch.int32)

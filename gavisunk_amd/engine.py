@@ -189,6 +189,15 @@ class DeviceTable:
     def from_db(cls, db: SunkDB, device: int = 0) -> "DeviceTable":
         return cls(db.k, db.keys, db.key_loc, db.key_row, device)
 
+    def clone(self) -> "DeviceTable":
+        """A second handle of the same table on its device (gs_table_clone: what a receiving rank of gs_table_broadcast does,
+        with device-to-device copies)."""
+        h = C.c_void_p()
+        check(lib().gs_table_clone(self._h, C.byref(h)))
+        t = DeviceTable.__new__(DeviceTable)
+        t._h, t.k, t.device, t.n = h, self.k, self.device, self.n
+        return t
+
     @property
     def nbytes(self) -> int:
         return lib().gs_table_bytes(self._h)
@@ -383,7 +392,10 @@ class Stream:
             check(st)
         self._keep.pop(0)
         hits = _view(hp.value, n.value, HIT_DTYPE)
-        return st, (hits.copy() if copy else hits), nr.value, ctr.as_dict()
+        if copy:  # the rows are ours now: the slot may take the next batch at once
+            hits = hits.copy()
+            lib().gs_stream_release(self._h)
+        return st, hits, nr.value, ctr.as_dict()
 
     def close(self):
         if getattr(self, "_h", None):

@@ -125,7 +125,8 @@ def _tag_host_batches(batches, db, table, ofile: str, batch_bases: int) -> int:
                 sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
                 return 1
             return 0
-        cap_reads = 1 << 22  # the reader's own limits: a batch has at most 2^22 reads and batch_bases bases (+ 2 words per read)
+        # the reader's own limits: a batch has at most 2^22 reads and batch_bases bases (+ 2 words per read)
+        cap_reads = min(1 << 22, max(batch_bases, 4096))
         cap_words = batch_bases // 32 + 2 * cap_reads + 64
         stream = engine.Stream(table, cap_words, cap_reads, depth=3)
         pending = []  # batches in flight (names are needed when the rows come back), with the device copy of an outsized one

@@ -35,6 +35,13 @@ class RcclComm:
         t.k = t.n = None
         return t
 
+    def allgather_pairs(self, a: int, b: int):
+        """ncclAllGather of two 64-bit words per rank (gs_comm_allgather_u64) -> [(a, b)] in rank order."""
+        mine = np.array([a, b], dtype=np.uint64)
+        out = np.zeros(2 * self.world, dtype=np.uint64)
+        check(lib().gs_comm_allgather_u64(self._h, mine.ctypes.data, 2, out.ctypes.data))
+        return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(self.world)]
+
     def gather_hits(self, table, reads, counts, read_offset: int, dst: int = 0, to_host: bool = True):
         """All ranks' hit lists of the last pass concatenated on rank dst: in its device memory, and (to_host) as a numpy
         HIT_DTYPE view of pinned host memory; None on the other ranks and when the rows are left on the device."""

@@ -261,6 +261,11 @@ uint32_t gs_stream_carry(const gs_stream *s);
 int gs_host_alloc(uint64_t bytes, void **out);
 void gs_host_free(void *p);
 void gs_counters_reset(gs_table *t);
+/* the table's counters as accumulated over every pass settled since the last reset (windows / raw_hits / emitted / tiles: of
+ * the pass settled last) */
+void gs_table_counters(const gs_table *t, gs_counters *out);
+/* packed words [word_lo, word_lo + n_words) of a resident batch back on the host (the gs_reads_upload layout) */
+int gs_reads_copy_words(const gs_reads *r, uint64_t word_lo, uint64_t n_words, uint64_t *dst);
 
 
 /* ------------------------------------------------------------------------------------------
@@ -283,9 +288,18 @@ void gs_comm_destroy(gs_comm *c);
 /* The root's BUILT table, device array by device array, to every other rank (ncclBroadcast): nobody else parses or builds.
  * The root passes its table and gets it back in *out; the others pass NULL and own the table they receive. */
 int gs_table_broadcast(gs_comm *c, int root, gs_table *mine, gs_table **out);
+/* What a receiving rank of gs_table_broadcast does -- the root's scalars, every array allocated from them (all of them before
+ * any transfer: a rank that cannot allocate fails ALL ranks instead of leaving them in a collective), a handle initialised
+ * without a build -- with device-to-device copies on ONE GPU: a second, independent handle of the same table. */
+int gs_table_clone(const gs_table *src, gs_table **out);
+/* ncclAllGather of n (1 or 2) 64-bit words per rank on the library's stream: the phase-1 summaries {has a raw hit, loc of the
+ * last one} of a read-sharded pass without a second transport.  out[rank * n + i], host. */
+int gs_comm_allgather_u64(gs_comm *c, const uint64_t *mine, uint32_t n, uint64_t *out);
 /* After a finished pass on every rank: all ranks' emitted hits concatenated in the ROOT'S DEVICE MEMORY, in rank order, `read`
  * shifted by the rank's read_offset.  Counts and offsets travel by ncclAllGather, the rows by grouped ncclSend / ncclRecv of
- * exactly their size.  Root: *n_out = total rows; `out` (host, `cap` rows) may be NULL: the rows then stay on the device
+ * exactly their size.  A rank whose pass failed (GS_E_KEYERROR: kmerpos_annot3.nim:90 is data-dependent, one shard meets it)
+ * still takes part in the exchange of the counts, which carries its status: EVERY rank then returns that code and no row is
+ * sent -- an N-GPU run exits 1 like the reference instead of hanging.  Root: *n_out = total rows; `out` (host, `cap` rows) may be NULL: the rows then stay on the device
  * (gs_gather_device) and cross PCIe only if gs_gather_view is called -- every rank's own rows already are on its own host
  * after gs_tag_finish.  Other ranks pass out = NULL. */
 int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read_offset, gs_hit *out, uint64_t cap, uint64_t *n_out);

@@ -13,6 +13,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import _gloo_helpers as gloo
+
 from gavisunk_amd import dist as gdist
 from gavisunk_amd import synth
 from gavisunk_amd._lib import GS_NONE
@@ -50,19 +52,19 @@ def _worker(rank, world, port, out_path):
     try:
         k, keys, loc, reads = _case()
         # table arrays travel from rank 0 through the collective backend
-        keys_b = gdist.broadcast_array(keys if rank == 0 else None, np.uint64)
-        loc_b = gdist.broadcast_array(loc if rank == 0 else None, np.uint32)
+        keys_b = gloo.broadcast_array(keys if rank == 0 else None, np.uint64)
+        loc_b = gloo.broadcast_array(loc if rank == 0 else None, np.uint32)
         assert np.array_equal(keys_b, keys) and np.array_equal(loc_b, loc)
         lo, hi = gdist.shard_bounds(len(reads), world, rank)
         shard = reads[lo:hi]
         # phase 1 (no carry known yet): summary of the shard
         _, has_raw, last_loc = _oracle_shard(k, keys_b, loc_b, shard, GS_NONE)
-        summ = gdist.exchange_summaries(has_raw, last_loc)
+        summ = gloo.exchange_summaries(has_raw, last_loc)
         carry = gdist.resolve_carry(summ, rank)
         # phase 2 with the resolved carry
         hits, _, _ = _oracle_shard(k, keys_b, loc_b, shard, carry)
         local = torch.from_numpy(np.stack([hits["read"], hits["pos"], hits["row"]], axis=1).astype(np.int32)).reshape(-1, 3)
-        allhits = gdist.gather_hits(local, lo)
+        allhits = gloo.gather_hits(local, lo)
         if rank == 0:
             np.save(out_path, allhits.numpy())
     finally:

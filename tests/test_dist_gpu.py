@@ -11,6 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import _gloo_helpers as gloo
+
 pytestmark = pytest.mark.gpu
 
 
@@ -43,7 +45,7 @@ def _worker(rank, world, port, out_path):
         dev = engine.DeviceReads(engine.ReadBatch.from_ascii(reads[lo:hi]), k)
         has, last = C.c_uint32(0), C.c_uint32(0)
         _lib.check(L.gs_tag_phase1(tab._h, dev._h, C.byref(has), C.byref(last)))
-        summ = gdist.exchange_summaries(has.value, last.value)
+        summ = gloo.exchange_summaries(has.value, last.value)
         _lib.check(L.gs_tag_phase2(tab._h, dev._h, gdist.resolve_carry(summ, rank)))
         n = C.c_uint64(0)
         _lib.check(L.gs_tag_finish(tab._h, dev._h, None, 0, C.byref(n), None, None))
@@ -51,7 +53,7 @@ def _worker(rank, world, port, out_path):
         _lib.check(L.gs_tag_hits_to_host(tab._h, dev._h, hits.ctypes.data, len(hits), None))
         hits = hits[: n.value]
         local = torch.from_numpy(np.stack([hits["read"], hits["pos"], hits["payload"]], axis=1).astype(np.int64).astype(np.int32)).reshape(-1, 3)
-        allhits = gdist.gather_hits(local, lo)
+        allhits = gloo.gather_hits(local, lo)
         if rank == 0:
             np.save(out_path, allhits.numpy())
     finally:
@@ -129,6 +131,57 @@ def test_comm_gloo_data_plane_on_one_gpu(world, tmp_path):
     _check_against_single_pass(out)
 
 
+def _keyerror_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gavisunk_amd import _lib, engine
+    from gavisunk_amd import dist as gdist
+    from oracle import oracle
+
+    L = _lib.lib()
+    comm = gdist.Comm(0, rccl=False)
+    k, keys, loc, reads = _case()
+    # a db k-mer without loc row (kmerpos_annot3.nim:90 -> KeyError), met by ONE read in the middle of the file
+    poison = b"ACGTTGCATTGACCAGTAGCATCAGGA"
+    keys = np.append(keys, oracle.canonical_windows(poison, k)[:1])
+    loc = np.append(loc, np.uint32(_lib.GS_MISSING))
+    reads = reads[:26] + [reads[26] + poison + reads[27][:100]] + reads[27:]
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    lo, hi = gdist.shard_bounds(len(reads), world, rank)
+    dev = engine.DeviceReads(engine.ReadBatch.from_ascii(reads[lo:hi]), k)
+    has, last = C.c_uint32(0), C.c_uint32(0)
+    _lib.check(L.gs_tag_phase1(tab._h, dev._h, C.byref(has), C.byref(last)))
+    summ = comm.exchange_summaries(has.value, last.value)
+    _lib.check(L.gs_tag_phase2(tab._h, dev._h, gdist.resolve_carry(summ, rank)))
+    n = C.c_uint64(0)
+    st = L.gs_tag_finish(tab._h, dev._h, None, 0, C.byref(n), None, None)
+    code = 0
+    try:
+        comm.gather_hits(tab, dev, n.value, lo)
+    except _lib.GsError as e:
+        code = e.status
+    np.save(f"{out_path}.{rank}.npy", np.array([st, code, int(lo <= 26 < hi)]))
+    dev.close()
+    tab.close()
+    comm.close()
+
+
+def test_a_keyerror_on_one_shard_fails_every_rank(tmp_path):
+    """The reference exits 1 when a read hits a db k-mer that has no loc row (kmerpos_annot3.nim:90).  With the reads sharded
+    that happens on ONE rank; the gather carries every rank's status with its count, so all ranks report the KeyError instead
+    of waiting for the failed one (3 processes sharing the GPU, gloo data plane: the same protocol gs_gather_hits follows
+    over RCCL)."""
+    out = str(tmp_path / "st")
+    mp.spawn(_keyerror_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    from gavisunk_amd import _lib
+
+    res = [np.load(f"{out}.{r}.npy") for r in range(3)]
+    assert sum(int(x[2]) for x in res) == 1
+    for x in res:
+        assert x[1] == _lib.GS_E_KEYERROR                      # every rank learns of it
+        assert (x[0] == _lib.GS_E_KEYERROR) == bool(x[2])       # only the shard with the read met it itself
+
+
 def test_comm_rccl_data_plane():
     """The RCCL data plane (table broadcast + hit gather through the C-ABI) on as many GPUs as the box has, at most 4;
     skipped on a one-GPU box (RCCL refuses two ranks on one device)."""
@@ -167,4 +220,15 @@ def test_rccl_single_rank_through_the_c_abi():
     got = comm.gather_hits(tab, dev, [len(whole)], 1000)
     assert len(got) == len(whole) > 50 and np.array_equal(got["read"], whole["read"] + 1000)
     assert np.array_equal(got["pos"], whole["pos"]) and np.array_equal(got["payload"], whole["payload"])
+    # the phase-1 summaries over ncclAllGather (gs_comm_allgather_u64), and a failed pass reported by the gather itself
+    assert comm.allgather_pairs(1, 0xFFFFFFFF) == [(1, 0xFFFFFFFF)]
+    keys2, loc2 = np.append(keys, keys[:1] ^ np.uint64(1)), np.append(loc, np.uint32(_lib.GS_MISSING))
+    from oracle import oracle
+
+    bad = engine.DeviceTable(k, np.append(keys, oracle.canonical_windows(b"ACGTTGCATTGACCAGTAGCATCAGGA", k)[:1]), loc2, np.arange(len(keys2), dtype=np.uint32))
+    dev2 = engine.DeviceReads(engine.ReadBatch.from_ascii(reads[:5] + [b"ACGTTGCATTGACCAGTAGCATCAGGA"]), k)
+    assert engine.tag(bad, dev2)[0] == _lib.GS_E_KEYERROR
+    with pytest.raises(_lib.GsError) as e:
+        comm.gather_hits(bad, dev2, None, 0)
+    assert e.value.status == _lib.GS_E_KEYERROR
     comm.close()

@@ -80,6 +80,24 @@ def test_cli_in_small_device_batches(golden, name, tmp_path, monkeypatch):
     assert out.read_text() == c.text(run["out"])
 
 
+@pytest.mark.parametrize("name", ["kat1", "kat2", "amy", "multi_k21", "kat2_missing"])
+@pytest.mark.parametrize("batch_bases", ["700", "20000"])
+def test_cli_host_parser_through_the_streaming_engine(golden, name, batch_bases, tmp_path, monkeypatch, table_layout):
+    """GAVISUNK_PARSE=host: batches of the native host reader go through gs_stream_* (upload of the next batch overlapped with
+    the pass of the current one, `prevLoc` handed on in device memory) -- the reference binary's bytes, KeyError included."""
+    if table_layout not in ("auto", "generic"):
+        pytest.skip("one fast and one slow layout are enough here")
+    monkeypatch.setenv("GAVISUNK_PARSE", "host")
+    monkeypatch.setenv("GAVISUNK_BATCH_BASES", batch_bases)
+    c = golden(name)
+    for run in c.meta["tag"]:
+        out = tmp_path / "out.sunkpos"
+        rc = kmerpos_annot3.main([c.path(run["reads"]), c.path(run["db"]), c.path(run["loc"]), str(out)])
+        assert rc == run["rc"]
+        got, exp = out.read_text(), c.text(run["out"])
+        assert got == exp if rc == 0 else got.startswith(exp), f"{name}: {run['reads']}"
+
+
 @pytest.mark.parametrize("name", ["kat1", "multi_k20", "multi_k25", "amy"])
 @pytest.mark.parametrize("batch_bases", [None, "900"])
 def test_cli_emulates_the_workflows_scatter_chunks(golden, name, batch_bases, tmp_path, monkeypatch):
@@ -460,6 +478,26 @@ def test_table_build_is_deterministic(table_layout, monkeypatch):
     assert all(np.array_equal(h, hits[0]) for h in hits[1:])
     rc, oh, _, _ = _oracle_hits(20, keys, loc, seqs)
     assert len(oh) == len(hits[0]) and np.array_equal(hits[0]["pos"], oh["pos"]) and np.array_equal(hits[0]["payload"], oh["row"])
+
+
+def test_table_clone_is_the_receiving_side_of_a_broadcast(table_layout):
+    """gs_table_clone: what a non-root rank of gs_table_broadcast does (scalars through TableMeta, every array allocated from
+    them, the handle initialised without a build), with device-to-device copies -- in every layout; the clone tags like the
+    original, also after the original is gone."""
+    k = 20
+    keys, loc, seqs = _random_case(44, k, n_reads=60, glen=80000, median=2500)
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    twin = tab.clone()
+    assert twin.layout == tab.layout and twin.nbytes == tab.nbytes
+    dev = engine.DeviceReads(engine.ReadBatch.from_ascii(seqs), k)
+    a = engine.tag(tab, dev)
+    tab.close()
+    b = engine.tag(twin, dev)
+    assert a[0] == b[0] == 0 and np.array_equal(a[1], b[1]) and a[2] == b[2] and b[3]["raw_hits"] == octr["raw_hits"]
+    assert len(b[1]) == len(oh) and np.array_equal(b[1]["pos"], oh["pos"]) and np.array_equal(b[1]["payload"], oh["row"])
+    dev.close()
+    twin.close()
 
 
 def test_table_without_keys():
