@@ -30,14 +30,18 @@ def stale(lib: str = LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tuning: bool = False, variant: str = "", defines=()) -> str:
     """tuning=True builds libgavisunk_tuning.so with -DGS_TUNING: the phase-off / pipeline-depth switches the timing
-    experiments under tools/ use (GAVISUNK_LIB=.../libgavisunk_tuning.so selects it).  The product library has none."""
+    experiments under tools/ use (GAVISUNK_LIB=.../libgavisunk_tuning.so selects it).  The product library has none.
+    variant="x" + defines: libgavisunk_x.so compiled with those -D switches (kernel A/B experiments, tools/kbench.sh)."""
     lib = LIB_TUNING if tuning else LIB
+    if variant:
+        lib = os.path.join(HERE, f"libgavisunk_{variant}.so")
+        force = True
     if not force and not stale(lib):
         return lib
     cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC] + (["-DGS_TUNING"] if tuning else []) + [
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC] + (["-DGS_TUNING"] if tuning else []) + list(defines) + [
            "-o", lib] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
@@ -57,5 +61,9 @@ def build_synth(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    build_synth(force="--force" in sys.argv, verbose=True)
-    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))
+    if "--variant" in sys.argv:
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        print(build(verbose=True, variant=name, defines=[x for x in sys.argv if x.startswith("-D")]))
+    else:
+        build_synth(force="--force" in sys.argv, verbose=True)
+        print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))
