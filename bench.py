@@ -201,7 +201,7 @@ def config2_leg(a, device):
 
     L = _lib.lib()
     t0 = time.perf_counter()
-    seq, sunks, names, reads = synth.config2(seed=20, n_reads=10000, k=K)
+    seq, sunks, names, reads = synth.config2(engine.define_sunks, seed=20, n_reads=10000, k=K)
     _, loc = np.unique(sunks.group, return_inverse=True)
     seqs = [synth.codes_to_ascii(r) for r in reads]
     n_bases = sum(len(s) for s in seqs)

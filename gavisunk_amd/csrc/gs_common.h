@@ -37,6 +37,8 @@ inline uint64_t encode_kmer(const char *s, size_t n) {
 int sort_pairs_u64_u32(const uint64_t *k_in, uint64_t *k_out, const uint32_t *v_in, uint32_t *v_out, uint64_t n, int end_bit,
                        void *stream);
 
+// radix sort of 64-bit keys on all 64 bits (rocPRIM; gs_sunkdef.hip)
+int sort_keys_u64(const uint64_t *k_in, uint64_t *k_out, uint64_t n, void *stream);
 // stable selection: out[] = in[i] for the i with flag[i] != 0, in order; *n_out = how many (rocPRIM select; gs_sunkdef.hip)
 int select_flagged_u32(const uint32_t *in, const uint8_t *flag, uint32_t *out, unsigned long long *d_count, uint64_t n, uint64_t *n_out,
                        void *stream);

@@ -1986,7 +1986,7 @@ struct gs_table {
     uint32_t mz_n_regions = 0;
     int mz_m = 0, mz_locbits = 0;
     uint32_t *mz_pay = nullptr;  // payload per slot
-    uint64_t mz_overflow = 0;
+    uint64_t mz_overflow = 0, mz_dup = 0;  // keys in the generic side table; keys stored under both strands' picks
     int join = 0;
     uint32_t join_chunk = kJoinChunkMax;
     uint64_t *j_ovf_code = nullptr;
@@ -2511,7 +2511,7 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
     while (t->mz) {
         const uint64_t nslots = (uint64_t)t->mz_n_regions * kMzWords;
         const bool knob = getenv("GAVISUNK_MZ_M") || getenv("GAVISUNK_MZ_LOAD");
-        const uint64_t ocap = std::max<uint64_t>(knob && force_mz ? n : n / 8, 1u << 16);
+        const uint64_t ocap = std::max<uint64_t>(knob && force_mz ? 2 * n : n / 8, 1u << 16);
         unsigned long long *dov = nullptr;
         DevBufs ot;
         if ((rc = dev_alloc((unsigned long long **)&t->mz_regions, nslots)) || (rc = dev_alloc(&t->mz_pay, nslots)) ||
@@ -2519,6 +2519,34 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
             return rc;
         HIP_TRY(hipMemsetAsync(t->mz_regions, 0xFF, nslots * sizeof(unsigned long long), t->stream));
         HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
+#if GS_MZ_RD
+        {  // one entry per key and strand pick (k_mz_entries), sorted by (region, key index)
+            uint64_t n2 = n;
+            uint64_t *reg1 = nullptr;
+            uint32_t *idx1 = nullptr;
+            DevBufs st;
+            {
+                DevBufs se;
+                uint64_t *ent0 = nullptr, *ent1 = nullptr;
+                unsigned long long *dnd = nullptr;
+                if ((rc = se.get(&ent0, 2 * n)) || (rc = st.get(&ent1, 2 * n)) || (rc = se.get(&dnd, 1))) return rc;
+                HIP_TRY(hipMemsetAsync(dnd, 0, sizeof(unsigned long long), t->stream));
+                hipLaunchKernelGGL(k_mz_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, dk, n, k, t->mz_m, t->mz_n_regions, ent0, dnd);
+                if ((rc = sort_keys_u64(ent0, ent1, 2 * n, t->stream))) return rc;
+                unsigned long long nd = 0;
+                HIP_TRY(hipMemcpyAsync(&nd, dnd, sizeof nd, hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                n2 = n + nd;
+                t->mz_dup = nd;
+                if ((rc = st.get(&reg1, n2)) || (rc = st.get(&idx1, n2))) return rc;
+                hipLaunchKernelGGL(k_mz_split_entries, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, t->stream, (const uint64_t *)ent1, n2, reg1, idx1);
+                HIP_TRY(hipStreamSynchronize(t->stream));
+            }
+            hipLaunchKernelGGL(k_mz_place, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, t->stream, reinterpret_cast<unsigned long long *>(t->mz_regions),
+                               t->mz_pay, k, t->mz_locbits, dk, dl, dp, (const uint64_t *)reg1, (const uint32_t *)idx1, n2, dov, dlist, ocap);
+            HIP_TRY(hipStreamSynchronize(t->stream));
+        }
+#else
         {  // keys sorted by region, stable (rocPRIM radix sort on the 32 region bits; a key's index rides along)
             DevBufs st;
             uint64_t *reg0 = nullptr, *reg1 = nullptr;
@@ -2532,6 +2560,7 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
                                t->mz_pay, k, t->mz_locbits, dk, dl, dp, (const uint64_t *)reg1, (const uint32_t *)idx1, n, dov, dlist, ocap);
             HIP_TRY(hipStreamSynchronize(t->stream));
         }
+#endif
         unsigned long long ov = 0;
         HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));

@@ -173,6 +173,38 @@ __global__ void k_mz_regions(const uint64_t *keys, uint64_t n, int k, int m, uin
     if (i < n) reg[i] = mz_region(mz_minimizer(keys[i], k, m), n_regions);
 }
 
+#if GS_MZ_RD
+// GS_MZ_RD build: one entry (region << 32 | key index) per key and strand pick.  A read shows a k-mer in either orientation
+// and the probe takes the leftmost smallest t-mer as shown: the key sits in the region of the pick in its canonical
+// orientation (entry i) and, where the other strand picks another region (equal t-mer orders at two places of the k-mer: a
+// few per cent of the keys), in that one too (entry n + i; ~0 = none).  Sorted on all 64 bits: a region's keys in the caller's
+// order, the same bytes every time.
+__device__ __forceinline__ uint64_t mz_revcomp(uint64_t c, int k) {
+    uint64_t r = 0;
+    for (int i = 0; i < k; i++) {
+        r = (r << 2) | (3ULL - (c & 3ULL));
+        c >>= 2;
+    }
+    return r;
+}
+__global__ void k_mz_entries(const uint64_t *keys, uint64_t n, int k, int m, uint32_t n_regions, uint64_t *ent, unsigned long long *n_dup) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c = keys[i];
+    const uint32_t a = mz_region(mz_minimizer(c, k, m), n_regions), b = mz_region(mz_minimizer(mz_revcomp(c, k), k, m), n_regions);
+    ent[i] = ((uint64_t)a << 32) | i;
+    ent[n + i] = a != b ? ((uint64_t)b << 32) | i : ~0ULL;
+    if (a != b) atomicAdd(n_dup, 1ULL);
+}
+__global__ void k_mz_split_entries(const uint64_t *ent, uint64_t n2, uint64_t *reg, uint32_t *idx) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n2) {
+        reg[p] = ent[p] >> 32;
+        idx[p] = (uint32_t)ent[p];
+    }
+}
+#endif
+
 __global__ void k_mz_place(unsigned long long *slots, uint32_t *pay, int k, int locbits, const uint64_t *keys, const uint32_t *loc,
                            const uint32_t *payload, const uint64_t *reg_sorted, const uint32_t *idx_sorted, uint64_t n,
                            unsigned long long *overflow, uint32_t *overflow_list, uint64_t overflow_cap) {
@@ -276,13 +308,18 @@ struct MzWin {
     uint32_t h;     // hash of the canonical m-mer that starts there
     uint32_t o;     // order (mz_tmer_order) of the canonical t-mer that starts there
 };
+__device__ __forceinline__ MzWin mz_win_from(uint64_t f, uint64_t r, int k, int m, uint64_t mmask);
 // the window whose first base is base (lane & 31) of the 64-base string a:b
 __device__ __forceinline__ MzWin mz_win_of(uint64_t a, uint64_t b, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
     const int sh = 2 * (lane & 31);
     const uint64_t x = sh ? ((a << sh) | (b >> (64 - sh))) : a;  // 32 bases from the window's first one
+    return mz_win_from(x >> (64 - 2 * k), ~revpairs(x) & kmask, k, m, mmask);  // (revpairs: base i of x, complemented, at bits 2i+1:2i)
+}
+// ... from the window's forward and reverse-complement codes
+__device__ __forceinline__ MzWin mz_win_from(uint64_t f, uint64_t r, int k, int m, uint64_t mmask) {
     MzWin o;
-    o.f = x >> (64 - 2 * k);
-    o.r = ~revpairs(x) & kmask;  // base i of x, complemented, at bits 2i+1:2i
+    o.f = f;
+    o.r = r;
     if (m <= 16) {  // wave-uniform: the m-mer fits a word
         const uint32_t fm = (uint32_t)(o.f >> (2 * (k - m))), rm = (uint32_t)o.r & (uint32_t)mmask;
         o.h = mz_mmer_hash((uint64_t)(fm < rm ? fm : rm));
@@ -480,8 +517,21 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 constexpr int kMzRunCap = 32;                  // runs of a step whose regions fit the LDS cache slot (2 KiB)
 constexpr int kMzDma = kMzRunCap * kMzPieces / 64;  // LDS-DMA wave-instructions per step
 constexpr int kMzStages = 2;                   // steps whose region fetches are in flight together
+#ifndef GS_MZ_RD
+#define GS_MZ_RD 0  // 1: a window's region = the pick of the leftmost smallest t-mer AS THE READ SHOWS THE K-MER (no strand test in
+                    // the probe); the table then holds a key under the pick of either strand (two places when they differ)
+#endif
+#ifndef GS_MZ_RCW
+#define GS_MZ_RCW 0  // 1: the tile staged as two dword streams (forward, reverse complement); windows extracted with v_alignbit
+#endif
+#if GS_MZ_RCW
+constexpr int kMzListCap = 176;                // maybe-hits held before the list is flushed (a step adds up to 64)
+constexpr int kMzDeferCap = 80;                // deferred generic-table lookups held before a flush
+#else
 constexpr int kMzListCap = 240;                // maybe-hits held before the list is flushed (a step adds up to 64)
 constexpr int kMzDeferCap = 96;                // deferred generic-table lookups held before a flush
+#endif
+constexpr int kMzStreamDwords = 2 * (kTileWords + 3);  // a tile's bases as 32-bit pieces: 64 words + 2 a window reaches into + 1 of padding
 constexpr int kMzFastCand = 64;                // candidates (location changes) of a tile before it is handed to the exact form
 static_assert(kMzListCap >= kMzCandLds, "the exact form borrows the hit list as its candidate buffer");
 constexpr int kMzWaves = 2;                    // waves per workgroup
@@ -495,8 +545,22 @@ struct MzWaveLds {
     uint32_t list[kMzListCap];              // loc + 1 of every maybe-hit (the exact form borrows this as its candidate buffer)
     uint32_t defer[kMzDeferCap];
     uint32_t cand[kMzFastCand];             // the tile's candidates (a tile with more is done over by the exact form)
+#if GS_MZ_RCW
+  union {
+    uint64_t words[kTileWords + 3];         // (instances without compile-time k: the words as they are)
+    struct {
+    // The tile's packed bases twice, as streams of dwords in BASE order (dword d = bases 16 d .. 16 d + 15, first base most
+    // significant): fd = the bases as they are (one dword of padding in front: the window extraction of lane 0 addresses it),
+    // rd = the reverse complement of the whole 67-word buffer, so that the reverse complement of the window at base P is the
+    // piece of rd at base (67 * 32 - k - P) -- computed ONCE per tile (one revpairs per word) instead of once per window.
+    uint32_t fd[1 + kMzStreamDwords];
+    uint32_t rd[1 + kMzStreamDwords];
+    };
+  };
+#else
     uint64_t words[kTileWords + 3];         // the tile's packed bases (+ 2 words a window of the last step reaches into, + 1 that
                                             // step's look-ahead read touches and never uses)
+#endif
     uint16_t list_w[kMzListCap];            // window offset of every maybe-hit
 };
 
@@ -531,6 +595,48 @@ __device__ __forceinline__ MzWin mz_window_lds(uint32_t words_a, uint32_t s, int
     asm volatile("ds_read2_b64 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     return mz_win_of((uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32), lane, k, m, kmask, mmask);
 }
+
+#if GS_MZ_RCW
+// ---- windows from the dword streams ------------------------------------------------------------------------------------------
+// The 64 bits that start at bit B of a stream of dwords d[0], d[1], .. are alignbit(d[q], d[q+1], n) : alignbit(d[q+1], d[q+2], n)
+// with q = (B - 1) >> 5 and n = (32 - (B - 32 q)) & 31 (v_alignbit_b32 takes 0..31: a piece that starts ON a dword boundary is
+// addressed from the dword before it, shift 0 -- hence the dword of padding in front of fd).  For the window that starts at base
+// 64 s + lane, q moves by 4 dwords per step and n never changes: both are per-lane constants of the tile.
+struct MzLaneGeom {
+    uint32_t f_addr, r_addr;  // LDS byte address of d[q] at step 0 (forward: + 16 per step; reverse complement: - 16 per step)
+    uint32_t f_n, r_n;        // alignbit shift
+};
+__device__ __forceinline__ MzLaneGeom mz_lane_geom(uint32_t fd_a, uint32_t rd_a, int lane, int k) {
+    MzLaneGeom g;
+    const int bf = 2 * lane, qf = lane ? (bf - 1) >> 5 : -1;
+    g.f_addr = fd_a + 4u * (uint32_t)(1 + qf);
+    g.f_n = (uint32_t)(32 - (bf - 32 * qf)) & 31u;
+    const int br = 2 * ((kTileWords + 3) * 32 - k - lane), qr = (br - 1) >> 5;  // >= 1 at every step of a tile
+    g.r_addr = rd_a + 4u * (uint32_t)qr;
+    g.r_n = (uint32_t)(32 - (br - 32 * qr)) & 31u;
+    return g;
+}
+__device__ __forceinline__ uint32_t mz_alignbit(uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbit(hi, lo, n); }
+// three consecutive dwords at a 4-byte aligned LDS address
+__device__ __forceinline__ void lds_read3_b32(uint32_t addr, uint32_t &a, uint32_t &b, uint32_t &c) {
+    uint2 ab;
+    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ab), "=&v"(c) : "v"(addr) : "memory");
+    a = ab.x;
+    b = ab.y;
+}
+// the window that starts at this lane's base in step s (k > 16: the code's high part is 2k - 32 bits of the first dword pair)
+__device__ __forceinline__ MzWin mz_window_rcw(const MzLaneGeom &g, uint32_t s, int k, int m, uint64_t mmask) {
+    uint32_t a, b, c, ra, rb, rc;
+    lds_read3_b32(g.f_addr + 16u * s, a, b, c);
+    lds_read3_b32(g.r_addr - 16u * s, ra, rb, rc);
+    const uint32_t fh = mz_alignbit(a, b, g.f_n), fl = mz_alignbit(b, c, g.f_n);      // 64 bits from the window's first base
+    const uint32_t rh = mz_alignbit(ra, rb, g.r_n), rl = mz_alignbit(rb, rc, g.r_n);  // 64 bits from its reverse complement's
+    const uint32_t sh = (uint32_t)(64 - 2 * k);  // 1 .. 31
+    const uint64_t f = ((uint64_t)(fh >> sh) << 32) | mz_alignbit(fh, fl, sh);
+    const uint64_t r = ((uint64_t)(rh >> sh) << 32) | mz_alignbit(rh, rl, sh);
+    return mz_win_from(f, r, k, m, mmask);
+}
+#endif
 
 // lane i <- lane i - 1, lane 0 <- fill
 __device__ __forceinline__ uint32_t mz_shift_up(uint32_t x, uint32_t fill) {
@@ -605,7 +711,12 @@ __device__ __forceinline__ uint32_t mz_pick(MzSlide<NT> &slide, uint32_t &e_cur,
     const uint32_t ew = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + nt - 1) & 63) * 4,
                                                                (int)(lane < nt - 1 ? e_nxt + kMzNextFrame : e_cur));
     e_cur = e_nxt;
+#if GS_MZ_RD
+    (void)rc_strand;
+    const uint32_t at = (ew & 0x7Fu) - 32u;  // lane of the chosen (leftmost smallest) t-mer (64.. = next step)
+#else
     const uint32_t at = rc_strand ? 95u - ((ew >> 16) & 0x7Fu) : (ew & 0x7Fu) - 32u;  // lane of the chosen t-mer (64.. = next step)
+#endif
     const uint32_t xoff = at - (uint32_t)lane;                                          // 0 .. nt - 1
     const uint32_t pm = WT == 4 ? (xoff & 3u) : xoff % (uint32_t)(WT ? WT : w);
     // the m-mer hash of lane + pm: of this step, or (last lanes) of the next one
@@ -614,6 +725,55 @@ __device__ __forceinline__ uint32_t mz_pick(MzSlide<NT> &slide, uint32_t &e_cur,
     const uint32_t h_next = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)nxt.h);
     return (uint32_t)lane + pm < 64u ? h_here : h_next;
 }
+
+// the m-mer hash of lane + pm: of this step, or (last lanes) of the next one
+__device__ __forceinline__ uint32_t mz_hash_at(uint32_t pm, const MzWin &cur, const MzWin &nxt, int lane) {
+    const int src = (int)(((uint32_t)lane + pm) & 63u) * 4;
+    const uint32_t h_here = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.h);
+    const uint32_t h_next = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)nxt.h);
+    return (uint32_t)lane + pm < 64u ? h_here : h_next;
+}
+#if GS_MZ_RD
+// ---- 16 t-mers per window (w = 4: k = 20 with m = 17): the sliding minimum inside the rows of 16 lanes ----------------------
+// A window's t-mers are lanes i .. i + 15 = the rest of its row of 16 lanes and the beginning of the next row.  With P = the
+// minimum over a row's lanes up to and including this one, S = over this lane to the end of the row (4 DPP row shifts each:
+// no LDS round trip, no wait), the window's minimum is min(S[i], P[i + 15]) -- P of the next row, or, for the last row, of the
+// NEXT step's first row.  Value = order << 7 | lane: the smaller lane wins a tie (the leftmost t-mer as the read shows it).
+struct MzRowSlide {
+    uint32_t P, S;  // of the step the slide was last advanced to
+    __device__ __forceinline__ void set(uint32_t order, int lane) {
+        uint32_t p = (order << 7) | (uint32_t)lane, q;
+        // v_min_u32 with a DPP source, in place: a lane whose source lies outside its row of 16 is switched off for that
+        // instruction and keeps its value.  (Written out: the compiler makes a copy, a DPP move and a minimum of every level.
+        // A DPP read needs two wait states after the write of its source: the two chains alternate, one s_nop between levels.)
+        asm("v_mov_b32 %1, %0\n\t"
+            "s_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_min_u32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_min_u32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_min_u32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_min_u32_dpp %1, %1, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1"
+            : "+v"(p), "=&v"(q));
+        P = p;
+        S = q;
+    }
+};
+// the m-mer offset (0..3) of the window that starts at this lane in the step the slide stands at, given the slide of the next
+// step; lane of the chosen t-mer = e & 0x7F (64.. = in the next step)
+__device__ __forceinline__ uint32_t mz_row_pick(const MzRowSlide &cur, const MzRowSlide &nxt, int lane) {
+    const uint32_t comb = lane < 16 ? nxt.P + 64u : cur.P;
+    const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 15) & 63) * 4, (int)comb);
+    const uint32_t e = min(cur.S, (lane & 15) ? q : 0xFFFFFFFFu);
+    return ((e & 0x7Fu) - (uint32_t)lane) & 3u;
+}
+#endif
 
 // self-test: the sliding pick against the rule applied lane by lane (mz_minimizer), on every window of the given tiles
 template <int KT, int MT>
@@ -633,14 +793,31 @@ __global__ __launch_bounds__(64) void k_mz_rule_check(int k_rt, int m_rt, const 
         __syncthreads();
         const uint32_t words_a = lds_addr(&s_words[0]);
         MzWin cur = mz_window_lds(words_a, 0, lane, k, m, kmask, mmask);
+        constexpr bool ROW = GS_MZ_RD && NT == 16;
         MzSlide<NT> slide;
         slide.reset();
-        uint32_t e_cur = slide.advance(mz_pk_of(cur.o, lane), lane, nt);
+        uint32_t e_cur = 0;
+#if GS_MZ_RD
+        MzRowSlide row_cur;
+        if constexpr (ROW) row_cur.set(cur.o, lane);
+        else
+#endif
+            e_cur = slide.advance(mz_pk_of(cur.o, lane), lane, nt);
         for (uint32_t s = 0; s < 32u; s++) {
             const MzWin nxt = mz_window_lds(words_a, s + 1u, lane, k, m, kmask, mmask);
             const bool rc_strand = cur.r < cur.f;
-            const uint32_t H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
-            const uint32_t want = mz_minimizer(rc_strand ? cur.r : cur.f, k, m);
+            uint32_t H;
+#if GS_MZ_RD
+            if constexpr (ROW) {
+                MzRowSlide row_nxt;
+                row_nxt.set(nxt.o, lane);
+                H = mz_hash_at(mz_row_pick(row_cur, row_nxt, lane), cur, nxt, lane);
+                row_cur = row_nxt;
+            } else
+#endif
+                H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
+            // the rule applied to this one k-mer: in its canonical orientation, or (GS_MZ_RD) as the read shows it
+            const uint32_t want = mz_minimizer(GS_MZ_RD ? cur.f : (rc_strand ? cur.r : cur.f), k, m);
             if (H != want) {
                 atomicAdd(&first_bad[4 + lane], 1u);  // per-lane histogram
                 if (atomicAdd(mismatches, 1ULL) == 0ULL) {
@@ -677,8 +854,26 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     const uint64_t locmask = (1ULL << locbits) - 1ULL;
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     // the tile's 64 words + the two after them (the buffer carries that much slack after the last read), staged in LDS
-    L.words[lane] = __builtin_nontemporal_load(words + td.wbase + lane);
-    if (lane < 3) L.words[64 + lane] = lane < 2 ? __builtin_nontemporal_load(words + td.wbase + 64 + lane) : 0ULL;
+    constexpr bool RCW = GS_MZ_RCW && KT > 16;
+    if constexpr (RCW) {
+#if GS_MZ_RCW
+        for (int j = lane; j < kTileWords + 3; j += 64) {  // (one more round for lanes 0..2)
+            const uint64_t wv = j < kTileWords + 2 ? __builtin_nontemporal_load(words + td.wbase + j) : 0ULL;
+            const uint64_t rv = ~revpairs(wv);  // the word's reverse complement: word (66 - j) of the reversed stream
+            L.fd[1 + 2 * j] = (uint32_t)(wv >> 32);
+            L.fd[2 + 2 * j] = (uint32_t)wv;
+            L.rd[2 * (kTileWords + 2 - j)] = (uint32_t)(rv >> 32);
+            L.rd[2 * (kTileWords + 2 - j) + 1] = (uint32_t)rv;
+        }
+        if (lane == 0) {
+            L.fd[0] = 0u;
+            L.rd[kMzStreamDwords] = 0u;
+        }
+#endif
+    } else {
+        L.words[lane] = __builtin_nontemporal_load(words + td.wbase + lane);
+        if (lane < 3) L.words[64 + lane] = lane < 2 ? __builtin_nontemporal_load(words + td.wbase + 64 + lane) : 0ULL;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint32_t nsteps = min((td.nwin_left + 63u) / 64u, 32u);
@@ -688,10 +883,26 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     // the key / tag to look for, lane r = region of run r, and the run count
     uint32_t fpT[kMzStages], regoff[kMzStages], runreg[kMzStages], nruns[kMzStages];  // fpT: fingerprint in all four bytes, bit 31 of regoff: invalid lane
     uint64_t want[kMzStages];
-    MzWin cur = mz_window_lds(words_a, 0, lane, k, m, kmask, mmask);
+#if GS_MZ_RCW
+    const MzLaneGeom geom = mz_lane_geom(lds_addr(&L.fd[0]), lds_addr(&L.rd[0]), lane, k);
+    auto window = [&](uint32_t s) {
+        if constexpr (RCW) return mz_window_rcw(geom, s, k, m, mmask);
+        else return mz_window_lds(words_a, s, lane, k, m, kmask, mmask);
+    };
+#else
+    auto window = [&](uint32_t s) { return mz_window_lds(words_a, s, lane, k, m, kmask, mmask); };
+#endif
+    MzWin cur = window(0u);
+    constexpr bool ROW = GS_MZ_RD && NT == 16;  // (the sliding minimum inside the rows of 16 lanes)
     MzSlide<NT> slide;
     slide.reset();
-    uint32_t e_cur = slide.advance(mz_pk_of(cur.o, lane), lane, nt);  // E of the step `cur` is the window of
+    uint32_t e_cur = 0;
+#if GS_MZ_RD
+    MzRowSlide row_cur;
+    if constexpr (ROW) row_cur.set(cur.o, lane);
+    else
+#endif
+        e_cur = slide.advance(mz_pk_of(cur.o, lane), lane, nt);  // E of the step `cur` is the window of
 
     // LDS-DMA wave-instructions that fetch the regions of (the first kMzRunCap of) R runs: 16 runs each
     constexpr uint32_t kRunsPerDma = 64 / kMzPieces;
@@ -711,9 +922,18 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     // FULL (compile-time): all 2048 windows of the tile exist (every tile of a read but its last), no lane is ever invalid
     auto stage = [&](uint32_t s, int slot, auto full_tile) {
         constexpr bool FULL = decltype(full_tile)::value;
-        const MzWin nxt = mz_window_lds(words_a, s + 1u, lane, k, m, kmask, mmask);
+        const MzWin nxt = window(s + 1u);
         const bool rc_strand = cur.r < cur.f;
-        const uint32_t H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
+        uint32_t H;
+#if GS_MZ_RD
+        if constexpr (ROW) {
+            MzRowSlide row_nxt;
+            row_nxt.set(nxt.o, lane);
+            H = mz_hash_at(mz_row_pick(row_cur, row_nxt, lane), cur, nxt, lane);
+            row_cur = row_nxt;
+        } else
+#endif
+            H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
         const uint64_t c = rc_strand ? cur.r : cur.f;
         cur = nxt;
         const MzKey key = mz_key_fmt<FMT>(c, k, locbits);
@@ -804,7 +1024,16 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
             if (j0 + (uint32_t)lane < dcount) {
                 const uint32_t ent = L.defer[j0 + lane];
                 const uint32_t wi = ent & 0xFFFFu;
-                const uint64_t a = L.words[wi >> 5], b2 = L.words[(wi >> 5) + 1];
+                uint64_t a, b2;
+                if constexpr (RCW) {
+#if GS_MZ_RCW
+                    a = ((uint64_t)L.fd[1 + 2 * (wi >> 5)] << 32) | L.fd[2 + 2 * (wi >> 5)];
+                    b2 = ((uint64_t)L.fd[3 + 2 * (wi >> 5)] << 32) | L.fd[4 + 2 * (wi >> 5)];
+#endif
+                } else {
+                    a = L.words[wi >> 5];
+                    b2 = L.words[(wi >> 5) + 1];
+                }
                 const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(wi & 31u), k, kmask);
                 uint64_t hh = slot_of(c, tab.shift);
                 Slot sl = load_slot(tab.slots + hh);

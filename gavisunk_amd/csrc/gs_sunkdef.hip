@@ -151,6 +151,23 @@ int gs::sort_pairs_u64_u32(const uint64_t *k_in, uint64_t *k_out, const uint32_t
     return GS_OK;
 }
 
+int gs::sort_keys_u64(const uint64_t *k_in, uint64_t *k_out, uint64_t n, void *stream) {
+    if (!n) return GS_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    size_t tb = 0;
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, k_in, k_out, n, 0u, 64u, st));
+    void *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+    hipError_t e = rocprim::radix_sort_keys(tmp, tb, k_in, k_out, n, 0u, 64u, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) {
+        set_error("radix sort failed: %s", hipGetErrorString(e));
+        return GS_E_NODEVICE;
+    }
+    return GS_OK;
+}
+
 struct gs_sunkset_dev {
     int device = 0, k = 0;
     uint64_t n = 0, n_groups = 0;

@@ -1,16 +1,10 @@
-"""Synthetic inputs for the SUNK-tagging path: assemblies, exact SUNK sets, ONT-like reads.
+"""Synthetic inputs for the SUNK-tagging path: assemblies and ONT-like reads.  BENCH / TEST SUPPORT, not on the product hot path.
 
-Nothing here is on the product hot path.  It exists because the reference ships no
-read data (`.test/data/*.ONT.fa.gz` are absent) and because the
-benchmark configurations of BASELINE.json are defined on synthetic surrogates
-(SURVEY.md §8d, Appendix B).  The SUNK definition below restates, with NumPy, what
-`workflow/rules/defineSUNKs.smk:22-127` obtains from jellyfish/mrsfast/bedtools:
-
-* canonical k-mers with count == 1 over all contigs of both haplotypes
-  (`jellyfish count -C`, `-U 1`; defineSUNKs.smk:39,59),
-* their exact positions (`mrsfast -e 0`, defineSUNKs.smk:101),
-* groups = merged overlapping / book-ended `[start, start+k)` intervals, group
-  id = start of the merged interval (`bedtools merge`, defineSUNKs.smk:124-126).
+It exists because the reference ships no read data (`.test/data/*.ONT.fa.gz` are absent) and because the
+benchmark configurations of BASELINE.json are defined on synthetic surrogates.  The SUNK set of
+an assembly comes from a `define` callable the caller supplies: the product's GPU definition (engine.define_sunks) in bench.py,
+the oracle's NumPy restatement of jellyfish / mrsfast / bedtools (oracle/sunkdef.py) in the tests -- the restatement itself is
+checker code and lives with the oracle, not here.
 """
 from __future__ import annotations
 
@@ -90,38 +84,6 @@ class SunkSet:
         with open(path, "w") as f:
             for ci, st, cd, g in zip(self.contig_id, self.start, self.code, self.group):
                 f.write(f"{self.contig_names[ci]}\t{int(st)}\t{decode_kmer(int(cd), self.k)}\t{int(g)}\n")
-
-
-def define_sunks(contigs: Sequence[Tuple[str, bytes]], k: int) -> SunkSet:
-    """Exact SUNK set of `contigs` [(name, ascii sequence)] (both haplotypes together)."""
-    codes_all, cid_all, pos_all = [], [], []
-    for ci, (_, seq) in enumerate(contigs):
-        a = np.frombuffer(seq, dtype=np.uint8)
-        cods = _CODE[a]
-        canon = canonical_codes(cods, k)
-        n = len(canon)
-        if n == 0:
-            continue
-        # windows containing a non-ACGT byte are not k-mers (jellyfish skips them)
-        bad = np.concatenate(([0], np.cumsum(~_IS_ACGT[a])))
-        ok = (bad[k:k + n] - bad[:n]) == 0
-        idx = np.nonzero(ok)[0]
-        codes_all.append(canon[idx])
-        cid_all.append(np.full(len(idx), ci, dtype=np.uint32))
-        pos_all.append(idx.astype(np.int64))
-    codes = np.concatenate(codes_all) if codes_all else np.zeros(0, np.uint64)
-    cid = np.concatenate(cid_all) if cid_all else np.zeros(0, np.uint32)
-    pos = np.concatenate(pos_all) if pos_all else np.zeros(0, np.int64)
-    _, first, counts = np.unique(codes, return_index=True, return_counts=True)
-    keep = np.sort(first[counts == 1])  # original order = (contig, pos) ascending
-    codes, cid, pos = codes[keep], cid[keep], pos[keep]
-    group = pos.copy()
-    if len(pos):
-        new = np.ones(len(pos), dtype=bool)
-        new[1:] = (cid[1:] != cid[:-1]) | ((pos[1:] - pos[:-1]) > k)
-        head = np.maximum.accumulate(np.where(new, np.arange(len(pos)), 0))  # index of each run's first SUNK
-        group = pos[head]
-    return SunkSet(k, [n for n, _ in contigs], cid, pos, codes, group.astype(np.int64))
 
 
 # ----------------------------------------------------------------------------------
@@ -214,10 +176,11 @@ def write_fasta(path: str, names: Sequence[str], reads: Sequence[np.ndarray], wi
                 f.write(b">" + n.encode() + b"\n" + s + b"\n")
 
 
-def config2(seed: int = 20, n_reads: int = 10000, k: int = 20, median: float = 20000.0):
-    """BASELINE.json configs[1]: 5 Mb contig, 10 k reads (N50 ~ 30 kb), k = 20."""
+def config2(define, seed: int = 20, n_reads: int = 10000, k: int = 20, median: float = 20000.0):
+    """BASELINE.json configs[1]: 5 Mb contig, 10 k reads (N50 ~ 30 kb), k = 20.  `define(contigs, k) -> SunkSet`: the SUNK
+    definition to use (engine.define_sunks on the GPU, oracle.sunkdef.define_sunks as the checker)."""
     seq, rng = genome_config2(seed)
-    sunks = define_sunks([("ctg5M", codes_to_ascii(seq))], k)
+    sunks = define([("ctg5M", codes_to_ascii(seq))], k)
     lens = lognormal_lengths(rng, n_reads, median)
     reads = simulate_reads(rng, [seq], lens)
     names = [f"r{i}" for i in range(n_reads)]

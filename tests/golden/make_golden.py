@@ -37,6 +37,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from gavisunk_amd import synth  # noqa: E402
+from oracle import sunkdef
 
 REF = "/root/reference"
 BIN = os.path.join(REF, "workflow", "scripts")
@@ -330,7 +331,7 @@ def case_multi(root, k):
     rng = np.random.default_rng(100 + k)
     contigs = _multi_genome(rng)
     names = ["ctgA", "ctgB#2", "ctgC"]
-    sunks = synth.define_sunks([(n, synth.codes_to_ascii(s)) for n, s in zip(names, contigs)], k)
+    sunks = sunkdef.define_sunks([(n, synth.codes_to_ascii(s)) for n, s in zip(names, contigs)], k)
     sunks.write_db(c.p("db"))
     sunks.write_loc(c.p("loc"))
     c.write("fai", "".join(f"{n}\t{len(s)}\t0\t60\t61\n" for n, s in zip(names[:2], contigs[:2])))
@@ -379,7 +380,7 @@ def case_amy(root):
     h1 = synth.read_fasta(os.path.join(REF, ".test/data/AMY.hap1.fa.gz"))
     h2 = synth.read_fasta(os.path.join(REF, ".test/data/AMY.hap2.fa.gz"))
     contigs = [(n, s.upper()) for n, s in h1 + h2]
-    sunks = synth.define_sunks(contigs, k)
+    sunks = sunkdef.define_sunks(contigs, k)
     sunks.write_db(c.p("db"))
     sunks.write_loc(c.p("loc"))
     for f in ("db", "loc"):

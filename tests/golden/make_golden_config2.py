@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Full-size golden for BASELINE.json configs[1] ("config 2": 5 Mb contig, 10 000 reads, k = 20): the reference's own
 prebuilt binaries (/root/reference/workflow/scripts/{kmerpos_annot3,rlen,diag_filter_v3,diag_filter_step2}; the
-commands of tagONT.smk:36,73,92,110) run on the exact inputs `gavisunk_amd.synth.config2(seed=20, n_reads=10000)`
+commands of tagONT.smk:36,73,92,110) run on the exact inputs `gavisunk_amd.synth.config2(oracle.sunkdef.define_sunks, seed=20, n_reads=10000)`
 produces -- the inputs of tests/test_fullsize_gpu.py and of bench.py's config-2 leg.
 
 The inputs (74 MiB db, 150 MiB loc, 230 MiB FASTA) are regenerated from the seed and never stored; what is kept under
@@ -29,6 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from gavisunk_amd import synth  # noqa: E402
+from oracle import sunkdef
 
 BIN = "/root/reference/workflow/scripts"
 K = 20
@@ -53,7 +54,7 @@ def decode_many(codes: np.ndarray, k: int) -> np.ndarray:
 
 
 def write_inputs(d):
-    seq, sunks, names, reads = synth.config2(seed=20, n_reads=10000, k=K)
+    seq, sunks, names, reads = synth.config2(sunkdef.define_sunks, seed=20, n_reads=10000, k=K)
     # db: one canonical k-mer per line, ascending code (jellyfish dump order does not matter to the tagger)
     kmers = decode_many(np.sort(sunks.code), K)
     with open(os.path.join(d, "c2.db"), "wb") as f:
@@ -97,7 +98,7 @@ def build(out_dir):
         n_sunks, n_bases = write_inputs(d)
         t_tag = run_reference(d)
         meta = {"k": K, "sunks": n_sunks, "reads": 10000, "bases": n_bases,
-                "generator": "gavisunk_amd.synth.config2(seed=20, n_reads=10000, k=20)",
+                "generator": "gavisunk_amd.synth.config2(sunkdef.define_sunks, seed=20, n_reads=10000, k=20)",
                 "reference_tagger_seconds_in_build_container": round(t_tag, 1),
                 "md5": {f: md5(os.path.join(d, f)) for f in ("c2.db", "c2.loc", "c2_reads.fa", "c2.fai", "c2.sunkpos", "c2.rlen",
                                                             "c2.diag", "c2.diag2")},

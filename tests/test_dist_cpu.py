@@ -18,14 +18,14 @@ import _gloo_helpers as gloo
 from gavisunk_amd import dist as gdist
 from gavisunk_amd import synth
 from gavisunk_amd._lib import GS_NONE
-from oracle import oracle
+from oracle import oracle, sunkdef
 
 
 def _case():
     k = 20
     rng = np.random.default_rng(11)
     g = rng.integers(0, 4, 40_000, dtype=np.uint8)
-    sunks = synth.define_sunks([("c", synth.codes_to_ascii(g))], k)
+    sunks = sunkdef.define_sunks([("c", synth.codes_to_ascii(g))], k)
     loc = (sunks.start // 700).astype(np.uint32)  # coarse groups: carries across reads do happen
     lens = synth.lognormal_lengths(rng, 41, median=900, sigma=0.7, lo=1, hi=20000)
     reads = [synth.codes_to_ascii(r) for r in synth.simulate_reads(rng, [g], lens, sub=0.005, dele=0.005, ins=0.005)]

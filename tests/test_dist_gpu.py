@@ -12,6 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import _gloo_helpers as gloo
+from oracle import sunkdef
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +23,7 @@ def _case():
     k = 20
     rng = np.random.default_rng(77)
     g = rng.integers(0, 4, 60_000, dtype=np.uint8)
-    sunks = synth.define_sunks([("c", synth.codes_to_ascii(g))], k)
+    sunks = sunkdef.define_sunks([("c", synth.codes_to_ascii(g))], k)
     loc = (sunks.start // 900).astype(np.uint32)
     lens = synth.lognormal_lengths(rng, 53, median=2500, sigma=0.8, lo=1, hi=30000)
     reads = [synth.codes_to_ascii(r) for r in synth.simulate_reads(rng, [g], lens, sub=0.005, dele=0.005, ins=0.005)]

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 from gavisunk_amd import _lib, engine, synth
-from oracle import oracle
+from oracle import oracle, sunkdef
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +27,7 @@ CONFIG2_ROWS = {}
 
 @pytest.fixture(scope="module")
 def config2():
-    seq, sunks, names, reads = synth.config2(seed=20, n_reads=10000, k=K)
+    seq, sunks, names, reads = synth.config2(sunkdef.define_sunks, seed=20, n_reads=10000, k=K)
     keys = sunks.code.astype(np.uint64)
     _, loc = np.unique(sunks.group, return_inverse=True)  # one contig: the group decides the location id
     loc = loc.astype(np.uint32)

@@ -2,7 +2,7 @@
 import pytest
 
 from conftest import DIAG_CASES, TAG_CASES
-from oracle import oracle
+from oracle import oracle, sunkdef
 
 
 @pytest.mark.parametrize("name", TAG_CASES)
@@ -75,7 +75,7 @@ def test_oracle_config2_full_size_against_reference_binary():
 
     d = os.path.join(GOLDEN, "config2_full")
     meta = json.load(open(os.path.join(d, "case.json")))
-    seq, sunks, names, reads = synth.config2(seed=20, n_reads=10000, k=20)
+    seq, sunks, names, reads = synth.config2(sunkdef.define_sunks, seed=20, n_reads=10000, k=20)
     assert len(sunks) == meta["sunks"] and sum(len(r) for r in reads) == meta["bases"]
     t = oracle.Table(20, sunks.code, sunks.code, sunks.contig_id, sunks.group)
     buf, off = oracle.concat_reads([synth.codes_to_ascii(r) for r in reads])

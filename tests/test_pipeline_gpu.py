@@ -7,7 +7,7 @@ import pytest
 
 from gavisunk_amd import (badsunks, define_sunks, diag_filter_step2, diag_filter_v3, kmerpos_annot3, process_by_contig,
                           rlen, synth)
-from oracle import oracle
+from oracle import oracle, sunkdef
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +31,7 @@ def test_file_to_file_pipeline(tmp_path):
         (d / f"hap{h}.fa.fai").write_text(f"hap{h}_ctg\t{len(s)}\t10\t{len(s)}\t{len(s) + 1}\n")
     # SUNK definition (GPU) -> db + loc, checked against the NumPy restatement
     assert define_sunks.main(["-k", "20", str(d / "hap1.fa"), str(d / "hap2.fa"), "--db", str(d / "db"), "--loc", str(d / "loc")]) == 0
-    exp = synth.define_sunks([("hap1_ctg", synth.codes_to_ascii(haps[0])), ("hap2_ctg", synth.codes_to_ascii(haps[1]))], 20)
+    exp = sunkdef.define_sunks([("hap1_ctg", synth.codes_to_ascii(haps[0])), ("hap2_ctg", synth.codes_to_ascii(haps[1]))], 20)
     exp.write_loc(str(d / "loc.exp"))
     assert (d / "loc").read_text() == (d / "loc.exp").read_text() and len(exp) > 1000
     sunkpos = {}

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from gavisunk_amd import _lib, engine, synth
-from oracle import oracle
+from oracle import oracle, sunkdef
 
 pytestmark = pytest.mark.gpu
 
@@ -16,7 +16,7 @@ def _case(seed, n_reads=300, glen=120000, median=2500, groups_div=40):
     rng = np.random.default_rng(seed)
     g = rng.integers(0, 4, glen, dtype=np.uint8)
     g[50000:53000] = g[10000:13000]
-    sunks = synth.define_sunks([("c", synth.codes_to_ascii(g))], K)
+    sunks = sunkdef.define_sunks([("c", synth.codes_to_ascii(g))], K)
     keys, loc = sunks.code, (sunks.start // groups_div).astype(np.uint32)
     lens = synth.lognormal_lengths(rng, n_reads, median=median, sigma=0.9, lo=1, hi=glen - 1)
     seqs = [synth.codes_to_ascii(r) for r in synth.simulate_reads(rng, [g], lens, sub=0.01, dele=0.01, ins=0.01)]

@@ -7,7 +7,7 @@ import pytest
 
 from conftest import TAG_CASES
 from gavisunk_amd import _lib, engine, kmerpos_annot3, synth
-from oracle import oracle
+from oracle import oracle, sunkdef
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +46,7 @@ def _random_case(seed, k, n_reads=40, glen=30000, median=1500, n_groups_div=50):
     rng = np.random.default_rng(seed)
     g = rng.integers(0, 4, glen, dtype=np.uint8)
     g[5000:6000] = g[1000:2000]  # a repeat: those k-mers are not unique
-    sunks = synth.define_sunks([("c", synth.codes_to_ascii(g))], k)
+    sunks = sunkdef.define_sunks([("c", synth.codes_to_ascii(g))], k)
     keys = sunks.code
     loc = (sunks.start // n_groups_div).astype(np.uint32)  # many small location groups
     lens = synth.lognormal_lengths(rng, n_reads, median=median, sigma=0.8, lo=1, hi=glen - 1)
@@ -406,7 +406,7 @@ def test_exact_reads_fill_and_flush_the_hit_list(groups_div, table_layout):
     k = 20
     rng = np.random.default_rng(77)
     g = rng.integers(0, 4, 50000, dtype=np.uint8)
-    sunks = synth.define_sunks([("c", synth.codes_to_ascii(g))], k)
+    sunks = sunkdef.define_sunks([("c", synth.codes_to_ascii(g))], k)
     keys, loc = sunks.code, (sunks.start // groups_div).astype(np.uint32)
     asc = synth.codes_to_ascii(g)
     seqs = [asc[100:9000], asc[20000:20019], asc[30000:49999], synth.codes_to_ascii((3 - g[::-1])[1000:7000])]

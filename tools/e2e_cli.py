@@ -4,12 +4,13 @@ import os, sys, time, tempfile, gzip, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gavisunk_amd import synth, kmerpos_annot3, engine, _lib
+from oracle import sunkdef
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 d = tempfile.mkdtemp(prefix="gs_e2e_")
 t0 = time.perf_counter()
 genome, rng = synth.genome_config2(20)
-sunks = synth.define_sunks([("ctg5M", synth.codes_to_ascii(genome))], 20)
+sunks = sunkdef.define_sunks([("ctg5M", synth.codes_to_ascii(genome))], 20)
 codes = np.sort(sunks.code)
 # fast writers (numpy): db and loc
 A = np.frombuffer(b"ACGT", np.uint8)

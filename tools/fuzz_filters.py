@@ -14,7 +14,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gavisunk_amd import badsunks, diag_filter_step2, diag_filter_v3, engine, process_by_contig, synth  # noqa: E402
-from oracle import oracle  # noqa: E402
+from oracle import oracle, sunkdef  # noqa: E402
 
 
 def fuzz_diag(seed, tmp):
@@ -120,7 +120,7 @@ def fuzz_sunkdef(seed, tmp):
     if contigs[0][1] and rng.random() < 0.5:  # a reverse-complement copy: those k-mers stop being unique
         src = synth.ascii_to_codes(contigs[0][1][:4000].upper().replace(b"N", b"A"))
         contigs.append(("rc0", synth.codes_to_ascii(synth.revcomp_codes(src))))
-    exp = synth.define_sunks(contigs, k)
+    exp = sunkdef.define_sunks(contigs, k)
     got = engine.define_sunks(contigs, k)
     same = (len(got) == len(exp) and np.array_equal(got.contig_id, exp.contig_id) and np.array_equal(got.start, exp.start)
             and np.array_equal(got.code, exp.code) and np.array_equal(got.group, exp.group))

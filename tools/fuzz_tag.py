@@ -14,7 +14,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gavisunk_amd import _lib, engine, synth  # noqa: E402
-from oracle import oracle  # noqa: E402
+from oracle import oracle, sunkdef  # noqa: E402
 
 K = 20  # k of the current round (most rounds: GAVISUNK's default 20)
 LAYOUTS = ["auto", "compact-lds", "compact-l2", "compact-hbm", "minimizer", "generic"]
@@ -33,7 +33,7 @@ def draw(seed):
     if rng.random() < 0.3:
         a = int(rng.integers(0, glen - 500))
         g[a:a + 400] = 0  # a poly-A stretch in the assembly
-    sunks = synth.define_sunks([("c", synth.codes_to_ascii(g))], K)
+    sunks = sunkdef.define_sunks([("c", synth.codes_to_ascii(g))], K)
     keys, start = sunks.code, sunks.start
     if len(keys) > 10 and rng.random() < 0.4:  # thin the table: lower hit rate
         keep = rng.random(len(keys)) < rng.uniform(0.05, 0.9)
