@@ -297,6 +297,57 @@ def config2_cli(sunks, names, reads, n_bases, want):
     return res
 
 
+def cli_large_leg(a, device):
+    """End to end at >= 1e8 keys (SURVEY.md section 8d measurement (iii)): the command-line drop-in on FILES -- a 200 Mb assembly
+    surrogate's k-mer list and location table (1e8 rows of text each, written natively) and a read file -- as rule SUNK_annot runs
+    it once per scatter chunk (tagONT.smk:19-37): parsing the two text files every time like the reference
+    (kmerpos_annot3.nim:20-72), and with the prebuilt sidecar (`--prepare`: parsed rows + built table, fingerprinted)."""
+    import shutil
+    import tempfile
+
+    from gavisunk_amd import engine, kmerpos_annot3, synth_gpu
+
+    if shutil.disk_usage("/tmp").free < 48 << 30:
+        return {"skipped": "less than 48 GiB free in /tmp"}
+    res = {}
+    with tempfile.TemporaryDirectory(prefix="gs_bench_cli_large_", dir="/tmp") as d:
+        t0 = time.perf_counter()
+        gen = synth_gpu.Genome(200_000_000, n_contigs=24, seed=31, device=device)
+        sunks = engine.DeviceSunkSet(gen.ptr, gen.off, 20, device)
+        sunks.write_files(gen.names, f"{d}/db", f"{d}/loc")
+        rng = np.random.default_rng(31)
+        rs = synth_gpu.ReadSet(gen, synth_gpu.lognormal_lengths(rng, 4000, median=32000.0), seed=31000)
+        gen.close()
+        with open(f"{d}/reads.fa", "wb") as f:
+            for i, sq in enumerate(rs.host_reads(0, rs.n_reads)):
+                f.write(b">r%d\n" % i + sq + b"\n")
+        n_bases, n_keys = rs.n_bases, sunks.n
+        rs.close()
+        sunks.close()
+        log(f"CLI at {n_keys} keys: files written ({time.perf_counter() - t0:.1f} s; db {os.path.getsize(f'{d}/db') / 2**30:.1f} GiB, loc {os.path.getsize(f'{d}/loc') / 2**30:.1f} GiB)")
+
+        def run(tag):
+            t1 = time.perf_counter()
+            rc = kmerpos_annot3.main([f"{d}/reads.fa", f"{d}/db", f"{d}/loc", f"{d}/out.{tag}"])
+            return rc, time.perf_counter() - t1
+
+        rc1, t_plain = run("plain")
+        t1 = time.perf_counter()
+        rc2 = kmerpos_annot3.main(["--prepare", f"{d}/db", f"{d}/loc"])
+        t_prep = time.perf_counter() - t1
+        rc3, t_side = run("side")
+        same = rc1 == rc2 == rc3 == 0 and open(f"{d}/out.plain", "rb").read() == open(f"{d}/out.side", "rb").read()
+        res = {"keys": int(n_keys), "read_bases": int(n_bases), "rows_out": open(f"{d}/out.plain", "rb").read().count(b"\n"),
+               "parse_and_build_every_run": {"seconds": round(t_plain, 2), "cli_bases_per_s": n_bases / t_plain},
+               "prepare_once": {"seconds": round(t_prep, 2), "sidecar_GiB": round(os.path.getsize(f"{d}/loc.gsidx") / 2**30, 2)},
+               "with_sidecar": {"seconds": round(t_side, 2), "cli_bases_per_s": n_bases / t_side},
+               "same_bytes": bool(same),
+               "note": "`python -m gavisunk_amd.kmerpos_annot3 reads.fa db loc out` in a warm process on a 200 Mb surrogate's files (the reference parses db and loc on every "
+                       "run, once per scatter chunk: kmerpos_annot3.nim:20-72, tagONT.smk:19-37); with_sidecar = after `--prepare db loc` (parsed location rows + built table in "
+                       "loc.gsidx, used only while its fingerprints of db and loc hold)"}
+    return res
+
+
 def engine_leg(a, table, batches, device, target_bases=2.2e10):
     """SURVEY.md section 8(d) measurement (ii): host-packed reads in PINNED host memory -> hits on the host, through the
     streaming engine (gs_stream_*): upload of batch i + 1 overlapped with the pass of batch i, hit lists fetched on the copy
@@ -355,7 +406,7 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="reads per shard (default: the workload's own)")
     ap.add_argument("--genome-mb", type=float, default=None, help="assembly size in Mb per haplotype (default: the workload's own)")
     ap.add_argument("--shards", type=int, default=None, help="diploid: read shards per rank (default 8 / ranks at N > 1, 1 at N = 1)")
-    ap.add_argument("--batches", type=int, default=None, help="resident device batches per shard (default 8; diploid 2)")
+    ap.add_argument("--batches", type=int, default=None, help="resident device batches per shard (default 8)")
     ap.add_argument("--k", type=int, default=20, help="SUNK length (headline: 20; 21 / 25 = BASELINE.json configs[4])")
     ap.add_argument("--check-reads", type=int, default=1000, help="reads of the stream the oracle walks for the parity leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-time budget of the CPU baseline sample")
@@ -365,6 +416,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra workload key (N = 1: one diploid shard; N > 1: config-3 weak scaling)")
     ap.add_argument("--cli", action="store_true", help="(default now) config-2 leg: also time the command-line drop-in")
     ap.add_argument("--no-cli", action="store_true", help="config-2 leg without the command-line timing")
+    ap.add_argument("--no-cli-large", action="store_true", help="skip the command-line timing at 1e8 keys (files of a 200 Mb surrogate, with / without the sidecar)")
     a = ap.parse_args()
     a.cli = not a.no_cli
 
@@ -597,7 +649,7 @@ def main():
     if wname == "diploid":
         per_rank = a.shards if a.shards else (max(8 // world, 1) if world > 1 else 1)
         shards = list(range(rank * per_rank, (rank + 1) * per_rank))
-        bps = a.batches or 2
+        bps = a.batches or 8
     else:
         shards = [rank]
         bps = a.batches or 8
@@ -658,7 +710,7 @@ def main():
     # ---- the other genome-scale workload as an extra key --------------------------------------------------------------
     if not a.no_extra and a.workload == "auto" and K == 20 and a.genome_mb is None and a.reads is None:
         if world == 1:
-            ex = run_workload("diploid", [0], 2, max(3, a.steps // 2), 1, want_sample=False)
+            ex = run_workload("diploid", [0], 8, max(3, a.steps // 2), 1, want_sample=False)
             if rank == 0:
                 d = describe(ex, False)
                 out["diploid_shard"] = {k_: d[k_] for k_ in ("value", "unit", "ms_per_step", "config", "roofline")}
@@ -674,6 +726,11 @@ def main():
     if rank == 0:
         if not a.no_config2 and world == 1 and K == 20:
             out["config2"] = config2_leg(a, device)
+            if a.cli and not a.no_cli_large and a.workload == "auto" and a.genome_mb is None:
+                try:
+                    out["cli_1e8_keys"] = cli_large_leg(a, device)
+                except Exception as e:  # (a measurement leg must not cost the headline)
+                    out["cli_1e8_keys"] = {"failed": str(e)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:

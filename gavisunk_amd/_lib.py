@@ -114,6 +114,8 @@ SIGNATURES = {
     "gs_comm_unique_id": (I, [P]),
     "gs_comm_init": (I, [I, I, I, P, C.POINTER(P)]),
     "gs_table_clone": (I, [P, C.POINTER(P)]),
+    "gs_sidecar_write": (I, [C.c_char_p, P, P, C.c_char_p, C.c_char_p]),
+    "gs_sidecar_open": (I, [C.c_char_p, C.c_char_p, C.c_char_p, I, C.POINTER(P), C.POINTER(P)]),
     "gs_comm_allgather_u64": (I, [P, P, U32, P]),
     "gs_comm_destroy": (None, [P]),
     "gs_table_broadcast": (I, [P, I, P, C.POINTER(P)]),
@@ -140,6 +142,7 @@ SIGNATURES = {
     "gs_union_regions": (I, [I, U64, P, P, U32, P, P, P, P]),
     "gs_sunks_define": (I, [I, I, U32, P, P, C.POINTER(P)]),
     "gs_sunks_define_device": (I, [I, I, U32, P, P, C.POINTER(P)]),
+    "gs_sunkset_dev_write_files": (I, [P, C.POINTER(C.c_char_p), U32, C.c_char_p, C.c_char_p]),
     "gs_sunkset_dev_free": (None, [P]),
     "gs_sunkset_dev_n": (U64, [P]),
     "gs_sunkset_dev_n_groups": (U64, [P]),

@@ -3469,3 +3469,4 @@ int gs_reads_copy_words(const gs_reads *r, uint64_t word_lo, uint64_t n_words, u
 
 #include "gs_stream.h"
 #include "gs_comm.h"
+#include "gs_sidecar.h"

@@ -106,8 +106,8 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
 }
 
 // One workgroup per read; scratch per row (all uint32): deg, rank, vert, parent, size, plus app / vidx / flag below.
-// n hits of a read give up to n (n - 1) / 2 edges (n ~ 10^2 .. 10^3 on diploid assemblies): every phase is spread over
-// the workgroup, O(n^2 + E) work per read.
+// n hits of a read give up to n (n - 1) / 2 edges (n ~ 10^2 .. 10^3 on diploid assemblies, more on ultra-long reads): every
+// phase is spread over the workgroup, O(n^2 + E) work per read -- no phase scans the rows more than once per row.
 //   deg[i]   occurrences of row i in mergedf = [first endpoints in edge order] ++ [second endpoints] (:160-163)
 //   rank[i]  where it first occurs there
 //   multi-position clean-up (:167-181), then the graph over ID values with vertices numbered by first appearance
@@ -150,37 +150,55 @@ __global__ __launch_bounds__(kGraphThreads) void k_pair_graph(uint32_t n_reads, 
     }
     __syncthreads();
     // IDs seen with more than one pos keep their most frequent pos (value_counts().index[0]; ties: the pos that appears
-    // first in mergedf); gp[row] = that pos for rows of such an ID, else "no constraint" (vt[row] = 0 / 1 marks which)
+    // first in mergedf); gp[row] = that pos for rows of such an ID, else "no constraint" (vt[row] = 0 / 1 marks which).
+    // Two passes of one scan over the read's rows each -- O(n^2) per read over the workgroup, like the pair enumeration:
+    //   A  per row: does its ID occur with another pos; occurrences of ITS (ID, pos) in mergedf (cs), where that pair first
+    //      occurs there (pa), and whether the row is the first one of its (ID, pos) (ap)
+    //   B  per row of a multi-position ID: the (ID, pos) with the most occurrences, the earliest on ties
     for (int a = tid; a < n; a += kGraphThreads) {
         vt[a] = 0;
+        cs[a] = 0;
+        pa[a] = kNone;
+        ap[a] = 0;
         if (!dg[a]) continue;
-        bool multi = false;
-        for (int b = 0; b < n; b++)
-            if (dg[b] && ID[b] == ID[a] && P[b] != P[a]) multi = true;
-        if (!multi) continue;
-        int64_t goodpos = 0;
-        uint64_t best_cnt = 0;
-        uint32_t best_rank = kNone;
+        bool multi = false, first_of_pos = true;
+        uint32_t cnt = 0, rnk = kNone;
+        const int64_t ida = ID[a], pa_ = P[a];
         for (int b = 0; b < n; b++) {
-            if (!dg[b] || ID[b] != ID[a]) continue;
-            bool first_of_pos = true;
-            uint64_t cnt = 0;
-            uint32_t rnk = kNone;
-            for (int c = 0; c < n; c++) {
-                if (!dg[c] || ID[c] != ID[a] || P[c] != P[b]) continue;
-                if (c < b) first_of_pos = false;
-                cnt += dg[c];
-                rnk = min(rnk, rk[c]);
+            if (!dg[b] || ID[b] != ida) continue;
+            if (P[b] != pa_) {
+                multi = true;
+                continue;
             }
-            if (!first_of_pos) continue;
-            if (cnt > best_cnt || (cnt == best_cnt && rnk < best_rank)) {
-                best_cnt = cnt;
-                best_rank = rnk;
+            cnt += dg[b];
+            rnk = min(rnk, rk[b]);
+            if (b < a) first_of_pos = false;
+        }
+        vt[a] = multi ? 1u : 0u;
+        cs[a] = cnt;
+        pa[a] = rnk;
+        ap[a] = first_of_pos ? 1u : 0u;
+    }
+    __syncthreads();
+    for (int a = tid; a < n; a += kGraphThreads) {
+        if (!vt[a]) continue;
+        int64_t goodpos = 0;
+        uint32_t best_cnt = 0, best_rank = kNone;
+        const int64_t ida = ID[a];
+        for (int b = 0; b < n; b++) {
+            if (!ap[b] || ID[b] != ida) continue;  // (ap is set only on rows that occur in mergedf)
+            if (cs[b] > best_cnt || (cs[b] == best_cnt && pa[b] < best_rank)) {
+                best_cnt = cs[b];
+                best_rank = pa[b];
                 goodpos = P[b];
             }
         }
         gp[a] = goodpos;
-        vt[a] = 1;
+    }
+    __syncthreads();
+    for (int a = tid; a < n; a += kGraphThreads) {  // (the scratch goes back to what the next phases expect)
+        ap[a] = kNone;
+        cs[a] = 0;
     }
     __syncthreads();
     // ... and lose the pairs that start at that ID and touch the good pos on neither side (:175-176); the first appearance of

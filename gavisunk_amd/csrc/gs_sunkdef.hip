@@ -12,6 +12,7 @@
 //   k_group_flags / inclusive sum-scan / k_group_loc   group = start of the run with gaps <= k, loc = dense id of the run
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -452,6 +453,102 @@ int gs_sunks_define_device(int device, int k, uint32_t n_contigs, const void *d_
         return rc;
     }
     *out = res;
+    return GS_OK;
+}
+
+// The two text files the tagger reads (workflow/rules/defineSUNKs.smk:59,126), written natively from a device-resident SUNK set:
+// <db> = one canonical k-mer per line in ascending code order, <loc> = `contig \t start \t k-mer \t group` rows in (contig,
+// start) order.  (The Python writer of the small-assembly path formats a row at a time: minutes at 1e8 rows.)
+int gs_sunkset_dev_write_files(const gs_sunkset_dev *s, const char *const *contig_names, uint32_t n_names, const char *db_path,
+                               const char *loc_path) {
+    if (!s || !db_path || !loc_path || (n_names && !contig_names)) {
+        set_error("gs_sunkset_dev_write_files: bad argument");
+        return GS_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    const uint64_t n = s->n;
+    const int k = s->k;
+    std::vector<uint64_t> code(n), pos(n);
+    std::vector<uint32_t> grp(n);
+    if (n) {
+        HIP_TRY(hipMemcpy(code.data(), s->code, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(pos.data(), s->pos, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(grp.data(), s->group, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    auto put_kmer = [k](char *o, uint64_t c) {
+        for (int j = 0; j < k; j++) o[j] = "ACGT"[(c >> (2 * (k - 1 - j))) & 3];
+    };
+    auto put_uint = [](char *o, uint64_t v) {
+        char tmp[24];
+        int m = 0;
+        do {
+            tmp[m++] = (char)('0' + v % 10);
+            v /= 10;
+        } while (v);
+        for (int j = 0; j < m; j++) o[j] = tmp[m - 1 - j];
+        return m;
+    };
+    {
+        FILE *f = fopen(loc_path, "wb");
+        if (!f) {
+            set_error("cannot create %s", loc_path);
+            return GS_E_IO;
+        }
+        std::vector<char> buf;
+        buf.reserve(1 << 22);
+        for (uint64_t i = 0; i < n; i++) {
+            const uint32_t c = (uint32_t)(pos[i] >> 32);
+            if (c >= n_names) {
+                fclose(f);
+                set_error("gs_sunkset_dev_write_files: contig %u has no name", c);
+                return GS_E_ARG;
+            }
+            const char *nm = contig_names[c];
+            const size_t ln = strlen(nm);
+            const size_t at = buf.size();
+            buf.resize(at + ln + k + 48);
+            char *o = buf.data() + at;
+            memcpy(o, nm, ln);
+            o += ln;
+            *o++ = '\t';
+            o += put_uint(o, pos[i] & 0xFFFFFFFFull);
+            *o++ = '\t';
+            put_kmer(o, code[i]);
+            o += k;
+            *o++ = '\t';
+            o += put_uint(o, grp[i]);
+            *o++ = '\n';
+            buf.resize((size_t)(o - buf.data()));
+            if (buf.size() > (1u << 22) - 256) {
+                fwrite(buf.data(), 1, buf.size(), f);
+                buf.clear();
+            }
+        }
+        fwrite(buf.data(), 1, buf.size(), f);
+        if (fclose(f) != 0) {
+            set_error("writing %s failed", loc_path);
+            return GS_E_IO;
+        }
+    }
+    std::sort(code.begin(), code.end());
+    FILE *f = fopen(db_path, "wb");
+    if (!f) {
+        set_error("cannot create %s", db_path);
+        return GS_E_IO;
+    }
+    std::vector<char> buf((size_t)(k + 1) * 65536);
+    for (uint64_t i0 = 0; i0 < n; i0 += 65536) {
+        const uint64_t m = std::min<uint64_t>(65536, n - i0);
+        for (uint64_t j = 0; j < m; j++) {
+            put_kmer(buf.data() + j * (k + 1), code[i0 + j]);
+            buf[j * (k + 1) + k] = '\n';
+        }
+        fwrite(buf.data(), 1, (size_t)m * (k + 1), f);
+    }
+    if (fclose(f) != 0) {
+        set_error("writing %s failed", db_path);
+        return GS_E_IO;
+    }
     return GS_OK;
 }
 

@@ -54,6 +54,50 @@ class SunkDB:
 
     __del__ = close
 
+    @classmethod
+    def _wrap(cls, h) -> "SunkDB":
+        self = cls.__new__(cls)
+        self._h = h
+        L = lib()
+        self.k = L.gs_sunkdb_k(h)
+        nk, nr = L.gs_sunkdb_n_keys(h), L.gs_sunkdb_n_rows(h)
+        self.keys = _view(L.gs_sunkdb_keys(h), nk, np.uint64)
+        self.key_row = _view(L.gs_sunkdb_key_row(h), nk, np.uint32)
+        self.key_loc = _view(L.gs_sunkdb_key_loc(h), nk, np.uint32)
+        self.row_contig = _view(L.gs_sunkdb_row_contig(h), nr, np.uint32)
+        self.row_start = _view(L.gs_sunkdb_row_start(h), nr, np.int64)
+        self.row_group = _view(L.gs_sunkdb_row_group(h), nr, np.int64)
+        self.row_loc = _view(L.gs_sunkdb_row_loc(h), 0, np.uint32)
+        self.contigs = [L.gs_sunkdb_contig_name(h, i).decode() for i in range(L.gs_sunkdb_n_contigs(h))]
+        return self
+
+
+def sidecar_path(loc_path: str) -> str:
+    return loc_path + ".gsidx"
+
+
+def open_sidecar(db_path: str, loc_path: str, device: int = 0):
+    """(SunkDB, DeviceTable) from the prebuilt sidecar of the two files (gs_sidecar_open), or None when there is none or it is
+    stale: the caller then parses and builds as the reference does on every run (kmerpos_annot3.nim:20-72)."""
+    side = sidecar_path(loc_path)
+    if not os.path.exists(side):
+        return None
+    dbh, th = C.c_void_p(), C.c_void_p()
+    st = lib().gs_sidecar_open(side.encode(), db_path.encode(), loc_path.encode(), device, C.byref(dbh), C.byref(th))
+    if st == _lib.GS_E_IO:
+        return None
+    check(st)
+    db = SunkDB._wrap(dbh)
+    t = DeviceTable.__new__(DeviceTable)
+    t._h, t.k, t.device, t.n = th, db.k, device, None
+    return db, t
+
+
+def write_sidecar(db: "SunkDB", table: "DeviceTable", db_path: str, loc_path: str) -> str:
+    side = sidecar_path(loc_path)
+    check(lib().gs_sidecar_write(side.encode(), db._h, table._h, db_path.encode(), loc_path.encode()))
+    return side
+
 
 class ReadBatch:
     """Host-side packed batch (gs_batch)."""
@@ -516,6 +560,11 @@ class DeviceSunkSet:
 
     def loc(self, lo=0, hi=None):
         return self._host(lib().gs_sunkset_dev_loc(self._h), np.uint32, lo, hi)
+
+    def write_files(self, contig_names: Sequence[str], db_path: str, loc_path: str) -> None:
+        """The tagger's two input files (<db>: k-mer list, <loc>: location table), written natively (gs_sunkset_dev_write_files)."""
+        arr = (C.c_char_p * len(contig_names))(*[n.encode() for n in contig_names])
+        check(lib().gs_sunkset_dev_write_files(self._h, arr, len(contig_names), db_path.encode(), loc_path.encode()))
 
     def table(self) -> "DeviceTable":
         """The tagger's table straight from the device arrays (payload of a hit = its kmer.loc row)."""

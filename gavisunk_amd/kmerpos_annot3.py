@@ -9,6 +9,12 @@ Environment: GAVISUNK_DEVICE (GPU index, default 0), GAVISUNK_BATCH_BASES (bases
 batch, default 2^31), GAVISUNK_PARSE=host (records parsed by the native host reader instead of on the GPU; the default
 falls back to it by itself for texts outside the regular FASTA / four-line FASTQ forms).
 
+Prebuilt sidecar: the rule runs this program once per scatter chunk (tagONT.smk:19-37) and the reference parses <kmers.db> and
+<kmer.loc> every time (kmerpos_annot3.nim:20-72: 1.5e9 text rows each at genome scale).  When `<kmer.loc>.gsidx` exists and
+its fingerprints of the two files still hold, the parsed location rows and the BUILT device table are taken from it instead
+(gs_sidecar_open); a stale or foreign one is ignored silently.  It is written by `--prepare <kmers.db> <kmer.loc>` (no reads:
+parse, build, write) or by any run with GAVISUNK_WRITE_SIDECAR=1.  The output bytes are the same either way.
+
 `--emulate-chunks N` (after the four positionals): <reads> is a WHOLE haplotype's read file
 and <out> becomes what the workflow's scatter produces for it -- the reads dealt to N chunk files record by record
 (`seqtk seq -F '#' | rustybam fastq-split`, tagONT.smk:2-18; round-robin, as rustybam is believed to deal them: the tool is
@@ -176,7 +182,9 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
     batches = _Prefetch(reads, batch_bases) if host_parse else None
     blocks = None if host_parse else _Prefetch(reads, min(batch_bases, 1 << 30), text=True, device=device)  # (read and copied meanwhile)
     try:
-        db = engine.SunkDB(kmers, locs)
+        pre = engine.open_sidecar(kmers, locs, device)  # the prebuilt rows + table, when valid
+        if pre is None:
+            db = engine.SunkDB(kmers, locs)
     except _lib.GsError as e:
         for pf in (batches, blocks):
             if pf is not None:
@@ -185,7 +193,15 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
         return 1
     sys.stderr.write("FINISHED READING KMERS\n")
     sys.stderr.write("FINISHED READING LOCS\n")
-    table = engine.DeviceTable.from_db(db, device)
+    if pre is not None:
+        db, table = pre
+    else:
+        table = engine.DeviceTable.from_db(db, device)
+        if os.environ.get("GAVISUNK_WRITE_SIDECAR") == "1":
+            try:
+                engine.write_sidecar(db, table, kmers, locs)
+            except (_lib.GsError, OSError) as e:  # (a read-only directory must not fail the run)
+                sys.stderr.write(f"sidecar not written: {e}\n")
     rc = None
     if not host_parse:  # records parsed on the GPU; texts it does not take (multi-line FASTQ, ...) go to the host parser
         try:
@@ -255,8 +271,25 @@ def run_chunked(reads: str, kmers: str, locs: str, ofile: str, nchunks: int, dev
     return rc
 
 
+def prepare(kmers: str, locs: str, device: int = 0) -> int:
+    """`--prepare <kmers.db> <kmer.loc>`: parse, build, write the sidecar (what every later run over the two files then skips)."""
+    try:
+        db = engine.SunkDB(kmers, locs)
+        table = engine.DeviceTable.from_db(db, device)
+        path = engine.write_sidecar(db, table, kmers, locs)
+    except _lib.GsError as e:
+        sys.stderr.write(e.msg + "\n")
+        return 1
+    sys.stderr.write(f"{path}: {len(db.row_contig)} location rows, table {table.layout.split(':')[0]} ({table.nbytes / 2**20:.0f} MiB)\n")
+    table.close()
+    db.close()
+    return 0
+
+
 def main(argv=None) -> int:
     argv = sys.argv[1:] if argv is None else argv
+    if len(argv) == 3 and argv[0] == "--prepare":
+        return prepare(argv[1], argv[2], device=int(os.environ.get("GAVISUNK_DEVICE", "0")))
     nchunks = 0
     if len(argv) == 6 and argv[4] == "--emulate-chunks":
         nchunks = int(argv[5])

@@ -311,6 +311,19 @@ int gs_gather_view(gs_comm *c, const gs_hit **out, uint64_t *n_out);
 
 
 /* ------------------------------------------------------------------------------------------
+ * Prebuilt sidecar of a (k-mer list, location table) pair.  `kmerpos_annot3 <reads> <db> <loc> <out>` parses both text files on
+ * every invocation (kmerpos_annot3.nim:20-72) and rule SUNK_annot runs once per scatter chunk (tagONT.smk:19-37): at genome
+ * scale that is 1.5e9 rows of text, 10 x 2 times per sample.  gs_sidecar_write keeps the parsed location rows and the BUILT
+ * device table in one binary file; gs_sidecar_open hands them back -- only while the file's fingerprints of <db> and <loc>
+ * (size, modification time, hashes of the first and last MiB) still hold; GS_E_IO = none / stale / other version: parse and
+ * build as before.  The gs_sunkdb it returns holds what a hit is formatted from (k, contig names, row_contig / row_start /
+ * row_group); its key arrays are empty (they live in the table).
+ * ---------------------------------------------------------------------------------------- */
+int gs_sidecar_write(const char *path, const gs_sunkdb *db, const gs_table *t, const char *db_path, const char *loc_path);
+int gs_sidecar_open(const char *path, const char *db_path, const char *loc_path, int device, gs_sunkdb **db_out, gs_table **t_out);
+
+
+/* ------------------------------------------------------------------------------------------
  * Diagonal filter (workflow/src/diag_filter_v3.nim + diag_filter_step2.nim).
  * ---------------------------------------------------------------------------------------- */
 
@@ -405,6 +418,10 @@ const int64_t *gs_sunkset_group(const gs_sunkset *s);
  * interval | loc u32 = dense id of the (contig, group) pair. */
 typedef struct gs_sunkset_dev gs_sunkset_dev;
 int gs_sunks_define_device(int device, int k, uint32_t n_contigs, const void *d_seq, const uint64_t *off, gs_sunkset_dev **out);
+/* <db> (one canonical k-mer per line, ascending code) and <loc> (`contig \t start \t k-mer \t group` rows in (contig, start)
+ * order) of a device-resident SUNK set: the two files `kmerpos_annot3` reads (defineSUNKs.smk:59,126), written natively */
+int gs_sunkset_dev_write_files(const gs_sunkset_dev *s, const char *const *contig_names, uint32_t n_names, const char *db_path,
+                               const char *loc_path);
 void gs_sunkset_dev_free(gs_sunkset_dev *s);
 uint64_t gs_sunkset_dev_n(const gs_sunkset_dev *s);
 uint64_t gs_sunkset_dev_n_groups(const gs_sunkset_dev *s);

@@ -403,6 +403,74 @@ def diag_filter_step2(sunkpos_text: str, diag_text: str) -> str:
 
 
 # ------------------------------------------------------------------------------ pair / component stage
+def pair_component_read_np(ids: Sequence[int], pos: Sequence[int], start: Sequence[int]) -> List[int]:
+    """pair_component_read below with NumPy / SciPy arrays instead of Python loops -- for reads with thousands of hits (the
+    loop form needs minutes beyond n ~ 10^3).  The same reference lines; tests/test_pair_golden.py holds the two against each
+    other on every fixture before the GPU tests rely on this one."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    ids = np.asarray(ids, dtype=np.int64)
+    posa = np.asarray(pos, dtype=np.int64)
+    sta = np.asarray(start, dtype=np.int64)
+    n = len(ids)
+    if n < 2:
+        return []
+    ii, jj = np.triu_indices(n, 1)                                   # pdist / combinations order (:140-144)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.abs(posa[ii].astype(np.float64) - posa[jj].astype(np.float64)) / np.abs(sta[ii].astype(np.float64) - sta[jj].astype(np.float64))
+    mask = ~((ratio >= 1.1) | (ratio <= 0.9))                        # :147 (NaN passes)
+    if not mask.any():                                               # :148
+        return []
+    sign = posa[ii] > posa[jj]                                        # :142
+    ones, zeros = int((mask & sign).sum()), int((mask & ~sign).sum())
+    keep = mask & (sign == (ones > zeros))                           # :150-153, tie -> 0
+    ei, ej = ii[keep], jj[keep]
+    E = len(ei)
+    # mergedf = concat(ID/pos1 rows, then ID2/pos2 rows) (:160-163); per ID the most frequent pos, first seen on ties
+    m_id = np.concatenate([ids[ei], ids[ej]])
+    m_pos = np.concatenate([posa[ei], posa[ej]])
+    # (ID, pos) pairs as one integer where they fit (np.unique over rows is an order of magnitude slower)
+    if len(m_id) and 0 <= m_id.min() and m_id.max() < (1 << 31) and 0 <= m_pos.min() and m_pos.max() < (1 << 32):
+        packed, first, inv, cnt = np.unique((m_id << 32) | m_pos, return_index=True, return_inverse=True, return_counts=True)
+        uniq = np.stack([packed >> 32, packed & 0xFFFFFFFF], axis=1)
+    else:
+        uniq, first, inv, cnt = np.unique(np.stack([m_id, m_pos], axis=1), axis=0, return_index=True, return_inverse=True, return_counts=True)
+    uid, uinv = np.unique(uniq[:, 0], return_inverse=True)
+    multi_id = uid[np.bincount(uinv.reshape(-1)) > 1]
+    bad = np.zeros(E, dtype=bool)
+    if len(multi_id):
+        # best (count desc, first occurrence asc) pair per ID
+        order = np.lexsort((first, -cnt, uniq[:, 0]))
+        best_of = {}
+        for q in order:
+            best_of.setdefault(int(uniq[q, 0]), int(uniq[q, 1]))
+        goodpos_of_edge = np.array([best_of[int(x)] for x in ids[ei]], dtype=np.int64)
+        is_multi = np.isin(ids[ei], multi_id)
+        bad = is_multi & ~((posa[ei] == goodpos_of_edge) | (posa[ej] == goodpos_of_edge))   # :175-176 (first ID only)
+    ei, ej = ei[~bad], ej[~bad]
+    if not len(ei):
+        return []
+    # vertices = ID values numbered by first appearance, source then target, edge by edge (:189-198)
+    seq = np.stack([ids[ei], ids[ej]], axis=1).reshape(-1)
+    vals, first_seen = np.unique(seq, return_index=True)
+    vorder = np.argsort(first_seen, kind="stable")
+    verts = vals[vorder]
+    vid_of_val = np.empty(len(vals), dtype=np.int64)
+    vid_of_val[vorder] = np.arange(len(vals))
+    a = vid_of_val[np.searchsorted(vals, ids[ei])]
+    b = vid_of_val[np.searchsorted(vals, ids[ej])]
+    nv = len(verts)
+    ncomp, lab = connected_components(coo_matrix((np.ones(len(a), np.int8), (a, b)), shape=(nv, nv)), directed=False)
+    # label_components labels in order of first vertex; largest = first arg-max over labels
+    _, first_v = np.unique(lab, return_index=True)
+    relabel = np.empty(ncomp, dtype=np.int64)
+    relabel[np.argsort(first_v, kind="stable")] = np.arange(ncomp)
+    lab = relabel[lab]
+    best = int(np.argmax(np.bincount(lab, minlength=ncomp)))
+    return [int(v) for v in verts[lab == best]]
+
+
 def pair_component_read(ids: Sequence[int], pos: Sequence[int], start: Sequence[int]) -> List[int]:
     """One read of process-by-contig_lowmem_AR.py:135-198.  Inputs are the read's rows after the
     pre-filters, sorted by `start` (stable), exact duplicates dropped.  Returns the IDs of the

@@ -32,6 +32,24 @@ def test_oracle_matches_reference_script(case):
     assert n > (500 if case in ("pair_synth", "pair_long") else 5)
 
 
+def test_array_form_of_the_oracle_equals_the_loop_form():
+    """oracle.pair_component_read_np (NumPy / SciPy; what the GPU tests use for reads with thousands of hits) against the
+    line-by-line restatement, on random reads with many multi-position IDs and `value_counts` ties."""
+    import numpy as np
+
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        n = int(rng.integers(2, 60))
+        p = np.sort(rng.choice(np.arange(1, 5000), size=n, replace=False))
+        s = 100000 + p + rng.integers(-40, 40, n)
+        jump = rng.random(n) < 0.15
+        s[jump] = rng.integers(0, 200000, int(jump.sum()))
+        order = np.argsort(s, kind="stable")
+        p, s = p[order], s[order]
+        g = (s // int(rng.choice([50, 200, 2000]))) * 50
+        assert oracle.pair_component_read(g.tolist(), p.tolist(), s.tolist()) == oracle.pair_component_read_np(g.tolist(), p.tolist(), s.tolist())
+
+
 def test_tie_census_of_the_goldens():
     """Which goldens can contain a decision of the graph_tool stand-in / of pandas 2.x (tests/golden/tie_census.py): the AMY
     locus, the two multi-contig cases and the long-read case (10^2 .. 10^3 hits per read, ~200 multi-position IDs) have no
