@@ -60,8 +60,7 @@ def alg_bytes_per_base(h_raw: float, h_emit: float) -> float:
 
 
 def kernel_names(layout: str) -> str:
-    return {"compact-lds": "k_join_bin+k_join_segT+k_join_probe+k_join_merge", "compact-l2": "k_probe_part+k_merge_part+k_probe",
-            "minimizer-hbm": "k_probe_mz"}.get(layout.split(":")[0], "k_probe")
+    return {"minimizer-hbm": "k_probe_mz"}.get(layout.split(":")[0], "k_probe")
 
 
 def source_hash() -> str:

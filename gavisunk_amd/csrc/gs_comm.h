@@ -107,7 +107,7 @@ __global__ void k_shift_reads(gs_hit *h, uint64_t n, uint32_t delta) {
 // the others inside a collective.
 TableMeta table_meta_of(const gs_table *t, uint64_t n_ovf) {
     return TableMeta{t->k, t->shift, t->compact, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64, t->mz, t->mz_m,
-                     t->mz_locbits, t->join, t->mz_n_regions, t->join_chunk, t->n, t->cap, t->c_overflow, t->mz_overflow, n_ovf};
+                     t->mz_locbits, 0, t->mz_n_regions, 0u, t->n, t->cap, t->c_overflow, t->mz_overflow, n_ovf};
 }
 
 struct TableArray {  // one device array of a table: where its pointer lives in the handle, and its size in bytes
@@ -131,22 +131,13 @@ std::vector<TableArray> table_arrays(const TableMeta &hm, gs_table *dst, const g
         const uint64_t nslots = (uint64_t)(4 * kNPart) << hm.c_qb;
         add((void **)&dst->cbuckets, src ? src->cbuckets : nullptr, (hm.c_w64 ? 2 * nslots : nslots) * sizeof(uint32_t));
         add((void **)&dst->cpayload, src ? src->cpayload : nullptr, nslots * sizeof(uint32_t));
-        if (hm.join) {
-            add((void **)&dst->j_ovf_start, src ? src->j_ovf_start : nullptr, ((uint64_t)kJoinSlices + 1) * sizeof(uint32_t));
-            add((void **)&dst->j_ovf_code, src ? src->j_ovf_code : nullptr, hm.n_ovf * sizeof(uint64_t));
-            add((void **)&dst->j_ovf_loc, src ? src->j_ovf_loc : nullptr, hm.n_ovf * sizeof(uint32_t));
-        }
     }
     return v;
 }
 
 int table_n_ovf(const gs_table *t, uint64_t *n_ovf) {
-    *n_ovf = 0;
-    if (t->join) {
-        uint32_t last = 0;
-        HIP_TRY(hipMemcpy(&last, t->j_ovf_start + kJoinSlices, sizeof last, hipMemcpyDeviceToHost));
-        *n_ovf = last;
-    }
+    (void)t;
+    *n_ovf = 0;  // (the LDS-join layout, retired in round 3, carried a sorted overflow list; the field stays in TableMeta)
     return GS_OK;
 }
 
@@ -164,9 +155,7 @@ int table_receive_init(gs_table *t, int device, const TableMeta &hm) {
     t->mz = hm.mz;
     t->mz_m = hm.mz_m;
     t->mz_locbits = hm.mz_locbits;
-    t->join = hm.join;
     t->mz_n_regions = hm.mz_n_regions;
-    t->join_chunk = hm.join_chunk;
     t->cap = hm.cap;
     t->c_overflow = hm.c_overflow;
     t->mz_overflow = hm.mz_overflow;
@@ -175,8 +164,6 @@ int table_receive_init(gs_table *t, int device, const TableMeta &hm) {
         if ((rc = dev_alloc(&p, a.bytes))) return rc;
         *a.dst = p;
     }
-    // (a join table without overflow keys still owns the two arrays, one element each, like a built one)
-    if (hm.join && !hm.n_ovf && ((rc = dev_alloc(&t->j_ovf_code, 1)) || (rc = dev_alloc(&t->j_ovf_loc, 1)))) return rc;
     return GS_OK;
 }
 

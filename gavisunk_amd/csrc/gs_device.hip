@@ -6,19 +6,18 @@
 //           on a word boundary and is followed by >= 1 zero word.
 //   tiles   a read is cut into tiles of 2048 windows = 64 words; a wavefront lane owns one word
 //           = windows [32 l, 32 l + 32) of a tile.
-//   tables  (1) compact: exact, 16 partitions x 2^qb buckets x 4 x 32-bit slots [flags|alt|remainder|loc],
-//               built on the GPU, + one payload word per slot;
-//           (2) generic: open-addressed, linear probing, 16-byte slots {key u64, loc u32, payload u32},
-//               load <= 0.5 -- everything when (1) does not apply, else only the keys (1) could not take.
+//   tables  (1) minimiser-addressed (gs_mz.h): 64-byte regions picked by a mod-minimiser of the k-mer, fetched once per run of
+//               windows -- the default for k >= 16;
+//           (2) compact: exact, 16 partitions x 2^qb buckets x 4 x 32-bit slots [flags|alt|remainder|loc], + one payload word
+//               per slot -- tables (1) does not take;
+//           (3) generic: open-addressed, linear probing, 16-byte slots {key u64, loc u32, payload u32},
+//               load <= 0.5 -- everything when neither applies, else only the keys (1) / (2) could not take.
 //
 // One `gs_tag` pass:
 //   phase 1, one of
-//     k_probe<false>   generic table, one wave per tile, 8 probes in flight per lane
-//     k_probe<true>    compact table out in HBM: one 16-byte bucket load (one 64-byte line) per window
-//     k_probe_part + k_merge_part (+ k_probe<true> on the few tiles that cannot be merged)
-//                      compact table resident in the XCD-partitioned L2s
-//     k_join_bin + k_join_segT + k_join_probe + k_join_merge (k = 20, the default for small tables)
-//                      windows routed to the CU that holds their 1/256 slice of the compact table in LDS
+//     k_probe_mz       (1): one wave per tile, lane = window, a region fetched once per run by LDS-DMA (gs_mz.h)
+//     k_probe<true>    (2): one 16-byte bucket load (one 64-byte line) per window
+//     k_probe<false>   (3): one wave per tile, 8 probes in flight per lane
 //   -> per tile {n_raw, first loc, last loc} and the ordered candidates (hits whose loc differs from the
 //      previous raw hit of the tile; the tile's first raw hit is always a candidate)
 //   scan A     over tiles: raw-hit prefix and the loc carried into each tile (`prevLoc` of
@@ -130,11 +129,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_
     return (uint32_t)x - v;
 }
 
-#ifndef GS_PART_WAVES
-#define GS_PART_WAVES 6  // waves per SIMD k_probe_part is compiled for (register budget); 6 x pipe 2 measured best
-#endif
-constexpr int kMaxRuns = 3;
-constexpr int kNPart = 16;  // key-space partitions; 8 are live at a time (one per XCD), kNPart / 8 passes
+constexpr int kNPart = 16;  // key-space partitions of the compact table (strand-symmetric: part_of)
 constexpr uint32_t kEmptySlot32 = 0xFFFFFFFFu;
 
 // Bijection on `kbits`-bit keys, cheap in 32-bit arithmetic, returning the pair (bucket, remainder)
@@ -498,52 +493,6 @@ __global__ __launch_bounds__(256) void k_probe(TableView tab, CompactView ct, Re
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Small-table fast path: an exact compact table that lives in the L2 caches.
-//
-// MI355X has 8 XCDs with a private 4 MiB L2 each, and workgroup b is dispatched to XCD b % 8
-// (observed, used for speed only: any other placement gives the same results, slower).  Random
-// probes that hit L2 run at ~270 G/s chip-wide; past L2 they run at ~55 G/s whatever the table
-// size (profiles/r01/ubench_*.txt).  So the key space is cut into 16 partitions, 8 of them live
-// at a time (two passes over the tiles), partition p is only probed by workgroups with
-// blockIdx % 8 == p % 8, and each XCD's L2 holds one 1/16 slice of the table at a time.
-//
-// The partition function is strand-symmetric, costs a few bit-parallel operations for all 32
-// windows of a lane at once, and is "free" in key bits.  With x_i the i-th base of a window,
-//
-//   part = (x_0 ^ x_{k-1}) << 2 | (x_1 ^ x_{k-2})
-//
-// is the same for a k-mer and its reverse complement, and given `part` the last two bases follow
-// from the first two, so the table only has to store the canonical code without them:
-//
-//   key~      = canonical code >> 4                       (2k-4 bits)
-//   y         = hmix(key~)                                a bijection on (2k-4)-bit values
-//   bucket    = y >> rembits                              2^qb buckets of 4 x 32-bit slots per partition
-//   slot      = flag << 31 | (y & remmask) << locbits | loc        0xFFFFFFFF = empty
-//
-// (partition, bucket, remainder) identifies the key exactly, so a match is a true hit.  A key whose
-// home bucket is full at build time stays in the generic table only and the bucket gets its
-// overflow flag (bit 31 of slot 0); a lookup that finds no match in a flagged bucket asks the
-// generic table, every other lookup without a match is an exact miss.
-//
-// k_probe_part  grid = 16 x ceil(tiles/4): wave (tile, p) finds which of the tile's 2048 windows
-//               belong to partition p with ~40 bit-parallel operations per lane, compacts them
-//               through an LDS queue so the probe loop runs with full waves and four bucket loads
-//               in flight per lane, and writes a run-length summary of its hits: up to 3 runs
-//               {loc, first window, last window, count}.
-// k_merge_part  per tile, merges the 16 summaries.  If runs of different loc never overlap in
-//               window range the interleaving of the partitions does not matter and the tile's
-//               {n_raw, first/last loc, candidates} follow exactly; otherwise the tile is queued
-//               for the generic probe_tile (k_probe with a tile list).
-// ------------------------------------------------------------------------------------------
-constexpr uint32_t kEmptySlot = kEmptySlot32;
-
-struct __align__(16) PartRec {
-    uint32_t head;  // nruns | complex << 8 | n_hits << 16
-    uint32_t run[kMaxRuns][3];  // loc, first | last << 16, count
-    uint32_t pad[2];
-};
-
 struct __align__(16) TileDesc {
     uint64_t wbase;      // first word of the tile
     uint32_t nwin_left;  // windows of the read from the tile's first window on
@@ -552,1004 +501,6 @@ struct __align__(16) TileDesc {
 
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int uniform_lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, uniform_lane);
-}
-
-// wave-uniform run-length state of one (tile, partition); completed runs go to LDS
-struct PartState {
-    uint32_t nruns, complex, have, hits, cur_loc, cur_first, cur_last, cur_cnt;
-    __device__ __forceinline__ void reset() { nruns = complex = have = hits = cur_loc = cur_first = cur_last = cur_cnt = 0; }
-    __device__ __forceinline__ void push(uint32_t (*runs)[3], int lane) {
-        if (nruns < (uint32_t)kMaxRuns) {
-            if (lane == 0) {
-                runs[nruns][0] = cur_loc;
-                runs[nruns][1] = cur_first | (cur_last << 16);
-                runs[nruns][2] = cur_cnt;
-            }
-            nruns++;
-        } else {
-            complex = 1;
-        }
-    }
-    // fold one ordered group of <= 64 items (one per lane) into the run list
-    __device__ __forceinline__ void step(bool hit, uint32_t loc, uint32_t woff, int lane, uint32_t (*runs)[3]) {
-        const unsigned long long hb = __ballot(hit);
-        if (!hb) return;
-        const int first_lane = __ffsll(hb) - 1, last_lane = 63 - __clzll((long long)hb);
-        const uint32_t loc0 = lane_value(loc, first_lane);
-        hits += __popcll(hb);
-        if (!__ballot(hit && loc != loc0)) {  // the usual case: every hit of the group has the same loc
-            if (!(have && cur_loc == loc0)) {
-                if (have) push(runs, lane);
-                cur_loc = loc0;
-                cur_first = lane_value(woff, first_lane);
-                cur_cnt = 0;
-                have = 1;
-            }
-            cur_cnt += __popcll(hb);
-            cur_last = lane_value(woff, last_lane);
-            return;
-        }
-        const unsigned long long below = hb & (lane ? (~0ULL >> (64 - lane)) : 0ULL);
-        const int src = below ? 63 - __clzll((long long)below) : -1;
-        const uint32_t ploc = __shfl(loc, src < 0 ? 0 : src);
-        const bool start = hit && (src < 0 ? (!have || loc != cur_loc) : (loc != ploc));
-        unsigned long long sb = __ballot(start);
-        int lo = 0;
-        while (sb) {  // wave-uniform
-            const int sl = __ffsll(sb) - 1;
-            sb &= sb - 1;
-            const unsigned long long seg = hb & ((1ULL << sl) - 1ULL) & ~((1ULL << lo) - 1ULL);
-            if (have) {
-                if (seg) {
-                    cur_cnt += __popcll(seg);
-                    cur_last = lane_value(woff, 63 - __clzll((long long)seg));
-                }
-                push(runs, lane);
-            }
-            cur_loc = lane_value(loc, sl);
-            cur_first = lane_value(woff, sl);
-            cur_last = cur_first;
-            cur_cnt = 0;
-            have = 1;
-            lo = sl;
-        }
-        const unsigned long long seg = hb & ~((1ULL << lo) - 1ULL);
-        cur_cnt += __popcll(seg);
-        cur_last = lane_value(woff, 63 - __clzll((long long)seg));
-    }
-};
-
-// A wave works on NT consecutive tiles of one partition per pass over its phases, so that every
-// phase has NT (or more) independent memory requests in flight per lane: descriptors, words,
-// first-chance buckets, second-chance buckets.  DBG: timing experiments (1 = no bucket loads,
-// 2 = stop after the queue); results are wrong for DBG != 0.
-template <int KT, int NT, int kPipe, int DBG>
-__global__ __launch_bounds__(256, GS_PART_WAVES) void k_probe_part(CompactView ct, TableView tab, const uint64_t *__restrict__ words,
-                                                    const TileDesc *__restrict__ tdesc, uint32_t n_tiles, PartRec *recs) {
-    static_assert(NT == 2 || NT == 4, "tile index takes 2 bits of a queue entry");
-    constexpr int QCAP = 640;  // queue window (items); more items are handled window by window
-    constexpr int PCAP = 64;   // deferred (second-chance / generic) lookups per flush
-    // queue entry: woff[0:11) | tile[11:13) | hit[13] | loc[14:32)
-    __shared__ uint32_t sA[4][NT][2 * (kTileWords + 2)];  // the tiles' 2-bit streams as 32-bit words in stream order
-    __shared__ uint32_t sQ[4][QCAP];
-    __shared__ uint32_t sP[4][PCAP][3];
-    __shared__ uint32_t sRun[4][kMaxRuns][3];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t nbatch = (n_tiles + NT - 1) / NT;
-    const uint32_t groups = (nbatch + 3) / 4;
-    // blocks [pass * 8 * groups, (pass + 1) * 8 * groups) work on partitions pass * 8 + (b % 8): dispatch order
-    // keeps one 1/kNPart slice of the table hot in each XCD's L2 at a time
-    const uint32_t pass = blockIdx.x / (8u * groups);
-    const uint32_t bip = blockIdx.x - pass * 8u * groups;
-    const uint32_t p = pass * 8u + (bip & 7u);
-    const uint32_t batch = (bip >> 3) * 4 + wave;
-    if (batch >= nbatch) return;  // waves are independent: no workgroup barrier below
-    const uint32_t tile0 = batch * NT;
-    const int k = KT ? KT : tab.k;
-    const uint32_t wlane = (uint32_t)lane * 32u;
-
-    uint64_t m[NT];
-    uint32_t ex[NT], tot[NT];
-    {
-        TileDesc td[NT];
-#pragma unroll
-        for (int q = 0; q < NT; q++) {
-            td[q] = tdesc[min(tile0 + q, n_tiles - 1)];
-            if (tile0 + q >= n_tiles) td[q].nwin_left = 0;
-        }
-        uint64_t a[NT], b2[NT];
-#pragma unroll
-        for (int q = 0; q < NT; q++) {
-            a[q] = __builtin_nontemporal_load(words + td[q].wbase + lane);
-            b2[q] = __builtin_nontemporal_load(words + td[q].wbase + lane + 1);
-        }
-        // Which of my 32 windows of each tile belong to partition p, all at once.  Base j of the 64-base string
-        // (a:b2) sits at bits 127-2j, 126-2j.  W1 field b = x_b ^ x_{b+k-1}; W2 field b+1 = x_{b+1} ^ x_{b+k-2}.
-        const int s1 = 2 * (k - 1), s2 = 2 * (k - 3);
-        const uint64_t t1 = (uint64_t)(p >> 2) * 0x5555555555555555ULL, t2 = (uint64_t)(p & 3u) * 0x5555555555555555ULL;
-        uint32_t cnt[NT];
-#pragma unroll
-        for (int q = 0; q < NT; q++) {
-            reinterpret_cast<uint2 *>(sA[wave][q])[lane] = make_uint2((uint32_t)(a[q] >> 32), (uint32_t)a[q]);
-            if (lane == 63) reinterpret_cast<uint2 *>(sA[wave][q])[64] = make_uint2((uint32_t)(b2[q] >> 32), (uint32_t)b2[q]);
-            const uint32_t nvalid = td[q].nwin_left > wlane ? min(td[q].nwin_left - wlane, 32u) : 0u;
-            const uint64_t w1 = a[q] ^ ((a[q] << s1) | (b2[q] >> (64 - s1)));
-            const uint64_t w2h = a[q] ^ ((a[q] << s2) | (b2[q] >> (64 - s2)));
-            const uint64_t w2l = b2[q] ^ (b2[q] << s2);
-            const uint64_t w2s = (w2h << 2) | (w2l >> 62);
-            const uint64_t e = (w1 ^ t1) | (w2s ^ t2);
-            uint64_t mm = ~(e | (e >> 1)) & 0x5555555555555555ULL;  // bit 62-2b set <=> window b is in partition p
-            mm &= nvalid >= 32 ? ~0ULL : ~(~0ULL >> (2 * nvalid));
-            m[q] = mm;
-            cnt[q] = __popcll(mm);
-        }
-        // per-tile exclusive prefix over lanes, two tiles per 32-bit scan (counts < 2^16)
-#pragma unroll
-        for (int q = 0; q < NT; q += 2) {
-            const uint32_t packed = cnt[q] | (cnt[q + 1] << 16);
-            uint32_t t;
-            const uint32_t e2 = wave_excl_scan(packed, lane, t);
-            ex[q] = e2 & 0xFFFFu;
-            tot[q] = t & 0xFFFFu;
-            ex[q + 1] = e2 >> 16;
-            tot[q + 1] = t >> 16;
-        }
-    }
-    uint32_t vbase[NT + 1];  // the tiles' item lists back to back
-    vbase[0] = 0;
-#pragma unroll
-    for (int q = 0; q < NT; q++) vbase[q + 1] = vbase[q] + tot[q];
-    const uint32_t V = vbase[NT];
-    if (DBG == 2) {
-        if (lane == 0)
-            for (int q = 0; q < NT; q++)
-                if (tile0 + q < n_tiles) recs[(uint64_t)(tile0 + q) * kNPart + p].head = 0;
-        return;
-    }
-
-    const int kbits = 2 * k - 4;
-    const uint64_t keymask = (1ULL << kbits) - 1ULL;
-    const uint32_t locmask = (1u << ct.locbits) - 1u;
-    const uint32_t tagmask = low_bits32(ct.rembits + 1);  // remainder + alt bit
-    const uint4 *part_buckets = ct.buckets + ((uint64_t)p << ct.qb);
-    uint32_t (*runs)[3] = sRun[wave];
-    PartState st;
-    st.reset();
-    int cur_q = 0;
-
-    auto canon_of = [&](uint32_t entry) -> uint64_t {  // canonical code of the window a queue entry names
-        const uint32_t q = (entry >> 11) & (uint32_t)(NT - 1), woff = entry & 2047u;
-        // the window's 2k <= 64 bits start at bit `ob` (< 32) of three consecutive 32-bit words of the stream
-        const uint32_t i32 = woff >> 4, ob = 2u * (woff & 15u);
-        const uint32_t h0 = sA[wave][q][i32], h1 = sA[wave][q][i32 + 1], h2 = sA[wave][q][i32 + 2];
-        const uint32_t xhi = (uint32_t)(((((uint64_t)h0 << 32) | h1) << ob) >> 32);
-        const uint32_t xlo = (uint32_t)(((((uint64_t)h1 << 32) | h2) << ob) >> 32);
-        const uint64_t f = (((uint64_t)xhi << 32) | xlo) >> (64 - 2 * k);
-        const uint64_t rr = (~revpairs(f)) >> (64 - 2 * k);  // reverse complement of the window itself
-        return f < rr ? f : rr;
-    };
-    // Branch-free bucket compare.  slot ^ (want << locbits) is zero in the tag field exactly for a match.  With the
-    // flag layout an empty slot (all ones) carries alt = 1, rem = all ones: it can only equal a second-chance tag
-    // whose remainder is all ones, so the explicit empty test is needed for second-chance lookups only.
-    const uint32_t fieldmask = tagmask << ct.locbits;
-    auto match4 = [&](const uint4 &b, uint32_t want, uint32_t &l, bool check_empty) -> uint32_t {
-        const uint32_t sl[4] = {b.x, b.y, b.z, b.w};
-        const uint32_t ws = want << ct.locbits;
-        bool h = false;
-        uint32_t pick = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool eq = (((sl[i] ^ ws) & fieldmask) == 0u) && (!check_empty || sl[i] != kEmptySlot);
-            h = h || eq;
-            pick = eq ? sl[i] : pick;
-        }
-        l = h ? (pick & locmask) : l;
-        return h ? 1u : 0u;
-    };
-    auto finish_tile = [&](int q) {  // wave-uniform
-        if (st.have) st.push(runs, lane);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (tile0 + q < n_tiles && lane < 3) {
-            const uint32_t nr = st.nruns;
-            uint4 v;
-            if (lane == 0)
-                v = make_uint4(nr | (st.complex << 8) | (st.hits << 16), nr > 0 ? runs[0][0] : 0u, nr > 0 ? runs[0][1] : 0u,
-                               nr > 0 ? runs[0][2] : 0u);
-            else if (lane == 1)
-                v = make_uint4(nr > 1 ? runs[1][0] : 0u, nr > 1 ? runs[1][1] : 0u, nr > 1 ? runs[1][2] : 0u,
-                               nr > 2 ? runs[2][0] : 0u);
-            else
-                v = make_uint4(nr > 2 ? runs[2][1] : 0u, nr > 2 ? runs[2][2] : 0u, 0u, 0u);
-            reinterpret_cast<uint4 *>(recs + (uint64_t)(tile0 + q) * kNPart + p)[lane] = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-        st.reset();
-    };
-
-    for (uint32_t vlo = 0; vlo < V; vlo += QCAP) {
-        const uint32_t nitems = min(V - vlo, (uint32_t)QCAP);
-        // queue window [vlo, vlo + nitems): one entry per matching window, in (tile, window) order
-#pragma unroll
-        for (int q = 0; q < NT; q++) {
-            uint64_t mm = m[q];
-            uint32_t v = vbase[q] + ex[q] - vlo;  // wraps below the window: the unsigned compare rejects it
-            while (mm) {
-                const int pb = __clzll((long long)mm);  // 1, 3, 5, ... (window b at bit 62-2b)
-                mm &= ~(0x8000000000000000ULL >> pb);
-                if (v < nitems) sQ[wave][v] = ((uint32_t)q << 11) | (wlane + (uint32_t)(pb >> 1));
-                v++;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        const uint32_t ngroups = DBG == 6 ? 0u : (nitems + 63u) / 64u;
-        uint32_t npend = 0;  // wave-uniform
-        auto flush_pending = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t j0 = 0; j0 < npend; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                const bool on = j < npend;
-                const uint32_t meta = sP[wave][on ? j : 0][0], tg = sP[wave][on ? j : 0][1], bkt = sP[wave][on ? j : 0][2];
-                const uint32_t idx = meta & 1023u;  // QCAP <= 1024
-                uint32_t h = 0, l = 0;
-                if (on && (meta & 1024u)) {  // second-chance bucket
-                    const uint4 b = part_buckets[alt_bucket(bkt, tg, ct.qb)];
-                    h = match4(b, tg | (1u << ct.rembits), l, true);
-                }
-                if (on && !h && (meta & 2048u)) {  // rare: both buckets were full at build time
-                    const uint64_t c = canon_of(sQ[wave][idx]);
-                    uint64_t hh = slot_of(c, tab.shift);
-                    Slot cur = load_slot(tab.slots + hh);
-                    while (cur.key != c && cur.key != kEmptyKey) {
-                        hh = (hh + 1) & tab.mask;
-                        cur = load_slot(tab.slots + hh);
-                    }
-                    if (cur.key == c) {
-                        h = 1;
-                        l = cur.loc;
-                    }
-                }
-                if (on && h) sQ[wave][idx] |= (1u << 13) | (l << 14);
-            }
-            npend = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        };
-
-        auto chunk = [&](uint32_t g0, auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;  // all kPipe groups exist: no guards, so the compiler can interleave them
-            // Straight-line per-lane code: lanes past the end compute on harmless values (every LDS and bucket
-            // index they form is in range) and are masked out at the end.
-            uint32_t entry[kPipe], tag[kPipe], bkt[kPipe];
-            uint4 bk[kPipe];
-#pragma unroll
-            for (int u = 0; u < kPipe; u++) {
-                if (FULL || g0 + u < ngroups) {  // wave-uniform
-                    entry[u] = sQ[wave][(g0 + u) * 64 + lane];
-                    const BucketRem br = hmix2((canon_of(entry[u]) >> 4) & keymask, kbits, ct.qb);
-                    tag[u] = (uint32_t)br.rem;
-                    bkt[u] = br.bucket;
-                    bk[u] = DBG == 1 ? make_uint4(kEmptySlot, kEmptySlot, kEmptySlot, br.rem) : part_buckets[br.bucket];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < kPipe; u++) {
-                if (!FULL && g0 + u >= ngroups) break;  // wave-uniform
-                const uint32_t idx = (g0 + u) * 64 + lane;
-                if (DBG == 4) {
-                    if ((bk[u].x ^ bk[u].y ^ bk[u].z ^ bk[u].w) == 0x12345u) sQ[wave][idx] = 1;
-                    continue;
-                }
-                const uint32_t live = idx < nitems;
-                uint32_t l = 0;
-                const uint32_t h = match4(bk[u], tag[u], l, !ct.has_flag) & live;
-                const uint32_t full = max(max(bk[u].x, bk[u].y), max(bk[u].z, bk[u].w)) != kEmptySlot;
-                const uint32_t miss_full = live & (h ^ 1u) & full;
-                const uint32_t again = ct.has_flag ? (miss_full & (bk[u].x >> 31)) : 0u;
-                const uint32_t generic = ct.has_flag ? (miss_full & ((bk[u].x >> 30) & 1u)) : miss_full;
-                if (h) sQ[wave][idx] = entry[u] | (1u << 13) | (l << 14);
-                const unsigned long long pb = __ballot((again | generic) != 0);
-                if (pb) {  // a few lanes per group at most: park them, resolve them together later
-                    const uint32_t np = __popcll(pb);
-                    if (npend + np > (uint32_t)PCAP) flush_pending();
-                    if (again | generic) {
-                        const uint32_t slot = npend + __popcll(pb & (lane ? (~0ULL >> (64 - lane)) : 0ULL));
-                        sP[wave][slot][0] = idx | (again << 10) | (generic << 11);
-                        sP[wave][slot][1] = tag[u];
-                        sP[wave][slot][2] = bkt[u];
-                    }
-                    npend += np;
-                }
-            }
-        };
-        {
-            uint32_t g0 = 0;
-            for (; g0 + kPipe <= ngroups; g0 += kPipe) chunk(g0, std::true_type{});
-            if (g0 < ngroups) chunk(g0, std::false_type{});
-        }
-        if (npend) flush_pending();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        if (V <= (uint32_t)QCAP && DBG < 3) {
-            // Usual case, the whole batch sits in this window: run-length pass tile by tile, three groups of 64
-            // entries at a time.  The group descriptors (hit ballot, first/last hit, "all the same loc") are
-            // independent of each other, only their merge into the run list is sequential and it is scalar.
-            for (int q = 0; q < NT; q++) {
-                const uint32_t n = tot[q], base = vbase[q];
-                for (uint32_t j0 = 0; j0 < n; j0 += 192) {
-                    uint32_t e[3];
-                    unsigned long long hb[3], nb[3];
-                    uint32_t floc[3], fw[3], lw[3];
-#pragma unroll
-                    for (int u = 0; u < 3; u++) {
-                        const uint32_t j = j0 + u * 64 + lane;
-                        e[u] = j < n ? sQ[wave][base + j] : 0u;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 3; u++) {
-                        const bool hit = ((e[u] >> 13) & 1u) != 0;
-                        hb[u] = __ballot(hit);
-                        const int fl = hb[u] ? __ffsll(hb[u]) - 1 : 0, ll = hb[u] ? 63 - __clzll((long long)hb[u]) : 0;
-                        floc[u] = lane_value(e[u] >> 14, fl);
-                        fw[u] = lane_value(e[u] & 2047u, fl);
-                        lw[u] = lane_value(e[u] & 2047u, ll);
-                        nb[u] = __ballot(hit && (e[u] >> 14) != floc[u]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 3; u++) {
-                        if (!hb[u]) continue;
-                        if (nb[u]) {  // a location change inside the group: the general fold
-                            st.step(((e[u] >> 13) & 1u) != 0, e[u] >> 14, e[u] & 2047u, lane, runs);
-                            continue;
-                        }
-                        const uint32_t c = (uint32_t)__popcll(hb[u]);
-                        if (!(st.have && st.cur_loc == floc[u])) {
-                            if (st.have) st.push(runs, lane);
-                            st.cur_loc = floc[u];
-                            st.cur_first = fw[u];
-                            st.cur_cnt = 0;
-                            st.have = 1;
-                        }
-                        st.cur_cnt += c;
-                        st.cur_last = lw[u];
-                        st.hits += c;
-                    }
-                }
-                finish_tile(q);
-            }
-            cur_q = NT;
-        } else {
-        // run-length pass over the resolved entries, tile by tile (a group of 64 may straddle tiles)
-        for (uint32_t g = 0; g < (DBG >= 3 ? 0u : ngroups); g++) {
-            const uint32_t idx = g * 64 + lane;
-            const uint32_t e = idx < nitems ? sQ[wave][idx] : 0u;
-            const bool hit = ((e >> 13) & 1u) != 0;
-            const int myq = (int)((e >> 11) & (uint32_t)(NT - 1));
-            const uint32_t vfirst = vlo + g * 64u, vlast = vlo + min(g * 64u + 63u, nitems - 1u);
-            int qlo = 0, qhi = 0;
-#pragma unroll
-            for (int i = 1; i < NT; i++) {
-                qlo += vfirst >= vbase[i] ? 1 : 0;
-                qhi += vlast >= vbase[i] ? 1 : 0;
-            }
-            for (int q = qlo; q <= qhi; q++) {  // wave-uniform
-                while (cur_q < q) finish_tile(cur_q++);
-                st.step(hit && myq == q, e >> 14, e & 2047u, lane, runs);
-            }
-        }
-        }
-    }
-    while (cur_q < NT) finish_tile(cur_q++);
-}
-
-// One wave merges 4 tiles: 16 lanes per tile, one partition summary (<= 3 runs) per lane.  The runs are
-// peeled loc by loc in order of first window: for the loc of the earliest remaining run, its hull
-// [min first, max last] and hit count over all remaining runs with that loc (three 16-lane reductions).
-// If the hulls are pairwise disjoint the order of hits across partitions is decided without knowing it:
-// the tile's raw hits are hull after hull, one candidate (location change) at each hull's first window,
-// with rank = hits of the earlier hulls.  Anything else (overlapping hulls, > 4 locs, a summary that
-// overflowed) is queued for the exact generic probe.
-constexpr int kMaxHulls = 4;
-__global__ __launch_bounds__(256) void k_merge_part(const PartRec *recs, uint32_t n_tiles, TileArrays ta, uint32_t *cand,
-                                                    uint32_t cand_cap, uint32_t *g_cand_count, uint32_t *complex_list,
-                                                    uint32_t *complex_n) {
-    const int lane = threadIdx.x & 63, part = lane & 15;
-    const uint32_t tile = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-    const bool on = tile < n_tiles;
-    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
-    if (on) {
-        const uint4 *rp = reinterpret_cast<const uint4 *>(recs + (uint64_t)tile * kNPart + part);
-        r0 = rp[0];
-        r1 = rp[1];
-        r2 = rp[2];
-    }
-    const uint32_t nr = r0.x & 0xFFu;
-    uint32_t rloc[kMaxRuns] = {r0.y, r1.x, r1.w};
-    uint32_t rfl[kMaxRuns] = {r0.z, r1.y, r2.x};  // first | last << 16
-    uint32_t rcnt[kMaxRuns] = {r0.w, r1.z, r2.y};
-    uint32_t alive = nr >= 3 ? 7u : (nr == 2 ? 3u : (nr == 1 ? 1u : 0u));
-    uint32_t bad = (r0.x >> 8) & 1u, total = r0.x >> 16;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        bad |= __shfl_xor(bad, d, 16);
-        total += __shfl_xor(total, d, 16);
-    }
-    uint32_t hull_loc[kMaxHulls], hull_first[kMaxHulls], hull_rank[kMaxHulls];
-    uint32_t nh = 0, seen = 0, max_last = 0;
-#pragma unroll
-    for (int it = 0; it <= kMaxHulls; it++) {
-        // earliest remaining run of the tile -> its loc
-        uint32_t key = 0xFFFFFFFFu;  // first << 16 | lane-local tie breaker is irrelevant: equal firsts share... see below
-        uint32_t kloc = 0;
-#pragma unroll
-        for (int i = 0; i < kMaxRuns; i++) {
-            const uint32_t f = rfl[i] & 0xFFFFu;
-            if (((alive >> i) & 1u) && f < key) {
-                key = f;
-                kloc = rloc[i];
-            }
-        }
-        // argmin over 16 lanes of (first, loc): two windows are never equal across partitions, so `first` alone decides
-        uint32_t best = key, bloc = kloc;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const uint32_t ob = __shfl_xor(best, d, 16), ol = __shfl_xor(bloc, d, 16);
-            if (ob < best) {
-                best = ob;
-                bloc = ol;
-            }
-        }
-        if (best == 0xFFFFFFFFu) continue;  // nothing left in this tile (other tiles of the wave may go on)
-        if (it == kMaxHulls) {
-            bad = 1;
-            continue;
-        }
-        uint32_t hl = 0, hc = 0;  // hull end and hits of loc `bloc`
-#pragma unroll
-        for (int i = 0; i < kMaxRuns; i++)
-            if (((alive >> i) & 1u) && rloc[i] == bloc) {
-                hl = max(hl, rfl[i] >> 16);
-                hc += rcnt[i];
-                alive &= ~(1u << i);
-            }
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            hl = max(hl, (uint32_t)__shfl_xor(hl, d, 16));
-            hc += __shfl_xor(hc, d, 16);
-        }
-        if (nh && best <= max_last) bad = 1;  // this hull starts inside an earlier one
-        max_last = max(max_last, hl);
-#pragma unroll
-        for (int i = 0; i < kMaxHulls; i++)
-            if ((uint32_t)i == nh) {
-                hull_loc[i] = bloc;
-                hull_first[i] = best;
-                hull_rank[i] = seen;
-            }
-        nh++;
-        seen += hc;
-    }
-    if (on && part == 0) {
-        if (bad) {
-            complex_list[atomicAdd(complex_n, 1u)] = tile;
-        } else {
-            ta.n_raw[tile] = total;
-            ta.n_cand[tile] = nh;
-            static_assert(kMaxHulls <= kDirectCand, "a merged tile's candidates live in its own slots");
-            const uint32_t off = tile * kDirectCand;
-            if (nh) {
-#pragma unroll
-                for (int i = 0; i < kMaxHulls; i++)
-                    if ((uint32_t)i < nh) cand[off + i] = (hull_rank[i] << 16) | hull_first[i];
-                ta.first_loc[tile] = hull_loc[0];
-                uint32_t ll = hull_loc[0];
-#pragma unroll
-                for (int i = 1; i < kMaxHulls; i++) ll = (uint32_t)i < nh ? hull_loc[i] : ll;
-                ta.last_loc[tile] = ll;
-            }
-            ta.cand_off[tile] = off;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// LDS join (k = 20, 32-bit compact table): the same exact table, probed from LDS.
-//
-// One L2 request per window is itself a wall (~270 G requests/s chip-wide), and finding "the windows of my
-// partition" inside every tile costs more instructions than the probes.  So the windows are routed instead,
-// like the probe side of a radix-partitioned hash join:
-//
-//   k_join_bin    a workgroup takes a batch of 4 tiles (8192 windows): canonical code, hash, and the
-//                 table slice (1 of 256: partition x top 4 bucket bits) of every window; a counting sort
-//                 in LDS groups the 32-bit hashed keys by slice; the batch goes out densely packed:
-//                 item[batch][8192] (+ the window of each item, + start/count per slice).
-//   k_join_segT   transposes the start/count table to [slice][batch] (so that a slice reads it contiguously).
-//   k_join_probe  one workgroup per slice stages its 2^(qb-4) buckets (<= 128 KiB) in LDS and streams the
-//                 slice's items of all batches: one ds_read_b128 per window instead of an L2 request.  A
-//                 wave takes 64 batches at a time and appends its hits {item position, loc + 1} to one
-//                 contiguous stream per (slice, 64 batches), with the start of every merge group noted.  Lookups
-//                 that need the second-chance bucket or the overflow list are parked and resolved a wave-full at
-//                 a time; their hits go to a short unordered side list.
-//   k_join_merge  a workgroup per 4 batches (16 tiles) scatters the hits of the 256 streams into window
-//                 order (LDS, 16 bits per window) and writes the same per-tile summary as probe_tile:
-//                 nothing downstream changes.
-//
-// All traffic is streaming and nothing is written in place (partial-sector writes cost a read-modify-write).
-// Exactness never depends on placement.  Degenerate input (more than 4096 windows of 64 consecutive batches in
-// one slice: homopolymer reads) sends those batches' tiles to the generic exact probe.
-// ------------------------------------------------------------------------------------------
-constexpr int kJoinTiles = 4;
-constexpr int kJoinWin = kJoinTiles * kTileWindows;  // windows per batch
-constexpr int kJoinSlices = 256;                     // kNPart x 16
-constexpr int kJoinSliceBuckets = 8192;              // LDS image of a slice: <= 128 KiB
-constexpr int kJoinOvfMax = 512;                     // overflow keys of a slice kept in LDS
-constexpr uint32_t kJoinChunkMax = 32768;            // batches per queue buffer (item indices stay below 2^28)
-constexpr uint32_t kJoinHitCap = 4096;               // hit records per (slice, 64 batches): the fast path cannot exceed it
-constexpr uint32_t kJoinLateCap = 256;                // late hit records per (slice, 64 batches); more = degenerate group
-constexpr int kJoinMergeBatches = 4;                 // batches per k_join_merge workgroup (64 KiB of LDS: two per CU)
-constexpr int kJoinSub = 64 / kJoinMergeBatches;     // such groups per hit stream
-
-struct JoinQ {
-    uint32_t *item;   // [batches][kJoinWin]     hashed key (bucket in slice | remainder), grouped by slice
-    uint16_t *woff;   // [batches][kJoinWin]     window of the item inside its batch
-    uint32_t *seg;    // [batches][kJoinSlices]  start | count << 16 of a slice's items inside the batch
-    uint32_t *segT;   // [kJoinSlices][bpad]     the same, transposed (bpad = batches rounded up to 64)
-    uint32_t *hits;   // [kJoinSlices][bpad / 64][kJoinHitCap]  window in its merge group (15 bits: batch & 3, window) | (loc + 1) << 16
-    uint32_t *hsub;   // [bpad / kJoinMergeBatches][kJoinSlices] start | count << 16 of a merge group inside its hit stream
-    uint32_t *gflag;  // [bpad / 64]             1 = degenerate group: its tiles go to the generic probe
-    uint2 *late;      // [kJoinSlices][bpad / 64][kJoinLateCap]  hits found in a second-chance bucket or the overflow list, in no
-                      //                          order: {batch & 63, window in the batch (19 bits), loc + 1}
-    uint32_t *nlate;  // [bpad / 64][kJoinSlices]
-    uint32_t bpad;
-};
-
-template <int KT>
-__global__ __launch_bounds__(512, 6) void k_join_bin(CompactView ct, const uint64_t *__restrict__ words,
-                                                      const TileDesc *__restrict__ tdesc, uint32_t n_tiles, uint32_t batch0,
-                                                      JoinQ jq) {
-    __shared__ __align__(16) uint32_t dkey[kJoinWin];
-    __shared__ __align__(16) uint16_t dwoff[kJoinWin];
-    __shared__ __align__(16) uint32_t cnt[kJoinSlices];
-    __shared__ __align__(16) uint32_t off[kJoinSlices];
-    constexpr int k = KT;
-    constexpr int kbits = 2 * k - 4;
-    static_assert(8 + KT - 1 <= 32, "8 consecutive windows must fit one 64-bit word");
-    constexpr uint64_t kmask = (1ULL << (2 * k)) - 1ULL, keymask = (1ULL << kbits) - 1ULL;
-    const int tid = threadIdx.x;
-    const uint32_t bl = blockIdx.x;
-    if (tid < kJoinSlices) cnt[tid] = 0;
-    // thread = 16 consecutive windows: word (tid >> 1) of the batch's 256 words, half (tid & 1) of it; three workgroups per CU
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 7), l = (tid >> 1) & 63, h = tid & 1;  // q is the same for a whole wave
-    const uint32_t tile = (batch0 + bl) * kJoinTiles + q;
-    TileDesc td = tdesc[min(tile, n_tiles - 1)];  // scalar load
-    if (tile >= n_tiles) td.nwin_left = 0;
-    const uint64_t a = __builtin_nontemporal_load(words + td.wbase + l);
-    const uint64_t b2 = __builtin_nontemporal_load(words + td.wbase + l + 1);
-    __syncthreads();
-    const uint32_t w0 = (uint32_t)l * 32u + (uint32_t)h * 16u;
-    const uint32_t nvalid = td.nwin_left > w0 ? min(td.nwin_left - w0, 16u) : 0u;
-    const int sb = ct.qb - 4;  // bucket bits inside a slice; sb + rembits = 32
-    uint32_t item[16], sr[16];
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int s = 32 * h + 16 * half;
-        const uint64_t X = s ? ((a << s) | (b2 >> (64 - s))) : a;  // 8 windows start at bases 0..7 of X (8 + k - 1 <= 32 bases)
-        const uint64_t R = ~revpairs(X);                            // base i of X, complemented, at bits 2i+1:2i
-        // the partition of every window at once (it is the same for a k-mer and its reverse complement, so the forward
-        // strand will do): field b of W1 = x_b ^ x_{b+k-1}, field b+1 of W2 = x_{b+1} ^ x_{b+k-2}; fields 0..8 sit in the high word
-        const uint32_t w1 = (uint32_t)((X ^ (X << (2 * (k - 1)))) >> 32), w2 = (uint32_t)((X ^ (X << (2 * (k - 3)))) >> 32);
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            const int j = half * 8 + jj;
-            const uint64_t f = (X << (2 * jj)) >> (64 - 2 * k);
-            const uint64_t r = (R >> (2 * jj)) & kmask;
-            const uint64_t c = f < r ? f : r;
-            const BucketRem br = hmix2((c >> 4) & keymask, kbits, ct.qb);
-            item[j] = ((br.bucket & ((1u << sb) - 1u)) << ct.rembits) | (uint32_t)br.rem;
-            const uint32_t part = (((w1 >> (30 - 2 * jj)) & 3u) << 2) | ((w2 >> (28 - 2 * jj)) & 3u);
-            const uint32_t slice = (part << 4) | (br.bucket >> sb);
-            // (an unconditional add to a dummy counter, so that the atomics overlap, measured slower)
-            sr[j] = slice | (((uint32_t)j < nvalid ? atomicAdd(&cnt[slice], 1u) : 0u) << 9);
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {  // exclusive prefix over the 256 counters, 4 per lane
-        const uint4 c4 = reinterpret_cast<const uint4 *>(cnt)[tid];
-        uint32_t total;
-        const uint32_t ex = wave_excl_scan(c4.x + c4.y + c4.z + c4.w, tid, total);
-        const uint4 o4 = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);
-        reinterpret_cast<uint4 *>(off)[tid] = o4;
-        reinterpret_cast<uint4 *>(jq.seg + (uint64_t)bl * kJoinSlices)[tid] =
-            make_uint4(o4.x | (c4.x << 16), o4.y | (c4.y << 16), o4.z | (c4.z << 16), o4.w | (c4.w << 16));
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; j++)
-        if ((uint32_t)j < nvalid) {
-            const uint32_t pos = off[sr[j] & 255u] + (sr[j] >> 9);
-            dkey[pos] = item[j];
-            dwoff[pos] = (uint16_t)(((uint32_t)q << 11) | (w0 + (uint32_t)j));
-        }
-    __syncthreads();
-    const uint32_t total = off[kJoinSlices - 1] + cnt[kJoinSlices - 1];
-    uint4 *gk = reinterpret_cast<uint4 *>(jq.item + (uint64_t)bl * kJoinWin);
-    uint4 *gw = reinterpret_cast<uint4 *>(jq.woff + (uint64_t)bl * kJoinWin);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t e4 = (uint32_t)tid + 512u * (uint32_t)i;
-        if (e4 * 4u < total) gk[e4] = reinterpret_cast<const uint4 *>(dkey)[e4];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const uint32_t e8 = (uint32_t)tid + 512u * (uint32_t)i;
-        if (e8 * 8u < total) gw[e8] = reinterpret_cast<const uint4 *>(dwoff)[e8];
-    }
-}
-
-// seg [nb][256] -> segT [256][bpad] in 64 x 64 pieces (batches past nb read as empty); also clears the group flags
-__global__ __launch_bounds__(256) void k_join_segT(JoinQ jq, uint32_t nb) {
-    __shared__ uint32_t tl[64][65];
-    const uint32_t b0 = blockIdx.x * 64u, s0 = blockIdx.y * 64u;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (blockIdx.y == 0 && threadIdx.x == 0) jq.gflag[blockIdx.x] = 0;
-    for (int i = ty; i < 64; i += 4) tl[i][tx] = b0 + i < nb ? jq.seg[(uint64_t)(b0 + i) * kJoinSlices + s0 + tx] : 0u;
-    __syncthreads();
-    for (int i = ty; i < 64; i += 4) jq.segT[(uint64_t)(s0 + i) * jq.bpad + b0 + tx] = tl[tx][i];
-}
-
-template <int KT, int PIPE, bool HASFLAG, int DBG>
-__global__ __launch_bounds__(1024) void k_join_probe(CompactView ct, JoinQ jq, uint32_t nb, uint32_t reps,
-                                                      const uint64_t *__restrict__ ovf_code,
-                                                      const uint32_t *__restrict__ ovf_loc,
-                                                      const uint32_t *__restrict__ ovf_start) {
-    constexpr int PCAP = 96;  // parked (second-chance / overflow) lookups; resolved 64 at a time
-    __shared__ uint4 sT[kJoinSliceBuckets];
-    __shared__ uint32_t sBase[16][65];
-    __shared__ unsigned long long sEnd[16][64];
-    __shared__ uint32_t sPend[16][PCAP][2];
-    __shared__ uint32_t sG[16][kJoinSub + 1];
-    __shared__ uint32_t sOvfKey[kJoinOvfMax], sOvfLoc[kJoinOvfMax];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t s = blockIdx.x % (uint32_t)kJoinSlices, rep = blockIdx.x / (uint32_t)kJoinSlices;
-    const int sb = ct.qb - 4;
-    const uint32_t n_ovf = ovf_start[s + 1] - ovf_start[s];
-    {
-        const uint4 *src = ct.buckets + ((uint64_t)(s >> 4) << ct.qb) + ((uint64_t)(s & 15u) << sb);
-        for (uint32_t i = tid; i < (1u << sb); i += blockDim.x) sT[i] = src[i];
-        if (n_ovf <= (uint32_t)kJoinOvfMax)
-            for (uint32_t i = tid; i < n_ovf; i += blockDim.x) {
-                sOvfKey[i] = (uint32_t)ovf_code[ovf_start[s] + i];  // the item part; the slice part is s
-                sOvfLoc[i] = ovf_loc[ovf_start[s] + i];
-            }
-    }
-    __syncthreads();
-    const int rembits = ct.rembits, locbits = ct.locbits;
-    const uint32_t remmask = (1u << rembits) - 1u;
-    const uint32_t locmask = (1u << locbits) - 1u;
-    constexpr uint32_t slot0mask = HASFLAG ? 0x3FFFFFFFu : 0xFFFFFFFFu;
-    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
-    const uint32_t ng64 = jq.bpad / 64u;
-
-    // second lookup of a parked item: its second-chance bucket (same slice, alt bit set in the slot), then the slice's
-    // overflow keys; returns loc + 1 or 0
-    auto second = [&](uint32_t key, uint32_t flags) -> uint32_t {
-        const uint32_t bucket = key >> rembits, rem = key & remmask;
-        uint32_t res = 0;
-        if (flags & 1u) {
-            const uint4 b = sT[alt_bucket(bucket, rem, ct.qb)];
-            const uint32_t wa = (rem | (1u << rembits)) << locbits;
-            const uint32_t sl[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t e = (sl[i] ^ wa) & (i == 0 ? slot0mask : 0xFFFFFFFFu);
-                if (sl[i] != kEmptySlot32 && e < locmask) res = e + 1u;
-            }
-        }
-        if (!res && (flags & 2u)) {  // rare: the key overflowed both buckets at build time
-            if (n_ovf <= (uint32_t)kJoinOvfMax) {
-                uint32_t lo = 0, hi = n_ovf;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (sOvfKey[mid] < key) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (lo < n_ovf && sOvfKey[lo] == key) res = sOvfLoc[lo] + 1u;
-            } else {  // more overflow keys than the LDS list holds (tables without second-chance buckets): search them in HBM
-                const uint64_t code = ((uint64_t)s << 32) | key;
-                uint32_t lo = ovf_start[s], hi = ovf_start[s + 1];
-                const uint32_t end = hi;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (ovf_code[mid] < code) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (lo < end && ovf_code[lo] == code) res = ovf_loc[lo] + 1u;
-            }
-        }
-        return res;
-    };
-
-    const uint32_t ngroups = (nb + 63u) / 64u;
-    const uint32_t nwaves = blockDim.x >> 6;  // 16; fewer only in occupancy experiments
-    const uint32_t gfirst = rep * nwaves + (uint32_t)wave, gstep = reps * nwaves;
-    uint32_t sg_next = gfirst < ngroups ? jq.segT[(uint64_t)s * jq.bpad + gfirst * 64u + (uint32_t)lane] : 0u;
-    for (uint32_t g = gfirst; g < ngroups; g += gstep) {
-        const uint32_t b = g * 64u + (uint32_t)lane;
-        const uint32_t sg = sg_next;  // batches past nb are empty
-        // the next group's start/count table is on its way while this group is probed
-        if (g + gstep < ngroups) sg_next = jq.segT[(uint64_t)s * jq.bpad + (g + gstep) * 64u + (uint32_t)lane];
-        const uint32_t cnt = sg >> 16, start = sg & 0xFFFFu;
-        uint32_t T;
-        const uint32_t ex = wave_excl_scan(cnt, lane, T);
-        uint32_t *hsub = jq.hsub + (uint64_t)g * kJoinSub * kJoinSlices + s;  // [merge groups of the 64 batches][slices]
-        if (T == 0 || T > kJoinHitCap) {
-            if (lane < kJoinSub) hsub[(uint32_t)lane * kJoinSlices] = 0u;
-            if (lane == 0) jq.nlate[(uint64_t)g * kJoinSlices + s] = 0u;
-            if (T && lane == 0) jq.gflag[g] = 1u;
-            continue;
-        }
-        // the items of the 64 batches as one stream: position -> batch through a bit vector of segment ends
-        const unsigned long long nz = __ballot(cnt != 0);
-        sEnd[wave][lane] = 0ULL;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) sBase[wave][__popcll(nz)] = 0u - T;  // positions past T (last step) name this entry: item[0..63]
-        if (cnt) {
-            sBase[wave][__popcll(nz & lt)] = b * (uint32_t)kJoinWin + start - ex;
-            const uint32_t e = ex + cnt - 1u;
-            atomicOr(&sEnd[wave][e >> 6], 1ULL << (e & 63u));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const unsigned long long word = sEnd[wave][lane];
-        uint32_t unused;
-        const uint32_t before = wave_excl_scan((uint32_t)__popcll(word), lane, unused);
-        const uint32_t wlo = (uint32_t)word, whi = (uint32_t)(word >> 32);
-        const uint32_t nsteps = (T + 63u) / 64u;
-        uint32_t *hout = jq.hits + ((uint64_t)s * ng64 + g) * kJoinHitCap;
-        uint32_t cursor = 0;  // hits written so far (wave-uniform)
-        // hit-stream position where each merge group starts: noted when the item stream crosses its first item
-        int jn = 0;         // next group whose start is not noted yet
-        uint32_t jpos = 0;  // its first item position (= ex of its first batch)
-
-        // two sets of window buffers {where a hit would be, item, home bucket}: one is probed while the other is loaded
-        uint32_t idx_a[PIPE], key_a[PIPE], idx_b[PIPE], key_b[PIPE];
-        uint4 bk_a[PIPE], bk_b[PIPE];
-        auto fetch = [&](uint32_t t0, uint32_t (&idx_n)[PIPE], uint32_t (&key_n)[PIPE]) {
-#pragma unroll
-            for (int u = 0; u < PIPE; u++) {
-                if (t0 + (uint32_t)u >= nsteps) break;  // wave-uniform: the last window of a group is usually short
-                const uint32_t t = (t0 + (uint32_t)u) & 63u, p = (t0 + (uint32_t)u) * 64u + (uint32_t)lane;
-                const uint32_t sl = lane_value(wlo, (int)t), sh = lane_value(whi, (int)t), sbv = lane_value(before, (int)t);
-                // lanes past T may name one segment past the last: sBase has a spare entry
-                const uint32_t ci = __builtin_amdgcn_mbcnt_hi(sh, __builtin_amdgcn_mbcnt_lo(sl, sbv));
-                const uint32_t ix = sBase[wave][ci] + p;
-                key_n[u] = jq.item[ix];  // lanes past T read some valid word (sBase's spare entry) and are masked below
-                // where a hit of this item is: batch & 63 | window inside the batch
-                idx_n[u] = (ix & 0x7E000u) | (uint32_t)jq.woff[ix];
-            }
-        };
-#pragma unroll
-        for (int u = 0; u < PIPE; u++) key_a[u] = key_b[u] = 0u;  // steps a short window does not have still name a valid bucket
-        fetch(0, idx_a, key_a);
-#pragma unroll
-        for (int u = 0; u < PIPE; u++) bk_a[u] = sT[(key_a[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1)];
-        uint2 *lout = jq.late + ((uint64_t)s * ng64 + g) * kJoinLateCap;
-        uint32_t npend = 0, nlate = 0;  // wave-uniform: parked lookups, late hits written
-        // resolve the parked lookups (at most one per lane); their hits go to the side list, in no particular order
-        auto flush_parked = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t j0 = 0; j0 < npend; j0 += 64u) {
-                uint32_t res = 0, where = 0;
-                if (j0 + (uint32_t)lane < npend) {
-                    where = sPend[wave][j0 + lane][1];
-                    res = second(sPend[wave][j0 + lane][0], where >> 19);
-                }
-                const unsigned long long hb = __ballot(res != 0);
-                const uint32_t nh = __popcll(hb);
-                if (nlate + nh > kJoinLateCap) {
-                    if (lane == 0) jq.gflag[g] = 1u;  // more late hits than the list holds: exact generic probe for this group
-                } else if (res) {  // {batch & 63, window inside the batch}, loc + 1
-                    lout[nlate + (uint32_t)__popcll(hb & lt)] = make_uint2(where & 0x7FFFFu, res);
-                }
-                nlate = min(nlate + nh, kJoinLateCap);
-            }
-            npend = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        };
-        auto window = [&](uint32_t t0, auto full_tag, uint32_t (&idx)[PIPE], uint32_t (&key)[PIPE], uint4 (&bk)[PIPE],
-                          uint32_t (&idx_n)[PIPE], uint32_t (&key_n)[PIPE], uint4 (&bk_n)[PIPE]) {
-            constexpr bool FULL = decltype(full_tag)::value;  // all PIPE steps exist: no guards
-            uint32_t rp[PIPE];  // loc + 1 of a hit in the home bucket, or 0
-            const bool more = t0 + PIPE < nsteps;  // wave-uniform
-            if (more) fetch(t0 + PIPE, idx_n, key_n);
-            if (npend > (uint32_t)PCAP - 64u) flush_parked();  // the one place inside a group: room for 64 more lookups
-#pragma unroll
-            for (int u = 0; u < PIPE; u++) {
-                if (!FULL && t0 + (uint32_t)u >= nsteps) {  // wave-uniform
-                    rp[u] = 0u;
-                    continue;
-                }
-                const bool live = (t0 + (uint32_t)u) * 64u + (uint32_t)lane < T;
-                const uint32_t ws = (key[u] & remmask) << locbits;
-                const uint32_t e0 = (bk[u].x ^ ws) & slot0mask, e1 = bk[u].y ^ ws, e2 = bk[u].z ^ ws, e3 = bk[u].w ^ ws;
-                const uint32_t m = min(min(e0, e1), min(e2, e3));
-                // a matching slot leaves its loc (< locmask: the all-ones loc is never stored); an empty slot leaves at least locmask
-                const bool hit = m < locmask;
-                rp[u] = live && hit ? m + 1u : 0u;
-                // bits 31:30 of slot 0: a key of this bucket lives in its second-chance bucket / in the overflow list only
-                // (set on full buckets only; an empty slot 0 has them set too, hence the test on slot 3: slots fill in order).
-                // Such lookups are parked: bit 0 try the second-chance bucket, bit 1 try the overflow list.
-                const uint32_t pf = HASFLAG ? ((bk[u].x >> 31) | ((bk[u].x >> 29) & 2u)) : 2u;
-                const bool pend = DBG != 2 && live && !hit && bk[u].w != kEmptySlot32 && pf != 0u;
-                const unsigned long long pb = __ballot(pend);
-                if (pb) {  // wave-uniform
-                    const uint32_t np = __popcll(pb);
-                    if (npend + np > (uint32_t)PCAP) {  // no room (a table with very many displaced keys): exact generic probe
-                        if (lane == 0) jq.gflag[g] = 1u;
-                        continue;
-                    }
-                    if (pend) {
-                        const uint32_t slot = npend + (uint32_t)__popcll(pb & lt);
-                        sPend[wave][slot][0] = key[u];
-                        sPend[wave][slot][1] = (pf << 19) | (idx[u] & 0x7FFFFu);  // batch & 63, index inside the batch
-                    }
-                    npend += np;
-                }
-            }
-            if (more) {  // the next window's bucket reads are in flight while this window is finished
-#pragma unroll
-                for (int u = 0; u < PIPE; u++)
-                    bk_n[u] = DBG == 3 ? make_uint4(key_n[u], ~0u, ~0u, ~0u) : sT[(key_n[u] >> rembits) & (uint32_t)(kJoinSliceBuckets - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < PIPE; u++) {
-                if (!FULL && t0 + (uint32_t)u >= nsteps) break;  // wave-uniform
-                const unsigned long long hb = __ballot(rp[u] != 0);
-                const uint32_t p0 = (t0 + (uint32_t)u) * 64u;
-                // merge groups that start inside [p0, p0 + 64): their hits start after the hits of the lanes before
-                while (jn < kJoinSub && jpos < p0 + 64u) {  // wave-uniform
-                    const uint32_t d = jpos > p0 ? jpos - p0 : 0u;
-                    const uint32_t v = DBG ? 0u : cursor + (uint32_t)__popcll(hb & (d ? (~0ULL >> (64 - d)) : 0ULL));
-                    if (lane == 0) sG[wave][jn] = v;
-                    jn++;
-                    jpos = jn < kJoinSub ? lane_value(ex, jn * kJoinMergeBatches) : 0xFFFFFFFFu;
-                }
-                if (DBG) {  // timing experiments: an empty hit stream keeps everything downstream well-defined
-                    if (DBG == 1 ? rp[u] == 0x12345u : (rp[u] != 0 && cursor == 0xFFFFFFF0u)) hout[(uint32_t)__popcll(hb & lt)] = idx[u];
-                    if (DBG == 1) continue;
-                    cursor += (uint32_t)__popcll(hb);
-                    continue;
-                }
-                // a hit record names its window inside the 4-batch merge group: (batch & 3) << 13 | window in the batch
-                if (rp[u]) hout[cursor + (uint32_t)__popcll(hb & lt)] = (idx[u] & 0x7FFFu) | (rp[u] << 16);
-                cursor += (uint32_t)__popcll(hb);
-            }
-        };
-        {
-            uint32_t t0 = 0;
-            bool in_a = true;  // wave-uniform: which set holds the window at t0
-            for (; t0 + 2 * PIPE <= nsteps; t0 += 2 * PIPE) {
-                window(t0, std::true_type{}, idx_a, key_a, bk_a, idx_b, key_b, bk_b);
-                window(t0 + PIPE, std::true_type{}, idx_b, key_b, bk_b, idx_a, key_a, bk_a);
-            }
-            if (t0 + PIPE <= nsteps) {
-                window(t0, std::true_type{}, idx_a, key_a, bk_a, idx_b, key_b, bk_b);
-                t0 += PIPE;
-                in_a = false;
-            }
-            if (t0 < nsteps) {
-                if (in_a) window(t0, std::false_type{}, idx_a, key_a, bk_a, idx_b, key_b, bk_b);
-                else window(t0, std::false_type{}, idx_b, key_b, bk_b, idx_a, key_a, bk_a);
-            }
-        }
-        if (npend) flush_parked();
-        if (lane == 0) jq.nlate[(uint64_t)g * kJoinSlices + s] = DBG ? 0u : nlate;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < kJoinSub) {
-            // groups whose first item was never reached have no items: they start (and end) at the end of the stream
-            const uint32_t st = DBG ? 0u : (lane < jn ? sG[wave][lane] : cursor);
-            const uint32_t en = DBG ? 0u : (lane + 1 < jn ? sG[wave][lane + 1] : cursor);
-            hsub[(uint32_t)lane * kJoinSlices] = st | ((en - st) << 16);
-        }
-    }
-}
-
-// One workgroup per 4 batches (16 tiles, one per wave).  loc + 1 per window in LDS, 16 bits each; lane l of the wave that owns a
-// tile reads its 32 windows as one 64-byte row, the 16-byte pieces of a row rotated by l to spread the banks.
-__global__ __launch_bounds__(1024, 8) void k_join_merge(JoinQ jq, uint32_t batch0, uint32_t nb, uint32_t n_tiles, TileArrays ta,
-                                                     uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
-                                                     uint32_t *complex_list, uint32_t *complex_n) {
-    __shared__ __align__(16) uint16_t locat[kJoinMergeBatches * kJoinWin];  // 64 KiB
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t g8 = blockIdx.x, g64 = g8 / (uint32_t)kJoinSub;  // g8: merge group
-    const uint32_t tile_lo = (batch0 + g8 * kJoinMergeBatches) * kJoinTiles;
-    if (jq.gflag[g64]) {  // degenerate group: exact generic probe for these tiles
-        if (tid < kJoinMergeBatches * kJoinTiles && tile_lo + tid < n_tiles) complex_list[atomicAdd(complex_n, 1u)] = tile_lo + tid;
-        return;
-    }
-    // the 16 hit streams this wave scatters (slices wave, wave + 16, ...): start/count first, so that the loads overlap the clear
-    const uint32_t hs_mine = lane < 16 ? jq.hsub[(uint64_t)g8 * kJoinSlices + (uint32_t)wave + 16u * (uint32_t)lane] : 0u;
-    const uint32_t ng64 = jq.bpad / 64u;
-    // side lists of the 64-batch group (hits found in second-chance buckets / the overflow list, a few per slice, unordered):
-    // 4 threads per slice
-    const uint32_t late_n = jq.nlate[(uint64_t)g64 * kJoinSlices + ((uint32_t)tid >> 2)];
-    const uint2 *late_l = jq.late + ((uint64_t)((uint32_t)tid >> 2) * ng64 + g64) * kJoinLateCap;
-    const uint32_t late_mine = g8 % (uint32_t)kJoinSub;  // (batch & 63) / kJoinMergeBatches of my batches
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(locat) / 16 / 1024); i++) reinterpret_cast<uint4 *>(locat)[tid + 1024 * i] = make_uint4(0, 0, 0, 0);
-    uint2 lrec[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t j = ((uint32_t)tid & 3u) + 4u * (uint32_t)i;
-        lrec[i] = j < late_n ? late_l[j] : make_uint2(0u, 0u);  // loc + 1 is never 0
-    }
-    __syncthreads();
-    auto put = [&](uint32_t rec) {
-        const uint32_t w = rec & 0x7FFFu;  // window inside the group
-        locat[(w & ~31u) | ((((w >> 3) + (w >> 5)) & 3u) << 3) | (w & 7u)] = (uint16_t)(rec >> 16);
-    };
-    constexpr int MU = 4;  // streams in flight per wave
-    for (int i0 = 0; i0 < 16; i0 += MU) {
-        uint32_t rec[MU], cnt[MU];
-        const uint32_t *h[MU];
-#pragma unroll
-        for (int u = 0; u < MU; u++) {
-            const uint32_t hs = lane_value(hs_mine, i0 + u);
-            const uint32_t sl = (uint32_t)wave + 16u * (uint32_t)(i0 + u);
-            cnt[u] = hs >> 16;
-            h[u] = jq.hits + ((uint64_t)sl * ng64 + g64) * kJoinHitCap + (hs & 0xFFFFu);
-            rec[u] = (uint32_t)lane < cnt[u] ? h[u][lane] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < MU; u++)
-            if (rec[u]) put(rec[u]);
-#pragma unroll
-        for (int u = 0; u < MU; u++)
-            for (uint32_t j = 64u + (uint32_t)lane; j < cnt[u]; j += 64u) put(h[u][j]);  // long streams (rare)
-    }
-    {  // the side lists: this merge group's records are taken (the first 16 of each list were loaded up front)
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (lrec[i].y && (lrec[i].x >> 13) / (uint32_t)kJoinMergeBatches == late_mine) put((lrec[i].x & 0x7FFFu) | (lrec[i].y << 16));
-        for (uint32_t j = 16u + ((uint32_t)tid & 3u); j < late_n; j += 4u) {
-            const uint2 r = late_l[j];
-            if ((r.x >> 13) / (uint32_t)kJoinMergeBatches == late_mine) put((r.x & 0x7FFFu) | (r.y << 16));
-        }
-    }
-    __syncthreads();
-    {
-        const uint32_t tl = (uint32_t)wave;  // tile inside the group
-        const uint32_t tile = tile_lo + tl;
-        if (tile >= n_tiles) return;
-        uint32_t raw = 0, chg = 0, first_loc = GS_NONE, prev = GS_NONE;
-        const uint4 *row = reinterpret_cast<const uint4 *>(locat + tl * kTileWindows + lane * 32);
-#pragma unroll
-        for (int pc = 0; pc < 4; pc++) {
-            const uint4 v4 = row[(pc + lane) & 3];
-            const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int bb = pc * 8 + c;
-                const uint32_t x = (v[c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
-                if (x) {
-                    const uint32_t loc = x - 1u;
-                    raw |= 1u << bb;
-                    if (prev == GS_NONE) first_loc = loc;
-                    else if (loc != prev) chg |= 1u << bb;
-                    prev = loc;
-                }
-            }
-        }
-        tile_summary(raw, chg, first_loc, prev, tile, n_tiles, ta, cand, cand_cap, g_cand_count);
-    }
 }
 
 #include "gs_mz.h"
@@ -1972,14 +923,12 @@ struct gs_table {
     uint64_t n = 0, cap = 0;
     int shift = 0;
     Slot *slots = nullptr;
-    // small-table fast path (exact compact table resident in the XCD-partitioned L2s)
-    int compact = 0;  // 0 generic only, 1 compact-l2, 2 compact-hbm
+    // exact compact copy ("compact-hbm"): tables the minimiser-addressed layout does not take
+    int compact = 0;  // 0 none, 2 compact
     uint4 *cbuckets = nullptr;
     uint32_t *cpayload = nullptr;  // payload per compact slot
     int c_qb = 0, c_rembits = 0, c_locbits = 0, c_has_flag = 0, c_w64 = 0;
     uint64_t c_overflow = 0;
-    // LDS join (k = 20): the compact table's slices are probed from LDS; keys that overflowed both buckets, in
-    // hashed form (slice << 32 | item), sorted
     // minimiser-addressed table (gs_mz.h): large tables
     int mz = 0;
     uint4 *mz_regions = nullptr;
@@ -1987,11 +936,6 @@ struct gs_table {
     int mz_m = 0, mz_locbits = 0;
     uint32_t *mz_pay = nullptr;  // payload per slot
     uint64_t mz_overflow = 0, mz_dup = 0;  // keys in the generic side table; keys stored under both strands' picks
-    int join = 0;
-    uint32_t join_chunk = kJoinChunkMax;
-    uint64_t *j_ovf_code = nullptr;
-    uint32_t *j_ovf_loc = nullptr;
-    uint32_t *j_ovf_start = nullptr;  // [kJoinSlices + 1] first overflow key of every slice
     hipStream_t stream = nullptr;       // every pass over this table runs here, in launch order
     hipStream_t copy_stream = nullptr;  // hit lists to the host: overlaps the next pass
     gs_counters ctr{};
@@ -2043,9 +987,6 @@ struct gs_reads {
     std::vector<uint32_t> seed_tiles;                    // tiles that carry a seed, in the order they were given
     std::vector<uint32_t> read_tile0_host;               // first tile of every read
     TileDesc *tile_desc = nullptr;     // [n_tiles]
-    PartRec *part_recs = nullptr;      // [n_tiles * kNPart], fast path only
-    uint32_t *complex_list = nullptr;  // [n_tiles]
-    JoinQ jq{};                        // LDS join queues for min(batches, kJoinChunk) batches
     PassState ps;
 };
 
@@ -2076,34 +1017,8 @@ int ensure_out_buffers(gs_reads *r, uint32_t cand_cap) {
     return GS_OK;
 }
 
-// batches per pass of the join kernels over one set of queues (GAVISUNK_JOIN_CHUNK, a test knob read once when the
-// table is created: small chunks exercise the chunk loop)
-uint32_t join_chunk_from_env() {
-    const char *e = getenv("GAVISUNK_JOIN_CHUNK");
-    const long v = e ? atol(e) : 0;
-    return v >= 64 && v <= (long)kJoinChunkMax ? (uint32_t)v / 64u * 64u : kJoinChunkMax;
-}
-
 int launch_phase1(gs_table *t, gs_reads *r) {
     HIP_TRY(hipSetDevice(t->device));
-    if (t->compact == 1 && t->join && r->n_tiles && !r->jq.item) {
-        int rc;
-        const uint64_t nb = std::min<uint64_t>(t->join_chunk, (r->n_tiles + kJoinTiles - 1) / kJoinTiles);
-        const uint64_t bpad = (nb + 63) / 64 * 64;
-        r->jq.bpad = (uint32_t)bpad;
-        if ((rc = dev_alloc(&r->jq.item, nb * kJoinWin)) || (rc = dev_alloc(&r->jq.woff, bpad * kJoinWin)) ||
-            (rc = dev_alloc(&r->jq.seg, nb * kJoinSlices)) || (rc = dev_alloc(&r->jq.segT, bpad * kJoinSlices)) ||
-            (rc = dev_alloc(&r->jq.hits, bpad / 64 * kJoinSlices * kJoinHitCap)) ||
-            (rc = dev_alloc(&r->jq.hsub, bpad / kJoinMergeBatches * kJoinSlices)) || (rc = dev_alloc(&r->jq.gflag, bpad / 64)) ||
-            (rc = dev_alloc(&r->jq.late, bpad / 64 * kJoinSlices * kJoinLateCap)) || (rc = dev_alloc(&r->jq.nlate, bpad / 64 * kJoinSlices)))
-            return rc;
-        if (!r->complex_list && (rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
-    }
-    if (t->compact == 1 && !t->join && r->n_tiles && !r->part_recs) {
-        int rc;
-        if ((rc = dev_alloc(&r->part_recs, (uint64_t)r->n_tiles * kNPart))) return rc;
-        if (!r->complex_list && (rc = dev_alloc(&r->complex_list, r->n_tiles))) return rc;
-    }
     memset(r->ps.h_init, 0, sizeof(PassStatus));
     r->ps.h_init->err_pos = ~0ULL;
     r->ps.h_init->totals[0].loc = r->ps.h_init->totals[1].loc = GS_NONE;
@@ -2138,101 +1053,7 @@ int launch_phase1(gs_table *t, gs_reads *r) {
             else
                 GS_LAUNCH_MZ(0, 0, -1);
 #undef GS_LAUNCH_MZ
-        } else if (t->compact == 1 && t->join) {
-            const uint32_t n_batches = (r->n_tiles + kJoinTiles - 1) / kJoinTiles;
-#ifdef GS_TUNING  // experiments only (tools/, libgavisunk_tuning.so): the shipped library has no such switches
-            const char *env_reps = getenv("GAVISUNK_JOIN_REPS");  // workgroups per table slice
-            const uint32_t reps = env_reps ? std::max(1, atoi(env_reps)) : 1u;
-            const char *env_jt = getenv("GAVISUNK_JOIN_THREADS");  // occupancy experiment: probe workgroup size (multiple of 64)
-            const uint32_t jthreads = env_jt ? std::min(1024, std::max(512, atoi(env_jt) / 64 * 64)) : 1024u;
-            const char *env_jp = getenv("GAVISUNK_JOIN_PIPE");  // item loads in flight per lane
-            const int jpipe = env_jp ? atoi(env_jp) : 4;
-#else
-            const uint32_t reps = 1u, jthreads = 1024u;
-#endif
-            const uint32_t chunk = std::min<uint32_t>(t->join_chunk, r->jq.bpad);  // what the queues were sized for
-            for (uint32_t b0 = 0; b0 < n_batches; b0 += chunk) {
-                const uint32_t nb = std::min(chunk, n_batches - b0);
-                const uint32_t ng64 = (nb + 63) / 64;
-                hipLaunchKernelGGL((k_join_bin<20>), dim3(nb), dim3(512), 0, t->stream, cv, (const uint64_t *)r->words,
-                                   (const TileDesc *)r->tile_desc, r->n_tiles, b0, r->jq);
-                hipLaunchKernelGGL(k_join_segT, dim3(ng64, kJoinSlices / 64), dim3(256), 0, t->stream, r->jq, nb);
-#define GS_LAUNCH_JOIN_PROBE(PIPE, HF) GS_LAUNCH_JOIN_PROBE_DBG(PIPE, HF, 0)
-#define GS_LAUNCH_JOIN_PROBE_DBG(PIPE, HF, DBG)                                                                                \
-    hipLaunchKernelGGL((k_join_probe<20, PIPE, HF, DBG>), dim3(kJoinSlices * reps), dim3(jthreads), 0, t->stream, cv, r->jq, nb, reps, \
-                       (const uint64_t *)t->j_ovf_code, (const uint32_t *)t->j_ovf_loc, (const uint32_t *)t->j_ovf_start)
-                if (!t->c_has_flag) {
-                    GS_LAUNCH_JOIN_PROBE(4, false);
-                } else {
-#ifdef GS_TUNING
-                    const char *jdbg = getenv("GAVISUNK_DEBUG_MODE");  // phases switched off for timing: RESULTS ARE WRONG
-                    const int jmode = jdbg ? atoi(jdbg) : 0;
-                    if (jmode == 11)
-                        GS_LAUNCH_JOIN_PROBE_DBG(4, true, 1);
-                    else if (jmode == 12)
-                        GS_LAUNCH_JOIN_PROBE_DBG(4, true, 2);
-                    else if (jmode == 13)
-                        GS_LAUNCH_JOIN_PROBE_DBG(4, true, 3);
-                    else if (jpipe == 3)
-                        GS_LAUNCH_JOIN_PROBE(3, true);
-                    else if (jpipe == 5)
-                        GS_LAUNCH_JOIN_PROBE(5, true);
-                    else
-#endif
-                        GS_LAUNCH_JOIN_PROBE(4, true);  // 4 steps per window, two windows in flight: measured best (118 VGPRs, no spills)
-                }
-#undef GS_LAUNCH_JOIN_PROBE
-#undef GS_LAUNCH_JOIN_PROBE_DBG
-                hipLaunchKernelGGL(k_join_merge, dim3((nb + kJoinMergeBatches - 1) / kJoinMergeBatches), dim3(1024), 0, t->stream,
-                                   r->jq, b0, nb, r->n_tiles, r->ta, r->cand, r->cand_cap, r->ps.d_cand_count, r->complex_list,
-                                   r->ps.d_complex_n);
-            }
-            // tiles of degenerate groups (none on ordinary reads): generic exact probe, grid-stride over the list
-            hipLaunchKernelGGL(k_probe<true>, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), cv,
-                               view(r), r->ta, r->cand, r->cand_cap, r->ps.d_cand_count, r->ps.d_err_pos,
-                               (const uint32_t *)r->complex_list, (const uint32_t *)r->ps.d_complex_n);
-        } else if (t->compact == 1) {
-            constexpr int nt = 4;
-            const uint32_t pblocks = ((r->n_tiles + nt - 1) / nt + 3) / 4 * kNPart;
-#define GS_LAUNCH_PART(KT, NT, PIPE, DBG)                                                                           \
-    hipLaunchKernelGGL((k_probe_part<KT, NT, PIPE, DBG>), dim3(pblocks), dim3(256), 0, t->stream, cv, view(t),      \
-                       (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->part_recs)
-            if (t->k != 20) {
-                GS_LAUNCH_PART(0, 4, 4, 0);
-            } else {
-#ifdef GS_TUNING
-                const char *dbg = getenv("GAVISUNK_DEBUG_MODE");  // phases switched off for timing: RESULTS ARE WRONG
-                const int mode = dbg ? atoi(dbg) : 0;
-                const char *env_pipe = getenv("GAVISUNK_PART_PIPE");
-                const int pipe = env_pipe ? atoi(env_pipe) : 2;
-                if (mode == 1)
-                    GS_LAUNCH_PART(20, 4, 4, 1);
-                else if (mode == 2)
-                    GS_LAUNCH_PART(20, 4, 4, 2);
-                else if (mode == 3)
-                    GS_LAUNCH_PART(20, 4, 2, 3);
-                else if (mode == 4)
-                    GS_LAUNCH_PART(20, 4, 2, 4);
-                else if (mode == 5)
-                    GS_LAUNCH_PART(20, 4, 2, 1);
-                else if (mode == 6)
-                    GS_LAUNCH_PART(20, 4, 2, 6);
-                else if (pipe == 8)
-                    GS_LAUNCH_PART(20, 4, 8, 0);
-                else if (pipe == 2)
-                    GS_LAUNCH_PART(20, 4, 2, 0);
-                else
-#endif
-                    GS_LAUNCH_PART(20, 4, 4, 0);
-            }
-#undef GS_LAUNCH_PART
-            hipLaunchKernelGGL(k_merge_part, dim3((r->n_tiles + 15) / 16), dim3(256), 0, t->stream, (const PartRec *)r->part_recs,
-                               r->n_tiles, r->ta, r->cand, r->cand_cap, r->ps.d_cand_count, r->complex_list, r->ps.d_complex_n);
-            // tiles whose partition summaries cannot be merged exactly: generic probe, grid-stride over the list
-            hipLaunchKernelGGL(k_probe<true>, dim3(std::min<uint32_t>(blocks, 1024u)), dim3(256), 0, t->stream, view(t), cv,
-                               view(r), r->ta, r->cand, r->cand_cap, r->ps.d_cand_count, r->ps.d_err_pos,
-                               (const uint32_t *)r->complex_list, (const uint32_t *)r->ps.d_complex_n);
-        } else if (t->compact == 2) {
+        } else if (t->compact) {
             hipLaunchKernelGGL(k_probe<true>, dim3(blocks), dim3(256), 0, t->stream, view(t), cv, view(r), r->ta, r->cand,
                                r->cand_cap, r->ps.d_cand_count, r->ps.d_err_pos, (const uint32_t *)nullptr,
                                (const uint32_t *)nullptr);
@@ -2314,8 +1135,7 @@ uint64_t revcomp_code(uint64_t c, int k) {
 }
 
 // Layout choice for the exact compact copy of the table:
-//   1 = "compact-l2":  32-bit slots, a 1/16 slice fits the L2 of an XCD next to the read stream (<= 2 MiB) -> k_probe_part
-//   2 = "compact-hbm": 32-bit slots, larger; one 16-byte bucket load per window                              -> k_probe<true>
+//   2 = "compact-hbm": 32-bit slots; one 16-byte bucket load per window                                       -> k_probe<true>
 //   3 = "compact-hbm": 64-bit slots (remainder + loc do not fit 32 bits: long k, many groups, huge tables)    -> k_probe<true>
 //   0 = generic 16-byte slots only (k < 16, or a key without loc row)
 int choose_compact(int k, uint64_t n, uint64_t generic_bytes, uint32_t maxloc, bool any_missing, const char *env, int &qb,
@@ -2340,8 +1160,7 @@ int choose_compact(int k, uint64_t n, uint64_t generic_bytes, uint32_t maxloc, b
     if (fits32) {
         rembits = kbits - qb;
         has_flag = rembits + 1 + locbits <= 30;
-        const bool l2 = (16ull << qb) <= (2ull << 20) && locbits <= 18 && !(env && !strcmp(env, "compact-hbm"));
-        return l2 ? 1 : 2;
+        return 2;
     }
     // 64-bit slots with the natural bucket count
     qb = qb_nat;
@@ -2483,26 +1302,18 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
     int lg_full;
     const uint64_t cap_full = pow2_cap(2 * n, lg_full);
     // Layout (GAVISUNK_TABLE forces one; read once per table).  The minimiser-addressed layout whenever it applies (k >= 16, the
-    // slot fits 64 bits): since round 2 its kernel is the fastest on every table size -- cache-resident tables included (config
-    // 2: 188 Gbase/s against 175 of the LDS join).  Otherwise, and when forced ("compact-lds": what small tables got by default
-    // before), an exact compact copy probed from LDS / the L2s, or one bucket load per window from HBM ("compact-hbm").  The
-    // generic 16-byte-slot table holds what those could not take, or everything.
+    // slot fits 64 bits): its kernel is the fastest on every table size, cache-resident tables included (the round-1 layouts for
+    // small tables -- an LDS join, XCD-partitioned L2 probing -- lost to it on their home ground and were retired in round 3).
+    // Otherwise an exact compact copy, one bucket load per window ("compact-hbm"); the generic 16-byte-slot table holds what
+    // those could not take, or everything ("generic": k < 16, a db k-mer without loc row).
     const char *env = getenv("GAVISUNK_TABLE");
     if (env && !strcmp(env, "auto")) env = nullptr;
     const bool force_mz = env && (!strcmp(env, "minimizer") || !strcmp(env, "minimizer-exact"));
-    const bool old_auto = env && !strcmp(env, "compact-lds");  // the compact layouts as they were chosen before
     if ((force_mz || !env) && mz_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_n_regions, t->mz_locbits)) {
         t->mz = force_mz && !strcmp(env, "minimizer-exact") ? 2 : 1;
         t->compact = 0;
     } else {
-        const char *cenv = force_mz || old_auto ? nullptr : env;
-        t->compact = choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, cenv, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
-        // a small-table layout forced on a table it does not apply to: the default layout
-        if ((t->compact == 2 || t->compact == 3) && (old_auto || (env && !strcmp(env, "compact-l2"))) &&
-            mz_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_n_regions, t->mz_locbits)) {
-            t->mz = 1;
-            t->compact = 0;
-        }
+        t->compact = choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, force_mz ? nullptr : env, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
     }
     uint64_t n_generic = n;
     // A minimiser length whose regions cannot hold the keys (more than an eighth of them overflow: clustered minimisers, a
@@ -2648,50 +1459,6 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
         HIP_TRY(hipGetLastError());
         t->c_overflow = ov;
         n_generic = ov;
-        // LDS join: k = 20 makes a slice (partition x top 4 bucket bits) exactly a 32-bit item space
-        t->join = t->compact == 1 && k == 20 && t->c_qb >= 5 && t->c_qb - 4 <= 13 && t->c_locbits <= 15 &&
-                  !(env && !strcmp(env, "compact-l2"));
-        if (t->join) {
-            t->join_chunk = join_chunk_from_env();
-            // the overflow keys in hashed form (slice << 32 | item), sorted: the probe kernel searches them per slice
-            std::vector<uint64_t> ok(ov);
-            std::vector<uint32_t> ol(ov);
-            if (ov) {
-                uint64_t *d_ok = nullptr;
-                uint32_t *d_ol = nullptr;
-                if ((rc = tmp.get(&d_ok, ov)) || (rc = tmp.get(&d_ol, ov))) return rc;
-                hipLaunchKernelGGL(k_gather_list, dim3((unsigned)((ov + 255) / 256)), dim3(256), 0, t->stream, dk, dl, dlist, ov, d_ok, d_ol);
-                HIP_TRY(hipMemcpyAsync(ok.data(), d_ok, ov * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
-                HIP_TRY(hipMemcpyAsync(ol.data(), d_ol, ov * sizeof(uint32_t), hipMemcpyDeviceToHost, t->stream));
-                HIP_TRY(hipStreamSynchronize(t->stream));
-            }
-            std::vector<std::pair<uint64_t, uint32_t>> codes(ov);
-            const int kbits = 2 * k - 4, sb = t->c_qb - 4;
-            for (uint64_t i = 0; i < ov; i++) {
-                const uint64_t c = ok[i];
-                const BucketRem br = hmix2((c >> 4) & ((1ULL << kbits) - 1ULL), kbits, t->c_qb);
-                const uint64_t slice = ((uint64_t)part_of(c, k) << 4) | (br.bucket >> sb);
-                const uint64_t item = ((uint64_t)(br.bucket & ((1u << sb) - 1u)) << t->c_rembits) | br.rem;
-                codes[i] = {(slice << 32) | item, ol[i]};
-            }
-            std::sort(codes.begin(), codes.end());
-            std::vector<uint64_t> hc(ov);
-            std::vector<uint32_t> hl(ov), hs(kJoinSlices + 1, 0);
-            for (uint64_t i = 0; i < ov; i++) {
-                hc[i] = codes[i].first;
-                hl[i] = codes[i].second;
-                hs[(codes[i].first >> 32) + 1]++;
-            }
-            for (int i = 0; i < kJoinSlices; i++) hs[i + 1] += hs[i];  // (a slice with more than kJoinOvfMax keys searches them in HBM)
-            if ((rc = dev_alloc(&t->j_ovf_code, ov)) || (rc = dev_alloc(&t->j_ovf_loc, ov)) ||
-                (rc = dev_alloc(&t->j_ovf_start, kJoinSlices + 1)))
-                return rc;
-            if (ov) {
-                HIP_TRY(hipMemcpy(t->j_ovf_code, hc.data(), ov * sizeof(uint64_t), hipMemcpyHostToDevice));
-                HIP_TRY(hipMemcpy(t->j_ovf_loc, hl.data(), ov * sizeof(uint32_t), hipMemcpyHostToDevice));
-            }
-            HIP_TRY(hipMemcpy(t->j_ovf_start, hs.data(), hs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        }
     }
     int lg;
     // (behind a minimiser-addressed table the generic slots are probed by deferred lookups, most of which miss: a load of 1/4
@@ -2863,7 +1630,7 @@ const char *gs_table_layout(const gs_table *t) {
                  t->mz_m, t->k - t->mz_m + 1, mz_t_of(t->k, t->mz_m), (unsigned long long)t->mz_overflow);
     else if (t->compact)
         snprintf(buf, sizeof buf, "%s: 16 partitions x 2^%d buckets x 4 x %s (%d-bit remainder, %d-bit loc%s), %llu overflow keys in a generic 16 B-slot side table",
-                 t->compact == 1 ? (t->join ? "compact-lds" : "compact-l2") : "compact-hbm", t->c_qb, t->c_w64 ? "u64" : "u32", t->c_rembits, t->c_locbits,
+                 "compact-hbm", t->c_qb, t->c_w64 ? "u64" : "u32", t->c_rembits, t->c_locbits,
                  t->c_has_flag ? ", second-chance buckets" : "", (unsigned long long)t->c_overflow);
     else
         snprintf(buf, sizeof buf, "generic: open-addressed 16 B slots in HBM");
@@ -2879,9 +1646,6 @@ void gs_table_destroy(gs_table *t) {
     (void)hipFree(t->cpayload);
     (void)hipFree(t->mz_regions);
     (void)hipFree(t->mz_pay);
-    (void)hipFree(t->j_ovf_code);
-    (void)hipFree(t->j_ovf_loc);
-    (void)hipFree(t->j_ovf_start);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     if (t->copy_stream) (void)hipStreamDestroy(t->copy_stream);
     delete t;
@@ -3211,17 +1975,6 @@ void gs_reads_destroy(gs_reads *r) {
     (void)hipFree(r->tile_desc);
     (void)hipFree(r->d_seed);
     (void)hipFree(r->d_seg_carry);
-    (void)hipFree(r->part_recs);
-    (void)hipFree(r->jq.item);
-    (void)hipFree(r->jq.woff);
-    (void)hipFree(r->jq.seg);
-    (void)hipFree(r->jq.segT);
-    (void)hipFree(r->jq.hits);
-    (void)hipFree(r->jq.hsub);
-    (void)hipFree(r->jq.gflag);
-    (void)hipFree(r->jq.late);
-    (void)hipFree(r->jq.nlate);
-    (void)hipFree(r->complex_list);
     pass_state_free(r->ps);
     delete r;
 }

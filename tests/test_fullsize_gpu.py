@@ -91,7 +91,7 @@ def test_config2_full_size_properties(config2, monkeypatch):
     assert carry != _lib.GS_NONE and carry <= loc.max()
 
     # the other probe paths agree bit for bit
-    for layout, want in (("compact-lds", "compact-lds"), ("compact-l2", "compact-l2"), ("compact-hbm", "compact-hbm")):
+    for layout, want in (("compact-hbm", "compact-hbm"), ("generic", "generic")):
         other, carry2, ctrs2, name2 = _tag(monkeypatch, layout, keys, loc, [seqs])
         assert name2 == want
         assert np.array_equal(other, whole) and carry2 == carry and ctrs2[0]["raw_hits"] == c["raw_hits"]

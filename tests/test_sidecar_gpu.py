@@ -50,7 +50,7 @@ def test_cli_with_sidecar_writes_the_reference_bytes(golden, name, tmp_path, mon
     assert cli("o5") == plain
 
 
-@pytest.mark.parametrize("layout", ["auto", "compact-lds", "compact-hbm", "generic"])
+@pytest.mark.parametrize("layout", ["auto", "compact-hbm", "generic"])
 def test_sidecar_keeps_every_layout(layout, golden, tmp_path, monkeypatch):
     """The table travels as it was built (the scalars + array list of a broadcast): whatever layout the first run chose."""
     monkeypatch.setenv("GAVISUNK_TABLE", layout)

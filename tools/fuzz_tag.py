@@ -17,7 +17,7 @@ from gavisunk_amd import _lib, engine, synth  # noqa: E402
 from oracle import oracle, sunkdef  # noqa: E402
 
 K = 20  # k of the current round (most rounds: GAVISUNK's default 20)
-LAYOUTS = ["auto", "compact-lds", "compact-l2", "compact-hbm", "minimizer", "generic"]
+LAYOUTS = ["auto", "compact-hbm", "minimizer", "minimizer-exact", "generic"]
 
 
 def draw(seed):
@@ -69,8 +69,6 @@ def draw(seed):
     env = {}
     if rng.random() < 0.25:
         env["GAVISUNK_COMPACT_QB"] = str(int(rng.integers(4, 13)))
-    if rng.random() < 0.3:
-        env["GAVISUNK_JOIN_CHUNK"] = str(int(rng.choice([64, 128, 192])))
     return keys, loc, seqs, env
 
 
@@ -104,7 +102,7 @@ def main():
     t0, rounds, names = time.time(), 0, {}
     while time.time() - t0 < budget:
         keys, loc, seqs, env = draw(seed)
-        for k in ("GAVISUNK_COMPACT_QB", "GAVISUNK_JOIN_CHUNK"):
+        for k in ("GAVISUNK_COMPACT_QB",):
             os.environ.pop(k, None)
         os.environ.update(env)
         rng = np.random.default_rng(seed + 7)
