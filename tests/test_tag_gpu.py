@@ -477,6 +477,28 @@ def test_table_clone_is_the_receiving_side_of_a_broadcast(table_layout):
     twin.close()
 
 
+def test_keyerror_after_a_million_rows(table_layout):
+    """A db k-mer without loc row met after more than 2^20 emitted rows: the rows before it are handed out -- the reference
+    has written them when it dies (kmerpos_annot3.nim:90-93).  (Lists beyond 2^20 rows are not mirrored to the host by the emit
+    kernel but fetched in one copy, decided by the pass's total, not by the truncated count.)"""
+    if table_layout not in ("auto", "generic"):
+        pytest.skip("one fast and one slow layout are enough here")
+    k = 20
+    rng = np.random.default_rng(12)
+    g = rng.integers(0, 4, 1_300_000, dtype=np.uint8)
+    sunks = sunkdef.define_sunks([("c", synth.codes_to_ascii(g))], k)
+    keys, loc = sunks.code, np.arange(len(sunks), dtype=np.uint32)  # every SUNK its own location: every hit is a row
+    bad = int(np.searchsorted(sunks.start, 1_250_000))
+    loc[bad] = _lib.GS_MISSING
+    seqs = [synth.codes_to_ascii(g), synth.codes_to_ascii(g[:5000])]
+    t = oracle.Table(k, keys, keys[loc != _lib.GS_MISSING], np.zeros(len(keys) - 1, np.uint32), loc[loc != _lib.GS_MISSING].astype(np.int64))
+    buf, off = oracle.concat_reads(seqs)
+    rc, oh, _, _ = t.tag(buf, off, cap=1 << 21)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert rc == -2 and st == _lib.GS_E_KEYERROR and len(gh) == len(oh) > (1 << 20)
+    assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"])
+
+
 def test_table_without_keys():
     st, h, carry, ctr = _engine_hits(20, np.zeros(0, np.uint64), np.zeros(0, np.uint32), [b"ACGT" * 100, b""])
     assert st == 0 and len(h) == 0 and carry == _lib.GS_NONE and ctr["raw_hits"] == 0
