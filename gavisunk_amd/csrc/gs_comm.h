@@ -89,9 +89,9 @@ Rccl *rccl() {
 
 // everything of a table that is not a pointer or a per-handle resource
 struct TableMeta {
-    int k, shift, compact, c_qb, c_rembits, c_locbits, c_has_flag, c_w64, mz, mz_m, mz_locbits, join;
+    int k, shift, compact, c_qb, c_rembits, c_locbits, c_has_flag, c_w64, mz, mz_m, mz_locbits, mz_place, mz_s;
     uint32_t mz_n_regions, join_chunk;
-    uint64_t n, cap, c_overflow, mz_overflow, n_ovf;
+    uint64_t n, cap, c_overflow, mz_overflow, n_ovf, mz_dup;
 };
 
 __global__ void k_shift_reads(gs_hit *h, uint64_t n, uint32_t delta) {
@@ -107,7 +107,7 @@ __global__ void k_shift_reads(gs_hit *h, uint64_t n, uint32_t delta) {
 // the others inside a collective.
 TableMeta table_meta_of(const gs_table *t, uint64_t n_ovf) {
     return TableMeta{t->k, t->shift, t->compact, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64, t->mz, t->mz_m,
-                     t->mz_locbits, 0, t->mz_n_regions, 0u, t->n, t->cap, t->c_overflow, t->mz_overflow, n_ovf};
+                     t->mz_locbits, t->mz_place, t->mz_s, t->mz_n_regions, 0u, t->n, t->cap, t->c_overflow, t->mz_overflow, n_ovf, t->mz_dup};
 }
 
 struct TableArray {  // one device array of a table: where its pointer lives in the handle, and its size in bytes
@@ -126,7 +126,7 @@ std::vector<TableArray> table_arrays(const TableMeta &hm, gs_table *dst, const g
     if (hm.mz) {
         const uint64_t nslots = (uint64_t)hm.mz_n_regions * kMzWords;
         add((void **)&dst->mz_regions, src ? src->mz_regions : nullptr, nslots * sizeof(unsigned long long));
-        add((void **)&dst->mz_pay, src ? src->mz_pay : nullptr, nslots * sizeof(uint32_t));
+        add((void **)&dst->mz_pay, src ? src->mz_pay : nullptr, nslots * sizeof(uint32_t));  // (place records: 8 base rows per region)
     } else if (hm.compact) {
         const uint64_t nslots = (uint64_t)(4 * kNPart) << hm.c_qb;
         add((void **)&dst->cbuckets, src ? src->cbuckets : nullptr, (hm.c_w64 ? 2 * nslots : nslots) * sizeof(uint32_t));
@@ -155,10 +155,13 @@ int table_receive_init(gs_table *t, int device, const TableMeta &hm) {
     t->mz = hm.mz;
     t->mz_m = hm.mz_m;
     t->mz_locbits = hm.mz_locbits;
+    t->mz_place = hm.mz_place;
+    t->mz_s = hm.mz_s;
     t->mz_n_regions = hm.mz_n_regions;
     t->cap = hm.cap;
     t->c_overflow = hm.c_overflow;
     t->mz_overflow = hm.mz_overflow;
+    t->mz_dup = hm.mz_dup;
     for (auto &a : table_arrays(hm, t, nullptr)) {
         uint8_t *p = nullptr;
         if ((rc = dev_alloc(&p, a.bytes))) return rc;

@@ -692,6 +692,11 @@ __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, MzV
         const uint64_t a = rd.words[wi], b2 = rd.words[wi + 1];
         const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(w & 31u), k, kmask);
         uint32_t payload = 0, loc_unused = 0;
+#if GS_MZ_PLACE
+        if (compact == 4 && mz.place) {
+            payload = mzp_payload(MzpView{mz.regions, mz.pay, mz.k, mz.m, mz.s}, tab, c);
+        } else
+#endif
         if (compact == 4) {
             payload = mz_payload(mz, tab, c);
         } else if (compact) {
@@ -936,6 +941,7 @@ struct gs_table {
     int mz_m = 0, mz_locbits = 0;
     uint32_t *mz_pay = nullptr;  // payload per slot
     uint64_t mz_overflow = 0, mz_dup = 0;  // keys in the generic side table; keys stored under both strands' picks
+    int mz_place = 0, mz_s = 0;            // place-record regions (gs_mzp.h): 2^(2 mz_m - mz_s) of them
     hipStream_t stream = nullptr;       // every pass over this table runs here, in launch order
     hipStream_t copy_stream = nullptr;  // hit lists to the host: overlaps the next pass
     gs_counters ctr{};
@@ -994,7 +1000,7 @@ namespace {
 
 TableView view(const gs_table *t) { return TableView{t->slots, t->cap - 1, t->shift, t->k}; }
 MzView mz_view(const gs_table *t) {
-    return MzView{t->mz_regions, t->mz_n_regions, t->k, t->mz_m, t->mz_locbits, t->mz_pay};
+    return MzView{t->mz_regions, t->mz_n_regions, t->k, t->mz_m, t->mz_locbits, t->mz_pay, t->mz_place, t->mz_s};
 }
 ReadsView view(const gs_reads *r) {
     return ReadsView{r->words, r->read_word_off, r->read_nwin, r->read_tile0, r->tile_read, r->n_tiles};
@@ -1029,6 +1035,25 @@ int launch_phase1(gs_table *t, gs_reads *r) {
         const uint32_t blocks = (r->n_tiles + 3) / 4;
         const CompactView cv{t->cbuckets, t->cpayload, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64};
         // GAVISUNK_TABLE=minimizer-exact: every tile by the per-lane form (the fast form's fallback)
+#if GS_MZ_PLACE
+        if (t->mz == 2 && t->mz_place) {
+            hipLaunchKernelGGL(k_probe_mzp_exact, dim3(blocks), dim3(256), 0, t->stream, MzpView{t->mz_regions, t->mz_pay, t->k, t->mz_m, t->mz_s},
+                               view(t), (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->ta, r->cand, r->cand_cap,
+                               r->ps.d_cand_count);
+        } else if (t->mz && t->mz_place) {
+#define GS_LAUNCH_MZP(KT, MT)                                                                                                         \
+    hipLaunchKernelGGL((k_probe_mz<KT, MT, 1, true>), dim3((r->n_tiles + kMzWaves - 1) / kMzWaves), dim3(64 * kMzWaves), 0, t->stream, \
+                       mz_view(t), view(t), (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->ta,             \
+                       r->cand, r->cand_cap, r->ps.d_cand_count, r->ps.d_complex_n)
+            if (t->k == 20 && t->mz_m == 14)
+                GS_LAUNCH_MZP(20, 14);
+            else if (t->k == 20 && t->mz_m == 15)
+                GS_LAUNCH_MZP(20, 15);
+            else
+                GS_LAUNCH_MZP(0, 0);
+#undef GS_LAUNCH_MZP
+        } else
+#endif
         if (t->mz == 2) {
             hipLaunchKernelGGL(k_probe_mz_exact, dim3(blocks), dim3(256), 0, t->stream, mz_view(t), view(t), (const uint64_t *)r->words,
                                (const TileDesc *)r->tile_desc, r->n_tiles, r->ta, r->cand, r->cand_cap, r->ps.d_cand_count);
@@ -1170,6 +1195,46 @@ int choose_compact(int k, uint64_t n, uint64_t generic_bytes, uint32_t maxloc, b
     return 3;
 }
 
+#if GS_MZ_PLACE
+// Place-record regions (gs_mzp.h): k - 6 <= m <= 15 (a tag word holds two flanks of w - 1 <= 6 bases; regions are addressed by
+// a bijection of the 2m-bit m-mer).  The shortest such m whose regions stay below ~2.5 places on average (7 fit); s from the
+// number of places: 2^(2m - s) regions, about one per place.
+int mzp_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, int &s, int m_from = 0) {
+    if (k < 16 || k > 21 || n == 0 || any_missing) return 0;
+    int m_lo = std::max(std::max(k - 6, 10), m_from), m_hi = std::min(15, k - 1);
+    if (m_lo > m_hi) return 0;
+    if (const char *e = getenv("GAVISUNK_MZ_M")) {  // tuning / test knob, read once per table
+        const int v = atoi(e);
+        if (v >= m_lo && v <= m_hi) m_lo = m_hi = v;
+    }
+    for (m = m_lo; m <= m_hi; m++) {
+        const double w = k - m + 1, places = 1.1 * (double)n / std::max(1.0, 0.6 * w);
+        // regions = the power of two next above places / 1.5 (s >= 1: half of the 2m-bit values are no canonical m-mers)
+        s = 1;
+        while (s < 16 && std::ldexp(1.0, 2 * m - (s + 1)) >= places / 1.5) s++;
+        const double load = places / std::ldexp(1.0, 2 * m - s);
+        if (const char *e = getenv("GAVISUNK_MZ_LOAD")) {  // test knob: crowded regions on purpose
+            const double v = atof(e);
+            if (v >= 0.25 && v <= 64.0) {
+                s = 1;
+                while (s < 16 && std::ldexp(1.0, 2 * m - (s + 1)) >= places / v) s++;
+            }
+        } else if ((load > 3.0 || (double)n > 3.0e8 * std::ldexp(1.0, 2 * (m - 14))) && m < m_hi) {
+            // (the m-mers a mod-minimiser samples are a biased subset of the 4^m values -- those that begin or end with a small
+            // t-mer -- so the places crowd into a fraction of the regions: measured, a 3e8-key table is what m = 14 takes)
+            continue;
+        }
+        while (s > 0 && ((uint64_t)maxloc + 2) >> (32 - s)) s--;  // the loc word holds fp and loc
+        if (((uint64_t)maxloc + 2) >> (32 - s)) return 0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+        if (std::ldexp(96.0, 2 * m - s) > 0.5 * (double)free_b) continue;
+        return 1;
+    }
+    return 0;
+}
+#endif
+
 // Minimiser-addressed layout (gs_mz.h): applies when a slot [2k-3 tag bits | loc] fits 64 bits.  m from the key count: the
 // places of the assembly that own a minimiser (about n / (0.65 (w + 1) / 2)) should be few against the 4^m / 2 values.
 int mz_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, uint32_t &n_regions, int &locbits) {
@@ -1308,18 +1373,101 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
     // those could not take, or everything ("generic": k < 16, a db k-mer without loc row).
     const char *env = getenv("GAVISUNK_TABLE");
     if (env && !strcmp(env, "auto")) env = nullptr;
-    const bool force_mz = env && (!strcmp(env, "minimizer") || !strcmp(env, "minimizer-exact"));
+    const bool force_mz = env && (!strcmp(env, "minimizer") || !strcmp(env, "minimizer-exact") || !strcmp(env, "minimizer-slots"));
+#if GS_MZ_PLACE
+    const bool want_slots = env && !strcmp(env, "minimizer-slots");  // the per-key-slot regions (the only form for k > 21)
+    if ((force_mz || !env) && !want_slots && mzp_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_s)) {
+        t->mz = force_mz && !strcmp(env, "minimizer-exact") ? 2 : 1;
+        t->mz_place = 1;
+        t->mz_n_regions = 1u << (2 * t->mz_m - t->mz_s);
+        t->mz_locbits = 32 - t->mz_s;
+        t->compact = 0;
+    } else if ((force_mz || !env) && mz_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_n_regions, t->mz_locbits)) {
+        t->mz = force_mz && !strcmp(env, "minimizer-exact") ? 2 : 1;
+        t->compact = 0;
+    } else {
+#else
     if ((force_mz || !env) && mz_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_n_regions, t->mz_locbits)) {
         t->mz = force_mz && !strcmp(env, "minimizer-exact") ? 2 : 1;
         t->compact = 0;
     } else {
+#endif
         t->compact = choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, force_mz ? nullptr : env, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
     }
     uint64_t n_generic = n;
     // A minimiser length whose regions cannot hold the keys (more than an eighth of them overflow: clustered minimisers, a
     // repeat-rich assembly) is no reason to fail: the next length is tried (shorter runs, emptier regions), and when none
     // does, the layouts below take the table -- only a FORCED layout reports the misfit.
+#if GS_MZ_PLACE
+    while (t->mz && t->mz_place) {
+        const uint64_t nreg = t->mz_n_regions;
+        const bool knob = getenv("GAVISUNK_MZ_M") || getenv("GAVISUNK_MZ_LOAD");
+        const uint64_t ocap = std::max<uint64_t>(knob && force_mz ? 2 * n : n / 16, 1u << 16);
+        unsigned long long *dov = nullptr;
+        if ((rc = dev_alloc((unsigned long long **)&t->mz_regions, nreg * kMzWords)) || (rc = dev_alloc(&t->mz_pay, nreg * 8)) ||
+            (rc = tmp.get(&dov, 1)) || (rc = tmp.get(&dlist, ocap)))
+            return rc;
+        HIP_TRY(hipMemsetAsync(t->mz_regions, 0, nreg * kMzWords * sizeof(unsigned long long), t->stream));
+        HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
+        uint64_t n2 = n;
+        {
+            DevBufs st;
+            uint64_t *ent1 = nullptr;
+            {
+                DevBufs se;
+                uint64_t *ent0 = nullptr;
+                unsigned long long *dnd = nullptr;
+                if ((rc = se.get(&ent0, 2 * n)) || (rc = st.get(&ent1, 2 * n)) || (rc = se.get(&dnd, 1))) return rc;
+                HIP_TRY(hipMemsetAsync(dnd, 0, sizeof(unsigned long long), t->stream));
+                hipLaunchKernelGGL(k_mzp_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, dk, n, k, t->mz_m, t->mz_s, ent0, dnd);
+                if ((rc = sort_keys_u64(ent0, ent1, 2 * n, t->stream))) return rc;
+                unsigned long long nd = 0;
+                HIP_TRY(hipMemcpyAsync(&nd, dnd, sizeof nd, hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                n2 = n + nd;
+                t->mz_dup = nd;
+            }
+            hipLaunchKernelGGL(k_mzp_place, dim3((unsigned)((n2 + 127) / 128)), dim3(128), 0, t->stream, const_cast<uint4 *>(t->mz_regions), t->mz_pay, k,
+                               t->mz_m, t->mz_s, dk, dl, dp, (const uint64_t *)ent1, n2, dov, dlist, ocap);
+            HIP_TRY(hipStreamSynchronize(t->stream));
+        }
+        unsigned long long ov = 0;
+        HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        HIP_TRY(hipGetLastError());
+        if (ov <= ocap) {
+            t->mz_overflow = ov;
+            n_generic = ov;
+            break;
+        }
+        // more than a sixteenth of the keys outside their regions: the next minimiser length (more, emptier regions), then the
+        // per-key-slot regions, then the compact / generic layouts -- only a forced geometry reports the misfit
+        if (knob && force_mz) {
+            set_error("gs_table_create: %llu of %llu keys do not fit the place records (m = %d, s = %d); force another layout with GAVISUNK_TABLE",
+                      ov, (unsigned long long)n, t->mz_m, t->mz_s);
+            return GS_E_NOMEM;
+        }
+        (void)hipFree(t->mz_regions);
+        (void)hipFree(t->mz_pay);
+        t->mz_regions = nullptr;
+        t->mz_pay = nullptr;
+        dlist = nullptr;
+        const int tried = t->mz_m;
+        if (!getenv("GAVISUNK_MZ_M") && mzp_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_s, tried + 1)) {
+            t->mz_n_regions = 1u << (2 * t->mz_m - t->mz_s);
+            t->mz_locbits = 32 - t->mz_s;
+            continue;
+        }
+        t->mz_place = 0;
+        if (!mz_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_n_regions, t->mz_locbits)) {
+            t->mz = 0;
+            t->compact = choose_compact(k, n, cap_full * sizeof(Slot), maxloc, any_missing, nullptr, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag);
+        }
+    }
+    while (t->mz && !t->mz_place) {
+#else
     while (t->mz) {
+#endif
         const uint64_t nslots = (uint64_t)t->mz_n_regions * kMzWords;
         const bool knob = getenv("GAVISUNK_MZ_M") || getenv("GAVISUNK_MZ_LOAD");
         const uint64_t ocap = std::max<uint64_t>(knob && force_mz ? 2 * n : n / 8, 1u << 16);
@@ -1622,9 +1770,12 @@ int gs_table_create_device(int device, int k, uint64_t n, const void *d_keys, co
 }
 
 const char *gs_table_layout(const gs_table *t) {
-    static thread_local char buf[256];
+    static thread_local char buf[448];
     if (!t) return "";
-    if (t->mz)
+    if (t->mz && t->mz_place)
+        snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 64 B (7 place records: flank bases of the minimiser's context + offset mask | %d-bit fp + loc), mod-minimiser of length %d (w = %d, t = %d), %llu keys under both strands' picks, %llu overflow keys in a generic 16 B-slot side table",
+                 t->mz_n_regions, t->mz_s, t->mz_m, t->k - t->mz_m + 1, mz_t_of(t->k, t->mz_m), (unsigned long long)t->mz_dup, (unsigned long long)t->mz_overflow);
+    else if (t->mz)
         snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 64 B (8 fingerprint bytes + 7 x u64 [%d-bit %s | %d-bit loc]), mod-minimiser of length %d (w = %d, t = %d), %llu overflow keys in a generic 16 B-slot side table",
                  t->mz_n_regions, mz_raw(t->k, t->mz_locbits) ? 2 * t->k : 2 * t->k - 3, mz_raw(t->k, t->mz_locbits) ? "key" : "tag", t->mz_locbits,
                  t->mz_m, t->k - t->mz_m + 1, mz_t_of(t->k, t->mz_m), (unsigned long long)t->mz_overflow);
@@ -1653,6 +1804,7 @@ void gs_table_destroy(gs_table *t) {
 
 uint64_t gs_table_bytes(const gs_table *t) {
     if (!t) return 0;
+    if (t->mz && t->mz_place) return t->cap * sizeof(Slot) + (uint64_t)t->mz_n_regions * 96;  // regions + 8 base rows each
     if (t->mz) return t->cap * sizeof(Slot) + (uint64_t)t->mz_n_regions * kMzWords * 12;  // regions + payload words
     return t->cap * sizeof(Slot) + (t->compact ? ((uint64_t)((t->c_w64 ? 48 : 32) * kNPart) << t->c_qb) : 0);  // slots + payloads
 }

@@ -48,11 +48,24 @@
 // They sit in a parallel array, one 32-bit word per slot, that only k_emit reads.
 #pragma once
 
+// ---- compile-time switches (kernel A/B variants: python -m gavisunk_amd.build --variant NAME -D...) ----
+#ifndef GS_MZ_PLACE
+#define GS_MZ_PLACE 1  // 1: + the place-record format of gs_mzp.h (k <= 21: a record per place, shorter minimisers, longer runs)
+#endif
+#ifndef GS_MZ_RD
+#define GS_MZ_RD GS_MZ_PLACE  // 1: a window's region = the pick of the leftmost smallest t-mer AS THE READ SHOWS THE K-MER (no strand test in
+                    // the probe); the table then holds a key under the pick of either strand (two places when they differ)
+#endif
+#ifndef GS_MZ_RCW
+#define GS_MZ_RCW 1  // 1: the tile staged as two dword streams (forward, reverse complement); windows extracted with v_alignbit
+#endif
+
 struct MzView {
     const uint4 *regions;  // [n_regions][8] pieces of two 64-bit slots
     uint32_t n_regions;
     int k, m, locbits;
     const uint32_t *pay;  // [n_regions][8]: payload of the key in slot i (word 0 of a region is unused)
+    int place, s;         // gs_mzp.h: place-record regions, 2^(2m - s) of them
 };
 
 constexpr uint64_t kMzEmpty = ~0ULL;
@@ -308,18 +321,27 @@ struct MzWin {
     uint32_t h;     // hash of the canonical m-mer that starts there
     uint32_t o;     // order (mz_tmer_order) of the canonical t-mer that starts there
 };
+template <bool PLACE = false>
 __device__ __forceinline__ MzWin mz_win_from(uint64_t f, uint64_t r, int k, int m, uint64_t mmask);
+__host__ __device__ __forceinline__ uint32_t mzp_mmer_word(uint32_t fm, uint32_t rm, int m);
+__host__ __device__ constexpr int mzp_t_of(int k, int m);
 // the window whose first base is base (lane & 31) of the 64-base string a:b
 __device__ __forceinline__ MzWin mz_win_of(uint64_t a, uint64_t b, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
     const int sh = 2 * (lane & 31);
     const uint64_t x = sh ? ((a << sh) | (b >> (64 - sh))) : a;  // 32 bases from the window's first one
-    return mz_win_from(x >> (64 - 2 * k), ~revpairs(x) & kmask, k, m, mmask);  // (revpairs: base i of x, complemented, at bits 2i+1:2i)
+    return mz_win_from<false>(x >> (64 - 2 * k), ~revpairs(x) & kmask, k, m, mmask);  // (revpairs: base i of x, complemented, at bits 2i+1:2i)
 }
 // ... from the window's forward and reverse-complement codes
+template <bool PLACE>
 __device__ __forceinline__ MzWin mz_win_from(uint64_t f, uint64_t r, int k, int m, uint64_t mmask) {
     MzWin o;
     o.f = f;
     o.r = r;
+#if GS_MZ_PLACE
+    if constexpr (PLACE) {  // (m <= 15) bij(canonical m-mer) << 1 | orientation: gs_mzp.h
+        o.h = mzp_mmer_word((uint32_t)(o.f >> (2 * (k - m))), (uint32_t)o.r & (uint32_t)mmask, m);
+    } else
+#endif
     if (m <= 16) {  // wave-uniform: the m-mer fits a word
         const uint32_t fm = (uint32_t)(o.f >> (2 * (k - m))), rm = (uint32_t)o.r & (uint32_t)mmask;
         o.h = mz_mmer_hash((uint64_t)(fm < rm ? fm : rm));
@@ -327,7 +349,11 @@ __device__ __forceinline__ MzWin mz_win_from(uint64_t f, uint64_t r, int k, int 
         const uint64_t fm = o.f >> (2 * (k - m)), rm = o.r & mmask;
         o.h = mz_mmer_hash(fm < rm ? fm : rm);
     }
+#if GS_MZ_PLACE
+    const int t = PLACE ? mzp_t_of(k, m) : mz_t_of(k, m);
+#else
     const int t = mz_t_of(k, m);
+#endif
     const uint32_t tmask = (1u << (2 * t)) - 1u;
     const uint32_t ft = (uint32_t)(o.f >> (2 * (k - t))), rt = (uint32_t)o.r & tmask;
     o.o = mz_tmer_order(ft < rt ? ft : rt);
@@ -494,6 +520,8 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
     mz_tile_exact(mz, tab, words, tdesc[tile], tile, n_tiles, ta, cand, cand_cap, g_cand_count, s_cand[wave]);
 }
 
+#include "gs_mzp.h"
+
 // ------------------------------------------------------------------------------------------
 // k_probe_mz: the fast form.  One wavefront per tile, lane = window, and per step of 64 windows:
 //
@@ -517,13 +545,6 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 constexpr int kMzRunCap = 32;                  // runs of a step whose regions fit the LDS cache slot (2 KiB)
 constexpr int kMzDma = kMzRunCap * kMzPieces / 64;  // LDS-DMA wave-instructions per step
 constexpr int kMzStages = 2;                   // steps whose region fetches are in flight together
-#ifndef GS_MZ_RD
-#define GS_MZ_RD 0  // 1: a window's region = the pick of the leftmost smallest t-mer AS THE READ SHOWS THE K-MER (no strand test in
-                    // the probe); the table then holds a key under the pick of either strand (two places when they differ)
-#endif
-#ifndef GS_MZ_RCW
-#define GS_MZ_RCW 0  // 1: the tile staged as two dword streams (forward, reverse complement); windows extracted with v_alignbit
-#endif
 #if GS_MZ_RCW
 constexpr int kMzListCap = 176;                // maybe-hits held before the list is flushed (a step adds up to 64)
 constexpr int kMzDeferCap = 80;                // deferred generic-table lookups held before a flush
@@ -562,6 +583,9 @@ struct MzWaveLds {
                                             // step's look-ahead read touches and never uses)
 #endif
     uint16_t list_w[kMzListCap];            // window offset of every maybe-hit
+#ifdef GS_MZ_PAD_LDS
+    uint32_t pad_lds[GS_MZ_PAD_LDS / 4];    // (occupancy experiment: fewer waves per CU)
+#endif
 };
 
 // LDS accesses of the main loop are written as asm: while an LDS-DMA is in flight hipcc puts `s_waitcnt vmcnt(0)` in
@@ -589,11 +613,15 @@ __device__ __forceinline__ void lds_write_b16(uint32_t addr, uint32_t v) {
 
 // the window that starts at this lane's base in step s, from the tile's 66 words staged in LDS (two 8-byte reads, one
 // instruction; lanes 0..31 share one address pair, lanes 32..63 the next)
+template <bool PLACE = false>
 __device__ __forceinline__ MzWin mz_window_lds(uint32_t words_a, uint32_t s, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
     uint4 v;
     const uint32_t addr = words_a + (2u * s + (uint32_t)(lane >> 5)) * 8u;
     asm volatile("ds_read2_b64 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return mz_win_of((uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32), lane, k, m, kmask, mmask);
+    const uint64_t a = (uint64_t)v.x | ((uint64_t)v.y << 32), b = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    const int sh = 2 * (lane & 31);
+    const uint64_t x = sh ? ((a << sh) | (b >> (64 - sh))) : a;  // 32 bases from the window's first one
+    return mz_win_from<PLACE>(x >> (64 - 2 * k), ~revpairs(x) & kmask, k, m, mmask);
 }
 
 #if GS_MZ_RCW
@@ -625,6 +653,7 @@ __device__ __forceinline__ void lds_read3_b32(uint32_t addr, uint32_t &a, uint32
     b = ab.y;
 }
 // the window that starts at this lane's base in step s (k > 16: the code's high part is 2k - 32 bits of the first dword pair)
+template <bool PLACE = false>
 __device__ __forceinline__ MzWin mz_window_rcw(const MzLaneGeom &g, uint32_t s, int k, int m, uint64_t mmask) {
     uint32_t a, b, c, ra, rb, rc;
     lds_read3_b32(g.f_addr + 16u * s, a, b, c);
@@ -634,7 +663,7 @@ __device__ __forceinline__ MzWin mz_window_rcw(const MzLaneGeom &g, uint32_t s, 
     const uint32_t sh = (uint32_t)(64 - 2 * k);  // 1 .. 31
     const uint64_t f = ((uint64_t)(fh >> sh) << 32) | mz_alignbit(fh, fl, sh);
     const uint64_t r = ((uint64_t)(rh >> sh) << 32) | mz_alignbit(rh, rl, sh);
-    return mz_win_from(f, r, k, m, mmask);
+    return mz_win_from<PLACE>(f, r, k, m, mmask);
 }
 #endif
 
@@ -706,7 +735,7 @@ struct MzSlide {
 // the last lanes), leftmost or rightmost as the canonical strand reads; the m-mer at (its offset mod w) is the one.
 template <int WT, int NT>  // WT: w at compile time or 0
 __device__ __forceinline__ uint32_t mz_pick(MzSlide<NT> &slide, uint32_t &e_cur, const MzWin &cur, const MzWin &nxt, bool rc_strand,
-                                           int lane, int w, int nt) {
+                                           int lane, int w, int nt, uint32_t *pm_out = nullptr) {
     const uint32_t e_nxt = slide.advance(mz_pk_of(nxt.o, lane), lane, nt);
     const uint32_t ew = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + nt - 1) & 63) * 4,
                                                                (int)(lane < nt - 1 ? e_nxt + kMzNextFrame : e_cur));
@@ -718,7 +747,10 @@ __device__ __forceinline__ uint32_t mz_pick(MzSlide<NT> &slide, uint32_t &e_cur,
     const uint32_t at = rc_strand ? 95u - ((ew >> 16) & 0x7Fu) : (ew & 0x7Fu) - 32u;  // lane of the chosen t-mer (64.. = next step)
 #endif
     const uint32_t xoff = at - (uint32_t)lane;                                          // 0 .. nt - 1
-    const uint32_t pm = WT == 4 ? (xoff & 3u) : xoff % (uint32_t)(WT ? WT : w);
+    // (xoff < nt: with a compile-time w and at most 2 w t-mers per window one conditional subtraction is the remainder)
+    const uint32_t pm = WT == 4 ? (xoff & 3u) : (WT && NT && NT <= 2 * WT) ? xoff - (xoff >= (uint32_t)WT ? (uint32_t)WT : 0u)
+                                                                         : xoff % (uint32_t)(WT ? WT : w);
+    if (pm_out) *pm_out = pm;
     // the m-mer hash of lane + pm: of this step, or (last lanes) of the next one
     const int src = (int)(((uint32_t)lane + pm) & 63u) * 4;
     const uint32_t h_here = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.h);
@@ -767,11 +799,15 @@ struct MzRowSlide {
 };
 // the m-mer offset (0..3) of the window that starts at this lane in the step the slide stands at, given the slide of the next
 // step; lane of the chosen t-mer = e & 0x7F (64.. = in the next step)
-__device__ __forceinline__ uint32_t mz_row_pick(const MzRowSlide &cur, const MzRowSlide &nxt, int lane) {
+template <int W = 4>
+__device__ __forceinline__ uint32_t mz_row_pick(const MzRowSlide &cur, const MzRowSlide &nxt, int lane, int w_rt = 4) {
     const uint32_t comb = lane < 16 ? nxt.P + 64u : cur.P;
     const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 15) & 63) * 4, (int)comb);
     const uint32_t e = min(cur.S, (lane & 15) ? q : 0xFFFFFFFFu);
-    return ((e & 0x7Fu) - (uint32_t)lane) & 3u;
+    const uint32_t xoff = (e & 0x7Fu) - (uint32_t)lane;  // 0 .. 15
+    if constexpr (W == 4) return xoff & 3u;
+    else if constexpr (W == 0) return xoff % (uint32_t)w_rt;
+    else return xoff - (uint32_t)W * (xoff >= (uint32_t)W) - (uint32_t)W * (xoff >= 2u * (uint32_t)W);  // (W >= 6: at most two wraps)
 }
 #endif
 
@@ -833,7 +869,8 @@ __global__ __launch_bounds__(64) void k_mz_rule_check(int k_rt, int m_rt, const 
 }
 
 // KT / MT: k and m as compile-time constants (0 = take them from the table); FMT: slot format (mz_key_fmt)
-template <int KT, int MT, int FMT>
+// PLACE: the place-record format of gs_mzp.h (FMT is then unused)
+template <int KT, int MT, int FMT, bool PLACE = false>
 __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableView tab, const uint64_t *__restrict__ words,
                                                            const TileDesc *__restrict__ tdesc, uint32_t n_tiles, TileArrays ta,
                                                            uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
@@ -847,8 +884,13 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     MzWaveLds &L = s_lds[wave];
     const TileDesc td = tdesc[tile];
     const int k = KT ? KT : mz.k, m = MT ? MT : mz.m, w = k - m + 1, locbits = mz.locbits;
+#if GS_MZ_PLACE
+    constexpr int NT = !KT ? 0 : PLACE ? KT - mzp_t_of(KT ? KT : 20, KT ? MT : 15) + 1 : KT - mz_t_of(KT ? KT : 20, KT ? MT : 17) + 1;
+    const int nt = k - (PLACE ? mzp_t_of(k, m) : mz_t_of(k, m)) + 1;  // t-mers per window
+#else
     constexpr int NT = KT ? KT - mz_t_of(KT ? KT : 20, KT ? MT : 17) + 1 : 0;
     const int nt = k - mz_t_of(k, m) + 1;  // t-mers per window
+#endif
     const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
     const uint64_t mmask = (1ULL << (2 * m)) - 1ULL;
     const uint64_t locmask = (1ULL << locbits) - 1ULL;
@@ -881,16 +923,17 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
 
     // per in-flight step (slot = step % kMzStages): the fingerprint to look for, where the lane's region is in the cache slot,
     // the key / tag to look for, lane r = region of run r, and the run count
+    // (PLACE: fpT = the fp word (fp << (32 - s)), want = tag word | mask word << 32)
     uint32_t fpT[kMzStages], regoff[kMzStages], runreg[kMzStages], nruns[kMzStages];  // fpT: fingerprint in all four bytes, bit 31 of regoff: invalid lane
     uint64_t want[kMzStages];
 #if GS_MZ_RCW
     const MzLaneGeom geom = mz_lane_geom(lds_addr(&L.fd[0]), lds_addr(&L.rd[0]), lane, k);
     auto window = [&](uint32_t s) {
-        if constexpr (RCW) return mz_window_rcw(geom, s, k, m, mmask);
-        else return mz_window_lds(words_a, s, lane, k, m, kmask, mmask);
+        if constexpr (RCW) return mz_window_rcw<PLACE>(geom, s, k, m, mmask);
+        else return mz_window_lds<PLACE>(words_a, s, lane, k, m, kmask, mmask);
     };
 #else
-    auto window = [&](uint32_t s) { return mz_window_lds(words_a, s, lane, k, m, kmask, mmask); };
+    auto window = [&](uint32_t s) { return mz_window_lds<PLACE>(words_a, s, lane, k, m, kmask, mmask); };
 #endif
     MzWin cur = window(0u);
     constexpr bool ROW = GS_MZ_RD && NT == 16;  // (the sliding minimum inside the rows of 16 lanes)
@@ -924,28 +967,50 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
         constexpr bool FULL = decltype(full_tile)::value;
         const MzWin nxt = window(s + 1u);
         const bool rc_strand = cur.r < cur.f;
-        uint32_t H;
+        uint32_t H, pm = 0;
 #if GS_MZ_RD
         if constexpr (ROW) {
             MzRowSlide row_nxt;
             row_nxt.set(nxt.o, lane);
-            H = mz_hash_at(mz_row_pick(row_cur, row_nxt, lane), cur, nxt, lane);
+            pm = mz_row_pick<(KT && KT - MT + 1 >= 6) || KT - MT + 1 == 4 ? KT - MT + 1 : 0>(row_cur, row_nxt, lane, w);
+            H = mz_hash_at(pm, cur, nxt, lane);
             row_cur = row_nxt;
         } else
 #endif
-            H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
-        const uint64_t c = rc_strand ? cur.r : cur.f;
-        cur = nxt;
-        const MzKey key = mz_key_fmt<FMT>(c, k, locbits);
-        const uint32_t reg = mz_region(H, mz.n_regions);
+            H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt, &pm);
+        uint32_t reg, fpw;
+        uint64_t wantw;
+#if GS_MZ_PLACE
+        if constexpr (PLACE) {
+            // H = bij(canonical m-mer) << 1 | orientation of the m-mer at lane + pm; the k-mer oriented like its m-mer, the
+            // m-mer's offset in it, the flank bases this window knows (gs_mzp.h)
+            const uint32_t y = H >> 1;
+            const bool rev = H & 1u;
+            const uint32_t p = rev ? (uint32_t)(w - 1) - pm : pm;
+            uint32_t tw, mk;
+            mzp_tag(rev ? cur.r : cur.f, p, k, m, tw, mk);
+            reg = y >> mz.s;
+            fpw = mz.s ? (y << (32 - mz.s)) : 0u;
+            wantw = (uint64_t)tw | ((uint64_t)mk << 32);
+            cur = nxt;
+        } else
+#endif
+        {
+            const uint64_t c = rc_strand ? cur.r : cur.f;
+            cur = nxt;
+            const MzKey key = mz_key_fmt<FMT>(c, k, locbits);
+            reg = mz_region(H, mz.n_regions);
+            fpw = key.fp * 0x01010101u;
+            wantw = key.tag << locbits;
+        }
         const bool valid = FULL || s * 64u + (uint32_t)lane < td.nwin_left;
         const bool leader = valid && (lane == 0 || reg != mz_shift_up(reg, ~reg));
         const unsigned long long lb = __ballot(leader);
         const uint32_t R = (uint32_t)__popcll(lb);  // >= 1: lane 0 of an existing step is valid
         const uint32_t myrun = (uint32_t)__popcll(lb & (lt | (1ULL << lane))) - 1u;
-        fpT[slot] = key.fp * 0x01010101u;
+        fpT[slot] = fpw;
         regoff[slot] = myrun * (uint32_t)(kMzWords * 8) | (valid ? 0u : 0x80000000u);  // byte offset of the run's region in the cache slot
-        want[slot] = key.tag << locbits;
+        want[slot] = wantw;
         nruns[slot] = R;
         // lane r <- region of run r (leaders push; the others push to lane 63, which holds a run only when all 64 lanes lead)
         runreg[slot] = (uint32_t)__builtin_amdgcn_ds_permute((int)((leader ? myrun : 63u) * 4u), (int)reg);
@@ -960,6 +1025,34 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
         const uint32_t off = regoff[u] & 0x7FFFFFFFu, myrun = off / (uint32_t)(kMzWords * 8);
         const bool mine = (FULL || !(regoff[u] >> 31)) && (!BIG || (myrun >= r0 && myrun < r0 + (uint32_t)kMzRunCap));
         const uint32_t reg_a = lds_addr(&L.cache[u][0]) + (FULL ? regoff[u] : off) - r0 * (uint32_t)(kMzWords * 8);
+        bool hit = false, defer = false;
+        uint64_t e = 0;
+#if GS_MZ_PLACE
+        if constexpr (PLACE) {
+            // the region's 7 tag words against this window's (TW, MK): the record that matches (at most one can), its loc word
+            const uint32_t tw = (uint32_t)want[u], mk = (uint32_t)(want[u] >> 32);
+            uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0, q2 = q0, q3 = q0;
+            if ((FULL && !BIG) || mine) {
+                q0 = lds_read_b128(reg_a);
+                q1 = lds_read_b128(reg_a + 16u);
+                q2 = lds_read_b128(reg_a + 32u);
+                q3 = lds_read_b128(reg_a + 48u);
+            }
+            uint32_t sel = 0xFFFFFFFFu;  // (tw has no bit outside mk)
+            sel = (q0.z & mk) == tw ? q2.y : sel;
+            sel = (q0.w & mk) == tw ? q2.z : sel;
+            sel = (q1.x & mk) == tw ? q2.w : sel;
+            sel = (q1.y & mk) == tw ? q3.x : sel;
+            sel = (q1.z & mk) == tw ? q3.y : sel;
+            sel = (q1.w & mk) == tw ? q3.z : sel;
+            sel = (q2.x & mk) == tw ? q3.w : sel;
+            const int sft = 32 - mz.s;
+            hit = mine && sel != 0xFFFFFFFFu && (!mz.s || ((sel ^ fpT[u]) >> sft) == 0u);
+            e = mz.s ? (uint64_t)(sel & ((1u << sft) - 1u)) : (uint64_t)sel;
+            defer = mine && !hit && (q0.x & kMzpOverflow);  // keys of this region in the generic table
+        } else
+#endif
+        {
         uint64_t F = ~0ULL;
         if (FULL && !BIG)
             F = lds_read_b64(reg_a);
@@ -967,8 +1060,6 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
             F = lds_read_b64(reg_a);
         MzCand cd = mz_candidates_T(F, fpT[u]);
         // the first slot whose fingerprint matches: the hit, nearly always (a second candidate needs a fingerprint collision)
-        bool hit = false;
-        uint64_t e = 0;
         {
             const bool lo = cd.m0 != 0u;
             const uint32_t x = lo ? cd.m0 : cd.m1;
@@ -995,8 +1086,9 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
                 }
             }
         }
-        bool defer = mine && !hit && mz_region_overflowed(F);  // generic table, later -- unless the region's filter word says no
+        defer = mine && !hit && mz_region_overflowed(F);  // generic table, later -- unless the region's filter word says no
         if (defer) defer = mz_filter_maybe(lds_read_b64(reg_a + (uint32_t)kMzSlots * 8u), mz_filter_bits(want[u] >> locbits));
+        }
         const bool mb_mine = hit || defer;
         const unsigned long long mb = __ballot(mb_mine), db = __ballot(defer);
         if (mb) {
@@ -1116,7 +1208,12 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     flush();
     if (n_cand > (uint32_t)kMzFastCand) {  // (wave-uniform, rare) more location changes than the candidate buffer holds
         if (lane == 0) atomicAdd(g_fallback_tiles, 1u);
-        mz_tile_exact(mz, tab, words, td, tile, n_tiles, ta, cand, cand_cap, g_cand_count, L.list);
+#if GS_MZ_PLACE
+        if constexpr (PLACE)
+            mzp_tile_exact(MzpView{mz.regions, mz.pay, k, m, mz.s}, tab, words, td, tile, n_tiles, ta, cand, cand_cap, g_cand_count, L.list);
+        else
+#endif
+            mz_tile_exact(mz, tab, words, td, tile, n_tiles, ta, cand, cand_cap, g_cand_count, L.list);
         return;
     }
     const uint32_t *cbuf = L.cand;

@@ -1,0 +1,373 @@
+// "minimizer-place": the minimiser-addressed table with one record per PLACE instead of one slot per key.  Included by
+// gs_device.hip after gs_mz.h (same anonymous namespace).
+//
+// Why.  k_probe_mz runs at the rate the memory system answers random requests (~60 G/s: profiles/r02/ubench_*.txt; the same
+// wall for a table in HBM and one that fits the 256 MB last-level cache), so what is left is the number of requests per window
+// = the density of the minimiser scheme, ~1 / w.  A longer run of windows per request needs a shorter minimiser (k = 20:
+// m = 17 gives w = 4, density 0.31; m = 14 gives w = 7, density 0.2) -- but the shorter the m-mer, the more k-mers share it:
+// a 14-mer occurs ~20 times in a human genome, and 64 bytes hold 7 keys.  They do hold 7 PLACES, though: the up to w SUNKs
+// that one occurrence of a minimiser owns are substrings of one (m + 2 (w - 1))-base context, they share their location group
+// (they lie within w - 1 < k bases: one merged interval, workflow/rules/defineSUNKs.smk:124-126), and their kmer.loc rows are
+// consecutive.  So:
+//
+//   y        = bij(canonical m-mer)                      a bijection on 2m bits (m <= 15)
+//   region   = y >> s,  fp = y & (2^s - 1)               64 bytes each; s (1..16) from the table size (2^(2m-s) regions)
+//   region   = 8 header bytes | 7 tag words | 7 loc words
+//     tag    [L flank: w-1 bases, bits 20..] [R flank: w-1 bases, bits 8..] [sign: bit 7] [mask: bits 0..w-1]
+//              the context of the place in the orientation in which its m-mer is canonical; mask bit p = the k-mer whose
+//              m-mer sits at offset p is a SUNK; flank bases no SUNK of the place covers are 0 and never looked at
+//     loc    fp << (32 - s) | loc id of the place
+//     header byte 0 bit 0 = keys of this region live in the generic side table (more than 7 places, or a place the format
+//              does not take: keys of one place with different locs or rows that are not consecutive)
+//   payload  (k_emit only) base row of the place, in a parallel array; the row of the key at offset p = base + sign * (number
+//              of mask bits below p)
+//
+// A window (as the read shows it: GS_MZ_RD rule, the leftmost smallest t-mer) knows p, the p bases left of the m-mer and the
+// w - 1 - p bases right of it: it builds (TW, MK) once and a record matches iff ((tag ^ TW) & MK) == 0 -- mask bit p included.
+// The builder makes sure no two records of a region can match the same window (records of different m-mers that share a region
+// AND agree on a window's flank bases: one of them goes to the generic table), so the first match is the match and its fp is
+// checked afterwards.  Exactness never depends on how well places merge: a record is a set of (offset, k-mer) pairs.
+#pragma once
+
+#ifndef GS_MZ_PLACE
+#define GS_MZ_PLACE 1
+#endif
+
+#if GS_MZ_PLACE
+#if !GS_MZ_RD
+#error "GS_MZ_PLACE needs GS_MZ_RD (a window's pick does not depend on its strand)"
+#endif
+
+constexpr int kMzpRecs = 7;            // places per region
+constexpr int kMzpTagWord0 = 2;        // 32-bit word of the region where the tags start (after 8 header bytes)
+constexpr int kMzpLocWord0 = 2 + kMzpRecs;
+constexpr uint32_t kMzpOverflow = 1u;  // header byte 0, bit 0
+
+#ifndef GS_MZP_T16
+#define GS_MZP_T16 0  // 1: t = k - 15, i.e. 16 t-mers per window whatever w (the sliding minimum inside the rows of 16 lanes)
+#endif
+// a bijection on 2m-bit values (multiplication by an odd constant): the region is taken from its HIGH bits, which every bit of
+// the m-mer reaches; the fp = its low s bits
+__host__ __device__ __forceinline__ uint32_t mzp_bij(uint32_t cm, int m) {
+    const uint32_t M = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    return (cm * 0x9E3779B1u) & M;
+}
+// length of the short t-mers whose minimum anchors the pick (gs_mz.h: mz_t_of).  With the pick taken as the read shows the k-mer
+// nothing needs the t-mer count to be a multiple of w: t = k - 15 gives 16 of them for every w.
+__host__ __device__ constexpr int mzp_t_of(int k, int m) { return GS_MZP_T16 ? (k - 15 < 4 ? 4 : k - 15) : mz_t_of(k, m); }
+// per lane: bij(canonical m-mer) << 1 | (the canonical form is the reverse complement of the m-mer as shown)
+__host__ __device__ __forceinline__ uint32_t mzp_mmer_word(uint32_t fm, uint32_t rm, int m) {
+    const bool rev = rm < fm;
+    return (mzp_bij(rev ? rm : fm, m) << 1) | (rev ? 1u : 0u);
+}
+
+struct MzpProbe {   // what a window looks for
+    uint32_t y;     // bij(canonical m-mer): region = y >> s, fp = y & (2^s - 1)
+    uint32_t tw, mk;
+    uint32_t p;     // offset of the m-mer in the oriented k-mer
+};
+// (TW, MK) of the oriented k-mer X (its m-mer canonical) with the m-mer at offset p
+__host__ __device__ __forceinline__ void mzp_tag(uint64_t X, uint32_t p, int k, int m, uint32_t &tw, uint32_t &mk) {
+    const int nf = k - m;  // flank bases per side = w - 1 (<= 6)
+    const uint32_t nl = 2u * p, nr = 2u * (uint32_t)nf - nl;
+    // the k-mer's first nf bases, then the last p of the first p + ... : its top 2 nf bits shifted down to 2 p bits (p = 0: none)
+    const uint32_t top = (uint32_t)(X >> (2 * (k - nf)));  // (a constant shift: one v_alignbit for k = 20)
+    const uint32_t xl = top >> (2u * (uint32_t)nf - nl);
+    const uint32_t ones_r = (1u << nr) - 1u, ones_l = (1u << nl) - 1u;
+    const uint32_t xr = (uint32_t)X & ones_r;
+    const uint32_t bit = 1u << p, sr = 8u + nl;
+    tw = bit | (xr << sr) | (xl << 20);
+    mk = bit | (ones_r << sr) | (ones_l << 20);
+}
+__host__ __device__ __forceinline__ uint64_t mzp_revcomp(uint64_t c, int k) {
+    uint64_t r = 0;
+    for (int i = 0; i < k; i++) {
+        r = (r << 2) | (3ULL - (c & 3ULL));
+        c >>= 2;
+    }
+    return r;
+}
+// the rule applied to ONE k-mer as shown (f; its reverse complement r): build side, emit, exact form
+__host__ __device__ __forceinline__ MzpProbe mzp_probe_of(uint64_t f, uint64_t r, int k, int m) {
+    const int w = k - m + 1, t = mzp_t_of(k, m), nt = k - t + 1;
+    const uint32_t tmask = (1u << (2 * t)) - 1u;
+    uint32_t best = 0xFFFFFFFFu;
+    int at = 0;
+    for (int j = 0; j < nt; j++) {  // the leftmost smallest canonical t-mer of the k-mer as shown
+        const uint32_t ft = (uint32_t)(f >> (2 * (k - t - j))) & tmask, rt = (uint32_t)(r >> (2 * j)) & tmask;
+        const uint32_t o = mz_tmer_order(ft < rt ? ft : rt);
+        if (o < best) {
+            best = o;
+            at = j;
+        }
+    }
+    const int x = at % w;
+    const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    const uint32_t fm = (uint32_t)(f >> (2 * (k - m - x))) & mmask, rm = (uint32_t)(r >> (2 * x)) & mmask;
+    const bool rev = rm < fm;
+    MzpProbe o;
+    o.y = mzp_bij(rev ? rm : fm, m);
+    o.p = rev ? (uint32_t)(w - 1 - x) : (uint32_t)x;
+    mzp_tag(rev ? r : f, o.p, k, m, o.tw, o.mk);
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// build
+// ------------------------------------------------------------------------------------------
+// one entry (region << 33 | key index << 1 | which strand's pick) per key and pick; the reverse strand's pick only when it is
+// another (region, offset, orientation) than the canonical strand's.  Sorted on all 64 bits.
+__global__ void k_mzp_entries(const uint64_t *keys, uint64_t n, int k, int m, int s, uint64_t *ent, unsigned long long *n_dup) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c = keys[i], rc = mzp_revcomp(c, k);
+    const MzpProbe a = mzp_probe_of(c, rc, k, m), b = mzp_probe_of(rc, c, k, m);
+    ent[i] = ((uint64_t)(a.y >> s) << 33) | (i << 1);
+    const bool dup = a.y != b.y || a.p != b.p || a.tw != b.tw;
+    ent[n + i] = dup ? ((uint64_t)(b.y >> s) << 33) | (i << 1) | 1ULL : ~0ULL;
+    if (dup) atomicAdd(n_dup, 1ULL);
+}
+
+// One thread per region (the thread of the region's first entry): its entries, in key order, become records -- an entry joins
+// the first record it is compatible with (same m-mer, same loc, agreeing flank bases, its offset still free), else opens a new
+// one.  An entry that a record of the region would already match (its offset taken there and the flank bases its windows know
+// equal: a record of ANOTHER m-mer that shares the region, since the keys are distinct) goes to the generic table, like what
+// does not fit 7 records: so no window can match two records, and the first match is the match.  Finally every record's rows
+// must be consecutive in offset order (base + sign * rank: what k_emit derives a row from); a record whose are not keeps its
+// first member only.
+__global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, const uint64_t *keys, const uint32_t *loc,
+                            const uint32_t *payload, const uint64_t *ent, uint64_t n2, unsigned long long *overflow,
+                            uint32_t *overflow_list, uint64_t overflow_cap) {
+    const uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e0 >= n2) return;
+    const uint64_t reg = ent[e0] >> 33;
+    if (e0 && (ent[e0 - 1] >> 33) == reg) return;  // not the region's first entry
+    const int w = k - m + 1;
+    const uint32_t fpmask = s ? (1u << s) - 1u : 0u, flank = 0xFFFFFF00u;
+    uint32_t tag[kMzpRecs], km[kMzpRecs], locw[kMzpRecs], rows[kMzpRecs][7], who[kMzpRecs][7];
+    uint32_t nrec = 0;
+    bool over = false;
+    auto spill = [&](uint32_t key_idx) {
+        const unsigned long long o = atomicAdd(overflow, 1ULL);
+        if (o < overflow_cap) overflow_list[o] = key_idx;
+        over = true;
+    };
+    for (uint64_t e = e0; e < n2 && (ent[e] >> 33) == reg; e++) {
+        const uint32_t i = (uint32_t)(ent[e] >> 1);
+        const uint64_t c = keys[i], rc = mzp_revcomp(c, k);
+        const MzpProbe q = (ent[e] & 1ULL) ? mzp_probe_of(rc, c, k, m) : mzp_probe_of(c, rc, k, m);
+        if (s && (loc[i] >> (32 - s))) {  // (a loc id that needs the fp's bits: not in this format)
+            spill(i);
+            continue;
+        }
+        const uint32_t lw = s ? (((q.y & fpmask) << (32 - s)) | loc[i]) : loc[i];
+        if (lw == 0xFFFFFFFFu) {  // (the lookups' "no record" value)
+            spill(i);
+            continue;
+        }
+        int home = -1;
+        bool clash = false;
+        for (uint32_t r = 0; r < nrec; r++) {
+            const bool taken = (tag[r] >> q.p) & 1u;
+            if (taken) {
+                if (((tag[r] ^ q.tw) & q.mk & flank) == 0u) clash = true;  // this key's windows would match record r
+            } else if (home < 0 && locw[r] == lw && ((tag[r] ^ q.tw) & km[r] & q.mk & flank) == 0u) {
+                home = (int)r;
+            }
+        }
+        if (clash || (home < 0 && nrec == (uint32_t)kMzpRecs)) {
+            spill(i);
+            continue;
+        }
+        if (home < 0) {
+            home = (int)nrec++;
+            tag[home] = 0u;
+            km[home] = 0u;
+            locw[home] = lw;
+        }
+        tag[home] |= q.tw;
+        km[home] |= q.mk;
+        rows[home][q.p] = payload[i];
+        who[home][q.p] = i;
+    }
+    uint32_t base[kMzpRecs];
+    for (uint32_t r = 0; r < nrec; r++) {
+        const uint32_t mask = tag[r] & ((1u << w) - 1u);
+        int first = -1, second = -1;
+        for (int p = 0; p < w; p++)
+            if ((mask >> p) & 1u) {
+                if (first < 0) first = p;
+                else if (second < 0) second = p;
+            }
+        base[r] = rows[r][first];
+        const bool down = second >= 0 && rows[r][second] + 1u == rows[r][first];
+        bool ok = true;
+        uint32_t rank = 0;
+        for (int p = 0; p < w; p++)
+            if ((mask >> p) & 1u) {
+                if (rows[r][p] != (down ? base[r] - rank : base[r] + rank)) ok = false;
+                rank++;
+            }
+        if (!ok) {  // rows that are not consecutive: the record keeps its first member
+            for (int p = first + 1; p < w; p++)
+                if ((mask >> p) & 1u) spill(who[r][p]);
+            tag[r] &= ~(((1u << w) - 1u) & ~(1u << first));
+        } else if (down) {
+            tag[r] |= 0x80u;
+        }
+    }
+    uint32_t wd[16];
+    wd[0] = over ? kMzpOverflow : 0u;
+    wd[1] = 0u;
+    for (int r = 0; r < kMzpRecs; r++) {
+        wd[kMzpTagWord0 + r] = (uint32_t)r < nrec ? tag[r] : 0u;
+        wd[kMzpLocWord0 + r] = (uint32_t)r < nrec ? locw[r] : 0u;
+    }
+    uint4 *dst = regions + reg * 4;
+    for (int q = 0; q < 4; q++) dst[q] = make_uint4(wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]);
+    for (int r = 0; r < kMzpRecs; r++) pay[reg * 8 + r] = (uint32_t)r < nrec ? base[r] : 0u;
+}
+
+// ------------------------------------------------------------------------------------------
+// lookups from global memory (exact form, emit)
+// ------------------------------------------------------------------------------------------
+struct MzpView {
+    const uint4 *regions;
+    const uint32_t *pay;
+    int k, m, s;
+};
+// -> record index 0..6 of the match, -1 none; *locw = its loc word, *hdr = the region's header word
+__device__ __forceinline__ int mzp_find(const MzpView &v, const MzpProbe &q, uint32_t *locw, uint32_t *hdr) {
+    const uint4 *rp = v.regions + (uint64_t)(q.y >> v.s) * 4;
+    const uint4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
+    const uint32_t wd[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    *hdr = wd[0];
+    const uint32_t fp = v.s ? (q.y & ((1u << v.s) - 1u)) : 0u;
+    for (int r = 0; r < kMzpRecs; r++)
+        if (((wd[kMzpTagWord0 + r] ^ q.tw) & q.mk) == 0u) {
+            const uint32_t lw = wd[kMzpLocWord0 + r];
+            if (v.s && (lw >> (32 - v.s)) != fp) return -1;  // (the only record that can match this window: another m-mer's)
+            *locw = lw;
+            return r;
+        }
+    return -1;
+}
+__device__ __forceinline__ uint32_t mzp_payload(const MzpView &v, const TableView &tab, uint64_t c) {
+    const MzpProbe q = mzp_probe_of(c, mzp_revcomp(c, v.k), v.k, v.m);
+    uint32_t lw = 0, hdr = 0;
+    const int r = mzp_find(v, q, &lw, &hdr);
+    if (r >= 0) {
+        const uint32_t *wp = reinterpret_cast<const uint32_t *>(v.regions + (uint64_t)(q.y >> v.s) * 4);
+        const uint32_t tg = wp[kMzpTagWord0 + r];
+        const uint32_t rank = (uint32_t)__popc(tg & ((1u << q.p) - 1u));
+        const uint32_t base = v.pay[(uint64_t)(q.y >> v.s) * 8 + r];
+        return (tg & 0x80u) ? base - rank : base + rank;
+    }
+    uint64_t hh = slot_of(c, tab.shift);  // a key the region could not take lives in the generic table
+    Slot sl = load_slot(tab.slots + hh);
+    while (sl.key != c && sl.key != kEmptyKey) {
+        hh = (hh + 1) & tab.mask;
+        sl = load_slot(tab.slots + hh);
+    }
+    return sl.payload;
+}
+// one window, from global memory: hit and loc
+__device__ __forceinline__ bool mzp_lookup(const MzpView &v, const TableView &tab, uint64_t f, uint64_t r, uint32_t *loc) {
+    const MzpProbe q = mzp_probe_of(f, r, v.k, v.m);
+    uint32_t lw = 0, hdr = 0;
+    if (mzp_find(v, q, &lw, &hdr) >= 0) {
+        *loc = v.s ? (lw & ((1u << (32 - v.s)) - 1u)) : lw;
+        return true;
+    }
+    if (!(hdr & kMzpOverflow)) return false;
+    const uint64_t c = f < r ? f : r;
+    uint64_t hh = slot_of(c, tab.shift);
+    Slot sl = load_slot(tab.slots + hh);
+    while (sl.key != c && sl.key != kEmptyKey) {
+        hh = (hh + 1) & tab.mask;
+        sl = load_slot(tab.slots + hh);
+    }
+    if (sl.key != c) return false;
+    *loc = sl.loc;
+    return true;
+}
+
+// the exact per-lane form of a tile: every window its own lookups (the fallback of the fast form, and the "minimizer-exact" layout)
+template <int MODE>
+__device__ __forceinline__ MzTileOut mzp_tile(const MzpView &v, const TableView &tab, const uint64_t *__restrict__ words,
+                                             const TileDesc td, uint32_t *cbuf) {
+    const int lane = threadIdx.x & 63;
+    const int k = v.k, m = v.m;
+    const uint64_t kmask = (1ULL << (2 * k)) - 1ULL, mmask = (1ULL << (2 * m)) - 1ULL;
+    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint64_t W0 = __builtin_nontemporal_load(words + td.wbase + lane);
+    const uint64_t W1 = __builtin_nontemporal_load(words + td.wbase + 64 + (lane & 1));
+    uint32_t n_raw = 0, n_cand = 0, first_loc = GS_NONE, carry = GS_NONE;  // wave-uniform
+    const uint32_t nsteps = min((td.nwin_left + 63u) / 64u, 32u);
+    for (uint32_t s = 0; s < nsteps; s++) {
+        const MzWin ww = mz_window(W0, W1, (int)s, lane, k, m, kmask, mmask);
+        uint32_t loc = 0;
+        const bool hit = s * 64u + (uint32_t)lane < td.nwin_left && mzp_lookup(v, tab, ww.f, ww.r, &loc);
+        const unsigned long long hb = __ballot(hit);
+        if (hb) {  // wave-uniform
+            const unsigned long long below = hb & lt;
+            const int src = below ? 63 - __clzll((long long)below) : 0;
+            const uint32_t pl = __shfl(loc, src);
+            const uint32_t prev = below ? pl : carry;
+            const bool chg = hit && loc != prev;  // the tile's first raw hit always is one (carry = none)
+            const unsigned long long cb = __ballot(chg);
+            if (chg) {
+                const uint32_t idx = n_cand + (uint32_t)__popcll(cb & lt);
+                const uint32_t rec = ((n_raw + (uint32_t)__popcll(below)) << 16) | (s * 64u + (uint32_t)lane);
+                if (MODE == 1 || idx < (uint32_t)kMzCandLds) cbuf[idx] = rec;
+            }
+            n_cand += (uint32_t)__popcll(cb);
+            if (first_loc == GS_NONE) first_loc = lane_value(loc, __ffsll((unsigned long long)hb) - 1);
+            carry = lane_value(loc, 63 - __clzll((long long)hb));
+            n_raw += (uint32_t)__popcll(hb);
+        }
+    }
+    return MzTileOut{n_raw, n_cand, first_loc, carry};
+}
+
+__device__ __forceinline__ void mzp_tile_exact(const MzpView &v, const TableView &tab, const uint64_t *__restrict__ words,
+                                               const TileDesc td, uint32_t tile, uint32_t n_tiles, const TileArrays &ta, uint32_t *cand,
+                                               uint32_t cand_cap, uint32_t *g_cand_count, uint32_t *s_cand) {
+    const int lane = threadIdx.x & 63;
+    MzTileOut o = mzp_tile<0>(v, tab, words, td, s_cand);
+    uint32_t off = tile * (uint32_t)kDirectCand;
+    if (o.n_cand > (uint32_t)kDirectCand) {
+        if (lane == 0) off = n_tiles * (uint32_t)kDirectCand + atomicAdd(g_cand_count, o.n_cand);
+        off = __shfl(off, 0);
+    }
+    if (o.n_cand && (uint64_t)off + o.n_cand <= cand_cap) {
+        if (o.n_cand <= (uint32_t)kMzCandLds) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < o.n_cand; i += 64u) cand[off + i] = s_cand[i];
+        } else {
+            mzp_tile<1>(v, tab, words, td, cand + off);  // (rare) walk the tile again, candidates straight to their place
+        }
+    }
+    if (lane == 0) {
+        ta.n_raw[tile] = o.n_raw;
+        ta.n_cand[tile] = o.n_cand;
+        ta.cand_off[tile] = off;
+        if (o.n_raw) {
+            ta.first_loc[tile] = o.first_loc;
+            ta.last_loc[tile] = o.last_loc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_probe_mzp_exact(MzpView v, TableView tab, const uint64_t *__restrict__ words,
+                                                         const TileDesc *__restrict__ tdesc, uint32_t n_tiles, TileArrays ta,
+                                                         uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count) {
+    __shared__ uint32_t s_cand[4][kMzCandLds];
+    const int wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * 4u + (uint32_t)wave;
+    if (tile >= n_tiles) return;
+    mzp_tile_exact(v, tab, words, tdesc[tile], tile, n_tiles, ta, cand, cand_cap, g_cand_count, s_cand[wave]);
+}
+
+#endif  // GS_MZ_PLACE

@@ -50,7 +50,7 @@ def test_cli_with_sidecar_writes_the_reference_bytes(golden, name, tmp_path, mon
     assert cli("o5") == plain
 
 
-@pytest.mark.parametrize("layout", ["auto", "compact-hbm", "generic"])
+@pytest.mark.parametrize("layout", ["auto", "minimizer-slots", "compact-hbm", "generic"])
 def test_sidecar_keeps_every_layout(layout, golden, tmp_path, monkeypatch):
     """The table travels as it was built (the scalars + array list of a broadcast): whatever layout the first run chose."""
     monkeypatch.setenv("GAVISUNK_TABLE", layout)
@@ -62,7 +62,7 @@ def test_sidecar_keeps_every_layout(layout, golden, tmp_path, monkeypatch):
     assert kmerpos_annot3.main(["--prepare", str(db), str(loc)]) == 0
     monkeypatch.delenv("GAVISUNK_TABLE")
     pre = engine.open_sidecar(str(db), str(loc))
-    assert pre is not None and pre[1].layout.split(":")[0] == {"auto": "minimizer-hbm"}.get(layout, layout)
+    assert pre is not None and pre[1].layout.split(":")[0] == {"auto": "minimizer-hbm", "minimizer-slots": "minimizer-hbm"}.get(layout, layout)
     pre[1].close()
     assert kmerpos_annot3.main([c.path(run["reads"]), str(db), str(loc), str(tmp_path / "o")]) == 0
     assert (tmp_path / "o").read_text() == c.text(run["out"])

@@ -12,12 +12,14 @@ from oracle import oracle, sunkdef
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "compact-hbm", "minimizer", "minimizer-exact", "generic"], autouse=True)
+@pytest.fixture(params=["auto", "compact-hbm", "minimizer", "minimizer-exact", "minimizer-slots", "generic"], autouse=True)
 def table_layout(request, monkeypatch):
-    """Every test runs five times: with the layout the library picks (the minimiser-addressed table for k >= 16, whatever
-    the size; the generic table below), with the exact compact copy (one bucket load per window: what tables get that the
-    minimiser layout does not take), with the minimiser-addressed layout forced (lane = window; "minimizer-exact" runs every
-    tile through the per-lane form that is the fast kernel's fallback), and with the generic 16-byte-slot table forced.
+    """Every test runs six times: with the layout the library picks (the minimiser-addressed table for k >= 16, whatever
+    the size -- place records for k <= 21, per-key slots beyond; the generic table below k = 16), with the exact compact copy
+    (one bucket load per window: what tables get that the minimiser layout does not take), with the minimiser-addressed layout
+    forced (lane = window; "minimizer-exact" runs every tile through the per-lane form that is the fast kernel's fallback;
+    "minimizer-slots" = the per-key-slot regions of round 2 also where place records apply), and with the generic
+    16-byte-slot table forced.
     (Round 1's small-table layouts -- the LDS join, XCD-partitioned L2 probing -- were retired in round 3: the minimiser kernel
     beats them on their home ground.)"""
     monkeypatch.setenv("GAVISUNK_TABLE", request.param)
@@ -203,13 +205,13 @@ def test_empty_and_tiny_batches():
 def test_layout_selection(table_layout):
     keys, loc, _ = _random_case(3, 20)
     tab = engine.DeviceTable(20, keys, loc, np.arange(len(keys), dtype=np.uint32))
-    assert tab.layout.startswith({"auto": "minimizer-hbm", "compact-hbm": "compact-hbm",
-                                  "minimizer": "minimizer-hbm", "minimizer-exact": "minimizer-hbm", "generic": "generic"}[table_layout])
+    want = {"auto": "minimizer-hbm", "compact-hbm": "compact-hbm", "minimizer": "minimizer-hbm", "minimizer-exact": "minimizer-hbm",
+            "minimizer-slots": "minimizer-hbm", "generic": "generic"}[table_layout]
+    assert tab.layout.startswith(want) and ("place records" in tab.layout) == (table_layout in ("auto", "minimizer", "minimizer-exact"))
     tab.close()
     keys, loc, _ = _random_case(3, 18)
     tab = engine.DeviceTable(18, keys, loc, np.arange(len(keys), dtype=np.uint32))
-    assert tab.layout.startswith({"auto": "minimizer-hbm", "compact-hbm": "compact-hbm",
-                                  "minimizer": "minimizer-hbm", "minimizer-exact": "minimizer-hbm", "generic": "generic"}[table_layout])
+    assert tab.layout.startswith(want)
     tab.close()
     keys, loc, _ = _random_case(3, 25)
     tab = engine.DeviceTable(25, keys, loc, np.arange(len(keys), dtype=np.uint32))
@@ -217,7 +219,7 @@ def test_layout_selection(table_layout):
     # minimiser-addressed layout is the default; forced, the one-bucket-load layout takes 64-bit slots
     if table_layout == "generic":
         assert tab.layout.startswith("generic")
-    elif table_layout in ("auto", "minimizer", "minimizer-exact"):
+    elif table_layout in ("auto", "minimizer", "minimizer-exact", "minimizer-slots"):  # (k > 21: per-key slots are the only form)
         assert tab.layout.startswith("minimizer-hbm") and "50-bit key" in tab.layout and "mod-minimiser of length 21 " in tab.layout
     else:
         assert "compact-hbm" in tab.layout and "x u64" in tab.layout
@@ -277,7 +279,7 @@ def test_low_complexity_reads_overflow_one_partition():
 def test_undersized_compact_table_uses_every_overflow_path(qb, monkeypatch, table_layout):
     """With far too few buckets most keys live in their second-chance bucket or only in the generic side table:
     deferred lookups, their flushes and the generic fallback carry the load, and the answer must not change."""
-    if table_layout in ("generic", "auto", "minimizer", "minimizer-exact"):
+    if table_layout != "compact-hbm":
         pytest.skip("needs a compact layout")
     monkeypatch.setenv("GAVISUNK_COMPACT_QB", qb)
     k = 20
@@ -338,21 +340,23 @@ def test_slots_without_a_spare_bit(k, qb, monkeypatch, table_layout):
     assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] > 10000 and len(gh) == len(oh) == 1
 
 
-@pytest.mark.parametrize("m,load", [("6", "2"), ("12", "8"), ("16", "6"), ("9", "0.5"), ("19", "2")])
+@pytest.mark.parametrize("m,load", [("6", "2"), ("12", "8"), ("16", "6"), ("9", "0.5"), ("19", "2"), ("14", "64"), ("15", "16"), ("14", "1")])
 def test_minimizer_table_walks_and_overflows(m, load, monkeypatch, table_layout):
-    """The minimiser-addressed layout with the wrong geometry on purpose: a short minimiser piles hundreds of keys on one
-    64-byte region (most keys then live in the generic side table: every lookup there is a deferred one); 8 or 6 keys per
-    7-slot region make full regions the rule; a sparse table is the easy case."""
-    if table_layout not in ("minimizer", "minimizer-exact"):
-        pytest.skip("minimiser-addressed layout only")
+    """The minimiser-addressed layouts with the wrong geometry on purpose.  Per-key slots: a short minimiser piles hundreds of
+    keys on one 64-byte region (most keys then live in the generic side table: every lookup there is a deferred one); 8 or 6
+    keys per 7-slot region make full regions the rule; a sparse table is the easy case.  Place records (m = 14 / 15 at k = 20):
+    dozens of places per 7-record region, and a roomy table."""
+    place = m in ("14", "15")
+    if table_layout not in (("minimizer", "minimizer-exact") if place else ("minimizer-slots",)):
+        pytest.skip("the minimiser-addressed layout this geometry belongs to")
     monkeypatch.setenv("GAVISUNK_MZ_M", m)
     monkeypatch.setenv("GAVISUNK_MZ_LOAD", load)
     k = 20
     keys, loc, seqs = _random_case(56, k, n_reads=60, glen=60000, median=4000)
     tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
-    assert tab.layout.startswith("minimizer-hbm") and f"mod-minimiser of length {m} " in tab.layout
-    n_ovf = int(tab.layout.split("), ")[-1].split(" overflow")[0])
-    assert n_ovf > (10000 if m == "6" else 50 if load in ("8", "6") else -1)
+    assert tab.layout.startswith("minimizer-hbm") and f"mod-minimiser of length {m} " in tab.layout and ("place records" in tab.layout) == place
+    n_ovf = int(tab.layout.split(", ")[-1].split(" overflow")[0])
+    assert n_ovf > (10000 if m == "6" else 50 if load in ("8", "6", "64") else 20 if load == "16" else -1)
     tab.close()
     seqs = seqs + [b"A" * 5000, b"ACGT" * 700, seqs[0][:19], b""]
     rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
@@ -370,7 +374,7 @@ def test_crowded_minimiser_regions_fall_back_instead_of_failing(monkeypatch, tab
         pytest.skip("layout choice of the default path")
     monkeypatch.setenv("GAVISUNK_MZ_LOAD", "16")
     k = 20
-    keys, loc, seqs = _random_case(58, k, n_reads=40, glen=200000, median=3000)
+    keys, loc, seqs = _random_case(58, k, n_reads=40, glen=2_000_000, median=3000)  # (dozens of places per region at any s)
     if table_layout == "minimizer":
         tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))  # forced + knob: everything may overflow
         assert tab.layout.startswith("minimizer-hbm")
@@ -438,8 +442,10 @@ def test_table_build_is_deterministic(table_layout, monkeypatch):
     scheduling did.  (An undersized compact table makes sure there are many of them.)"""
     if table_layout in ("generic", "minimizer-exact"):
         pytest.skip("nothing to overflow")
-    if table_layout not in ("minimizer", "auto"):
+    if table_layout not in ("minimizer", "auto", "minimizer-slots"):
         monkeypatch.setenv("GAVISUNK_COMPACT_QB", "9")
+    elif table_layout != "minimizer-slots":
+        monkeypatch.setenv("GAVISUNK_MZ_LOAD", "12")  # (place records: crowded regions, so that keys do overflow)
     keys, loc, seqs = _random_case(57, 20, n_reads=30, glen=300000, median=3000)
     loc = (loc % 7).astype(np.uint32)
     seen, hits = set(), []
@@ -451,7 +457,7 @@ def test_table_build_is_deterministic(table_layout, monkeypatch):
         hits.append(h)
         dev.close()
         tab.close()
-    assert len(seen) == 1 and int(next(iter(seen)).split("), ")[-1].split(" overflow")[0]) > 100
+    assert len(seen) == 1 and int(next(iter(seen)).split(", ")[-1].split(" overflow")[0]) > 100
     assert all(np.array_equal(h, hits[0]) for h in hits[1:])
     rc, oh, _, _ = _oracle_hits(20, keys, loc, seqs)
     assert len(oh) == len(hits[0]) and np.array_equal(hits[0]["pos"], oh["pos"]) and np.array_equal(hits[0]["payload"], oh["row"])

@@ -17,7 +17,7 @@ from gavisunk_amd import _lib, engine, synth  # noqa: E402
 from oracle import oracle, sunkdef  # noqa: E402
 
 K = 20  # k of the current round (most rounds: GAVISUNK's default 20)
-LAYOUTS = ["auto", "compact-hbm", "minimizer", "minimizer-exact", "generic"]
+LAYOUTS = ["auto", "compact-hbm", "minimizer", "minimizer-exact", "minimizer-slots", "generic"]
 
 
 def draw(seed):
