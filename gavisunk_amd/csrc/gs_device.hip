@@ -1049,6 +1049,8 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                 GS_LAUNCH_MZP(20, 14);
             else if (t->k == 20 && t->mz_m == 15)
                 GS_LAUNCH_MZP(20, 15);
+            else if (t->k == 21 && t->mz_m == 15)
+                GS_LAUNCH_MZP(21, 15);  // BASELINE.json configs[4], k = 21 (k = 25 is beyond the place records: per-key slots)
             else
                 GS_LAUNCH_MZP(0, 0);
 #undef GS_LAUNCH_MZP
@@ -1199,8 +1201,15 @@ int choose_compact(int k, uint64_t n, uint64_t generic_bytes, uint32_t maxloc, b
 // Place-record regions (gs_mzp.h): k - 6 <= m <= 15 (a tag word holds two flanks of w - 1 <= 6 bases; regions are addressed by
 // a bijection of the 2m-bit m-mer).  The shortest such m whose regions stay below ~2.5 places on average (7 fit); s from the
 // number of places: 2^(2m - s) regions, about one per place.
-int mzp_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, int &s, int m_from = 0) {
+int mzp_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, int &s, int m_from = 0, bool forced = false) {
     if (k < 16 || k > 21 || n == 0 || any_missing) return 0;
+    // An assembly whose SUNKs come from point variants inside otherwise repeated sequence (a diploid assembly: a SNP in one copy
+    // of a repeat family makes the ~k k-mers over it unique) has them in many small location groups, and under a SHORT
+    // minimiser dozens of copies' variants share one m-mer: the region overflows, reads visit it in proportion to the copies,
+    // nearly always without a match, and each such window becomes a lookup in the generic table (measured on BASELINE.json
+    // configs[3]: 18 % of all windows, probe kernel 130 ms instead of 92).  A longer minimiser mostly CONTAINS the variant and
+    // is the copy's own: such tables take the per-key-slot regions (m >= k - 4).  Fewer than 2000 keys per group decides.
+    if (!forced && (double)n < 2000.0 * ((double)maxloc + 1.0)) return 0;
     int m_lo = std::max(std::max(k - 6, 10), m_from), m_hi = std::min(15, k - 1);
     if (m_lo > m_hi) return 0;
     if (const char *e = getenv("GAVISUNK_MZ_M")) {  // tuning / test knob, read once per table
@@ -1376,7 +1385,7 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
     const bool force_mz = env && (!strcmp(env, "minimizer") || !strcmp(env, "minimizer-exact") || !strcmp(env, "minimizer-slots"));
 #if GS_MZ_PLACE
     const bool want_slots = env && !strcmp(env, "minimizer-slots");  // the per-key-slot regions (the only form for k > 21)
-    if ((force_mz || !env) && !want_slots && mzp_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_s)) {
+    if ((force_mz || !env) && !want_slots && mzp_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_s, 0, force_mz)) {
         t->mz = force_mz && !strcmp(env, "minimizer-exact") ? 2 : 1;
         t->mz_place = 1;
         t->mz_n_regions = 1u << (2 * t->mz_m - t->mz_s);
@@ -1405,10 +1414,10 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
         const uint64_t ocap = std::max<uint64_t>(knob && force_mz ? 2 * n : n / 16, 1u << 16);
         unsigned long long *dov = nullptr;
         if ((rc = dev_alloc((unsigned long long **)&t->mz_regions, nreg * kMzWords)) || (rc = dev_alloc(&t->mz_pay, nreg * 8)) ||
-            (rc = tmp.get(&dov, 1)) || (rc = tmp.get(&dlist, ocap)))
+            (rc = tmp.get(&dov, 8)) || (rc = tmp.get(&dlist, ocap)))
             return rc;
         HIP_TRY(hipMemsetAsync(t->mz_regions, 0, nreg * kMzWords * sizeof(unsigned long long), t->stream));
-        HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
+        HIP_TRY(hipMemsetAsync(dov, 0, 8 * sizeof(unsigned long long), t->stream));
         uint64_t n2 = n;
         {
             DevBufs st;
@@ -1431,10 +1440,14 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
                                t->mz_m, t->mz_s, dk, dl, dp, (const uint64_t *)ent1, n2, dov, dlist, ocap);
             HIP_TRY(hipStreamSynchronize(t->stream));
         }
-        unsigned long long ov = 0;
-        HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
+        unsigned long long ovs[8] = {0};
+        HIP_TRY(hipMemcpyAsync(ovs, dov, sizeof ovs, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         HIP_TRY(hipGetLastError());
+        const unsigned long long ov = ovs[0];
+        if (getenv("GAVISUNK_DEBUG_BUILD"))
+            fprintf(stderr, "place records m = %d s = %d: %llu of %llu keys to the generic table (loc too wide %llu, reserved value %llu, clash %llu, region full %llu, rows %llu), %llu in hot regions, %llu under both picks\n",
+                    t->mz_m, t->mz_s, ov, (unsigned long long)n, ovs[1], ovs[2], ovs[3], ovs[4], ovs[5], ovs[6], (unsigned long long)t->mz_dup);
         if (ov <= ocap) {
             t->mz_overflow = ov;
             n_generic = ov;
@@ -1453,7 +1466,7 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
         t->mz_pay = nullptr;
         dlist = nullptr;
         const int tried = t->mz_m;
-        if (!getenv("GAVISUNK_MZ_M") && mzp_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_s, tried + 1)) {
+        if (!getenv("GAVISUNK_MZ_M") && mzp_choose(k, n, maxloc, any_missing, t->mz_m, t->mz_s, tried + 1, force_mz)) {
             t->mz_n_regions = 1u << (2 * t->mz_m - t->mz_s);
             t->mz_locbits = 32 - t->mz_s;
             continue;

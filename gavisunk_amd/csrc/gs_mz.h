@@ -1109,6 +1109,9 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     // they came from -- and the list starts over.  Runs when a step might not fit any more, and after the last step.
     uint32_t n_raw = 0, n_cand = 0, first_loc = GS_NONE, carry = GS_NONE;  // of the tile so far
     auto flush = [&]() {
+#ifdef GS_MZ_COUNT_DEFER  // (experiment: the fallback-tile counter counts deferred generic-table lookups instead)
+        if (lane == 0 && dcount) atomicAdd(g_fallback_tiles, dcount);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -147,22 +147,27 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
     uint32_t tag[kMzpRecs], km[kMzpRecs], locw[kMzpRecs], rows[kMzpRecs][7], who[kMzpRecs][7];
     uint32_t nrec = 0;
     bool over = false;
-    auto spill = [&](uint32_t key_idx) {
+    // (overflow[1..5]: why -- 1 loc too wide for the loc word, 2 the "no record" value, 3 a record would match its windows
+    //  already, 4 the region's 7 records are taken, 5 a record whose rows are not consecutive)
+    auto spill = [&](uint32_t key_idx, int why) {
         const unsigned long long o = atomicAdd(overflow, 1ULL);
+        atomicAdd(overflow + why, 1ULL);
         if (o < overflow_cap) overflow_list[o] = key_idx;
         over = true;
     };
+    uint32_t n_ent = 0;
     for (uint64_t e = e0; e < n2 && (ent[e] >> 33) == reg; e++) {
+        n_ent++;
         const uint32_t i = (uint32_t)(ent[e] >> 1);
         const uint64_t c = keys[i], rc = mzp_revcomp(c, k);
         const MzpProbe q = (ent[e] & 1ULL) ? mzp_probe_of(rc, c, k, m) : mzp_probe_of(c, rc, k, m);
         if (s && (loc[i] >> (32 - s))) {  // (a loc id that needs the fp's bits: not in this format)
-            spill(i);
+            spill(i, 1);
             continue;
         }
         const uint32_t lw = s ? (((q.y & fpmask) << (32 - s)) | loc[i]) : loc[i];
         if (lw == 0xFFFFFFFFu) {  // (the lookups' "no record" value)
-            spill(i);
+            spill(i, 2);
             continue;
         }
         int home = -1;
@@ -176,7 +181,7 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
             }
         }
         if (clash || (home < 0 && nrec == (uint32_t)kMzpRecs)) {
-            spill(i);
+            spill(i, clash ? 3 : 4);
             continue;
         }
         if (home < 0) {
@@ -190,6 +195,10 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
         rows[home][q.p] = payload[i];
         who[home][q.p] = i;
     }
+    // overflow[6]: keys of HOT regions (dozens of places under one minimiser: an m-mer of a repeat family that SUNKs of many of
+    // its copies share).  Reads visit such a region in proportion to the copies, nearly always without a match, and every such
+    // window becomes a lookup in the generic table: the host weighs this count when it picks the layout.
+    if (n_ent > 32u) atomicAdd(overflow + 6, (unsigned long long)n_ent);
     uint32_t base[kMzpRecs];
     for (uint32_t r = 0; r < nrec; r++) {
         const uint32_t mask = tag[r] & ((1u << w) - 1u);
@@ -210,7 +219,7 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
             }
         if (!ok) {  // rows that are not consecutive: the record keeps its first member
             for (int p = first + 1; p < w; p++)
-                if ((mask >> p) & 1u) spill(who[r][p]);
+                if ((mask >> p) & 1u) spill(who[r][p], 5);
             tag[r] &= ~(((1u << w) - 1u) & ~(1u << first));
         } else if (down) {
             tag[r] |= 0x80u;

@@ -207,6 +207,11 @@ def test_layout_selection(table_layout):
     tab = engine.DeviceTable(20, keys, loc, np.arange(len(keys), dtype=np.uint32))
     want = {"auto": "minimizer-hbm", "compact-hbm": "compact-hbm", "minimizer": "minimizer-hbm", "minimizer-exact": "minimizer-hbm",
             "minimizer-slots": "minimizer-hbm", "generic": "generic"}[table_layout]
+    # place records when forced; by itself the library gives them to tables of LONG location groups (here ~50 keys per group: an
+    # assembly whose SUNKs sit on point variants, like a diploid one, takes the per-key slots: gs_device.hip, mzp_choose)
+    assert tab.layout.startswith(want) and ("place records" in tab.layout) == (table_layout in ("minimizer", "minimizer-exact"))
+    tab.close()
+    tab = engine.DeviceTable(20, keys, (loc // 1000).astype(np.uint32), np.arange(len(keys), dtype=np.uint32))
     assert tab.layout.startswith(want) and ("place records" in tab.layout) == (table_layout in ("auto", "minimizer", "minimizer-exact"))
     tab.close()
     keys, loc, _ = _random_case(3, 18)
