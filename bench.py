@@ -67,7 +67,7 @@ def source_hash() -> str:
     """Hash of the kernel sources as the compiler sees them: `//` comments and blank lines do not count (so that a comment
     edit does not orphan the measured traffic figure; any code edit does)."""
     h = hashlib.sha256()
-    for f in ("gs_device.hip", "gs_mz.h"):
+    for f in ("gs_device.hip", "gs_mz.h", "gs_mzp.h"):
         for ln in open(os.path.join(ROOT, "gavisunk_amd", "csrc", f), "r"):
             code = ln.split("//", 1)[0].rstrip()
             if code:
@@ -77,9 +77,9 @@ def source_hash() -> str:
 
 def traffic_for(workload_key: str):
     """HBM bytes per launch from a separate rocprofv3 --pmc run (never collected inside the bench); quoted only for the
-    exact workload and kernel sources they were measured on (profiles/r02/traffic.json)."""
+    exact workload and kernel sources they were measured on (profiles/r03/traffic.json)."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03", "traffic.json")))
         e = tj[workload_key]
         if e.get("source_hash") == source_hash():
             return e["hbm_bytes_per_launch"], e.get("note")
@@ -589,7 +589,7 @@ def main():
                 gather_check = bool(g is not None and sum(len(x) for x in g) == tot_rows)
                 log(f"gathered list: {sum(len(x) for x in g) if g is not None else None} rows of {tot_rows}: {gather_check}")
         L.gs_table_counters(table._h, C.byref(ctr))
-        res = {"w": w, "wname": wname, "table": table, "batches": batches, "n_bases": n_bases, "total_bases": total_bases, "dt": dt,
+        res = {"w": w, "wname": wname, "shards": list(shards), "table": table, "batches": batches, "n_bases": n_bases, "total_bases": total_bases, "dt": dt,
                "steps": steps, "step_s": step_s, "n_sunks": n_sunks, "n_groups": n_groups, "sample": sample, "head": head,
                "last": dict(last), "rlen": rlen_all, "n_launch": n_launch, "gather_check": gather_check, "ctr": ctr.as_dict(), "stream": stream}
         return res
@@ -620,6 +620,7 @@ def main():
                                    f": {(a.genome_mb if a.genome_mb is not None else w['genome_mb']):g} Mb{' per haplotype' if w['kind'] == 'diploid' else ''} in 24 contigs, exact SUNK set, "
                                    f"{len(res['rlen'])} synthetic ONT reads per GPU, N50 {n50}, k={K}",
                        "reads_per_gpu": int(len(res["rlen"])), "bases_per_gpu": n_bases, "device_batches_per_gpu": len(res["batches"]),
+                       "read_shards_per_gpu": len(res["shards"]),
                        "sunks": int(res["n_sunks"]), "sunk_groups": int(res["n_groups"]),
                        "windows": last["windows"], "raw_hits": last["raw"], "emitted_rows": last["emitted"],
                        "h_raw": round(h_raw, 5), "h_emit": round(h_emit, 7), "tiles": last["tiles"],

@@ -43,18 +43,16 @@ constexpr int kMzpTagWord0 = 2;        // 32-bit word of the region where the ta
 constexpr int kMzpLocWord0 = 2 + kMzpRecs;
 constexpr uint32_t kMzpOverflow = 1u;  // header byte 0, bit 0
 
-#ifndef GS_MZP_T16
-#define GS_MZP_T16 0  // 1: t = k - 15, i.e. 16 t-mers per window whatever w (the sliding minimum inside the rows of 16 lanes)
-#endif
 // a bijection on 2m-bit values (multiplication by an odd constant): the region is taken from its HIGH bits, which every bit of
 // the m-mer reaches; the fp = its low s bits
 __host__ __device__ __forceinline__ uint32_t mzp_bij(uint32_t cm, int m) {
     const uint32_t M = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
     return (cm * 0x9E3779B1u) & M;
 }
-// length of the short t-mers whose minimum anchors the pick (gs_mz.h: mz_t_of).  With the pick taken as the read shows the k-mer
-// nothing needs the t-mer count to be a multiple of w: t = k - 15 gives 16 of them for every w.
-__host__ __device__ constexpr int mzp_t_of(int k, int m) { return GS_MZP_T16 ? (k - 15 < 4 ? 4 : k - 15) : mz_t_of(k, m); }
+// length of the short t-mers whose minimum anchors the pick: the mod-minimiser's (gs_mz.h: mz_t_of).  (Tried: t = k - 15, i.e. 16
+// t-mers per window whatever w, so that the sliding minimum runs inside the rows of 16 lanes -- the density lost by a t-mer
+// count that is no multiple of w cost more than the cheaper minimum gave: 172.7 against 211.2 Gbase/s at m = 14.)
+__host__ __device__ constexpr int mzp_t_of(int k, int m) { return mz_t_of(k, m); }
 // per lane: bij(canonical m-mer) << 1 | (the canonical form is the reverse complement of the m-mer as shown)
 __host__ __device__ __forceinline__ uint32_t mzp_mmer_word(uint32_t fm, uint32_t rm, int m) {
     const bool rev = rm < fm;
