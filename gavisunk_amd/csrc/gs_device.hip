@@ -1233,7 +1233,7 @@ int mzp_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, int
             // t-mer -- so the places crowd into a fraction of the regions: measured, a 3e8-key table is what m = 14 takes)
             continue;
         }
-        while (s > 0 && ((uint64_t)maxloc + 2) >> (32 - s)) s--;  // the loc word holds fp and loc
+        while (s > 1 && ((uint64_t)maxloc + 2) >> (32 - s)) s--;  // the loc word holds fp and loc (s >= 1: k_probe_mz shifts by 32 - s)
         if (((uint64_t)maxloc + 2) >> (32 - s)) return 0;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;

@@ -318,9 +318,13 @@ __device__ __forceinline__ uint64_t mz_word(uint64_t W0, uint64_t W1, int idx) {
 
 struct MzWin {
     uint64_t f, r;  // forward code and reverse-complement code of the window that starts at this lane's base
-    uint32_t h;     // hash of the canonical m-mer that starts there
-    uint32_t o;     // order (mz_tmer_order) of the canonical t-mer that starts there
+    uint32_t h;     // hash of the canonical m-mer that ENDS the window (the m-mer at offset w - 1)
+    uint32_t o;     // order (mz_tmer_order) of the canonical t-mer that ENDS the window (the t-mer at offset k - t)
+    uint32_t fa, ra;  // (place format, dword-stream windows only) the 16 bases from the window's first one / from its reverse complement's
 };
+// Why the LAST t-mer and m-mer: the window at lane i owns the t-mers that start at lanes i .. i + k - t; when lane j holds the
+// t-mer that starts at base j + (k - t), those are the values of lanes i - (k - t) .. i -- every pull of the sliding minimum
+// and of the pick reaches DOWN the lanes, i.e. into this step or the one before, and a step needs no look-ahead.
 template <bool PLACE = false>
 __device__ __forceinline__ MzWin mz_win_from(uint64_t f, uint64_t r, int k, int m, uint64_t mmask);
 __host__ __device__ __forceinline__ uint32_t mzp_mmer_word(uint32_t fm, uint32_t rm, int m);
@@ -337,16 +341,17 @@ __device__ __forceinline__ MzWin mz_win_from(uint64_t f, uint64_t r, int k, int 
     MzWin o;
     o.f = f;
     o.r = r;
+    o.fa = o.ra = 0u;
 #if GS_MZ_PLACE
     if constexpr (PLACE) {  // (m <= 15) bij(canonical m-mer) << 1 | orientation: gs_mzp.h
-        o.h = mzp_mmer_word((uint32_t)(o.f >> (2 * (k - m))), (uint32_t)o.r & (uint32_t)mmask, m);
+        o.h = mzp_mmer_word((uint32_t)o.f & (uint32_t)mmask, (uint32_t)(o.r >> (2 * (k - m))), m);
     } else
 #endif
     if (m <= 16) {  // wave-uniform: the m-mer fits a word
-        const uint32_t fm = (uint32_t)(o.f >> (2 * (k - m))), rm = (uint32_t)o.r & (uint32_t)mmask;
+        const uint32_t fm = (uint32_t)o.f & (uint32_t)mmask, rm = (uint32_t)(o.r >> (2 * (k - m)));
         o.h = mz_mmer_hash((uint64_t)(fm < rm ? fm : rm));
     } else {
-        const uint64_t fm = o.f >> (2 * (k - m)), rm = o.r & mmask;
+        const uint64_t fm = o.f & mmask, rm = o.r >> (2 * (k - m));
         o.h = mz_mmer_hash(fm < rm ? fm : rm);
     }
 #if GS_MZ_PLACE
@@ -355,7 +360,7 @@ __device__ __forceinline__ MzWin mz_win_from(uint64_t f, uint64_t r, int k, int 
     const int t = mz_t_of(k, m);
 #endif
     const uint32_t tmask = (1u << (2 * t)) - 1u;
-    const uint32_t ft = (uint32_t)(o.f >> (2 * (k - t))), rt = (uint32_t)o.r & tmask;
+    const uint32_t ft = (uint32_t)o.f & tmask, rt = (uint32_t)(o.r >> (2 * (k - t)));
     o.o = mz_tmer_order(ft < rt ? ft : rt);
     return o;
 }
@@ -556,14 +561,14 @@ constexpr int kMzStreamDwords = 2 * (kTileWords + 3);  // a tile's bases as 32-b
 constexpr int kMzFastCand = 64;                // candidates (location changes) of a tile before it is handed to the exact form
 static_assert(kMzListCap >= kMzCandLds, "the exact form borrows the hit list as its candidate buffer");
 constexpr int kMzWaves = 2;                    // waves per workgroup
-// a list entry = (window offset in the tile: 16 bits, loc + 1: 32 bits, 0 = no hit after all) in two parallel arrays, so that
+// a list entry = (window offset in the tile: 16 bits; loc: 32 bits, kMzPending = no hit after all) in two parallel arrays, so that
 // tables with any number of location groups the slot format holds (2^27 for k = 20) take this kernel -- a human assembly has
 // millions of groups (one per stretch of SUNKs with gaps <= k), a diploid one (BASELINE.json configs[3]) one per SNP
-constexpr uint32_t kMzPending = 0xFFFFFFFFu;   // loc of an entry whose generic-table lookup is still to come
+constexpr uint32_t kMzPending = 0xFFFFFFFFu;   // an entry whose generic-table lookup is still to come, or that turned out no hit
 
 struct MzWaveLds {
     uint4 cache[kMzStages][kMzRunCap * kMzPieces];
-    uint32_t list[kMzListCap];              // loc + 1 of every maybe-hit (the exact form borrows this as its candidate buffer)
+    uint32_t list[kMzListCap];              // loc of every maybe-hit (the exact form borrows this as its candidate buffer)
     uint32_t defer[kMzDeferCap];
     uint32_t cand[kMzFastCand];             // the tile's candidates (a tile with more is done over by the exact form)
 #if GS_MZ_RCW
@@ -594,6 +599,18 @@ struct MzWaveLds {
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
+// (the lanes where p holds; HIP's __ballot takes an int: the compiler turns the flag into 0 / 1 and compares again)
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// lane is set in `mask` ? a : b
+__device__ __forceinline__ uint32_t select_by_mask(unsigned long long mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+// lanes below this one that are set in `mask`, + acc
+__device__ __forceinline__ uint32_t mbcnt(unsigned long long mask, uint32_t acc = 0u) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, acc));
+}
 __device__ __forceinline__ uint4 lds_read_b128(uint32_t addr) {
     uint4 v;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
@@ -611,12 +628,13 @@ __device__ __forceinline__ void lds_write_b16(uint32_t addr, uint32_t v) {
     asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-// the window that starts at this lane's base in step s, from the tile's 66 words staged in LDS (two 8-byte reads, one
-// instruction; lanes 0..31 share one address pair, lanes 32..63 the next)
+// the window that starts at this lane's base in step s (-1 .. 31), from the tile's words staged in LDS (two 8-byte reads, one
+// instruction; lanes 0..31 share one address pair, lanes 32..63 the next).  Step -1 = the 64 bases before the tile: its
+// high lanes' windows end inside the tile (what they read in front of the words is never looked at).
 template <bool PLACE = false>
-__device__ __forceinline__ MzWin mz_window_lds(uint32_t words_a, uint32_t s, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
+__device__ __forceinline__ MzWin mz_window_lds(uint32_t words_a, int s, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
     uint4 v;
-    const uint32_t addr = words_a + (2u * s + (uint32_t)(lane >> 5)) * 8u;
+    const uint32_t addr = words_a + (uint32_t)((2 * s + (lane >> 5)) * 8);
     asm volatile("ds_read2_b64 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     const uint64_t a = (uint64_t)v.x | ((uint64_t)v.y << 32), b = (uint64_t)v.z | ((uint64_t)v.w << 32);
     const int sh = 2 * (lane & 31);
@@ -624,7 +642,6 @@ __device__ __forceinline__ MzWin mz_window_lds(uint32_t words_a, uint32_t s, int
     return mz_win_from<PLACE>(x >> (64 - 2 * k), ~revpairs(x) & kmask, k, m, mmask);
 }
 
-#if GS_MZ_RCW
 // ---- windows from the dword streams ------------------------------------------------------------------------------------------
 // The 64 bits that start at bit B of a stream of dwords d[0], d[1], .. are alignbit(d[q], d[q+1], n) : alignbit(d[q+1], d[q+2], n)
 // with q = (B - 1) >> 5 and n = (32 - (B - 32 q)) & 31 (v_alignbit_b32 takes 0..31: a piece that starts ON a dword boundary is
@@ -645,177 +662,168 @@ __device__ __forceinline__ MzLaneGeom mz_lane_geom(uint32_t fd_a, uint32_t rd_a,
     return g;
 }
 __device__ __forceinline__ uint32_t mz_alignbit(uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbit(hi, lo, n); }
-// three consecutive dwords at a 4-byte aligned LDS address
-__device__ __forceinline__ void lds_read3_b32(uint32_t addr, uint32_t &a, uint32_t &b, uint32_t &c) {
-    uint2 ab;
-    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ab), "=&v"(c) : "v"(addr) : "memory");
-    a = ab.x;
-    b = ab.y;
-}
-// the window that starts at this lane's base in step s (k > 16: the code's high part is 2k - 32 bits of the first dword pair)
+// the window that starts at this lane's base in step s (-1 .. 31; k > 16: the code's high part is 2k - 32 bits of the first dword pair)
 template <bool PLACE = false>
-__device__ __forceinline__ MzWin mz_window_rcw(const MzLaneGeom &g, uint32_t s, int k, int m, uint64_t mmask) {
-    uint32_t a, b, c, ra, rb, rc;
-    lds_read3_b32(g.f_addr + 16u * s, a, b, c);
-    lds_read3_b32(g.r_addr - 16u * s, ra, rb, rc);
-    const uint32_t fh = mz_alignbit(a, b, g.f_n), fl = mz_alignbit(b, c, g.f_n);      // 64 bits from the window's first base
-    const uint32_t rh = mz_alignbit(ra, rb, g.r_n), rl = mz_alignbit(rb, rc, g.r_n);  // 64 bits from its reverse complement's
+__device__ __forceinline__ MzWin mz_window_rcw(const MzLaneGeom &g, int s, int k, int m, uint64_t mmask) {
+    uint2 ab, rab;
+    uint32_t c, rc;
+    // (both streams' reads leave together; one wait)
+    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read_b32 %1, %4 offset:8\n\t"
+                 "ds_read2_b32 %2, %5 offset1:1\n\tds_read_b32 %3, %5 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(ab), "=&v"(c), "=&v"(rab), "=&v"(rc)
+                 : "v"(g.f_addr + (uint32_t)(16 * s)), "v"(g.r_addr - (uint32_t)(16 * s))
+                 : "memory");
+    const uint32_t fh = mz_alignbit(ab.x, ab.y, g.f_n), fl = mz_alignbit(ab.y, c, g.f_n);      // 64 bits from the window's first base
+    const uint32_t rh = mz_alignbit(rab.x, rab.y, g.r_n), rl = mz_alignbit(rab.y, rc, g.r_n);  // 64 bits from its reverse complement's
     const uint32_t sh = (uint32_t)(64 - 2 * k);  // 1 .. 31
+#if GS_MZ_PLACE
+    if constexpr (PLACE) {
+        // (k <= 21, m <= 15, t <= 12: everything the stage needs is a piece of one dword -- the forward code's low word holds
+        //  the t-mer and the m-mer that end the window, the reverse complement's first dword their reverse complements)
+        MzWin o;
+        const uint32_t flo = mz_alignbit(fh, fl, sh);
+        o.f = (uint64_t)flo;  // (low word only: what the tag takes its right flank from)
+        o.r = (uint64_t)mz_alignbit(rh, rl, sh);
+        o.fa = fh;
+        o.ra = rh;
+        o.h = mzp_mmer_word(flo & (uint32_t)mmask, rh >> (32 - 2 * m), m);
+        const int t = mzp_t_of(k, m);
+        const uint32_t ft = flo & ((1u << (2 * t)) - 1u), rt = rh >> (32 - 2 * t);
+        o.o = mz_tmer_order(ft < rt ? ft : rt);
+        return o;
+    }
+#endif
     const uint64_t f = ((uint64_t)(fh >> sh) << 32) | mz_alignbit(fh, fl, sh);
     const uint64_t r = ((uint64_t)(rh >> sh) << 32) | mz_alignbit(rh, rl, sh);
     return mz_win_from<PLACE>(f, r, k, m, mmask);
 }
-#endif
 
 // lane i <- lane i - 1, lane 0 <- fill
 __device__ __forceinline__ uint32_t mz_shift_up(uint32_t x, uint32_t fill) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 }
 
-// ---- the sliding leftmost / rightmost minimum over the NT t-mers of every window -----------------------------------------
-// One 32-bit value per t-mer position = two 16-bit halves, order << 7 | position: the low half with the position counted up
-// (its minimum = the leftmost smallest t-mer), the high half with it counted down (the rightmost one); v_pk_min_u16 works on
-// both at once.  Positions are in the frame of a step: lane + 32, so that the step before (-64) and the step after (+64)
-// fit the 7 bits too.  E[T] = minimum over t-mers T - NT + 1 .. T, by doubling (levels of spans 1, 2, 4 ..; lanes are shifted
-// by wave_shr:1 or ds_bpermute), the low lanes taking what they need from the same level of the step before.
-__device__ __forceinline__ uint32_t mz_pk_min(uint32_t a, uint32_t b) {
-    uint32_t d;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
+// ---- the sliding leftmost minimum over the NT t-mers of every window -------------------------------------------------------
+// Lane j of a step holds V[j] = order << 8 | (j + 32) of the t-mer that starts at base j + NT - 1 of the step (MzWin::o), so
+// the window at lane i owns V[i - NT + 1 .. i] and the smaller lane wins a tie: the leftmost smallest t-mer as the read shows
+// the k-mer.  Lanes below 0 are the step before: its values, kept from the last call, are the same numbers - 64.
+//   NT = 16 (w = 4): inside the rows of 16 lanes.  P = minimum over a row's lanes up to this one, S = from this one to the end
+//            of the row (4 DPP row shifts each: no LDS round trip, no wait); E[i] = min(P[i], S[i - 15]) -- one lane pull.
+//   other compile-time NT: X2 = pairs (wave_shr:1), X4 = fours (one pull by 2), then E[i] = min of X4[i - d] over d = 0, 4, 8 ..
+//            and NT - 4: pulls that do not depend on each other, one wait.
+//   NT = 0 (k, m only known at run time): NT - 1 shifts of one lane.
+constexpr uint32_t kMzInf = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t mz_value_of(uint32_t order, int lane) { return (order << 8) | (uint32_t)(lane + 32); }  // (the lane in a byte of its own: one SDWA operand)
+// lane i <- x of lane i - d; lanes i < d <- `before` (already in this step's frame) of lane 64 + i - d
+__device__ __forceinline__ uint32_t mz_pull(uint32_t x, uint32_t before, int d, int lane) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(((lane - d) & 63) * 4, (int)(lane >= 64 - d ? before : x));
 }
-constexpr uint32_t kMzPrevFrame = 0x003FFFC0u;  // + : a value of the step before in this step's frame (low half - 64, high + 64)
-constexpr uint32_t kMzNextFrame = 0xFFC00040u;  // + : a value of the step after in this step's frame
-__device__ __forceinline__ uint32_t mz_pk_of(uint32_t order, int lane) {
-    return order * 0x00800080u + (uint32_t)(lane + 32) + ((uint32_t)(95 - lane) << 16);
+__device__ __forceinline__ void mz_row_minima(uint32_t v, uint32_t &P, uint32_t &S) {
+    uint32_t p = v, q;
+    // v_min_u32 with a DPP source, in place: a lane whose source lies outside its row of 16 is switched off for that
+    // instruction and keeps its value.  (Written out: the compiler makes a copy, a DPP move and a minimum of every level.
+    // A DPP read needs two wait states after the write of its source: the two chains alternate, one s_nop between levels.)
+    asm("v_mov_b32 %1, %0\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(p), "=&v"(q));
+    P = p;
+    S = q;
 }
-constexpr int mz_log2_floor(int x) { return x < 2 ? 0 : 1 + mz_log2_floor(x / 2); }
-
-template <int NT>  // NT > 0: compile-time count of t-mers per window;  NT = 0: taken at run time (shifts of one lane)
+template <int NT>
 struct MzSlide {
-    static constexpr int L = mz_log2_floor(NT ? NT : 1);
-    static constexpr int kLevels = NT ? L + ((1 << L) != NT ? 1 : 0) : 1;
-    uint32_t b[kLevels];  // inputs of every level, of the step this was last advanced to
-    __device__ __forceinline__ void reset() {
+    uint32_t a, b, c;  // of the step before: (NT = 16) c = S;  (else) a = V, b = X2, c = X4;  (NT = 0) a = V
+    __device__ __forceinline__ void reset() { a = b = c = kMzInf; }  // "no step before": never the minimum
+    // V of this step in, E of this step out
+    __device__ __forceinline__ uint32_t advance(uint32_t v, int lane, int nt_runtime) {
+        if constexpr (NT == 16) {
+            uint32_t P, S;
+            mz_row_minima(v, P, S);
+            const uint32_t e = min(P, mz_pull(S, c - 64u, 15, lane));  // (lane 15 of a row pulls its own row's whole minimum: harmless)
+            c = S;
+            return e;
+        } else if constexpr (NT >= 8) {
+            const uint32_t x2 = min(v, mz_shift_up(v, lane_value(a, 63) - 64u));
+            a = v;
+            const uint32_t x4 = min(x2, mz_pull(x2, b - 64u, 2, lane));
+            b = x2;
+            const uint32_t before = c - 64u;
+            c = x4;
+            constexpr int n4 = NT / 4, tail = NT % 4 ? NT - 4 : 0;
+            uint32_t y[5];
 #pragma unroll
-        for (int l = 0; l < kLevels; l++) b[l] = 0xFFFFFFFFu;  // "no step before": never the minimum
-    }
-    // advance to the step whose packed t-mer values are n0: returns its E
-    __device__ __forceinline__ uint32_t advance(uint32_t n0, int lane, int nt_runtime) {
-        uint32_t x = n0;
-        if constexpr (NT == 0) {
-            const uint32_t prev = b[0] + kMzPrevFrame;
-            b[0] = n0;
-            uint32_t y = n0;
-            for (int j = 1; j < nt_runtime; j++) {
-                y = mz_shift_up(y, lane_value(prev, 64 - j));
-                x = mz_pk_min(x, y);
-            }
+            for (int j = 1; j < n4; j++) y[j] = mz_pull(x4, before, 4 * j, lane);
+            if constexpr (tail != 0) y[0] = mz_pull(x4, before, tail, lane);
+            uint32_t e = x4;
+#pragma unroll
+            for (int j = 1; j < n4; j++) e = min(e, y[j]);
+            if constexpr (tail != 0) e = min(e, y[0]);
+            return e;
         } else {
-#pragma unroll
-            for (int l = 0; l < kLevels; l++) {
-                const int sft = l < L ? (1 << l) : NT - (1 << L);
-                const uint32_t prev = b[l] + kMzPrevFrame;
-                b[l] = x;
-                uint32_t y;
-                if (sft == 1) {
-                    y = mz_shift_up(x, lane_value(prev, 63));
-                } else {
-                    const uint32_t comb = lane >= 64 - sft ? prev : x;
-                    y = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane - sft) & 63) * 4, (int)comb);
-                }
-                x = mz_pk_min(x, y);
+            static_assert(NT == 0, "compile-time NT: 8 or more t-mers per window");
+            const uint32_t before = a - 64u;
+            a = v;
+            uint32_t x = v, y = v;
+            for (int j = 1; j < nt_runtime; j++) {
+                y = mz_shift_up(y, lane_value(before, 64 - j));
+                x = min(x, y);
             }
+            return x;
         }
-        return x;
     }
 };
 
-// The region hash of the window that starts at this lane in the step `cur` is the window of (e_cur = its E; `nxt` = the
-// step after; the slide is advanced to it).  The smallest t-mer of a window ends nt - 1 positions on (in the next step for
-// the last lanes), leftmost or rightmost as the canonical strand reads; the m-mer at (its offset mod w) is the one.
+// What a step's windows pick.  `before`: the step before this one (for step 0 of a tile: mz_picker_start), `win`: this step's
+// windows.  -> the m-mer's offset in the window (0 .. w - 1) and the m-mer hash / word (MzWin::h) of the m-mer there.
 template <int WT, int NT>  // WT: w at compile time or 0
-__device__ __forceinline__ uint32_t mz_pick(MzSlide<NT> &slide, uint32_t &e_cur, const MzWin &cur, const MzWin &nxt, bool rc_strand,
-                                           int lane, int w, int nt, uint32_t *pm_out = nullptr) {
-    const uint32_t e_nxt = slide.advance(mz_pk_of(nxt.o, lane), lane, nt);
-    const uint32_t ew = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + nt - 1) & 63) * 4,
-                                                               (int)(lane < nt - 1 ? e_nxt + kMzNextFrame : e_cur));
-    e_cur = e_nxt;
-#if GS_MZ_RD
-    (void)rc_strand;
-    const uint32_t at = (ew & 0x7Fu) - 32u;  // lane of the chosen (leftmost smallest) t-mer (64.. = next step)
-#else
-    const uint32_t at = rc_strand ? 95u - ((ew >> 16) & 0x7Fu) : (ew & 0x7Fu) - 32u;  // lane of the chosen t-mer (64.. = next step)
-#endif
-    const uint32_t xoff = at - (uint32_t)lane;                                          // 0 .. nt - 1
-    // (xoff < nt: with a compile-time w and at most 2 w t-mers per window one conditional subtraction is the remainder)
-    const uint32_t pm = WT == 4 ? (xoff & 3u) : (WT && NT && NT <= 2 * WT) ? xoff - (xoff >= (uint32_t)WT ? (uint32_t)WT : 0u)
-                                                                         : xoff % (uint32_t)(WT ? WT : w);
-    if (pm_out) *pm_out = pm;
-    // the m-mer hash of lane + pm: of this step, or (last lanes) of the next one
-    const int src = (int)(((uint32_t)lane + pm) & 63u) * 4;
-    const uint32_t h_here = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.h);
-    const uint32_t h_next = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)nxt.h);
-    return (uint32_t)lane + pm < 64u ? h_here : h_next;
-}
-
-// the m-mer hash of lane + pm: of this step, or (last lanes) of the next one
-__device__ __forceinline__ uint32_t mz_hash_at(uint32_t pm, const MzWin &cur, const MzWin &nxt, int lane) {
-    const int src = (int)(((uint32_t)lane + pm) & 63u) * 4;
-    const uint32_t h_here = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.h);
-    const uint32_t h_next = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)nxt.h);
-    return (uint32_t)lane + pm < 64u ? h_here : h_next;
-}
-#if GS_MZ_RD
-// ---- 16 t-mers per window (w = 4: k = 20 with m = 17): the sliding minimum inside the rows of 16 lanes ----------------------
-// A window's t-mers are lanes i .. i + 15 = the rest of its row of 16 lanes and the beginning of the next row.  With P = the
-// minimum over a row's lanes up to and including this one, S = over this lane to the end of the row (4 DPP row shifts each:
-// no LDS round trip, no wait), the window's minimum is min(S[i], P[i + 15]) -- P of the next row, or, for the last row, of the
-// NEXT step's first row.  Value = order << 7 | lane: the smaller lane wins a tie (the leftmost t-mer as the read shows it).
-struct MzRowSlide {
-    uint32_t P, S;  // of the step the slide was last advanced to
-    __device__ __forceinline__ void set(uint32_t order, int lane) {
-        uint32_t p = (order << 7) | (uint32_t)lane, q;
-        // v_min_u32 with a DPP source, in place: a lane whose source lies outside its row of 16 is switched off for that
-        // instruction and keeps its value.  (Written out: the compiler makes a copy, a DPP move and a minimum of every level.
-        // A DPP read needs two wait states after the write of its source: the two chains alternate, one s_nop between levels.)
-        asm("v_mov_b32 %1, %0\n\t"
-            "s_nop 1\n\t"
-            "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_min_u32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 0\n\t"
-            "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-            "v_min_u32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 0\n\t"
-            "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-            "v_min_u32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 0\n\t"
-            "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_min_u32_dpp %1, %1, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 1"
-            : "+v"(p), "=&v"(q));
-        P = p;
-        S = q;
+struct MzPicker {
+    MzSlide<NT> slide;
+    uint32_t h_before;
+    uint32_t c_xoff, c_src4;  // per-lane constants (kept opaque: the compiler would rather re-derive them from the lane every step)
+    // the step before a tile's first one: only the lanes whose t-mer / m-mer lies inside the tile count
+    __device__ __forceinline__ void start(const MzWin &before, int lane, int w, int nt) {
+        slide.reset();
+        (void)slide.advance(lane >= 64 - (nt - 1) ? mz_value_of(before.o, lane) : kMzInf, lane, nt);
+        h_before = before.h;
+        c_xoff = (uint32_t)(lane + 33 - nt);
+        c_src4 = 4u * (uint32_t)(lane + 64 - (w - 1));
+        asm volatile("" : "+v"(c_xoff), "+v"(c_src4));
+    }
+    __device__ __forceinline__ uint32_t pick(const MzWin &win, int lane, int w, int nt, uint32_t &pm_out) {
+        const uint32_t e = slide.advance(mz_value_of(win.o, lane), lane, nt);
+        // the chosen t-mer is V of lane (e & 255) - 32 = the t-mer at offset that + (nt - 1) - lane of this lane's window
+        const uint32_t xoff = (e & 0xFFu) - c_xoff;  // 0 .. nt - 1
+        uint32_t pm;
+        if constexpr (WT == 4) pm = xoff & 3u;
+        else if constexpr (WT != 0 && NT != 0 && NT <= 2 * WT) pm = min(xoff, xoff - (uint32_t)WT);  // (unsigned: the wrapped difference is large)
+        else if constexpr (WT != 0 && NT != 0 && NT <= 3 * WT) pm = min(min(xoff, xoff - (uint32_t)WT), xoff - 2u * (uint32_t)WT);
+        else pm = xoff % (uint32_t)(WT ? WT : w);
+        pm_out = pm;
+        // its m-mer starts at offset pm: the m-mer that ENDS the window of lane + pm - (w - 1), of this step or the one before
+        const uint32_t src4 = c_src4 + 4u * pm;  // 4 (lane + 64 - (w - 1) + pm): + 64, never negative
+        const uint32_t h_here = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src4 & 0xFCu), (int)win.h);
+        const uint32_t h_prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src4 & 0xFCu), (int)h_before);
+        h_before = win.h;
+        return src4 >= 256u ? h_here : h_prev;
     }
 };
-// the m-mer offset (0..3) of the window that starts at this lane in the step the slide stands at, given the slide of the next
-// step; lane of the chosen t-mer = e & 0x7F (64.. = in the next step)
-template <int W = 4>
-__device__ __forceinline__ uint32_t mz_row_pick(const MzRowSlide &cur, const MzRowSlide &nxt, int lane, int w_rt = 4) {
-    const uint32_t comb = lane < 16 ? nxt.P + 64u : cur.P;
-    const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 15) & 63) * 4, (int)comb);
-    const uint32_t e = min(cur.S, (lane & 15) ? q : 0xFFFFFFFFu);
-    const uint32_t xoff = (e & 0x7Fu) - (uint32_t)lane;  // 0 .. 15
-    if constexpr (W == 4) return xoff & 3u;
-    else if constexpr (W == 0) return xoff % (uint32_t)w_rt;
-    else return xoff - (uint32_t)W * (xoff >= (uint32_t)W) - (uint32_t)W * (xoff >= 2u * (uint32_t)W);  // (W >= 6: at most two wraps)
-}
-#endif
 
 // self-test: the sliding pick against the rule applied lane by lane (mz_minimizer), on every window of the given tiles
 template <int KT, int MT>
 __global__ __launch_bounds__(64) void k_mz_rule_check(int k_rt, int m_rt, const uint64_t *__restrict__ words, uint32_t n_tiles,
                                                       unsigned long long *mismatches, uint32_t *first_bad) {
-    __shared__ uint64_t s_words[kTileWords + 3];
+    __shared__ uint64_t s_words[2 + kTileWords + 3];  // (two words in front: what step -1 reads and never looks at)
     const int lane = threadIdx.x;
     const int k = KT ? KT : k_rt, m = MT ? MT : m_rt, w = k - m + 1;
     constexpr int NT = KT ? KT - mz_t_of(KT ? KT : 20, KT ? MT : 17) + 1 : 0;
@@ -824,46 +832,28 @@ __global__ __launch_bounds__(64) void k_mz_rule_check(int k_rt, int m_rt, const 
     const uint64_t mmask = (1ULL << (2 * m)) - 1ULL;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();
-        s_words[lane] = words[(uint64_t)tile * kTileWords + lane];
-        if (lane < 3) s_words[64 + lane] = words[(uint64_t)tile * kTileWords + 64 + lane];
+        s_words[2 + lane] = words[(uint64_t)tile * kTileWords + lane];
+        if (lane < 3) s_words[2 + 64 + lane] = words[(uint64_t)tile * kTileWords + 64 + lane];
+        if (lane < 2) s_words[lane] = 0x5555555555555555ULL * (uint64_t)(lane + 1);
         __syncthreads();
-        const uint32_t words_a = lds_addr(&s_words[0]);
-        MzWin cur = mz_window_lds(words_a, 0, lane, k, m, kmask, mmask);
-        constexpr bool ROW = GS_MZ_RD && NT == 16;
-        MzSlide<NT> slide;
-        slide.reset();
-        uint32_t e_cur = 0;
-#if GS_MZ_RD
-        MzRowSlide row_cur;
-        if constexpr (ROW) row_cur.set(cur.o, lane);
-        else
-#endif
-            e_cur = slide.advance(mz_pk_of(cur.o, lane), lane, nt);
-        for (uint32_t s = 0; s < 32u; s++) {
-            const MzWin nxt = mz_window_lds(words_a, s + 1u, lane, k, m, kmask, mmask);
-            const bool rc_strand = cur.r < cur.f;
-            uint32_t H;
-#if GS_MZ_RD
-            if constexpr (ROW) {
-                MzRowSlide row_nxt;
-                row_nxt.set(nxt.o, lane);
-                H = mz_hash_at(mz_row_pick(row_cur, row_nxt, lane), cur, nxt, lane);
-                row_cur = row_nxt;
-            } else
-#endif
-                H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt);
-            // the rule applied to this one k-mer: in its canonical orientation, or (GS_MZ_RD) as the read shows it
-            const uint32_t want = mz_minimizer(GS_MZ_RD ? cur.f : (rc_strand ? cur.r : cur.f), k, m);
+        const uint32_t words_a = lds_addr(&s_words[2]);
+        MzPicker<KT ? KT - MT + 1 : 0, NT> picker;
+        picker.start(mz_window_lds(words_a, -1, lane, k, m, kmask, mmask), lane, w, nt);
+        for (int s = 0; s < 32; s++) {
+            const MzWin cur = mz_window_lds(words_a, s, lane, k, m, kmask, mmask);
+            uint32_t pm;
+            const uint32_t H = picker.pick(cur, lane, w, nt, pm);
+            // the rule applied to this one k-mer as the read shows it
+            const uint32_t want = mz_minimizer(cur.f, k, m);
             if (H != want) {
                 atomicAdd(&first_bad[4 + lane], 1u);  // per-lane histogram
                 if (atomicAdd(mismatches, 1ULL) == 0ULL) {
                     first_bad[0] = tile;
-                    first_bad[1] = s * 64u + (uint32_t)lane;
+                    first_bad[1] = (uint32_t)s * 64u + (uint32_t)lane;
                     first_bad[2] = H;
                     first_bad[3] = want;
                 }
             }
-            cur = nxt;
         }
     }
 }
@@ -894,7 +884,6 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
     const uint64_t mmask = (1ULL << (2 * m)) - 1ULL;
     const uint64_t locmask = (1ULL << locbits) - 1ULL;
-    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     // the tile's 64 words + the two after them (the buffer carries that much slack after the last read), staged in LDS
     constexpr bool RCW = GS_MZ_RCW && KT > 16;
     if constexpr (RCW) {
@@ -926,26 +915,13 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     // (PLACE: fpT = the fp word (fp << (32 - s)), want = tag word | mask word << 32)
     uint32_t fpT[kMzStages], regoff[kMzStages], runreg[kMzStages], nruns[kMzStages];  // fpT: fingerprint in all four bytes, bit 31 of regoff: invalid lane
     uint64_t want[kMzStages];
-#if GS_MZ_RCW
     const MzLaneGeom geom = mz_lane_geom(lds_addr(&L.fd[0]), lds_addr(&L.rd[0]), lane, k);
-    auto window = [&](uint32_t s) {
+    auto window = [&](int s) {
         if constexpr (RCW) return mz_window_rcw<PLACE>(geom, s, k, m, mmask);
         else return mz_window_lds<PLACE>(words_a, s, lane, k, m, kmask, mmask);
     };
-#else
-    auto window = [&](uint32_t s) { return mz_window_lds<PLACE>(words_a, s, lane, k, m, kmask, mmask); };
-#endif
-    MzWin cur = window(0u);
-    constexpr bool ROW = GS_MZ_RD && NT == 16;  // (the sliding minimum inside the rows of 16 lanes)
-    MzSlide<NT> slide;
-    slide.reset();
-    uint32_t e_cur = 0;
-#if GS_MZ_RD
-    MzRowSlide row_cur;
-    if constexpr (ROW) row_cur.set(cur.o, lane);
-    else
-#endif
-        e_cur = slide.advance(mz_pk_of(cur.o, lane), lane, nt);  // E of the step `cur` is the window of
+    MzPicker<KT ? KT - MT + 1 : 0, NT> picker;
+    picker.start(window(-1), lane, w, nt);
 
     // LDS-DMA wave-instructions that fetch the regions of (the first kMzRunCap of) R runs: 16 runs each
     constexpr uint32_t kRunsPerDma = 64 / kMzPieces;
@@ -965,55 +941,47 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     // FULL (compile-time): all 2048 windows of the tile exist (every tile of a read but its last), no lane is ever invalid
     auto stage = [&](uint32_t s, int slot, auto full_tile) {
         constexpr bool FULL = decltype(full_tile)::value;
-        const MzWin nxt = window(s + 1u);
-        const bool rc_strand = cur.r < cur.f;
-        uint32_t H, pm = 0;
-#if GS_MZ_RD
-        if constexpr (ROW) {
-            MzRowSlide row_nxt;
-            row_nxt.set(nxt.o, lane);
-            pm = mz_row_pick<(KT && KT - MT + 1 >= 6) || KT - MT + 1 == 4 ? KT - MT + 1 : 0>(row_cur, row_nxt, lane, w);
-            H = mz_hash_at(pm, cur, nxt, lane);
-            row_cur = row_nxt;
-        } else
-#endif
-            H = mz_pick<KT ? KT - MT + 1 : 0>(slide, e_cur, cur, nxt, rc_strand, lane, w, nt, &pm);
+        const MzWin win = window((int)s);
+        uint32_t pm;
+        const uint32_t H = picker.pick(win, lane, w, nt, pm);
         uint32_t reg, fpw;
         uint64_t wantw;
 #if GS_MZ_PLACE
         if constexpr (PLACE) {
-            // H = bij(canonical m-mer) << 1 | orientation of the m-mer at lane + pm; the k-mer oriented like its m-mer, the
+            // H = orientation << 31 | bij(canonical m-mer) of the m-mer at offset pm; the k-mer oriented like its m-mer, the
             // m-mer's offset in it, the flank bases this window knows (gs_mzp.h)
-            const uint32_t y = H >> 1;
-            const bool rev = H & 1u;
+            const uint32_t y = H & 0x7FFFFFFFu;
+            const bool rev = (int32_t)H < 0;
             const uint32_t p = rev ? (uint32_t)(w - 1) - pm : pm;
             uint32_t tw, mk;
-            mzp_tag(rev ? cur.r : cur.f, p, k, m, tw, mk);
+            if constexpr (RCW) mzp_tag_parts((rev ? win.ra : win.fa) >> (32 - 2 * (k - m)), (uint32_t)(rev ? win.r : win.f), p, k, m, tw, mk);
+            else mzp_tag(rev ? win.r : win.f, p, k, m, tw, mk);
             reg = y >> mz.s;
-            fpw = mz.s ? (y << (32 - mz.s)) : 0u;
+            fpw = y << (32 - mz.s);  // (s >= 1: gs_device.hip, mzp_choose)
             wantw = (uint64_t)tw | ((uint64_t)mk << 32);
-            cur = nxt;
         } else
 #endif
         {
-            const uint64_t c = rc_strand ? cur.r : cur.f;
-            cur = nxt;
+            const uint64_t c = win.r < win.f ? win.r : win.f;
             const MzKey key = mz_key_fmt<FMT>(c, k, locbits);
             reg = mz_region(H, mz.n_regions);
             fpw = key.fp * 0x01010101u;
             wantw = key.tag << locbits;
         }
         const bool valid = FULL || s * 64u + (uint32_t)lane < td.nwin_left;
-        const bool leader = valid && (lane == 0 || reg != mz_shift_up(reg, ~reg));
-        const unsigned long long lb = __ballot(leader);
-        const uint32_t R = (uint32_t)__popcll(lb);  // >= 1: lane 0 of an existing step is valid
-        const uint32_t myrun = (uint32_t)__popcll(lb & (lt | (1ULL << lane))) - 1u;
+        // leaders: lanes whose region is another than the lane's below (lane 0 sees 0 there: it leads whatever its region,
+        // being valid in every step that exists)
+        const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)reg, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+        const unsigned long long lb = ballot(valid && reg != below) | 1ULL;
+        const uint32_t R = (uint32_t)__popcll(lb);
+        // the leaders at or below this lane, less one = those among lanes 1 .. lane (v_mbcnt: the lanes below, of a mask)
+        const uint32_t myrun = mbcnt(lb >> 1);
         fpT[slot] = fpw;
         regoff[slot] = myrun * (uint32_t)(kMzWords * 8) | (valid ? 0u : 0x80000000u);  // byte offset of the run's region in the cache slot
         want[slot] = wantw;
         nruns[slot] = R;
         // lane r <- region of run r (leaders push; the others push to lane 63, which holds a run only when all 64 lanes lead)
-        runreg[slot] = (uint32_t)__builtin_amdgcn_ds_permute((int)((leader ? myrun : 63u) * 4u), (int)reg);
+        runreg[slot] = (uint32_t)__builtin_amdgcn_ds_permute((int)select_by_mask(lb, myrun * 4u, 63u * 4u), (int)reg);
         fetch(slot, runreg[slot], R, 0u);
     };
 
@@ -1032,13 +1000,14 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
             // the region's 7 tag words against this window's (TW, MK): the record that matches (at most one can), its loc word
             const uint32_t tw = (uint32_t)want[u], mk = (uint32_t)(want[u] >> 32);
             uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0, q2 = q0, q3 = q0;
-            if ((FULL && !BIG) || mine) {
-                q0 = lds_read_b128(reg_a);
-                q1 = lds_read_b128(reg_a + 16u);
-                q2 = lds_read_b128(reg_a + 32u);
-                q3 = lds_read_b128(reg_a + 48u);
+            if ((FULL && !BIG) || mine) {  // (the four reads leave together; one wait)
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                             "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(reg_a) : "memory");
             }
-            uint32_t sel = 0xFFFFFFFFu;  // (tw has no bit outside mk)
+            // (tw has no bit outside mk.)  Without a match the loc word stays one whose fp bits are NOT this window's: the fp
+            // test below then fails by itself (s >= 1)
+            uint32_t sel = ~fpT[u];
             sel = (q0.z & mk) == tw ? q2.y : sel;
             sel = (q0.w & mk) == tw ? q2.z : sel;
             sel = (q1.x & mk) == tw ? q2.w : sel;
@@ -1046,10 +1015,9 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
             sel = (q1.z & mk) == tw ? q3.y : sel;
             sel = (q1.w & mk) == tw ? q3.z : sel;
             sel = (q2.x & mk) == tw ? q3.w : sel;
-            const int sft = 32 - mz.s;
-            hit = mine && sel != 0xFFFFFFFFu && (!mz.s || ((sel ^ fpT[u]) >> sft) == 0u);
-            e = mz.s ? (uint64_t)(sel & ((1u << sft) - 1u)) : (uint64_t)sel;
-            defer = mine && !hit && (q0.x & kMzpOverflow);  // keys of this region in the generic table
+            hit = mine && ((sel ^ fpT[u]) >> (32 - mz.s)) == 0u;
+            e = (uint64_t)sel;  // (fp bits and all: the flush takes them off)
+            defer = mine && !hit && q0.x != 0u;  // header word 0 = kMzpOverflow: keys of this region in the generic table
         } else
 #endif
         {
@@ -1073,9 +1041,9 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
                 }
             }
             const bool more = any && !hit && (((x & (x - 1u)) | (lo ? cd.m1 : 0u)) != 0u);
-            if (__ballot(more)) {  // (wave-uniform, rare) walk the other candidates
+            if (ballot(more)) {  // (wave-uniform, rare) walk the other candidates
                 if (any) cd.pop();
-                while (__ballot(mine && !hit && cd.any())) {
+                while (ballot(mine && !hit && cd.any())) {
                     if (mine && !hit && cd.any()) {
                         const uint64_t e2 = lds_read_b64(reg_a + cd.pop() * 8u) ^ want[u];
                         if (e2 < locmask) {
@@ -1090,15 +1058,15 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
         if (defer) defer = mz_filter_maybe(lds_read_b64(reg_a + (uint32_t)kMzSlots * 8u), mz_filter_bits(want[u] >> locbits));
         }
         const bool mb_mine = hit || defer;
-        const unsigned long long mb = __ballot(mb_mine), db = __ballot(defer);
+        const unsigned long long mb = ballot(mb_mine), db = ballot(defer);
         if (mb) {
             // (a big step calls this twice, lower lanes first: its entries still land in lane order)
-            const uint32_t idx = lcount + (uint32_t)__popcll(mb & lt);
+            const uint32_t rank = mbcnt(mb);  // (the list's fill level joins the address on the scalar side)
             if (mb_mine) {
-                lds_write_b32(list_a + idx * 4u, hit ? (uint32_t)e + 1u : kMzPending);
-                lds_write_b16(listw_a + idx * 2u, s * 64u + (uint32_t)lane);
+                lds_write_b32(list_a + lcount * 4u + rank * 4u, hit ? (uint32_t)e : kMzPending);
+                lds_write_b16(listw_a + lcount * 2u + rank * 2u, s * 64u + (uint32_t)lane);
             }
-            if (defer) lds_write_b32(defer_a + (dcount + (uint32_t)__popcll(db & lt)) * 4u, (s * 64u + (uint32_t)lane) | (idx << 16));
+            if (defer) lds_write_b32(defer_a + dcount * 4u + mbcnt(db) * 4u, (s * 64u + (uint32_t)lane) | ((lcount + rank) << 16));
             lcount += (uint32_t)__popcll(mb);
             dcount += (uint32_t)__popcll(db);
         }
@@ -1136,16 +1104,17 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
                     hh = (hh + 1) & tab.mask;
                     sl = load_slot(tab.slots + hh);
                 }
-                L.list[ent >> 16] = sl.key == c ? sl.loc + 1u : 0u;
+                L.list[ent >> 16] = sl.key == c ? sl.loc : kMzPending;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
         for (uint32_t i0 = 0; i0 < lcount; i0 += 64u) {
             const bool have = i0 + (uint32_t)lane < lcount;
-            const uint32_t lv = have ? L.list[i0 + (uint32_t)lane] : 0u, woff = have ? (uint32_t)L.list_w[i0 + (uint32_t)lane] : 0u;
-            const bool hit = lv != 0u;
-            const uint32_t loc = lv - 1u;
+            const uint32_t lv = have ? L.list[i0 + (uint32_t)lane] : kMzPending, woff = have ? (uint32_t)L.list_w[i0 + (uint32_t)lane] : 0u;
+            const bool hit = lv != kMzPending;
+            const uint32_t loc = lv & (uint32_t)locmask;  // (place format: the loc word's fp bits go)
             const unsigned long long hb = __ballot(hit);
             if (!hb) continue;
             const unsigned long long below = hb & lt;

@@ -53,10 +53,11 @@ __host__ __device__ __forceinline__ uint32_t mzp_bij(uint32_t cm, int m) {
 // t-mers per window whatever w, so that the sliding minimum runs inside the rows of 16 lanes -- the density lost by a t-mer
 // count that is no multiple of w cost more than the cheaper minimum gave: 172.7 against 211.2 Gbase/s at m = 14.)
 __host__ __device__ constexpr int mzp_t_of(int k, int m) { return mz_t_of(k, m); }
-// per lane: bij(canonical m-mer) << 1 | (the canonical form is the reverse complement of the m-mer as shown)
+// per lane: bit 31 = the canonical form is the reverse complement of the m-mer as shown, bits 0 .. 2m - 1 = bij(canonical m-mer)
+// (m <= 15: the difference of the two 30-bit codes carries the comparison in its sign bit)
 __host__ __device__ __forceinline__ uint32_t mzp_mmer_word(uint32_t fm, uint32_t rm, int m) {
-    const bool rev = rm < fm;
-    return (mzp_bij(rev ? rm : fm, m) << 1) | (rev ? 1u : 0u);
+    const uint32_t d = rm - fm;  // negative: rm < fm
+    return (mzp_bij(rm < fm ? rm : fm, m) & 0x7FFFFFFFu) | (d & 0x80000000u);
 }
 
 struct MzpProbe {   // what a window looks for
@@ -64,18 +65,22 @@ struct MzpProbe {   // what a window looks for
     uint32_t tw, mk;
     uint32_t p;     // offset of the m-mer in the oriented k-mer
 };
-// (TW, MK) of the oriented k-mer X (its m-mer canonical) with the m-mer at offset p
+// (TW, MK) of the oriented k-mer X (its m-mer canonical) with the m-mer at offset p.  Bits 8.. of a tag are the place's context
+// with the m-mer cut out -- the w - 1 bases left of it, then the w - 1 bases right of it -- and a window knows a CONTIGUOUS
+// stretch of that: its k-mer minus the m-mer (the last p bases of the left flank, the first w - 1 - p of the right one), which
+// is the k-mer's top 2 (w - 1) bits with their low 2 (w - 1 - p) bits replaced by the k-mer's own lowest bits (one v_bfi).
+// xtop = X >> 2 m;  xlow = X's low 32 bits (bits above the right flank are not looked at).
+__host__ __device__ __forceinline__ void mzp_tag_parts(uint32_t xtop, uint32_t xlow, uint32_t p, int k, int m, uint32_t &tw, uint32_t &mk) {
+    const uint32_t nf2 = 2u * (uint32_t)(k - m);  // flank bits per side = 2 (w - 1) (<= 12)
+    const uint32_t nl = 2u * p, sr = 8u + nl;
+    const uint32_t ones_r = (1u << (nf2 - nl)) - 1u;
+    const uint32_t cut = (xlow & ones_r) | (xtop & ~ones_r);
+    const uint32_t bit = 1u << p;
+    tw = (cut << sr) | bit;
+    mk = (((1u << nf2) - 1u) << sr) | bit;
+}
 __host__ __device__ __forceinline__ void mzp_tag(uint64_t X, uint32_t p, int k, int m, uint32_t &tw, uint32_t &mk) {
-    const int nf = k - m;  // flank bases per side = w - 1 (<= 6)
-    const uint32_t nl = 2u * p, nr = 2u * (uint32_t)nf - nl;
-    // the k-mer's first nf bases, then the last p of the first p + ... : its top 2 nf bits shifted down to 2 p bits (p = 0: none)
-    const uint32_t top = (uint32_t)(X >> (2 * (k - nf)));  // (a constant shift: one v_alignbit for k = 20)
-    const uint32_t xl = top >> (2u * (uint32_t)nf - nl);
-    const uint32_t ones_r = (1u << nr) - 1u, ones_l = (1u << nl) - 1u;
-    const uint32_t xr = (uint32_t)X & ones_r;
-    const uint32_t bit = 1u << p, sr = 8u + nl;
-    tw = bit | (xr << sr) | (xl << 20);
-    mk = bit | (ones_r << sr) | (ones_l << 20);
+    mzp_tag_parts((uint32_t)(X >> (2 * m)), (uint32_t)X, p, k, m, tw, mk);
 }
 __host__ __device__ __forceinline__ uint64_t mzp_revcomp(uint64_t c, int k) {
     uint64_t r = 0;
