@@ -994,6 +994,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
         const bool mine = (FULL || !(regoff[u] >> 31)) && (!BIG || (myrun >= r0 && myrun < r0 + (uint32_t)kMzRunCap));
         const uint32_t reg_a = lds_addr(&L.cache[u][0]) + (FULL ? regoff[u] : off) - r0 * (uint32_t)(kMzWords * 8);
         bool hit = false, defer = false;
+        unsigned long long hitb, deferb;  // the same as wave masks (the scalar unit combines them)
         uint64_t e = 0;
 #if GS_MZ_PLACE
         if constexpr (PLACE) {
@@ -1015,9 +1016,10 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
             sel = (q1.z & mk) == tw ? q3.y : sel;
             sel = (q1.w & mk) == tw ? q3.z : sel;
             sel = (q2.x & mk) == tw ? q3.w : sel;
-            hit = mine && ((sel ^ fpT[u]) >> (32 - mz.s)) == 0u;
+            // (lanes that are not `mine` read nothing: no record, no header -- neither a hit nor deferred)
+            hitb = ballot(((sel ^ fpT[u]) >> (32 - mz.s)) == 0u);
             e = (uint64_t)sel;  // (fp bits and all: the flush takes them off)
-            defer = mine && !hit && q0.x != 0u;  // header word 0 = kMzpOverflow: keys of this region in the generic table
+            deferb = ballot(q0.x != 0u) & ~hitb;  // header word 0 = kMzpOverflow: keys of this region in the generic table
         } else
 #endif
         {
@@ -1057,18 +1059,22 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
         defer = mine && !hit && mz_region_overflowed(F);  // generic table, later -- unless the region's filter word says no
         if (defer) defer = mz_filter_maybe(lds_read_b64(reg_a + (uint32_t)kMzSlots * 8u), mz_filter_bits(want[u] >> locbits));
         }
-        const bool mb_mine = hit || defer;
-        const unsigned long long mb = ballot(mb_mine), db = ballot(defer);
+        if constexpr (!PLACE) {
+            hitb = ballot(hit);
+            deferb = ballot(defer);
+        }
+        const unsigned long long mb = hitb | deferb;
         if (mb) {
             // (a big step calls this twice, lower lanes first: its entries still land in lane order)
             const uint32_t rank = mbcnt(mb);  // (the list's fill level joins the address on the scalar side)
-            if (mb_mine) {
-                lds_write_b32(list_a + lcount * 4u + rank * 4u, hit ? (uint32_t)e : kMzPending);
+            if (__builtin_amdgcn_inverse_ballot_w64(mb)) {
+                lds_write_b32(list_a + lcount * 4u + rank * 4u, select_by_mask(hitb, (uint32_t)e, kMzPending));
                 lds_write_b16(listw_a + lcount * 2u + rank * 2u, s * 64u + (uint32_t)lane);
             }
-            if (defer) lds_write_b32(defer_a + dcount * 4u + mbcnt(db) * 4u, (s * 64u + (uint32_t)lane) | ((lcount + rank) << 16));
+            if (__builtin_amdgcn_inverse_ballot_w64(deferb))
+                lds_write_b32(defer_a + dcount * 4u + mbcnt(deferb) * 4u, (s * 64u + (uint32_t)lane) | ((lcount + rank) << 16));
             lcount += (uint32_t)__popcll(mb);
-            dcount += (uint32_t)__popcll(db);
+            dcount += (uint32_t)__popcll(deferb);
         }
     };
 
