@@ -1019,7 +1019,8 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
             // (lanes that are not `mine` read nothing: no record, no header -- neither a hit nor deferred)
             hitb = ballot(((sel ^ fpT[u]) >> (32 - mz.s)) == 0u);
             e = (uint64_t)sel;  // (fp bits and all: the flush takes them off)
-            deferb = ballot(q0.x != 0u) & ~hitb;  // header word 0 = kMzpOverflow: keys of this region in the generic table
+            // header word 1: the filter of the region's keys in the generic table (0: it has none there)
+            deferb = ballot((int32_t)(q0.y << mzp_filter_shift(tw, fpT[u])) < 0) & ~hitb;
         } else
 #endif
         {

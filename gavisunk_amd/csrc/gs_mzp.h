@@ -13,17 +13,20 @@
 //   y        = bij(canonical m-mer)                      a bijection on 2m bits (m <= 15)
 //   region   = y >> s,  fp = y & (2^s - 1)               64 bytes each; s (1..16) from the table size (2^(2m-s) regions)
 //   region   = 8 header bytes | 7 tag words | 7 loc words
-//     tag    [L flank: w-1 bases, bits 20..] [R flank: w-1 bases, bits 8..] [sign: bit 7] [mask: bits 0..w-1]
-//              the context of the place in the orientation in which its m-mer is canonical; mask bit p = the k-mer whose
-//              m-mer sits at offset p is a SUNK; flank bases no SUNK of the place covers are 0 and never looked at
+//     tag    [context: 2 (w-1) bases, bits 8..] [sign: bit 7] [mask: bits 0..w-1]
+//              context = the w - 1 bases left of the place's m-mer, then the w - 1 bases right of it, in the orientation in
+//              which the m-mer is canonical; mask bit p = the k-mer whose m-mer sits at offset p is a SUNK; context bases no
+//              SUNK of the place covers are 0 and never looked at
 //     loc    fp << (32 - s) | loc id of the place
-//     header byte 0 bit 0 = keys of this region live in the generic side table (more than 7 places, or a place the format
-//              does not take: keys of one place with different locs or rows that are not consecutive)
+//     header word 0 bit 0 = keys of this region live in the generic side table (more than 7 places, or a place the format
+//              does not take: keys of one place with different locs or rows that are not consecutive); word 1 = a 32-bit
+//              filter of those keys (mzp_filter_shift)
 //   payload  (k_emit only) base row of the place, in a parallel array; the row of the key at offset p = base + sign * (number
 //              of mask bits below p)
 //
 // A window (as the read shows it: GS_MZ_RD rule, the leftmost smallest t-mer) knows p, the p bases left of the m-mer and the
-// w - 1 - p bases right of it: it builds (TW, MK) once and a record matches iff ((tag ^ TW) & MK) == 0 -- mask bit p included.
+// w - 1 - p bases right of it -- a contiguous stretch of the context: it builds (TW, MK) once and a record matches iff
+// ((tag ^ TW) & MK) == 0 -- mask bit p included.
 // The builder makes sure no two records of a region can match the same window (records of different m-mers that share a region
 // AND agree on a window's flank bases: one of them goes to the generic table), so the first match is the match and its fp is
 // checked afterwards.  Exactness never depends on how well places merge: a record is a set of (offset, k-mer) pairs.
@@ -82,6 +85,11 @@ __host__ __device__ __forceinline__ void mzp_tag_parts(uint32_t xtop, uint32_t x
 __host__ __device__ __forceinline__ void mzp_tag(uint64_t X, uint32_t p, int k, int m, uint32_t &tw, uint32_t &mk) {
     mzp_tag_parts((uint32_t)(X >> (2 * m)), (uint32_t)X, p, k, m, tw, mk);
 }
+// Header word 1 of a region whose keys did not all fit = a 32-bit filter of the ones in the generic table: the bit of a window
+// (from what it looks for: tag word and fp word).  A window that finds no record asks the generic table only when its bit is
+// set -- a crowded region is one that reads visit often (a minimiser of a repeat family), nearly always for k-mers that are no
+// SUNKs at all.  The shift is the bit's distance from bit 31 (the lookup shifts it there and tests the sign).
+__host__ __device__ __forceinline__ uint32_t mzp_filter_shift(uint32_t tw, uint32_t fpw) { return ((tw ^ fpw) * 0x9E3779B1u) >> 27; }
 __host__ __device__ __forceinline__ uint64_t mzp_revcomp(uint64_t c, int k) {
     uint64_t r = 0;
     for (int i = 0; i < k; i++) {
@@ -147,16 +155,18 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
     if (e0 && (ent[e0 - 1] >> 33) == reg) return;  // not the region's first entry
     const int w = k - m + 1;
     const uint32_t fpmask = s ? (1u << s) - 1u : 0u, flank = 0xFFFFFF00u;
-    uint32_t tag[kMzpRecs], km[kMzpRecs], locw[kMzpRecs], rows[kMzpRecs][7], who[kMzpRecs][7];
+    uint32_t tag[kMzpRecs], km[kMzpRecs], locw[kMzpRecs], rows[kMzpRecs][7], who[kMzpRecs][7], twm[kMzpRecs][7];
     uint32_t nrec = 0;
     bool over = false;
     // (overflow[1..5]: why -- 1 loc too wide for the loc word, 2 the "no record" value, 3 a record would match its windows
     //  already, 4 the region's 7 records are taken, 5 a record whose rows are not consecutive)
-    auto spill = [&](uint32_t key_idx, int why) {
+    uint32_t filter = 0u;
+    auto spill = [&](uint32_t key_idx, int why, uint32_t tw, uint32_t fpw) {
         const unsigned long long o = atomicAdd(overflow, 1ULL);
         atomicAdd(overflow + why, 1ULL);
         if (o < overflow_cap) overflow_list[o] = key_idx;
         over = true;
+        filter |= 0x80000000u >> mzp_filter_shift(tw, fpw);
     };
     uint32_t n_ent = 0;
     for (uint64_t e = e0; e < n2 && (ent[e] >> 33) == reg; e++) {
@@ -164,13 +174,14 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
         const uint32_t i = (uint32_t)(ent[e] >> 1);
         const uint64_t c = keys[i], rc = mzp_revcomp(c, k);
         const MzpProbe q = (ent[e] & 1ULL) ? mzp_probe_of(rc, c, k, m) : mzp_probe_of(c, rc, k, m);
+        const uint32_t fpw = s ? (q.y & fpmask) << (32 - s) : 0u;
         if (s && (loc[i] >> (32 - s))) {  // (a loc id that needs the fp's bits: not in this format)
-            spill(i, 1);
+            spill(i, 1, q.tw, fpw);
             continue;
         }
-        const uint32_t lw = s ? (((q.y & fpmask) << (32 - s)) | loc[i]) : loc[i];
-        if (lw == 0xFFFFFFFFu) {  // (the lookups' "no record" value)
-            spill(i, 2);
+        const uint32_t lw = fpw | loc[i];
+        if (lw == 0xFFFFFFFFu) {  // (never a loc word: kept out of the way of the lookups' sentinels)
+            spill(i, 2, q.tw, fpw);
             continue;
         }
         int home = -1;
@@ -184,7 +195,7 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
             }
         }
         if (clash || (home < 0 && nrec == (uint32_t)kMzpRecs)) {
-            spill(i, clash ? 3 : 4);
+            spill(i, clash ? 3 : 4, q.tw, fpw);
             continue;
         }
         if (home < 0) {
@@ -197,6 +208,7 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
         km[home] |= q.mk;
         rows[home][q.p] = payload[i];
         who[home][q.p] = i;
+        twm[home][q.p] = q.tw;
     }
     // overflow[6]: keys of HOT regions (dozens of places under one minimiser: an m-mer of a repeat family that SUNKs of many of
     // its copies share).  Reads visit such a region in proportion to the copies, nearly always without a match, and every such
@@ -222,7 +234,7 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
             }
         if (!ok) {  // rows that are not consecutive: the record keeps its first member
             for (int p = first + 1; p < w; p++)
-                if ((mask >> p) & 1u) spill(who[r][p], 5);
+                if ((mask >> p) & 1u) spill(who[r][p], 5, twm[r][p], s ? locw[r] & ~((1u << (32 - s)) - 1u) : 0u);
             tag[r] &= ~(((1u << w) - 1u) & ~(1u << first));
         } else if (down) {
             tag[r] |= 0x80u;
@@ -230,7 +242,7 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
     }
     uint32_t wd[16];
     wd[0] = over ? kMzpOverflow : 0u;
-    wd[1] = 0u;
+    wd[1] = filter;
     for (int r = 0; r < kMzpRecs; r++) {
         wd[kMzpTagWord0 + r] = (uint32_t)r < nrec ? tag[r] : 0u;
         wd[kMzpLocWord0 + r] = (uint32_t)r < nrec ? locw[r] : 0u;

@@ -43,7 +43,7 @@ bool file_stamp(const char *path, FileStamp *out) {
 }
 
 struct SidecarHeader {
-    char magic[8];  // "GSSIDE04"
+    char magic[8];  // "GSSIDE05"
     uint32_t header_bytes, meta_bytes;
     FileStamp db, loc;
     uint64_t n_rows, names_bytes;
