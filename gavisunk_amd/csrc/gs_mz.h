@@ -148,9 +148,10 @@ __host__ __device__ __forceinline__ uint32_t mz_mmer_hash(uint64_t cm) {
     return x * 0x9E3779B1u;
 }
 // the mod-minimiser rule: length of the short t-mers whose minimum anchors the pick (t = m mod w, 5 <= t <= 12), their
-// order (9 bits: with the 7-bit position it fills the 16-bit halves the sliding minimum of k_probe_mz works on)
+// order (24 bits of a multiplicative hash: with the lane in the low byte it is the 32-bit value the sliding minimum of
+// k_probe_mz works on -- one v_and_or from the product)
 __host__ __device__ constexpr int mz_t_of(int k, int m) { return 5 + (m - 5) % (k - m + 1); }
-__host__ __device__ __forceinline__ uint32_t mz_tmer_order(uint32_t ct) { return (ct * 0x9E3779B1u) >> 23; }
+__host__ __device__ __forceinline__ uint32_t mz_tmer_order(uint32_t ct) { return (ct * 0x9E3779B1u) >> 8; }
 // region hash of a k-mer from its CANONICAL code (so either strand of a k-mer gives the same value); build side and slow paths
 __host__ __device__ __forceinline__ uint32_t mz_minimizer(uint64_t c, int k, int m) {
     uint64_t r = 0, x = c;
@@ -812,8 +813,9 @@ struct MzPicker {
         pm_out = pm;
         // its m-mer starts at offset pm: the m-mer that ENDS the window of lane + pm - (w - 1), of this step or the one before
         const uint32_t src4 = c_src4 + 4u * pm;  // 4 (lane + 64 - (w - 1) + pm): + 64, never negative
-        const uint32_t h_here = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src4 & 0xFCu), (int)win.h);
-        const uint32_t h_prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src4 & 0xFCu), (int)h_before);
+        // (ds_bpermute takes the lane from address bits 7:2: no mask needed)
+        const uint32_t h_here = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)win.h);
+        const uint32_t h_prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)h_before);
         h_before = win.h;
         return src4 >= 256u ? h_here : h_prev;
     }
@@ -922,6 +924,8 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     };
     MzPicker<KT ? KT - MT + 1 : 0, NT> picker;
     picker.start(window(-1), lane, w, nt);
+    uint32_t c_regbits = (uint32_t)(31 - mz.s);  // (place format) width of the region index in H; in a VGPR: the bit-field extract takes one scalar operand
+    asm volatile("" : "+v"(c_regbits));
 
     // LDS-DMA wave-instructions that fetch the regions of (the first kMzRunCap of) R runs: 16 runs each
     constexpr uint32_t kRunsPerDma = 64 / kMzPieces;
@@ -950,14 +954,13 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
         if constexpr (PLACE) {
             // H = orientation << 31 | bij(canonical m-mer) of the m-mer at offset pm; the k-mer oriented like its m-mer, the
             // m-mer's offset in it, the flank bases this window knows (gs_mzp.h)
-            const uint32_t y = H & 0x7FFFFFFFu;
             const bool rev = (int32_t)H < 0;
             const uint32_t p = rev ? (uint32_t)(w - 1) - pm : pm;
             uint32_t tw, mk;
             if constexpr (RCW) mzp_tag_parts((rev ? win.ra : win.fa) >> (32 - 2 * (k - m)), (uint32_t)(rev ? win.r : win.f), p, k, m, tw, mk);
             else mzp_tag(rev ? win.r : win.f, p, k, m, tw, mk);
-            reg = y >> mz.s;
-            fpw = y << (32 - mz.s);  // (s >= 1: gs_device.hip, mzp_choose)
+            reg = __builtin_amdgcn_ubfe(H, (uint32_t)mz.s, c_regbits);  // y >> s, y = H less its orientation bit
+            fpw = H << (32 - mz.s);  // y << (32 - s) (s >= 1: gs_device.hip, mzp_choose)
             wantw = (uint64_t)tw | ((uint64_t)mk << 32);
         } else
 #endif
@@ -1094,17 +1097,21 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
             if (j0 + (uint32_t)lane < dcount) {
                 const uint32_t ent = L.defer[j0 + lane];
                 const uint32_t wi = ent & 0xFFFFu;
-                uint64_t a, b2;
+                uint64_t c;
                 if constexpr (RCW) {
-#if GS_MZ_RCW
-                    a = ((uint64_t)L.fd[1 + 2 * (wi >> 5)] << 32) | L.fd[2 + 2 * (wi >> 5)];
-                    b2 = ((uint64_t)L.fd[3 + 2 * (wi >> 5)] << 32) | L.fd[4 + 2 * (wi >> 5)];
-#endif
+                    // the window's code and its reverse complement's from the two dword streams (mz_lane_geom, for window wi)
+                    const int bf = 2 * (int)wi, qf = (bf - 1) >> 5;  // (wi = 0: -1, the dword of padding)
+                    const uint32_t nf = (uint32_t)(32 - (bf - 32 * qf)) & 31u;
+                    const int br = 2 * ((kTileWords + 3) * 32 - k - (int)wi), qr = (br - 1) >> 5;
+                    const uint32_t nr = (uint32_t)(32 - (br - 32 * qr)) & 31u;
+                    const uint32_t fh = mz_alignbit(L.fd[1 + qf], L.fd[2 + qf], nf), fl = mz_alignbit(L.fd[2 + qf], L.fd[3 + qf], nf);
+                    const uint32_t rh = mz_alignbit(L.rd[qr], L.rd[qr + 1], nr), rl = mz_alignbit(L.rd[qr + 1], L.rd[qr + 2], nr);
+                    const uint64_t f = (((uint64_t)fh << 32) | fl) >> (64 - 2 * k), r = (((uint64_t)rh << 32) | rl) >> (64 - 2 * k);
+                    c = f < r ? f : r;
                 } else {
-                    a = L.words[wi >> 5];
-                    b2 = L.words[(wi >> 5) + 1];
+                    const uint64_t a = L.words[wi >> 5], b2 = L.words[(wi >> 5) + 1];
+                    c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(wi & 31u), k, kmask);
                 }
-                const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(wi & 31u), k, kmask);
                 uint64_t hh = slot_of(c, tab.shift);
                 Slot sl = load_slot(tab.slots + hh);
                 while (sl.key != c && sl.key != kEmptyKey) {
@@ -1122,16 +1129,16 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
             const uint32_t lv = have ? L.list[i0 + (uint32_t)lane] : kMzPending, woff = have ? (uint32_t)L.list_w[i0 + (uint32_t)lane] : 0u;
             const bool hit = lv != kMzPending;
             const uint32_t loc = lv & (uint32_t)locmask;  // (place format: the loc word's fp bits go)
-            const unsigned long long hb = __ballot(hit);
+            const unsigned long long hb = ballot(hit);
             if (!hb) continue;
             const unsigned long long below = hb & lt;
             const int src = below ? 63 - __clzll((long long)below) : 0;
             const uint32_t pl = __shfl(loc, src);
             const uint32_t prev = below ? pl : carry;
             const bool chg = hit && loc != prev;
-            const unsigned long long cb = __ballot(chg);
-            const uint32_t ci = n_cand + (uint32_t)__popcll(cb & lt);
-            if (chg && ci < (uint32_t)kMzFastCand) L.cand[ci] = ((n_raw + (uint32_t)__popcll(below)) << 16) | woff;
+            const unsigned long long cb = ballot(chg);
+            const uint32_t ci = mbcnt(cb, n_cand);
+            if (chg && ci < (uint32_t)kMzFastCand) L.cand[ci] = (mbcnt(hb, n_raw) << 16) | woff;
             n_cand += (uint32_t)__popcll(cb);
             if (first_loc == GS_NONE) first_loc = lane_value(loc, __ffsll((unsigned long long)hb) - 1);
             carry = lane_value(loc, 63 - __clzll((long long)hb));

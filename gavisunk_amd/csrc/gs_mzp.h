@@ -75,8 +75,8 @@ struct MzpProbe {   // what a window looks for
 // xtop = X >> 2 m;  xlow = X's low 32 bits (bits above the right flank are not looked at).
 __host__ __device__ __forceinline__ void mzp_tag_parts(uint32_t xtop, uint32_t xlow, uint32_t p, int k, int m, uint32_t &tw, uint32_t &mk) {
     const uint32_t nf2 = 2u * (uint32_t)(k - m);  // flank bits per side = 2 (w - 1) (<= 12)
-    const uint32_t nl = 2u * p, sr = 8u + nl;
-    const uint32_t ones_r = (1u << (nf2 - nl)) - 1u;
+    const uint32_t sr = 8u + 2u * p;
+    const uint32_t ones_r = (1u << (nf2 + 8u - sr)) - 1u;
     const uint32_t cut = (xlow & ones_r) | (xtop & ~ones_r);
     const uint32_t bit = 1u << p;
     tw = (cut << sr) | bit;

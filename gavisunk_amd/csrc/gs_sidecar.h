@@ -50,7 +50,7 @@ struct SidecarHeader {
     uint32_t n_contigs, pad;
     TableMeta meta;
 };
-constexpr char kSidecarMagic[8] = {'G', 'S', 'S', 'I', 'D', 'E', '0', '4'};
+constexpr char kSidecarMagic[8] = {'G', 'S', 'S', 'I', 'D', 'E', '0', '5'};
 constexpr size_t kSidecarChunk = (size_t)64 << 20;
 
 struct FileCloser {
