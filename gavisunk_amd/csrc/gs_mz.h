@@ -14,13 +14,13 @@
 // Pibiri 2024): look for the smallest short t-mer of the k-mer (t = 5 .. 5 + w - 1, t = m mod w; there are k - t + 1 of them, a
 // multiple of w), at position x, and take the m-mer at position x mod w.  The smallest t-mer stays the same over ~k - t
 // windows while x mod w walks with the windows: runs of 1 / 0.31 = 3.2 windows for k = 20, m = 17, where the plain
-// minimiser (smallest m-mer hash) gives 2.5 -- a fifth fewer requests on the same table geometry.  Everything is canonical
-// (a t-mer or m-mer counts as the smaller of itself and its reverse complement) and ties go to the leftmost t-mer of the
-// k-mer IN ITS CANONICAL ORIENTATION, so both strands of a k-mer pick the same m-mer (k - t + 1 = 0 mod w makes x mod w
-// mirror correctly).
+// minimiser (smallest m-mer hash) gives 2.5 -- a fifth fewer requests on the same table geometry.  t-mers and m-mers are
+// canonical (the smaller of itself and its reverse complement), and ties go to the leftmost t-mer of the k-mer AS THE READ
+// SHOWS IT: the probe never asks which strand of the k-mer is the canonical one before it picks, and the table holds a key
+// under the pick of either strand (two entries when they differ: ~1 % of the keys).
 //
-//   x       = leftmost argmin over the k - t + 1 t-mers of the canonical k-mer of (t-mer or its rc, the smaller) * c >> 23
-//   H       = mix_a(min(m-mer at x mod w, its reverse complement))                                 strand-symmetric
+//   x       = leftmost argmin over the k - t + 1 t-mers of the k-mer as shown of (t-mer or its rc, the smaller) * c >> 8
+//   H       = mix_a(min(m-mer at x mod w, its reverse complement))
 //   region  = mul_hi(H, n_regions)                                                                 64 bytes each
 //   RAW slots (2k + locbits <= 64):      tag = the canonical code,  fp = min((low word * c) >> 24, 0xFE)
 //   HASHED slots (longer k-mers):        l | hi = mix_a(low word) ^ mix_b(high bits), high bits      a bijection
@@ -531,37 +531,49 @@ __global__ __launch_bounds__(256) void k_probe_mz_exact(MzView mz, TableView tab
 // ------------------------------------------------------------------------------------------
 // k_probe_mz: the fast form.  One wavefront per tile, lane = window, and per step of 64 windows:
 //
-//   stage    minimiser -> region of every window; a RUN = adjacent lanes with the same region (its first lane is the
-//            leader).  The whole 64-byte region of every run is fetched ONCE, straight into LDS:
-//            run by LDS-DMA (global_load_lds_dwordx4): 4 lanes x 16 bytes per run, 16 runs per wave-instruction (runs
-//            past the last one repeat it: same line, no new request).  One request per run is what the fabric sees.
-//   consume  (kMzStages - 1 steps later, behind a counted vmcnt) a window reads its region's fingerprint word from LDS,
-//            then the slots whose fingerprint matches.  Outcome: hit (loc), miss, or -- the region's count byte says that keys
-//            of it did not fit (mz_region_overflowed), none of its 6 is this one and its filter word does not rule the key out
-//            -- "ask the generic table", which is deferred: such a window takes a place in the tile's hit list like a
-//            hit does.  A step with more than kMzRunCap runs (rare) is consumed in two halves, the second fetched on the spot.
-//   flush    when the hit list or the deferred queue might not hold one more step, and after the last step: the deferred
-//            lookups go to the generic table 64 at a time (their latencies overlap), then one ordered pass over the dense hit
-//            list does the bookkeeping exactly as mz_tile does, and the list starts over (the small list is what lets 24
-//            waves share a CU's LDS: 6.5 KB each, 79 VGPRs).
+//   stage    the window's pieces from the tile's two dword streams in LDS (forward, reverse complement: v_alignbit); the
+//            sliding minimum over its t-mers and the pick (MzPicker: every pull reaches down the lanes, no look-ahead);
+//            region of every window; a RUN = adjacent lanes with the same region (its first lane is the leader).  The whole
+//            64-byte region of every run is fetched ONCE, straight into LDS, by LDS-DMA (global_load_lds_dwordx4): 4 lanes x
+//            16 bytes per run, 16 runs per wave-instruction (runs past the last one repeat it: same line, no new request).
+//            One request per run is what the fabric sees.
+//   consume  (kMzStages - 1 steps later, behind a counted vmcnt) a window reads its region from LDS.  Slot format: the
+//            fingerprint word, then the slots whose fingerprint matches.  Place format (gs_mzp.h): all 64 bytes, the 7 tag
+//            words against the window's (tag, mask).  Outcome: hit (loc), miss, or -- the region says that keys of it live in
+//            the generic table and its filter does not rule this one out -- "ask the generic table", which is deferred:
+//            such a window takes a place in the tile's hit list like a hit does.  A step with more than kMzRunCap runs
+//            (rare) is consumed a slot-full of runs at a time, the later ones fetched on the spot.
+//   flush    when the hit list might not hold one more step, and after the last step: one ordered pass over the dense hit
+//            list, 64 entries at a time -- the deferred ones among them go to the generic table together (their latencies
+//            overlap) -- does the bookkeeping exactly as mz_tile does, and the list starts over.  The small list, one cache
+//            slot of 28 runs and 68 VGPRs are what lets 28 waves share a CU (5.7 KB of LDS each, four to a workgroup).
 //
-// A tile with more candidates (location changes) than the LDS buffer holds (kMzCandLds) is done over by mz_tile_exact:
+// A tile with more candidates (location changes) than the LDS buffer holds (kMzFastCand) is done over by mz_tile_exact:
 // exactness never depends on the budgets.
 // ------------------------------------------------------------------------------------------
-constexpr int kMzRunCap = 32;                  // runs of a step whose regions fit the LDS cache slot (2 KiB)
-constexpr int kMzDma = kMzRunCap * kMzPieces / 64;  // LDS-DMA wave-instructions per step
-constexpr int kMzStages = 2;                   // steps whose region fetches are in flight together
-#if GS_MZ_RCW
-constexpr int kMzListCap = 176;                // maybe-hits held before the list is flushed (a step adds up to 64)
-constexpr int kMzDeferCap = 80;                // deferred generic-table lookups held before a flush
-#else
-constexpr int kMzListCap = 240;                // maybe-hits held before the list is flushed (a step adds up to 64)
-constexpr int kMzDeferCap = 96;                // deferred generic-table lookups held before a flush
+#ifndef GS_MZ_RUN_CAP
+#define GS_MZ_RUN_CAP 28
 #endif
-constexpr int kMzStreamDwords = 2 * (kTileWords + 3);  // a tile's bases as 32-bit pieces: 64 words + 2 a window reaches into + 1 of padding
-constexpr int kMzFastCand = 64;                // candidates (location changes) of a tile before it is handed to the exact form
+#ifndef GS_MZ_FAST_CAND
+#define GS_MZ_FAST_CAND 64
+#endif
+#ifndef GS_MZ_MIN_WAVES
+#define GS_MZ_MIN_WAVES 7  // waves per SIMD the register allocation leaves room for (the LDS per wave decides how many run)
+#endif
+constexpr int kMzRunCap = GS_MZ_RUN_CAP;       // runs of a step whose regions fit the LDS cache slot (64 bytes each)
+constexpr int kMzDma = (kMzRunCap * kMzPieces + 63) / 64;  // LDS-DMA wave-instructions per step (the last one may fill only part of its 16 runs)
+constexpr int kMzStages = 2;                   // steps whose region fetches are in flight together
+#ifndef GS_MZ_LIST_CAP
+#define GS_MZ_LIST_CAP 136
+#endif
+constexpr int kMzListCap = GS_MZ_LIST_CAP;     // maybe-hits (hits and deferred lookups) held before the list is flushed (a step adds up to 64)
+constexpr int kMzStreamDwords = 2 * (kTileWords + 3);  // a tile's bases as 32-bit pieces: 64 words + 2 the last windows reach into + 1 of padding
+constexpr int kMzFastCand = GS_MZ_FAST_CAND;   // candidates (location changes) of a tile before it is handed to the exact form
 static_assert(kMzListCap >= kMzCandLds, "the exact form borrows the hit list as its candidate buffer");
-constexpr int kMzWaves = 2;                    // waves per workgroup
+#ifndef GS_MZ_WG_WAVES
+#define GS_MZ_WG_WAVES 4
+#endif
+constexpr int kMzWaves = GS_MZ_WG_WAVES;       // waves per workgroup (each with its own MzWaveLds: what decides how many fit a CU's 160 KB)
 // a list entry = (window offset in the tile: 16 bits; loc: 32 bits, kMzPending = no hit after all) in two parallel arrays, so that
 // tables with any number of location groups the slot format holds (2^27 for k = 20) take this kernel -- a human assembly has
 // millions of groups (one per stretch of SUNKs with gaps <= k), a diploid one (BASELINE.json configs[3]) one per SNP
@@ -570,7 +582,6 @@ constexpr uint32_t kMzPending = 0xFFFFFFFFu;   // an entry whose generic-table l
 struct MzWaveLds {
     uint4 cache[kMzStages][kMzRunCap * kMzPieces];
     uint32_t list[kMzListCap];              // loc of every maybe-hit (the exact form borrows this as its candidate buffer)
-    uint32_t defer[kMzDeferCap];
     uint32_t cand[kMzFastCand];             // the tile's candidates (a tile with more is done over by the exact form)
 #if GS_MZ_RCW
   union {
@@ -863,7 +874,7 @@ __global__ __launch_bounds__(64) void k_mz_rule_check(int k_rt, int m_rt, const 
 // KT / MT: k and m as compile-time constants (0 = take them from the table); FMT: slot format (mz_key_fmt)
 // PLACE: the place-record format of gs_mzp.h (FMT is then unused)
 template <int KT, int MT, int FMT, bool PLACE = false>
-__global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableView tab, const uint64_t *__restrict__ words,
+__global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzView mz, TableView tab, const uint64_t *__restrict__ words,
                                                            const TileDesc *__restrict__ tdesc, uint32_t n_tiles, TileArrays ta,
                                                            uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
                                                            uint32_t *g_fallback_tiles) {
@@ -910,7 +921,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint32_t nsteps = min((td.nwin_left + 63u) / 64u, 32u);
-    const uint32_t list_a = lds_addr(&L.list[0]), listw_a = lds_addr(&L.list_w[0]), defer_a = lds_addr(&L.defer[0]), words_a = lds_addr(&L.words[0]);
+    const uint32_t list_a = lds_addr(&L.list[0]), listw_a = lds_addr(&L.list_w[0]), words_a = lds_addr(&L.words[0]);
 
     // per in-flight step (slot = step % kMzStages): the fingerprint to look for, where the lane's region is in the cache slot,
     // the key / tag to look for, lane r = region of run r, and the run count
@@ -939,7 +950,12 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
             const uint32_t q = min(r0 + (uint32_t)(it * (int)kRunsPerDma + lane / kMzPieces), R - 1u);
             const uint32_t rr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q * 4u), (int)rr_lane);
             const uint4 *src = mz.regions + (uint64_t)rr * kMzPieces + (lane % kMzPieces);
-            __builtin_amdgcn_global_load_lds(src, &L.cache[slot][it * 64], 16, 0, 0);
+            if constexpr (kMzRunCap % (int)kRunsPerDma != 0) {  // (a slot that ends inside the last instruction's 16 runs: its other lanes stay out)
+                if (it < kMzDma - 1 || lane < (kMzRunCap % (int)kRunsPerDma) * kMzPieces)
+                    __builtin_amdgcn_global_load_lds(src, &L.cache[slot][it * 64], 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds(src, &L.cache[slot][it * 64], 16, 0, 0);
+            }
         }
     };
     // FULL (compile-time): all 2048 windows of the tile exist (every tile of a read but its last), no lane is ever invalid
@@ -988,7 +1004,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
         fetch(slot, runreg[slot], R, 0u);
     };
 
-    uint32_t lcount = 0, dcount = 0;     // wave-uniform: entries of the list / of the deferred queue
+    uint32_t lcount = 0;                 // wave-uniform: entries of the list
     // the windows of step s whose run is in [r0, r0 + kMzRunCap): their regions are in cache slot u
     // BIG (compile-time): the step has more runs than a cache slot holds and is looked up in two halves
     auto lookups = [&](uint32_t s, int u, uint32_t r0, auto full_tile, auto big_step) {
@@ -1075,10 +1091,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
                 lds_write_b32(list_a + lcount * 4u + rank * 4u, select_by_mask(hitb, (uint32_t)e, kMzPending));
                 lds_write_b16(listw_a + lcount * 2u + rank * 2u, s * 64u + (uint32_t)lane);
             }
-            if (__builtin_amdgcn_inverse_ballot_w64(deferb))
-                lds_write_b32(defer_a + dcount * 4u + mbcnt(deferb) * 4u, (s * 64u + (uint32_t)lane) | ((lcount + rank) << 16));
             lcount += (uint32_t)__popcll(mb);
-            dcount += (uint32_t)__popcll(deferb);
         }
     };
 
@@ -1087,46 +1100,47 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
     // they came from -- and the list starts over.  Runs when a step might not fit any more, and after the last step.
     uint32_t n_raw = 0, n_cand = 0, first_loc = GS_NONE, carry = GS_NONE;  // of the tile so far
     auto flush = [&]() {
-#ifdef GS_MZ_COUNT_DEFER  // (experiment: the fallback-tile counter counts deferred generic-table lookups instead)
-        if (lane == 0 && dcount) atomicAdd(g_fallback_tiles, dcount);
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t j0 = 0; j0 < dcount; j0 += 64u) {
-            if (j0 + (uint32_t)lane < dcount) {
-                const uint32_t ent = L.defer[j0 + lane];
-                const uint32_t wi = ent & 0xFFFFu;
-                uint64_t c;
-                if constexpr (RCW) {
-                    // the window's code and its reverse complement's from the two dword streams (mz_lane_geom, for window wi)
-                    const int bf = 2 * (int)wi, qf = (bf - 1) >> 5;  // (wi = 0: -1, the dword of padding)
-                    const uint32_t nf = (uint32_t)(32 - (bf - 32 * qf)) & 31u;
-                    const int br = 2 * ((kTileWords + 3) * 32 - k - (int)wi), qr = (br - 1) >> 5;
-                    const uint32_t nr = (uint32_t)(32 - (br - 32 * qr)) & 31u;
-                    const uint32_t fh = mz_alignbit(L.fd[1 + qf], L.fd[2 + qf], nf), fl = mz_alignbit(L.fd[2 + qf], L.fd[3 + qf], nf);
-                    const uint32_t rh = mz_alignbit(L.rd[qr], L.rd[qr + 1], nr), rl = mz_alignbit(L.rd[qr + 1], L.rd[qr + 2], nr);
-                    const uint64_t f = (((uint64_t)fh << 32) | fl) >> (64 - 2 * k), r = (((uint64_t)rh << 32) | rl) >> (64 - 2 * k);
-                    c = f < r ? f : r;
-                } else {
-                    const uint64_t a = L.words[wi >> 5], b2 = L.words[(wi >> 5) + 1];
-                    c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(wi & 31u), k, kmask);
-                }
-                uint64_t hh = slot_of(c, tab.shift);
-                Slot sl = load_slot(tab.slots + hh);
-                while (sl.key != c && sl.key != kEmptyKey) {
-                    hh = (hh + 1) & tab.mask;
-                    sl = load_slot(tab.slots + hh);
-                }
-                L.list[ent >> 16] = sl.key == c ? sl.loc : kMzPending;
-            }
-        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
         for (uint32_t i0 = 0; i0 < lcount; i0 += 64u) {
             const bool have = i0 + (uint32_t)lane < lcount;
-            const uint32_t lv = have ? L.list[i0 + (uint32_t)lane] : kMzPending, woff = have ? (uint32_t)L.list_w[i0 + (uint32_t)lane] : 0u;
+            uint32_t lv = have ? L.list[i0 + (uint32_t)lane] : kMzPending;
+            const uint32_t woff = have ? (uint32_t)L.list_w[i0 + (uint32_t)lane] : 0u;
+            // the deferred lookups among these entries go to the generic table together (their latencies overlap)
+            const bool pend = have && lv == kMzPending;
+            const unsigned long long pb = ballot(pend);
+            if (pb) {  // wave-uniform
+#ifdef GS_MZ_COUNT_DEFER  // (experiment: the fallback-tile counter counts deferred generic-table lookups instead)
+                if (lane == 0) atomicAdd(g_fallback_tiles, (uint32_t)__popcll(pb));
+#endif
+                if (pend) {
+                    const uint32_t wi = woff;
+                    uint64_t c;
+                    if constexpr (RCW) {
+                        // the window's code and its reverse complement's from the two dword streams (mz_lane_geom, for window wi)
+                        const int bf = 2 * (int)wi, qf = (bf - 1) >> 5;  // (wi = 0: -1, the dword of padding)
+                        const uint32_t nf = (uint32_t)(32 - (bf - 32 * qf)) & 31u;
+                        const int br = 2 * ((kTileWords + 3) * 32 - k - (int)wi), qr = (br - 1) >> 5;
+                        const uint32_t nr = (uint32_t)(32 - (br - 32 * qr)) & 31u;
+                        const uint32_t fh = mz_alignbit(L.fd[1 + qf], L.fd[2 + qf], nf), fl = mz_alignbit(L.fd[2 + qf], L.fd[3 + qf], nf);
+                        const uint32_t rh = mz_alignbit(L.rd[qr], L.rd[qr + 1], nr), rl = mz_alignbit(L.rd[qr + 1], L.rd[qr + 2], nr);
+                        const uint64_t f = (((uint64_t)fh << 32) | fl) >> (64 - 2 * k), r = (((uint64_t)rh << 32) | rl) >> (64 - 2 * k);
+                        c = f < r ? f : r;
+                    } else {
+                        const uint64_t a = L.words[wi >> 5], b2 = L.words[(wi >> 5) + 1];
+                        c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(wi & 31u), k, kmask);
+                    }
+                    uint64_t hh = slot_of(c, tab.shift);
+                    Slot sl = load_slot(tab.slots + hh);
+                    while (sl.key != c && sl.key != kEmptyKey) {
+                        hh = (hh + 1) & tab.mask;
+                        sl = load_slot(tab.slots + hh);
+                    }
+                    lv = sl.key == c ? sl.loc : kMzPending;
+                }
+            }
             const bool hit = lv != kMzPending;
             const uint32_t loc = lv & (uint32_t)locmask;  // (place format: the loc word's fp bits go)
             const unsigned long long hb = ballot(hit);
@@ -1146,7 +1160,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        lcount = dcount = 0;
+        lcount = 0;
     };
 
     static_assert(kMzStages == 2, "the prologue below stages steps 0 and 1 by hand (slot indices must be compile-time)");
@@ -1160,7 +1174,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
             for (int u = 0; u < kMzStages; u++) {
                 const uint32_t s = s0 + (uint32_t)u;
                 if (s >= nsteps) break;  // wave-uniform
-                if (lcount + 64u > (uint32_t)kMzListCap || dcount + 64u > (uint32_t)kMzDeferCap) flush();  // (wave-uniform) room for this step
+                if (lcount + 64u > (uint32_t)kMzListCap) flush();  // (wave-uniform) room for this step
                 // the fetches of step s have landed once at most those of the next step (1 to kMzDma instructions) are outstanding
                 static_assert(kMzDma == 2, "the waits below count at most two instructions of the next step");
                 switch (s + 1 < nsteps ? dma_count(nruns[u ^ 1]) : 0u) {  // wave-uniform
@@ -1171,13 +1185,15 @@ __global__ __launch_bounds__(64 * kMzWaves, 6) void k_probe_mz(MzView mz, TableV
                 if (nruns[u] <= (uint32_t)kMzRunCap) {
                     lookups(s, u, 0u, full_tile, small_step);
                 } else {
-                    // a big step: its windows in lane order are runs 0..31 then 32..63, and a hit list entry is written at its
-                    // rank among the step's maybe-hits -- so the first half is looked up first, and the ranks line up
+                    // a big step: its windows in lane order are the runs in order, and a hit list entry is written at its rank
+                    // among the step's maybe-hits -- so a slot-full of runs at a time is looked up, lowest first, and the ranks line up
                     lookups(s, u, 0u, full_tile, big_step);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    fetch(u, runreg[u], nruns[u], (uint32_t)kMzRunCap);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    lookups(s, u, (uint32_t)kMzRunCap, full_tile, big_step);
+                    for (uint32_t r0 = (uint32_t)kMzRunCap; r0 < nruns[u]; r0 += (uint32_t)kMzRunCap) {  // wave-uniform
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        fetch(u, runreg[u], nruns[u], r0);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        lookups(s, u, r0, full_tile, big_step);
+                    }
                 }
                 if (s + kMzStages < nsteps) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of this slot are done before it is refilled
