@@ -91,7 +91,7 @@ Rccl *rccl() {
 struct TableMeta {
     int k, shift, compact, c_qb, c_rembits, c_locbits, c_has_flag, c_w64, mz, mz_m, mz_locbits, mz_place, mz_s;
     uint32_t mz_n_regions, join_chunk;
-    uint64_t n, cap, c_overflow, mz_overflow, n_ovf, mz_dup;
+    uint64_t n, cap, c_overflow, mz_overflow, n_ovf, mz_dup, mz_hot;
 };
 
 __global__ void k_shift_reads(gs_hit *h, uint64_t n, uint32_t delta) {
@@ -107,7 +107,7 @@ __global__ void k_shift_reads(gs_hit *h, uint64_t n, uint32_t delta) {
 // the others inside a collective.
 TableMeta table_meta_of(const gs_table *t, uint64_t n_ovf) {
     return TableMeta{t->k, t->shift, t->compact, t->c_qb, t->c_rembits, t->c_locbits, t->c_has_flag, t->c_w64, t->mz, t->mz_m,
-                     t->mz_locbits, t->mz_place, t->mz_s, t->mz_n_regions, 0u, t->n, t->cap, t->c_overflow, t->mz_overflow, n_ovf, t->mz_dup};
+                     t->mz_locbits, t->mz_place, t->mz_s, t->mz_n_regions, 0u, t->n, t->cap, t->c_overflow, t->mz_overflow, n_ovf, t->mz_dup, t->mz_hot};
 }
 
 struct TableArray {  // one device array of a table: where its pointer lives in the handle, and its size in bytes
@@ -162,6 +162,7 @@ int table_receive_init(gs_table *t, int device, const TableMeta &hm) {
     t->c_overflow = hm.c_overflow;
     t->mz_overflow = hm.mz_overflow;
     t->mz_dup = hm.mz_dup;
+    t->mz_hot = hm.mz_hot;
     for (auto &a : table_arrays(hm, t, nullptr)) {
         uint8_t *p = nullptr;
         if ((rc = dev_alloc(&p, a.bytes))) return rc;

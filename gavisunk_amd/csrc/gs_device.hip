@@ -940,7 +940,7 @@ struct gs_table {
     uint32_t mz_n_regions = 0;
     int mz_m = 0, mz_locbits = 0;
     uint32_t *mz_pay = nullptr;  // payload per slot
-    uint64_t mz_overflow = 0, mz_dup = 0;  // keys in the generic side table; keys stored under both strands' picks
+    uint64_t mz_overflow = 0, mz_dup = 0, mz_hot = 0;  // keys in the generic side table; keys stored under both strands' picks; (place format) placed keys that hot regions gave up
     int mz_place = 0, mz_s = 0;            // place-record regions (gs_mzp.h): 2^(2 mz_m - mz_s) of them
     hipStream_t stream = nullptr;       // every pass over this table runs here, in launch order
     hipStream_t copy_stream = nullptr;  // hit lists to the host: overlaps the next pass
@@ -1201,15 +1201,20 @@ int choose_compact(int k, uint64_t n, uint64_t generic_bytes, uint32_t maxloc, b
 // Place-record regions (gs_mzp.h): k - 6 <= m <= 15 (a tag word holds two flanks of w - 1 <= 6 bases; regions are addressed by
 // a bijection of the 2m-bit m-mer).  The shortest such m whose regions stay below ~2.5 places on average (7 fit); s from the
 // number of places: 2^(2m - s) regions, about one per place.
+// An assembly whose SUNKs come from point variants inside otherwise repeated sequence (a diploid assembly: a SNP in one copy
+// of a repeat family makes the ~k k-mers over it unique) has them in many small location groups, and under a short minimiser
+// dozens of copies' variants share one m-mer: such a region overflows many times over, reads visit it in proportion to the
+// copies, nearly always for the k-mers the copies have in common, and a 32-bit filter of that many keys is all ones (measured
+// on BASELINE.json configs[3]: 6 % of all windows went on to the generic table).  Tables with fewer than 2000 keys per
+// location group are built with HOT regions (k_mzp_place): a region with that many misfits keeps no record at all, its keys
+// live in the generic table and its 60 bytes are one filter of them.
+uint32_t mzp_hot_min(uint64_t n, uint32_t maxloc) {
+    if (const char *e = getenv("GAVISUNK_MZ_HOT")) return (uint32_t)std::max(0, atoi(e));  // test knob (0: never, n: regions with n misfits)
+    return (double)n < 2000.0 * ((double)maxloc + 1.0) ? 6u : 0u;
+}
 int mzp_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, int &s, int m_from = 0, bool forced = false) {
+    (void)forced;
     if (k < 16 || k > 21 || n == 0 || any_missing) return 0;
-    // An assembly whose SUNKs come from point variants inside otherwise repeated sequence (a diploid assembly: a SNP in one copy
-    // of a repeat family makes the ~k k-mers over it unique) has them in many small location groups, and under a SHORT
-    // minimiser dozens of copies' variants share one m-mer: the region overflows, reads visit it in proportion to the copies,
-    // nearly always without a match, and each such window becomes a lookup in the generic table (measured on BASELINE.json
-    // configs[3]: 18 % of all windows, probe kernel 130 ms instead of 92).  A longer minimiser mostly CONTAINS the variant and
-    // is the copy's own: such tables take the per-key-slot regions (m >= k - 4).  Fewer than 2000 keys per group decides.
-    if (!forced && (double)n < 2000.0 * ((double)maxloc + 1.0)) return 0;
     int m_lo = std::max(std::max(k - 6, 10), m_from), m_hi = std::min(15, k - 1);
     if (m_lo > m_hi) return 0;
     if (const char *e = getenv("GAVISUNK_MZ_M")) {  // tuning / test knob, read once per table
@@ -1411,7 +1416,8 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
     while (t->mz && t->mz_place) {
         const uint64_t nreg = t->mz_n_regions;
         const bool knob = getenv("GAVISUNK_MZ_M") || getenv("GAVISUNK_MZ_LOAD");
-        const uint64_t ocap = std::max<uint64_t>(knob && force_mz ? 2 * n : n / 16, 1u << 16);
+        const uint32_t hot_min = mzp_hot_min(n, maxloc);
+        const uint64_t ocap = std::max<uint64_t>(knob && force_mz ? 2 * n : hot_min ? n / 4 : n / 16, 1u << 16);
         unsigned long long *dov = nullptr;
         if ((rc = dev_alloc((unsigned long long **)&t->mz_regions, nreg * kMzWords)) || (rc = dev_alloc(&t->mz_pay, nreg * 8)) ||
             (rc = tmp.get(&dov, 8)) || (rc = tmp.get(&dlist, ocap)))
@@ -1437,7 +1443,7 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
                 t->mz_dup = nd;
             }
             hipLaunchKernelGGL(k_mzp_place, dim3((unsigned)((n2 + 127) / 128)), dim3(128), 0, t->stream, const_cast<uint4 *>(t->mz_regions), t->mz_pay, k,
-                               t->mz_m, t->mz_s, dk, dl, dp, (const uint64_t *)ent1, n2, dov, dlist, ocap);
+                               t->mz_m, t->mz_s, dk, dl, dp, (const uint64_t *)ent1, n2, dov, dlist, ocap, hot_min);
             HIP_TRY(hipStreamSynchronize(t->stream));
         }
         unsigned long long ovs[8] = {0};
@@ -1446,10 +1452,11 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
         HIP_TRY(hipGetLastError());
         const unsigned long long ov = ovs[0];
         if (getenv("GAVISUNK_DEBUG_BUILD"))
-            fprintf(stderr, "place records m = %d s = %d: %llu of %llu keys to the generic table (loc too wide %llu, reserved value %llu, clash %llu, region full %llu, rows %llu), %llu in hot regions, %llu under both picks\n",
-                    t->mz_m, t->mz_s, ov, (unsigned long long)n, ovs[1], ovs[2], ovs[3], ovs[4], ovs[5], ovs[6], (unsigned long long)t->mz_dup);
+            fprintf(stderr, "place records m = %d s = %d: %llu of %llu keys to the generic table (loc too wide %llu, reserved value %llu, clash %llu, region full %llu, rows %llu, placed keys of hot regions %llu), %llu entries in regions of more than 32, %llu under both picks\n",
+                    t->mz_m, t->mz_s, ov, (unsigned long long)n, ovs[1], ovs[2], ovs[3], ovs[4], ovs[5], ovs[6], ovs[7], (unsigned long long)t->mz_dup);
         if (ov <= ocap) {
             t->mz_overflow = ov;
+            t->mz_hot = ovs[6];
             n_generic = ov;
             break;
         }
@@ -1786,8 +1793,9 @@ const char *gs_table_layout(const gs_table *t) {
     static thread_local char buf[448];
     if (!t) return "";
     if (t->mz && t->mz_place)
-        snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 64 B (7 place records: flank bases of the minimiser's context + offset mask | %d-bit fp + loc), mod-minimiser of length %d (w = %d, t = %d), %llu keys under both strands' picks, %llu overflow keys in a generic 16 B-slot side table",
-                 t->mz_n_regions, t->mz_s, t->mz_m, t->k - t->mz_m + 1, mz_t_of(t->k, t->mz_m), (unsigned long long)t->mz_dup, (unsigned long long)t->mz_overflow);
+        snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 64 B (7 place records: flank bases of the minimiser's context + offset mask | %d-bit fp + loc), mod-minimiser of length %d (w = %d, t = %d), %llu keys under both strands' picks, %llu overflow keys in a generic 16 B-slot side table%s",
+                 t->mz_n_regions, t->mz_s, t->mz_m, t->k - t->mz_m + 1, mz_t_of(t->k, t->mz_m), (unsigned long long)t->mz_dup, (unsigned long long)t->mz_overflow,
+                 t->mz_hot ? " (crowded regions kept as filters of their keys)" : "");
     else if (t->mz)
         snprintf(buf, sizeof buf, "minimizer-hbm: %u regions of 64 B (8 fingerprint bytes + 7 x u64 [%d-bit %s | %d-bit loc]), mod-minimiser of length %d (w = %d, t = %d), %llu overflow keys in a generic 16 B-slot side table",
                  t->mz_n_regions, mz_raw(t->k, t->mz_locbits) ? 2 * t->k : 2 * t->k - 3, mz_raw(t->k, t->mz_locbits) ? "key" : "tag", t->mz_locbits,

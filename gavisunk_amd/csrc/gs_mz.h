@@ -1039,7 +1039,18 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
             hitb = ballot(((sel ^ fpT[u]) >> (32 - mz.s)) == 0u);
             e = (uint64_t)sel;  // (fp bits and all: the flush takes them off)
             // header word 1: the filter of the region's keys in the generic table (0: it has none there)
-            deferb = ballot((int32_t)(q0.y << mzp_filter_shift(tw, fpT[u])) < 0) & ~hitb;
+            const uint32_t fh = mzp_filter_hash(tw, fpT[u]);
+            deferb = ballot((int32_t)(q0.y << (fh >> 27)) < 0) & ~hitb;
+            // hot regions (header word 0 = kMzpOverflow | kMzpHot): no records, 15 filter words -- what looked like tags is none
+            const unsigned long long hotb = ballot(q0.x > kMzpOverflow);
+            if (hotb) {  // wave-uniform; rare outside variant-dominated assemblies
+                uint32_t wv = 0u;
+                if (__builtin_amdgcn_inverse_ballot_w64(hotb)) {
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(wv) : "v"(reg_a + 4u * mzp_hot_word(fh)) : "memory");
+                }
+                hitb &= ~hotb;
+                deferb = (deferb & ~hotb) | (ballot((wv >> mzp_hot_bit(fh)) & 1u) & hotb);
+            }
         } else
 #endif
         {

@@ -44,7 +44,10 @@
 constexpr int kMzpRecs = 7;            // places per region
 constexpr int kMzpTagWord0 = 2;        // 32-bit word of the region where the tags start (after 8 header bytes)
 constexpr int kMzpLocWord0 = 2 + kMzpRecs;
-constexpr uint32_t kMzpOverflow = 1u;  // header byte 0, bit 0
+constexpr uint32_t kMzpOverflow = 1u;  // header word 0, bit 0: keys of this region live in the generic table
+constexpr uint32_t kMzpHot = 2u;       // header word 0, bit 1: ALL of them do, and words 1..15 are a 480-bit filter of them (a crowded
+                                       // minimiser of a variant-dominated assembly: k_mzp_place, hot_min)
+constexpr int kMzpHotWords = 15;
 
 // a bijection on 2m-bit values (multiplication by an odd constant): the region is taken from its HIGH bits, which every bit of
 // the m-mer reaches; the fp = its low s bits
@@ -89,7 +92,11 @@ __host__ __device__ __forceinline__ void mzp_tag(uint64_t X, uint32_t p, int k, 
 // (from what it looks for: tag word and fp word).  A window that finds no record asks the generic table only when its bit is
 // set -- a crowded region is one that reads visit often (a minimiser of a repeat family), nearly always for k-mers that are no
 // SUNKs at all.  The shift is the bit's distance from bit 31 (the lookup shifts it there and tests the sign).
-__host__ __device__ __forceinline__ uint32_t mzp_filter_shift(uint32_t tw, uint32_t fpw) { return ((tw ^ fpw) * 0x9E3779B1u) >> 27; }
+__host__ __device__ __forceinline__ uint32_t mzp_filter_hash(uint32_t tw, uint32_t fpw) { return (tw ^ fpw) * 0x9E3779B1u; }
+__host__ __device__ __forceinline__ uint32_t mzp_filter_shift(uint32_t tw, uint32_t fpw) { return mzp_filter_hash(tw, fpw) >> 27; }
+// hot regions: word (1..15) and bit of a window in the 480-bit filter
+__host__ __device__ __forceinline__ uint32_t mzp_hot_word(uint32_t h) { return 1u + (((h >> 27) * (uint32_t)kMzpHotWords) >> 5); }
+__host__ __device__ __forceinline__ uint32_t mzp_hot_bit(uint32_t h) { return (h >> 22) & 31u; }
 __host__ __device__ __forceinline__ uint64_t mzp_revcomp(uint64_t c, int k) {
     uint64_t r = 0;
     for (int i = 0; i < k; i++) {
@@ -148,7 +155,7 @@ __global__ void k_mzp_entries(const uint64_t *keys, uint64_t n, int k, int m, in
 // first member only.
 __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, const uint64_t *keys, const uint32_t *loc,
                             const uint32_t *payload, const uint64_t *ent, uint64_t n2, unsigned long long *overflow,
-                            uint32_t *overflow_list, uint64_t overflow_cap) {
+                            uint32_t *overflow_list, uint64_t overflow_cap, uint32_t hot_min) {
     const uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e0 >= n2) return;
     const uint64_t reg = ent[e0] >> 33;
@@ -160,12 +167,14 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
     bool over = false;
     // (overflow[1..5]: why -- 1 loc too wide for the loc word, 2 the "no record" value, 3 a record would match its windows
     //  already, 4 the region's 7 records are taken, 5 a record whose rows are not consecutive)
-    uint32_t filter = 0u;
+    uint32_t filter = 0u, n_spilled = 0u;
+    uint32_t hotf[kMzpHotWords + 1] = {0u};  // (hot_min) the 480-bit filter of EVERY entry of the region, in case it turns out hot
     auto spill = [&](uint32_t key_idx, int why, uint32_t tw, uint32_t fpw) {
         const unsigned long long o = atomicAdd(overflow, 1ULL);
         atomicAdd(overflow + why, 1ULL);
         if (o < overflow_cap) overflow_list[o] = key_idx;
         over = true;
+        n_spilled++;
         filter |= 0x80000000u >> mzp_filter_shift(tw, fpw);
     };
     uint32_t n_ent = 0;
@@ -175,6 +184,10 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
         const uint64_t c = keys[i], rc = mzp_revcomp(c, k);
         const MzpProbe q = (ent[e] & 1ULL) ? mzp_probe_of(rc, c, k, m) : mzp_probe_of(c, rc, k, m);
         const uint32_t fpw = s ? (q.y & fpmask) << (32 - s) : 0u;
+        {
+            const uint32_t h = mzp_filter_hash(q.tw, fpw);
+            hotf[mzp_hot_word(h)] |= 1u << mzp_hot_bit(h);
+        }
         if (s && (loc[i] >> (32 - s))) {  // (a loc id that needs the fp's bits: not in this format)
             spill(i, 1, q.tw, fpw);
             continue;
@@ -213,7 +226,7 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
     // overflow[6]: keys of HOT regions (dozens of places under one minimiser: an m-mer of a repeat family that SUNKs of many of
     // its copies share).  Reads visit such a region in proportion to the copies, nearly always without a match, and every such
     // window becomes a lookup in the generic table: the host weighs this count when it picks the layout.
-    if (n_ent > 32u) atomicAdd(overflow + 6, (unsigned long long)n_ent);
+    if (n_ent > 32u) atomicAdd(overflow + 7, (unsigned long long)n_ent);
     uint32_t base[kMzpRecs];
     for (uint32_t r = 0; r < nrec; r++) {
         const uint32_t mask = tag[r] & ((1u << w) - 1u);
@@ -247,6 +260,18 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
         wd[kMzpTagWord0 + r] = (uint32_t)r < nrec ? tag[r] : 0u;
         wd[kMzpLocWord0 + r] = (uint32_t)r < nrec ? locw[r] : 0u;
     }
+    // A HOT region (hot_min > 0: variant-dominated assemblies): so many of its keys did not fit that the 32-bit filter is
+    // mostly ones -- a minimiser that dozens of copies of a repeat share, each copy with SUNKs of its own over its variants.
+    // Reads visit it in proportion to the copies, nearly always for the k-mers the copies have in COMMON (no SUNKs).  All its
+    // keys go to the generic table, and the region's 60 bytes become one filter of them.
+    if (hot_min && n_spilled >= hot_min) {
+        for (uint32_t r = 0; r < nrec; r++)
+            for (int p = 0; p < w; p++)
+                if ((tag[r] >> p) & 1u) spill(who[r][p], 6, 0u, 0u);
+        wd[0] = kMzpOverflow | kMzpHot;
+        for (int j = 1; j <= kMzpHotWords; j++) wd[j] = hotf[j];
+        nrec = 0;
+    }
     uint4 *dst = regions + reg * 4;
     for (int q = 0; q < 4; q++) dst[q] = make_uint4(wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]);
     for (int r = 0; r < kMzpRecs; r++) pay[reg * 8 + r] = (uint32_t)r < nrec ? base[r] : 0u;
@@ -266,6 +291,7 @@ __device__ __forceinline__ int mzp_find(const MzpView &v, const MzpProbe &q, uin
     const uint4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
     const uint32_t wd[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
     *hdr = wd[0];
+    if (wd[0] & kMzpHot) return -1;  // (no records: a filter; the caller goes to the generic table)
     const uint32_t fp = v.s ? (q.y & ((1u << v.s) - 1u)) : 0u;
     for (int r = 0; r < kMzpRecs; r++)
         if (((wd[kMzpTagWord0 + r] ^ q.tw) & q.mk) == 0u) {

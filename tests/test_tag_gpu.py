@@ -207,9 +207,9 @@ def test_layout_selection(table_layout):
     tab = engine.DeviceTable(20, keys, loc, np.arange(len(keys), dtype=np.uint32))
     want = {"auto": "minimizer-hbm", "compact-hbm": "compact-hbm", "minimizer": "minimizer-hbm", "minimizer-exact": "minimizer-hbm",
             "minimizer-slots": "minimizer-hbm", "generic": "generic"}[table_layout]
-    # place records when forced; by itself the library gives them to tables of LONG location groups (here ~50 keys per group: an
-    # assembly whose SUNKs sit on point variants, like a diploid one, takes the per-key slots: gs_device.hip, mzp_choose)
-    assert tab.layout.startswith(want) and ("place records" in tab.layout) == (table_layout in ("minimizer", "minimizer-exact"))
+    # place records for every k <= 21 table (here ~50 keys per location group: an assembly whose SUNKs sit on point variants, like a
+    # diploid one -- such tables are built with hot regions: gs_device.hip, mzp_hot_min); per-key slots only when forced
+    assert tab.layout.startswith(want) and ("place records" in tab.layout) == (table_layout in ("auto", "minimizer", "minimizer-exact"))
     tab.close()
     tab = engine.DeviceTable(20, keys, (loc // 1000).astype(np.uint32), np.arange(len(keys), dtype=np.uint32))
     assert tab.layout.startswith(want) and ("place records" in tab.layout) == (table_layout in ("auto", "minimizer", "minimizer-exact"))
@@ -362,6 +362,30 @@ def test_minimizer_table_walks_and_overflows(m, load, monkeypatch, table_layout)
     assert tab.layout.startswith("minimizer-hbm") and f"mod-minimiser of length {m} " in tab.layout and ("place records" in tab.layout) == place
     n_ovf = int(tab.layout.split(", ")[-1].split(" overflow")[0])
     assert n_ovf > (10000 if m == "6" else 50 if load in ("8", "6", "64") else 20 if load == "16" else -1)
+    tab.close()
+    seqs = seqs + [b"A" * 5000, b"ACGT" * 700, seqs[0][:19], b""]
+    rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
+    st, gh, carry, ctr = _engine_hits(k, keys, loc, seqs)
+    assert st == 0 and ctr["raw_hits"] == octr["raw_hits"] and ctr["windows"] == octr["windows"] and len(gh) == len(oh) > 100
+    assert np.array_equal(gh["read"], oh["read"]) and np.array_equal(gh["pos"], oh["pos"])
+    assert np.array_equal(gh["payload"], oh["row"]) and carry == (loc[oprev] if oprev != oracle.NONE else _lib.GS_NONE)
+
+
+@pytest.mark.parametrize("hot", ["0", "1", "3", "40"])
+def test_place_records_hot_regions(hot, monkeypatch, table_layout):
+    """Place records with crowded regions on purpose (16 places per 7-record region): a region with at least GAVISUNK_MZ_HOT
+    keys that did not fit keeps no record at all -- all its keys live in the generic table and its 60 bytes are a filter of
+    them (gs_mzp.h, kMzpHot: what variant-dominated assemblies get by default).  Same rows whatever the threshold."""
+    if table_layout not in ("minimizer", "minimizer-exact"):
+        pytest.skip("place-record layouts")
+    monkeypatch.setenv("GAVISUNK_MZ_M", "15")
+    monkeypatch.setenv("GAVISUNK_MZ_LOAD", "16")
+    monkeypatch.setenv("GAVISUNK_MZ_HOT", hot)
+    k = 20
+    keys, loc, seqs = _random_case(57, k, n_reads=60, glen=60000, median=4000)
+    tab = engine.DeviceTable(k, keys, loc, np.arange(len(keys), dtype=np.uint32))
+    assert "place records" in tab.layout
+    assert ("crowded regions kept as filters" in tab.layout) == (hot in ("1", "3")), tab.layout
     tab.close()
     seqs = seqs + [b"A" * 5000, b"ACGT" * 700, seqs[0][:19], b""]
     rc, oh, oprev, octr = _oracle_hits(k, keys, loc, seqs)
