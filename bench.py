@@ -10,7 +10,8 @@ scaling) with the table replicated.
 
 A step = one full tagging pass over the rank's resident reads (inputs already in HBM): probe kernel, tile scans, emit
 kernel, hit list to the rank's host; at N > 1 also the carry exchange (all_gather) and the RCCL gather of the hit buffers
-into the root's device memory.
+into the root's device memory (the gather of pass i runs beside the probe kernels of pass i + 1; the last one is flushed
+inside the timed region).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -519,10 +520,16 @@ def main():
                         tot[k_] += v
                 last.update(tot)
                 return head
+            # the probe kernels of every batch are queued first; while they run, the rows of the PREVIOUS pass (still in device
+            # memory: phase 2 of this pass has not started) go to the root over xGMI -- the gather of pass i overlaps the probing
+            # of pass i + 1, and the last pass's gather is flushed inside the timed region (flush_gathers below)
+            for dr, _, _ in batches:
+                _lib.check(L.gs_tag_phase1_launch(table._h, dr._h))
+            flush_gathers()
             summ_local = []
             for dr, _, _ in batches:
                 has, lastloc = C.c_uint32(0), C.c_uint32(0)
-                _lib.check(L.gs_tag_phase1(table._h, dr._h, C.byref(has), C.byref(lastloc)))
+                _lib.check(L.gs_tag_phase1_wait(table._h, dr._h, C.byref(has), C.byref(lastloc)))
                 summ_local.append((has.value, lastloc.value))
             mine = next(((1, l) for h, l in reversed(summ_local) if h), (0, _lib.GS_NONE))
             summ = comm.exchange_summaries(*mine)
@@ -531,7 +538,6 @@ def main():
                 _lib.check(L.gs_tag_phase2(table._h, dr._h, carry))
                 if h:
                     carry = l
-            rows_g = []
             ctr = _lib.GsCounters()
             for dr, r0, _ in batches:
                 n_hits = C.c_uint64(0)
@@ -541,13 +547,22 @@ def main():
                     tot[k_] += v
                 # every rank's rows are on its own host now (as at N = 1); the concatenated list is gathered into the root's
                 # device memory over xGMI (north_star's "hit buffers concatenated via an RCCL gather") and stays there
-                g = comm.gather_hits(table, dr, n_hits.value, read_lo + r0, to_host=gather_to_host)
-                if gather_to_host and g is not None:
-                    rows_g.append(g.copy())
+                pending_gathers.append((dr, n_hits.value, read_lo + r0))
             last.update(tot)
             if gather_to_host:
-                gathered["rows"] = rows_g
+                gathered["rows"] = flush_gathers(to_host=True)
             return None
+
+        pending_gathers = []
+
+        def flush_gathers(to_host=False):
+            rows_g = []
+            while pending_gathers:
+                dr, n_hits, off = pending_gathers.pop(0)
+                g = comm.gather_hits(table, dr, n_hits, off, to_host=to_host)
+                if to_host and g is not None:
+                    rows_g.append(g.copy())
+            return rows_g
 
         # global index of this rank's first read (the ranks before it hold shards of the same size)
         read_lo = rank * sum(len(b[2]) for b in batches)
@@ -560,6 +575,8 @@ def main():
         for i in range(warmup):
             step()
             log(f"{wname} warmup {i}: {last['rows']} rows")
+        if world > 1:
+            flush_gathers()  # (the timed region starts with nothing pending)
         L.gs_counters_reset(table._h)
         sync()
         step_s = []
@@ -568,6 +585,8 @@ def main():
             t1 = time.perf_counter()
             step()
             step_s.append(time.perf_counter() - t1)
+        if world > 1:
+            flush_gathers()  # (the last pass's rows: inside the timed region)
         sync()
         dt = time.perf_counter() - t0
         ctr = _lib.GsCounters()

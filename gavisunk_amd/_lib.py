@@ -94,6 +94,8 @@ SIGNATURES = {
     "gs_tag_finish": (I, [P, P, P, U64, C.POINTER(U64), C.POINTER(U32), C.POINTER(GsCounters)]),
     "gs_tag_phase1": (I, [P, P, C.POINTER(U32), C.POINTER(U32)]),
     "gs_tag_phase2": (I, [P, P, U32]),
+    "gs_tag_phase1_launch": (I, [P, P]),
+    "gs_tag_phase1_wait": (I, [P, P, C.POINTER(U32), C.POINTER(U32)]),
     "gs_tag_hits_to_host": (I, [P, P, P, U64, C.POINTER(U64)]),
     "gs_tag_hits_to_device": (I, [P, P, P, U64, C.POINTER(U64)]),
     "gs_tag_launch_after": (I, [P, P, P]),

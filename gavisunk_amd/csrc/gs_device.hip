@@ -2189,7 +2189,7 @@ int gs_tag_launch_after(gs_table *t, gs_reads *r, const gs_reads *prev) {
 static hipError_t wait_stream(hipStream_t st);
 static hipError_t wait_event(hipEvent_t ev);
 
-int gs_tag_phase1(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_loc) {
+int gs_tag_phase1_launch(gs_table *t, gs_reads *r) {
     int rc;
     if ((rc = check_pair(t, r, "gs_tag_phase1"))) return rc;
     if ((rc = launch_phase1(t, r))) return rc;
@@ -2197,12 +2197,26 @@ int gs_tag_phase1(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_lo
     r->ps.last_carry_in = GS_NONE;
     HIP_TRY(hipMemcpyAsync(r->ps.d_carry_in, &r->ps.last_carry_in, sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
     if ((rc = launch_scan(t, r, 0))) return rc;
-    Agg tot;
-    HIP_TRY(hipMemcpyAsync(&tot, r->ps.d_totals, sizeof tot, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(wait_stream(t->stream));
+    HIP_TRY(hipMemcpyAsync(r->ps.h_status, r->ps.d_status, sizeof(PassStatus), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipEventRecord(r->ps.ev[3], t->stream));
+    return GS_OK;
+}
+
+int gs_tag_phase1_wait(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_loc) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_phase1"))) return rc;
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(wait_event(r->ps.ev[3]));
+    const Agg tot = r->ps.h_status->totals[0];
     if (has_raw) *has_raw = tot.has & 1u;
     if (last_loc) *last_loc = (tot.has & 1u) ? tot.loc : GS_NONE;
     return GS_OK;
+}
+
+int gs_tag_phase1(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_loc) {
+    int rc;
+    if ((rc = gs_tag_phase1_launch(t, r))) return rc;
+    return gs_tag_phase1_wait(t, r, has_raw, last_loc);
 }
 
 int gs_tag_phase2(gs_table *t, gs_reads *r, uint32_t carry_in) {

@@ -220,6 +220,11 @@ int gs_tag_finish(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uint64_t 
  * the shard has a raw hit and the loc id of its last one; phase 2 takes the carry-in. */
 int gs_tag_phase1(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_loc);
 int gs_tag_phase2(gs_table *t, gs_reads *r, uint32_t carry_in);
+/* gs_tag_phase1 in two halves: _launch queues the probe kernel and the summary scan and returns at once (the rows of the batch's
+ * LAST finished pass stay valid in device memory until its phase 2: a gather of them -- gs_gather_hits -- can run beside the
+ * probe kernels of the next pass); _wait blocks until the summary is on the host. */
+int gs_tag_phase1_launch(gs_table *t, gs_reads *r);
+int gs_tag_phase1_wait(gs_table *t, gs_reads *r, uint32_t *has_raw, uint32_t *last_loc);
 /* Copy the emitted hits of the last pass again, to host memory or into caller-provided DEVICE
  * memory (for a collective); n_out as in gs_tag_finish. */
 int gs_tag_hits_to_host(gs_table *t, gs_reads *r, gs_hit *out, uint64_t cap, uint64_t *n_out);
