@@ -24,7 +24,7 @@
 //              kmerpos_annot3.nim:82-84 crosses reads, so the scan is global); drops a tile's first
 //              candidate when it equals the carried loc
 //   scan B     emitted-hit prefix
-//   k_emit     pos = window - (raw hits before it in the read - emitted hits before it in the read)
+//   k_emit     pos = window - (raw hits before it in the read - emitted hits before it in the read); rows dealt out over the lanes
 //              [`continue` at kmerpos_annot3.nim:92 skips `inc i` at :96], payload by re-probing the
 //              (rare) emitted windows; writes gs_hit in stream order
 #include <hip/hip_runtime.h>
@@ -655,7 +655,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(TileArrays ta, uint
 }
 
 // ------------------------------------------------------------------------------------------
-// k_emit: one thread per tile
+// k_emit: a wave takes 64 tiles and deals their emitted rows out over its lanes (a tile has 0 .. dozens of them: one thread per
+// tile would run the row loop as often as the wave's busiest tile needs, with most lanes idle)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, MzView mz, int compact, ReadsView rd, TileArrays ta,
                                               const uint32_t *cand, uint32_t cand_cap, gs_hit *hits, gs_hit *hits_host,
@@ -664,31 +665,56 @@ __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, MzV
     // are fetched in one bulk copy instead (scattered 12-byte writes across PCIe are slow)
     const bool mirror = emit_total->sum <= kMirrorRows;
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= rd.n_tiles) return;
-    const uint32_t nc = ta.n_cand[tile];
-    if (!nc) return;
-    const uint32_t ne = ta.n_emit[tile];
-    const uint32_t supp = nc - ne;
-    const uint32_t off = ta.cand_off[tile];
-    if ((uint64_t)off + nc > cand_cap) return;  // overflowed pass; the host re-runs with a larger buffer
-    const uint32_t r = rd.tile_read[tile];
-    const uint32_t t0 = rd.read_tile0[r];
-    const uint32_t tin = tile - t0;
-    const uint64_t raw_before = ta.raw_prefix[tile] - ta.raw_prefix[t0];
-    const uint64_t emit_before = ta.emit_prefix[tile] - ta.emit_prefix[t0];
-    const uint64_t out0 = ta.emit_prefix[tile];
-    const uint64_t rwoff = rd.read_word_off[r];
+    const int lane = threadIdx.x & 63;
+    // this lane's tile (none, no candidates, or an overflowed pass -- the host re-runs it with a larger buffer: no rows)
+    uint32_t ne = 0, supp = 0, off = 0, r = 0, tin = 0;
+    uint64_t raw_before = 0, emit_before = 0, out0 = 0, rwoff = 0;
+    if (tile < rd.n_tiles) {
+        const uint32_t nc = ta.n_cand[tile];
+        off = ta.cand_off[tile];
+        if (nc && (uint64_t)off + nc <= cand_cap) {
+            ne = ta.n_emit[tile];
+            supp = nc - ne;
+            r = rd.tile_read[tile];
+            const uint32_t t0 = rd.read_tile0[r];
+            tin = tile - t0;
+            raw_before = ta.raw_prefix[tile] - ta.raw_prefix[t0];
+            emit_before = ta.emit_prefix[tile] - ta.emit_prefix[t0];
+            out0 = ta.emit_prefix[tile];
+            rwoff = rd.read_word_off[r];
+        }
+    }
+    // rows of the lanes up to and including this one
+    uint32_t inc = ne;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(inc, d);
+        if (lane >= d) inc += y;
+    }
+    const uint32_t total = __shfl(inc, 63);
     const int k = tab.k;
     const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
-    for (uint32_t j = supp; j < nc; j++) {
-        const uint32_t cv = cand[off + j];
+    for (uint32_t q0 = 0; q0 < total; q0 += 64u) {  // wave-uniform
+        const uint32_t q = q0 + (uint32_t)lane;  // the wave's q-th row
+        // its tile = the first lane whose running count exceeds q (the counts never decrease: a bisection over the lanes)
+        int own = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+            if (__shfl(inc, own + step - 1) <= q) own += step;
+        own = min(own, 63);
+        const uint32_t o_ne = __shfl(ne, own), o_inc = __shfl(inc, own), o_supp = __shfl(supp, own), o_off = __shfl(off, own);
+        const uint32_t o_r = __shfl(r, own), o_tin = __shfl(tin, own);
+        const uint64_t o_raw = __shfl(raw_before, own), o_emit = __shfl(emit_before, own), o_out0 = __shfl(out0, own), o_rwoff = __shfl(rwoff, own);
+        const uint32_t jj = q - (o_inc - o_ne);  // the row's index among its tile's emitted candidates
+        const uint64_t o = o_out0 + jj;
+        if (q >= total || o >= hit_cap) continue;
+        const uint32_t j = o_supp + jj;
+        const uint32_t cv = cand[o_off + j];
         const uint32_t woff = cv & 0xFFFFu, rank = cv >> 16;
-        const uint32_t w = tin * kTileWindows + woff;
-        const uint64_t suppressed_before = (raw_before + rank) - (emit_before + (j - supp));
-        const uint64_t o = out0 + (j - supp);
-        if (o >= hit_cap) return;
+        const uint32_t w = o_tin * kTileWindows + woff;
+        const uint64_t suppressed_before = (o_raw + rank) - (o_emit + jj);
         // payload: re-probe this one window
-        const uint64_t wi = rwoff + (w >> 5);
+        const uint64_t wi = o_rwoff + (w >> 5);
         const uint64_t a = rd.words[wi], b2 = rd.words[wi + 1];
         const uint64_t c = canon_at(a, b2, ~revpairs(a), ~revpairs(b2), (int)(w & 31u), k, kmask);
         uint32_t payload = 0, loc_unused = 0;
@@ -711,7 +737,7 @@ __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, MzV
             payload = cur.payload;
         }
         gs_hit hrec;
-        hrec.read = r;
+        hrec.read = o_r;
         hrec.pos = (uint32_t)(w - suppressed_before);
         hrec.payload = payload;
         hits[o] = hrec;

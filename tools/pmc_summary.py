@@ -8,7 +8,7 @@ for d in sys.argv[1:]:
             k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in acc.items():
-            if not k.startswith(("k_probe", "k_merge", "k_join")):
+            if not k.startswith(tuple(__import__("os").environ.get("PMC_KERNELS", "k_probe").split(","))):
                 continue
             dur = None
             print(k, " ".join(f"{c}={sum(v)/len(v):.5g}" for c, v in sorted(cs.items())), f"(n={len(next(iter(cs.values())))})")
