@@ -1524,7 +1524,6 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
             return rc;
         HIP_TRY(hipMemsetAsync(t->mz_regions, 0xFF, nslots * sizeof(unsigned long long), t->stream));
         HIP_TRY(hipMemsetAsync(dov, 0, sizeof(unsigned long long), t->stream));
-#if GS_MZ_RD
         {  // one entry per key and strand pick (k_mz_entries), sorted by (region, key index)
             uint64_t n2 = n;
             uint64_t *reg1 = nullptr;
@@ -1551,21 +1550,6 @@ int table_build(gs_table *t, const uint64_t *dk, const uint32_t *dl, const uint3
                                t->mz_pay, k, t->mz_locbits, dk, dl, dp, (const uint64_t *)reg1, (const uint32_t *)idx1, n2, dov, dlist, ocap);
             HIP_TRY(hipStreamSynchronize(t->stream));
         }
-#else
-        {  // keys sorted by region, stable (rocPRIM radix sort on the 32 region bits; a key's index rides along)
-            DevBufs st;
-            uint64_t *reg0 = nullptr, *reg1 = nullptr;
-            uint32_t *idx0 = nullptr, *idx1 = nullptr;
-            if ((rc = st.get(&reg0, n)) || (rc = st.get(&reg1, n)) || (rc = st.get(&idx0, n)) || (rc = st.get(&idx1, n))) return rc;
-            const unsigned nb = (unsigned)((n + 255) / 256);
-            hipLaunchKernelGGL(k_mz_regions, dim3(nb), dim3(256), 0, t->stream, dk, n, k, t->mz_m, t->mz_n_regions, reg0);
-            hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, t->stream, idx0, n);
-            if ((rc = sort_pairs_u64_u32(reg0, reg1, idx0, idx1, n, 32, t->stream))) return rc;
-            hipLaunchKernelGGL(k_mz_place, dim3(nb), dim3(256), 0, t->stream, reinterpret_cast<unsigned long long *>(t->mz_regions),
-                               t->mz_pay, k, t->mz_locbits, dk, dl, dp, (const uint64_t *)reg1, (const uint32_t *)idx1, n, dov, dlist, ocap);
-            HIP_TRY(hipStreamSynchronize(t->stream));
-        }
-#endif
         unsigned long long ov = 0;
         HIP_TRY(hipMemcpyAsync(&ov, dov, sizeof ov, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));

@@ -52,14 +52,6 @@
 #ifndef GS_MZ_PLACE
 #define GS_MZ_PLACE 1  // 1: + the place-record format of gs_mzp.h (k <= 21: a record per place, shorter minimisers, longer runs)
 #endif
-#ifndef GS_MZ_RD
-#define GS_MZ_RD GS_MZ_PLACE  // 1: a window's region = the pick of the leftmost smallest t-mer AS THE READ SHOWS THE K-MER (no strand test in
-                    // the probe); the table then holds a key under the pick of either strand (two places when they differ)
-#endif
-#ifndef GS_MZ_RCW
-#define GS_MZ_RCW 1  // 1: the tile staged as two dword streams (forward, reverse complement); windows extracted with v_alignbit
-#endif
-
 struct MzView {
     const uint4 *regions;  // [n_regions][8] pieces of two 64-bit slots
     uint32_t n_regions;
@@ -187,8 +179,7 @@ __global__ void k_mz_regions(const uint64_t *keys, uint64_t n, int k, int m, uin
     if (i < n) reg[i] = mz_region(mz_minimizer(keys[i], k, m), n_regions);
 }
 
-#if GS_MZ_RD
-// GS_MZ_RD build: one entry (region << 32 | key index) per key and strand pick.  A read shows a k-mer in either orientation
+// One entry (region << 32 | key index) per key and strand pick.  A read shows a k-mer in either orientation
 // and the probe takes the leftmost smallest t-mer as shown: the key sits in the region of the pick in its canonical
 // orientation (entry i) and, where the other strand picks another region (equal t-mer orders at two places of the k-mer: a
 // few per cent of the keys), in that one too (entry n + i; ~0 = none).  Sorted on all 64 bits: a region's keys in the caller's
@@ -217,7 +208,6 @@ __global__ void k_mz_split_entries(const uint64_t *ent, uint64_t n2, uint64_t *r
         idx[p] = (uint32_t)ent[p];
     }
 }
-#endif
 
 __global__ void k_mz_place(unsigned long long *slots, uint32_t *pay, int k, int locbits, const uint64_t *keys, const uint32_t *loc,
                            const uint32_t *payload, const uint64_t *reg_sorted, const uint32_t *idx_sorted, uint64_t n,
@@ -370,11 +360,6 @@ __device__ __forceinline__ MzWin mz_window(uint64_t W0, uint64_t W1, int s, int 
     const uint64_t A = mz_word(W0, W1, 2 * s), B = mz_word(W0, W1, 2 * s + 1), C = mz_word(W0, W1, 2 * s + 2);
     const bool hsel = lane >= 32;
     return mz_win_of(hsel ? B : A, hsel ? C : B, lane, k, m, kmask, mmask);
-}
-
-// lane i <- lane i + 1, lane 63 <- fill (wave-uniform)
-__device__ __forceinline__ uint32_t mz_shift_down(uint32_t x, uint32_t fill) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
 }
 
 struct MzTileOut {
@@ -583,7 +568,6 @@ struct MzWaveLds {
     uint4 cache[kMzStages][kMzRunCap * kMzPieces];
     uint32_t list[kMzListCap];              // loc of every maybe-hit (the exact form borrows this as its candidate buffer)
     uint32_t cand[kMzFastCand];             // the tile's candidates (a tile with more is done over by the exact form)
-#if GS_MZ_RCW
   union {
     uint64_t words[kTileWords + 3];         // (instances without compile-time k: the words as they are)
     struct {
@@ -595,10 +579,6 @@ struct MzWaveLds {
     uint32_t rd[1 + kMzStreamDwords];
     };
   };
-#else
-    uint64_t words[kTileWords + 3];         // the tile's packed bases (+ 2 words a window of the last step reaches into, + 1 that
-                                            // step's look-ahead read touches and never uses)
-#endif
     uint16_t list_w[kMzListCap];            // window offset of every maybe-hit
 #ifdef GS_MZ_PAD_LDS
     uint32_t pad_lds[GS_MZ_PAD_LDS / 4];    // (occupancy experiment: fewer waves per CU)
@@ -898,9 +878,8 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
     const uint64_t mmask = (1ULL << (2 * m)) - 1ULL;
     const uint64_t locmask = (1ULL << locbits) - 1ULL;
     // the tile's 64 words + the two after them (the buffer carries that much slack after the last read), staged in LDS
-    constexpr bool RCW = GS_MZ_RCW && KT > 16;
+    constexpr bool RCW = KT > 16;  // (compile-time k: the tile staged as two dword streams; else the words as they are)
     if constexpr (RCW) {
-#if GS_MZ_RCW
         for (int j = lane; j < kTileWords + 3; j += 64) {  // (one more round for lanes 0..2)
             const uint64_t wv = j < kTileWords + 2 ? __builtin_nontemporal_load(words + td.wbase + j) : 0ULL;
             const uint64_t rv = ~revpairs(wv);  // the word's reverse complement: word (66 - j) of the reversed stream
@@ -913,7 +892,6 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
             L.fd[0] = 0u;
             L.rd[kMzStreamDwords] = 0u;
         }
-#endif
     } else {
         L.words[lane] = __builtin_nontemporal_load(words + td.wbase + lane);
         if (lane < 3) L.words[64 + lane] = lane < 2 ? __builtin_nontemporal_load(words + td.wbase + 64 + lane) : 0ULL;

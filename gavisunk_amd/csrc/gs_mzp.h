@@ -24,7 +24,7 @@
 //   payload  (k_emit only) base row of the place, in a parallel array; the row of the key at offset p = base + sign * (number
 //              of mask bits below p)
 //
-// A window (as the read shows it: GS_MZ_RD rule, the leftmost smallest t-mer) knows p, the p bases left of the m-mer and the
+// A window (as the read shows it: the leftmost smallest t-mer) knows p, the p bases left of the m-mer and the
 // w - 1 - p bases right of it -- a contiguous stretch of the context: it builds (TW, MK) once and a record matches iff
 // ((tag ^ TW) & MK) == 0 -- mask bit p included.
 // The builder makes sure no two records of a region can match the same window (records of different m-mers that share a region
@@ -37,9 +37,6 @@
 #endif
 
 #if GS_MZ_PLACE
-#if !GS_MZ_RD
-#error "GS_MZ_PLACE needs GS_MZ_RD (a window's pick does not depend on its strand)"
-#endif
 
 constexpr int kMzpRecs = 7;            // places per region
 constexpr int kMzpTagWord0 = 2;        // 32-bit word of the region where the tags start (after 8 header bytes)
