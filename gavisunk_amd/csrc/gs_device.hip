@@ -1067,18 +1067,22 @@ int launch_phase1(gs_table *t, gs_reads *r) {
                                view(t), (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->ta, r->cand, r->cand_cap,
                                r->ps.d_cand_count);
         } else if (t->mz && t->mz_place) {
-#define GS_LAUNCH_MZP(KT, MT)                                                                                                         \
-    hipLaunchKernelGGL((k_probe_mz<KT, MT, 1, true>), dim3((r->n_tiles + kMzWaves - 1) / kMzWaves), dim3(64 * kMzWaves), 0, t->stream, \
+#define GS_LAUNCH_MZP(KT, MT, PL)                                                                                                     \
+    hipLaunchKernelGGL((k_probe_mz<KT, MT, 1, PL>), dim3((r->n_tiles + kMzWaves - 1) / kMzWaves), dim3(64 * kMzWaves), 0, t->stream,   \
                        mz_view(t), view(t), (const uint64_t *)r->words, (const TileDesc *)r->tile_desc, r->n_tiles, r->ta,             \
                        r->cand, r->cand_cap, r->ps.d_cand_count, r->ps.d_complex_n)
             if (t->k == 20 && t->mz_m == 14)
-                GS_LAUNCH_MZP(20, 14);
+                GS_LAUNCH_MZP(20, 14, 1);
             else if (t->k == 20 && t->mz_m == 15)
-                GS_LAUNCH_MZP(20, 15);
+                GS_LAUNCH_MZP(20, 15, 1);
             else if (t->k == 21 && t->mz_m == 15)
-                GS_LAUNCH_MZP(21, 15);  // BASELINE.json configs[4], k = 21 (k = 25 is beyond the place records: per-key slots)
+                GS_LAUNCH_MZP(21, 15, 1);  // BASELINE.json configs[4], k = 21
+            else if (t->k == 25 && t->mz_m == 19)
+                GS_LAUNCH_MZP(25, 19, 2);  // BASELINE.json configs[4], k = 25 (a 38-bit minimiser: two registers)
+            else if (t->mz_m > 15)
+                GS_LAUNCH_MZP(0, 0, 2);
             else
-                GS_LAUNCH_MZP(0, 0);
+                GS_LAUNCH_MZP(0, 0, 1);
 #undef GS_LAUNCH_MZP
         } else
 #endif
@@ -1240,8 +1244,10 @@ uint32_t mzp_hot_min(uint64_t n, uint32_t maxloc) {
 }
 int mzp_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, int &s, int m_from = 0, bool forced = false) {
     (void)forced;
-    if (k < 16 || k > 21 || n == 0 || any_missing) return 0;
-    int m_lo = std::max(std::max(k - 6, 10), m_from), m_hi = std::min(15, k - 1);
+    // k <= 21: m = k - 6 .. 15 by size; k = 22 .. 27: m = k - 6 only (w = 7: a 32-bit tag holds the 2 x 6 flank bases, the 7
+    // offset bits and the sign; the minimiser's value then is 2m = 32 .. 42 bits: two registers in k_probe_mz)
+    if (k < 16 || k > 27 || n == 0 || any_missing) return 0;
+    int m_lo = std::max(std::max(k - 6, 10), m_from), m_hi = k > 21 ? k - 6 : std::min(15, k - 1);
     if (m_lo > m_hi) return 0;
     if (const char *e = getenv("GAVISUNK_MZ_M")) {  // tuning / test knob, read once per table
         const int v = atoi(e);
@@ -1250,21 +1256,23 @@ int mzp_choose(int k, uint64_t n, uint32_t maxloc, bool any_missing, int &m, int
     for (m = m_lo; m <= m_hi; m++) {
         const double w = k - m + 1, places = 1.1 * (double)n / std::max(1.0, 0.6 * w);
         // regions = the power of two next above places / 1.5 (s >= 1: half of the 2m-bit values are no canonical m-mers)
-        s = 1;
-        while (s < 16 && std::ldexp(1.0, 2 * m - (s + 1)) >= places / 1.5) s++;
+        // (m > 15: s <= 2m - 14, at least 2^14 regions; s >= 2m - 31: the region index is 31 bits)
+        const int s_hi = m <= 15 ? 16 : std::min(2 * m - 14, 31), s_lo = std::max(1, 2 * m - 31);
+        s = s_lo;
+        while (s < s_hi && std::ldexp(1.0, 2 * m - (s + 1)) >= places / 1.5) s++;
         const double load = places / std::ldexp(1.0, 2 * m - s);
         if (const char *e = getenv("GAVISUNK_MZ_LOAD")) {  // test knob: crowded regions on purpose
             const double v = atof(e);
             if (v >= 0.25 && v <= 64.0) {
-                s = 1;
-                while (s < 16 && std::ldexp(1.0, 2 * m - (s + 1)) >= places / v) s++;
+                s = s_lo;
+                while (s < s_hi && std::ldexp(1.0, 2 * m - (s + 1)) >= places / v) s++;
             }
         } else if ((load > 3.0 || (double)n > 3.0e8 * std::ldexp(1.0, 2 * (m - 14))) && m < m_hi) {
             // (the m-mers a mod-minimiser samples are a biased subset of the 4^m values -- those that begin or end with a small
             // t-mer -- so the places crowd into a fraction of the regions: measured, a 3e8-key table is what m = 14 takes)
             continue;
         }
-        while (s > 1 && ((uint64_t)maxloc + 2) >> (32 - s)) s--;  // the loc word holds fp and loc (s >= 1: k_probe_mz shifts by 32 - s)
+        while (s > s_lo && ((uint64_t)maxloc + 2) >> (32 - s)) s--;  // the loc word holds fp and loc (s >= 1: k_probe_mz shifts by 32 - s)
         if (((uint64_t)maxloc + 2) >> (32 - s)) return 0;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;

@@ -310,15 +310,17 @@ __device__ __forceinline__ uint64_t mz_word(uint64_t W0, uint64_t W1, int idx) {
 struct MzWin {
     uint64_t f, r;  // forward code and reverse-complement code of the window that starts at this lane's base
     uint32_t h;     // hash of the canonical m-mer that ENDS the window (the m-mer at offset w - 1)
+    uint32_t hx;    // (place format, m > 15) its bits 32.. and, in bit 31, its orientation (m <= 15: both are in h)
     uint32_t o;     // order (mz_tmer_order) of the canonical t-mer that ENDS the window (the t-mer at offset k - t)
     uint32_t fa, ra;  // (place format, dword-stream windows only) the 16 bases from the window's first one / from its reverse complement's
 };
 // Why the LAST t-mer and m-mer: the window at lane i owns the t-mers that start at lanes i .. i + k - t; when lane j holds the
 // t-mer that starts at base j + (k - t), those are the values of lanes i - (k - t) .. i -- every pull of the sliding minimum
 // and of the pick reaches DOWN the lanes, i.e. into this step or the one before, and a step needs no look-ahead.
-template <bool PLACE = false>
+template <int PLACE = 0>
 __device__ __forceinline__ MzWin mz_win_from(uint64_t f, uint64_t r, int k, int m, uint64_t mmask);
 __host__ __device__ __forceinline__ uint32_t mzp_mmer_word(uint32_t fm, uint32_t rm, int m);
+__host__ __device__ __forceinline__ uint64_t mzp_bij64(uint64_t cm, int m);
 __host__ __device__ constexpr int mzp_t_of(int k, int m);
 // the window whose first base is base (lane & 31) of the 64-base string a:b
 __device__ __forceinline__ MzWin mz_win_of(uint64_t a, uint64_t b, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
@@ -327,14 +329,21 @@ __device__ __forceinline__ MzWin mz_win_of(uint64_t a, uint64_t b, int lane, int
     return mz_win_from<false>(x >> (64 - 2 * k), ~revpairs(x) & kmask, k, m, mmask);  // (revpairs: base i of x, complemented, at bits 2i+1:2i)
 }
 // ... from the window's forward and reverse-complement codes
-template <bool PLACE>
+template <int PLACE>
 __device__ __forceinline__ MzWin mz_win_from(uint64_t f, uint64_t r, int k, int m, uint64_t mmask) {
     MzWin o;
     o.f = f;
     o.r = r;
     o.fa = o.ra = 0u;
+    o.hx = 0u;
 #if GS_MZ_PLACE
-    if constexpr (PLACE) {  // (m <= 15) bij(canonical m-mer) << 1 | orientation: gs_mzp.h
+    if constexpr (PLACE == 2) {  // bij(canonical m-mer) on 2m <= 42 bits: low word | high bits, orientation in bit 31 of the second
+        const uint64_t fm = o.f & mmask, rm = o.r >> (2 * (k - m));
+        const bool rev = rm < fm;
+        const uint64_t y = mzp_bij64(rev ? rm : fm, m);
+        o.h = (uint32_t)y;
+        o.hx = (uint32_t)(y >> 32) | (rev ? 0x80000000u : 0u);
+    } else if constexpr (PLACE == 1) {  // (m <= 15) orientation << 31 | bij(canonical m-mer): gs_mzp.h
         o.h = mzp_mmer_word((uint32_t)o.f & (uint32_t)mmask, (uint32_t)(o.r >> (2 * (k - m))), m);
     } else
 #endif
@@ -623,7 +632,7 @@ __device__ __forceinline__ void lds_write_b16(uint32_t addr, uint32_t v) {
 // the window that starts at this lane's base in step s (-1 .. 31), from the tile's words staged in LDS (two 8-byte reads, one
 // instruction; lanes 0..31 share one address pair, lanes 32..63 the next).  Step -1 = the 64 bases before the tile: its
 // high lanes' windows end inside the tile (what they read in front of the words is never looked at).
-template <bool PLACE = false>
+template <int PLACE = 0>
 __device__ __forceinline__ MzWin mz_window_lds(uint32_t words_a, int s, int lane, int k, int m, uint64_t kmask, uint64_t mmask) {
     uint4 v;
     const uint32_t addr = words_a + (uint32_t)((2 * s + (lane >> 5)) * 8);
@@ -655,7 +664,7 @@ __device__ __forceinline__ MzLaneGeom mz_lane_geom(uint32_t fd_a, uint32_t rd_a,
 }
 __device__ __forceinline__ uint32_t mz_alignbit(uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbit(hi, lo, n); }
 // the window that starts at this lane's base in step s (-1 .. 31; k > 16: the code's high part is 2k - 32 bits of the first dword pair)
-template <bool PLACE = false>
+template <int PLACE = 0>
 __device__ __forceinline__ MzWin mz_window_rcw(const MzLaneGeom &g, int s, int k, int m, uint64_t mmask) {
     uint2 ab, rab;
     uint32_t c, rc;
@@ -669,10 +678,11 @@ __device__ __forceinline__ MzWin mz_window_rcw(const MzLaneGeom &g, int s, int k
     const uint32_t rh = mz_alignbit(rab.x, rab.y, g.r_n), rl = mz_alignbit(rab.y, rc, g.r_n);  // 64 bits from its reverse complement's
     const uint32_t sh = (uint32_t)(64 - 2 * k);  // 1 .. 31
 #if GS_MZ_PLACE
-    if constexpr (PLACE) {
+    if constexpr (PLACE == 1) {
         // (k <= 21, m <= 15, t <= 12: everything the stage needs is a piece of one dword -- the forward code's low word holds
         //  the t-mer and the m-mer that end the window, the reverse complement's first dword their reverse complements)
         MzWin o;
+        o.hx = 0u;
         const uint32_t flo = mz_alignbit(fh, fl, sh);
         o.f = (uint64_t)flo;  // (low word only: what the tag takes its right flank from)
         o.r = (uint64_t)mz_alignbit(rh, rl, sh);
@@ -778,21 +788,22 @@ struct MzSlide {
 
 // What a step's windows pick.  `before`: the step before this one (for step 0 of a tile: mz_picker_start), `win`: this step's
 // windows.  -> the m-mer's offset in the window (0 .. w - 1) and the m-mer hash / word (MzWin::h) of the m-mer there.
-template <int WT, int NT>  // WT: w at compile time or 0
+template <int WT, int NT, bool WIDE = false>  // WT: w at compile time or 0; WIDE: the m-mer word is two registers (MzWin::h, hx)
 struct MzPicker {
     MzSlide<NT> slide;
-    uint32_t h_before;
+    uint32_t h_before, hx_before;
     uint32_t c_xoff, c_src4;  // per-lane constants (kept opaque: the compiler would rather re-derive them from the lane every step)
     // the step before a tile's first one: only the lanes whose t-mer / m-mer lies inside the tile count
     __device__ __forceinline__ void start(const MzWin &before, int lane, int w, int nt) {
         slide.reset();
         (void)slide.advance(lane >= 64 - (nt - 1) ? mz_value_of(before.o, lane) : kMzInf, lane, nt);
         h_before = before.h;
+        hx_before = before.hx;
         c_xoff = (uint32_t)(lane + 33 - nt);
         c_src4 = 4u * (uint32_t)(lane + 64 - (w - 1));
         asm volatile("" : "+v"(c_xoff), "+v"(c_src4));
     }
-    __device__ __forceinline__ uint32_t pick(const MzWin &win, int lane, int w, int nt, uint32_t &pm_out) {
+    __device__ __forceinline__ uint32_t pick(const MzWin &win, int lane, int w, int nt, uint32_t &pm_out, uint32_t *hx_out = nullptr) {
         const uint32_t e = slide.advance(mz_value_of(win.o, lane), lane, nt);
         // the chosen t-mer is V of lane (e & 255) - 32 = the t-mer at offset that + (nt - 1) - lane of this lane's window
         const uint32_t xoff = (e & 0xFFu) - c_xoff;  // 0 .. nt - 1
@@ -808,6 +819,12 @@ struct MzPicker {
         const uint32_t h_here = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)win.h);
         const uint32_t h_prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)h_before);
         h_before = win.h;
+        if constexpr (WIDE) {
+            const uint32_t x_here = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)win.hx);
+            const uint32_t x_prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)hx_before);
+            hx_before = win.hx;
+            *hx_out = src4 >= 256u ? x_here : x_prev;
+        }
         return src4 >= 256u ? h_here : h_prev;
     }
 };
@@ -852,8 +869,9 @@ __global__ __launch_bounds__(64) void k_mz_rule_check(int k_rt, int m_rt, const 
 }
 
 // KT / MT: k and m as compile-time constants (0 = take them from the table); FMT: slot format (mz_key_fmt)
-// PLACE: the place-record format of gs_mzp.h (FMT is then unused)
-template <int KT, int MT, int FMT, bool PLACE = false>
+// PLACE: 0 = per-key slots; the place-record format of gs_mzp.h (FMT is then unused): 1 = m <= 15 (the minimiser's value and
+// orientation in one register), 2 = longer minimisers (k = 22 .. 27: two registers)
+template <int KT, int MT, int FMT, int PLACE = 0>
 __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzView mz, TableView tab, const uint64_t *__restrict__ words,
                                                            const TileDesc *__restrict__ tdesc, uint32_t n_tiles, TileArrays ta,
                                                            uint32_t *cand, uint32_t cand_cap, uint32_t *g_cand_count,
@@ -911,7 +929,7 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
         if constexpr (RCW) return mz_window_rcw<PLACE>(geom, s, k, m, mmask);
         else return mz_window_lds<PLACE>(words_a, s, lane, k, m, kmask, mmask);
     };
-    MzPicker<KT ? KT - MT + 1 : 0, NT> picker;
+    MzPicker<KT ? KT - MT + 1 : 0, NT, PLACE == 2> picker;
     picker.start(window(-1), lane, w, nt);
     uint32_t c_regbits = (uint32_t)(31 - mz.s);  // (place format) width of the region index in H; in a VGPR: the bit-field extract takes one scalar operand
     asm volatile("" : "+v"(c_regbits));
@@ -940,20 +958,21 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
     auto stage = [&](uint32_t s, int slot, auto full_tile) {
         constexpr bool FULL = decltype(full_tile)::value;
         const MzWin win = window((int)s);
-        uint32_t pm;
-        const uint32_t H = picker.pick(win, lane, w, nt, pm);
+        uint32_t pm, Hx = 0u;
+        const uint32_t H = picker.pick(win, lane, w, nt, pm, &Hx);
         uint32_t reg, fpw;
         uint64_t wantw;
 #if GS_MZ_PLACE
-        if constexpr (PLACE) {
-            // H = orientation << 31 | bij(canonical m-mer) of the m-mer at offset pm; the k-mer oriented like its m-mer, the
+        if constexpr (PLACE != 0) {
+            // H (, Hx) = orientation and bij(canonical m-mer) of the m-mer at offset pm; the k-mer oriented like its m-mer, the
             // m-mer's offset in it, the flank bases this window knows (gs_mzp.h)
-            const bool rev = (int32_t)H < 0;
+            const bool rev = PLACE == 2 ? (int32_t)Hx < 0 : (int32_t)H < 0;
             const uint32_t p = rev ? (uint32_t)(w - 1) - pm : pm;
             uint32_t tw, mk;
-            if constexpr (RCW) mzp_tag_parts((rev ? win.ra : win.fa) >> (32 - 2 * (k - m)), (uint32_t)(rev ? win.r : win.f), p, k, m, tw, mk);
+            if constexpr (RCW && PLACE == 1) mzp_tag_parts((rev ? win.ra : win.fa) >> (32 - 2 * (k - m)), (uint32_t)(rev ? win.r : win.f), p, k, m, tw, mk);
             else mzp_tag(rev ? win.r : win.f, p, k, m, tw, mk);
-            reg = __builtin_amdgcn_ubfe(H, (uint32_t)mz.s, c_regbits);  // y >> s, y = H less its orientation bit
+            if constexpr (PLACE == 2) reg = (uint32_t)((((uint64_t)(Hx & 0x7FFFFFFFu) << 32) | H) >> mz.s);  // y >> s
+            else reg = __builtin_amdgcn_ubfe(H, (uint32_t)mz.s, c_regbits);  // y >> s, y = H less its orientation bit
             fpw = H << (32 - mz.s);  // y << (32 - s) (s >= 1: gs_device.hip, mzp_choose)
             wantw = (uint64_t)tw | ((uint64_t)mk << 32);
         } else
@@ -994,7 +1013,7 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
         unsigned long long hitb, deferb;  // the same as wave masks (the scalar unit combines them)
         uint64_t e = 0;
 #if GS_MZ_PLACE
-        if constexpr (PLACE) {
+        if constexpr (PLACE != 0) {
             // the region's 7 tag words against this window's (TW, MK): the record that matches (at most one can), its loc word
             const uint32_t tw = (uint32_t)want[u], mk = (uint32_t)(want[u] >> 32);
             uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0, q2 = q0, q3 = q0;
@@ -1068,7 +1087,7 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
         defer = mine && !hit && mz_region_overflowed(F);  // generic table, later -- unless the region's filter word says no
         if (defer) defer = mz_filter_maybe(lds_read_b64(reg_a + (uint32_t)kMzSlots * 8u), mz_filter_bits(want[u] >> locbits));
         }
-        if constexpr (!PLACE) {
+        if constexpr (PLACE == 0) {
             hitb = ballot(hit);
             deferb = ballot(defer);
         }
@@ -1200,7 +1219,7 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
     if (n_cand > (uint32_t)kMzFastCand) {  // (wave-uniform, rare) more location changes than the candidate buffer holds
         if (lane == 0) atomicAdd(g_fallback_tiles, 1u);
 #if GS_MZ_PLACE
-        if constexpr (PLACE)
+        if constexpr (PLACE != 0)
             mzp_tile_exact(MzpView{mz.regions, mz.pay, k, m, mz.s}, tab, words, td, tile, n_tiles, ta, cand, cand_cap, g_cand_count, L.list);
         else
 #endif

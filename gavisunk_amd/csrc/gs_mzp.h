@@ -47,10 +47,15 @@ constexpr uint32_t kMzpHot = 2u;       // header word 0, bit 1: ALL of them do, 
 constexpr int kMzpHotWords = 15;
 
 // a bijection on 2m-bit values (multiplication by an odd constant): the region is taken from its HIGH bits, which every bit of
-// the m-mer reaches; the fp = its low s bits
+// the m-mer reaches; the fp = its low s bits.  m <= 15: one 32-bit multiply (the narrow form the k <= 21 kernels carry in one
+// register); longer m-mers (k = 22 .. 27, w = 7: m = k - 6 <= 21): the same on 64 bits.
 __host__ __device__ __forceinline__ uint32_t mzp_bij(uint32_t cm, int m) {
     const uint32_t M = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
     return (cm * 0x9E3779B1u) & M;
+}
+__host__ __device__ __forceinline__ uint64_t mzp_bij64(uint64_t cm, int m) {
+    if (m <= 15) return (uint64_t)mzp_bij((uint32_t)cm, m);  // (one definition for every m: the narrow kernels' values are these)
+    return (cm * 0x9E3779B97F4A7C15ULL) & ((1ULL << (2 * m)) - 1ULL);
 }
 // length of the short t-mers whose minimum anchors the pick: the mod-minimiser's (gs_mz.h: mz_t_of).  (Tried: t = k - 15, i.e. 16
 // t-mers per window whatever w, so that the sliding minimum runs inside the rows of 16 lanes -- the density lost by a t-mer
@@ -64,7 +69,7 @@ __host__ __device__ __forceinline__ uint32_t mzp_mmer_word(uint32_t fm, uint32_t
 }
 
 struct MzpProbe {   // what a window looks for
-    uint32_t y;     // bij(canonical m-mer): region = y >> s, fp = y & (2^s - 1)
+    uint64_t y;     // bij(canonical m-mer) (2m bits): region = y >> s, fp = y & (2^s - 1)
     uint32_t tw, mk;
     uint32_t p;     // offset of the m-mer in the oriented k-mer
 };
@@ -117,11 +122,11 @@ __host__ __device__ __forceinline__ MzpProbe mzp_probe_of(uint64_t f, uint64_t r
         }
     }
     const int x = at % w;
-    const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
-    const uint32_t fm = (uint32_t)(f >> (2 * (k - m - x))) & mmask, rm = (uint32_t)(r >> (2 * x)) & mmask;
+    const uint64_t mmask = (1ULL << (2 * m)) - 1ULL;
+    const uint64_t fm = (f >> (2 * (k - m - x))) & mmask, rm = (r >> (2 * x)) & mmask;
     const bool rev = rm < fm;
     MzpProbe o;
-    o.y = mzp_bij(rev ? rm : fm, m);
+    o.y = mzp_bij64(rev ? rm : fm, m);
     o.p = rev ? (uint32_t)(w - 1 - x) : (uint32_t)x;
     mzp_tag(rev ? r : f, o.p, k, m, o.tw, o.mk);
     return o;
@@ -180,7 +185,7 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
         const uint32_t i = (uint32_t)(ent[e] >> 1);
         const uint64_t c = keys[i], rc = mzp_revcomp(c, k);
         const MzpProbe q = (ent[e] & 1ULL) ? mzp_probe_of(rc, c, k, m) : mzp_probe_of(c, rc, k, m);
-        const uint32_t fpw = s ? (q.y & fpmask) << (32 - s) : 0u;
+        const uint32_t fpw = s ? ((uint32_t)q.y & fpmask) << (32 - s) : 0u;
         {
             const uint32_t h = mzp_filter_hash(q.tw, fpw);
             hotf[mzp_hot_word(h)] |= 1u << mzp_hot_bit(h);
@@ -289,7 +294,7 @@ __device__ __forceinline__ int mzp_find(const MzpView &v, const MzpProbe &q, uin
     const uint32_t wd[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
     *hdr = wd[0];
     if (wd[0] & kMzpHot) return -1;  // (no records: a filter; the caller goes to the generic table)
-    const uint32_t fp = v.s ? (q.y & ((1u << v.s) - 1u)) : 0u;
+    const uint32_t fp = v.s ? ((uint32_t)q.y & ((1u << v.s) - 1u)) : 0u;
     for (int r = 0; r < kMzpRecs; r++)
         if (((wd[kMzpTagWord0 + r] ^ q.tw) & q.mk) == 0u) {
             const uint32_t lw = wd[kMzpLocWord0 + r];

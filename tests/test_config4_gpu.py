@@ -22,9 +22,10 @@ def test_other_sunk_lengths_full_size(k):
     gen.close()
     reads = engine.device_reads_from_device_ascii(rs.ptr, rs.off, k)
     try:
-        # k = 21: place records (m = 15, w = 7); k = 25: per-key slots (m = 21: a tag word holds flanks of at most 6 bases)
-        assert table.layout.startswith("minimizer-hbm") and f"mod-minimiser of length {15 if k == 21 else 21} " in table.layout
-        assert ("place records" in table.layout) == (k == 21)
+        # place records under a minimiser of k - 6 bases (w = 7: a tag word holds the 2 x 6 flank bases): k = 21: m = 15, one
+        # register per minimiser value (k_probe_mz<21,15,.,1>); k = 25: m = 19, 38 bits in two (k_probe_mz<25,19,.,2>)
+        assert table.layout.startswith("minimizer-hbm") and f"mod-minimiser of length {k - 6} (w = 7" in table.layout
+        assert "place records" in table.layout
         assert sunks.n > 800_000_000 and rs.n_bases > 3.5e10 and synth_gpu.n50(rs.off[1:] - rs.off[:-1]) > 95_000
         n = W["reads"]
         full_size_checks(table, reads, rs, sunks, k, cuts=[0, 1, 150_000, 150_001, 499_000, n],

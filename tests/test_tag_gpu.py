@@ -224,7 +224,9 @@ def test_layout_selection(table_layout):
     # minimiser-addressed layout is the default; forced, the one-bucket-load layout takes 64-bit slots
     if table_layout == "generic":
         assert tab.layout.startswith("generic")
-    elif table_layout in ("auto", "minimizer", "minimizer-exact", "minimizer-slots"):  # (k > 21: per-key slots are the only form)
+    elif table_layout in ("auto", "minimizer", "minimizer-exact"):  # (k = 22 .. 27: place records under a minimiser of k - 6 bases, w = 7)
+        assert tab.layout.startswith("minimizer-hbm") and "place records" in tab.layout and "mod-minimiser of length 19 (w = 7, t = 5)" in tab.layout
+    elif table_layout == "minimizer-slots":
         assert tab.layout.startswith("minimizer-hbm") and "50-bit key" in tab.layout and "mod-minimiser of length 21 " in tab.layout
     else:
         assert "compact-hbm" in tab.layout and "x u64" in tab.layout
