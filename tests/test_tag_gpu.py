@@ -115,7 +115,7 @@ def test_cli_emulates_the_workflows_scatter_chunks(golden, name, batch_bases, tm
         assert rc == 0 and out.read_text() == c.text(run["out"]), f"{name}: {run['nchunks']} chunks"
 
 
-@pytest.mark.parametrize("k", [11, 16, 18, 20, 21, 25, 31, 32])
+@pytest.mark.parametrize("k", [11, 16, 18, 20, 21, 23, 25, 27, 31, 32])
 @pytest.mark.parametrize("seed", [1, 2])
 def test_random_inputs_match_oracle(k, seed):
     keys, loc, seqs = _random_case(seed * 100 + k, k)
