@@ -50,7 +50,7 @@
 
 // ---- compile-time switches (kernel A/B variants: python -m gavisunk_amd.build --variant NAME -D...) ----
 #ifndef GS_MZ_PLACE
-#define GS_MZ_PLACE 1  // 1: + the place-record format of gs_mzp.h (k <= 21: a record per place, shorter minimisers, longer runs)
+#define GS_MZ_PLACE 1  // 1: + the place-record format of gs_mzp.h (k <= 27: a record per place, shorter minimisers, longer runs)
 #endif
 struct MzView {
     const uint4 *regions;  // [n_regions][8] pieces of two 64-bit slots
