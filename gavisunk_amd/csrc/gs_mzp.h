@@ -10,8 +10,9 @@
 // (they lie within w - 1 < k bases: one merged interval, workflow/rules/defineSUNKs.smk:124-126), and their kmer.loc rows are
 // consecutive.  So:
 //
-//   y        = bij(canonical m-mer)                      a bijection on 2m bits (m <= 15)
-//   region   = y >> s,  fp = y & (2^s - 1)               64 bytes each; s (1..16) from the table size (2^(2m-s) regions)
+//   y        = bij(canonical m-mer)                      a bijection on 2m bits (k <= 21: m <= 15, one register in k_probe_mz;
+//                                                        k = 22 .. 27: m = k - 6 <= 21, w = 7 -- the widest context a tag holds -- two)
+//   region   = y >> s,  fp = y & (2^s - 1)               64 bytes each; s from the table size (2^(2m-s) regions, at most 2^31)
 //   region   = 8 header bytes | 7 tag words | 7 loc words
 //     tag    [context: 2 (w-1) bases, bits 8..] [sign: bit 7] [mask: bits 0..w-1]
 //              context = the w - 1 bases left of the place's m-mer, then the w - 1 bases right of it, in the orientation in
@@ -20,7 +21,9 @@
 //     loc    fp << (32 - s) | loc id of the place
 //     header word 0 bit 0 = keys of this region live in the generic side table (more than 7 places, or a place the format
 //              does not take: keys of one place with different locs or rows that are not consecutive); word 1 = a 32-bit
-//              filter of those keys (mzp_filter_shift)
+//              filter of those keys (mzp_filter_shift).  Bit 1 (kMzpHot): the region keeps NO record, all its keys live in
+//              the generic table and words 1..15 are one 480-bit filter of them (crowded minimisers of variant-dominated
+//              assemblies: k_mzp_place, hot_min)
 //   payload  (k_emit only) base row of the place, in a parallel array; the row of the key at offset p = base + sign * (number
 //              of mask bits below p)
 //
