@@ -221,6 +221,23 @@ def test_rccl_single_rank_through_the_c_abi():
     got = comm.gather_hits(tab, dev, [len(whole)], 1000)
     assert len(got) == len(whole) > 50 and np.array_equal(got["read"], whole["read"] + 1000)
     assert np.array_equal(got["pos"], whole["pos"]) and np.array_equal(got["payload"], whole["payload"])
+    # the rows of a finished pass stay valid in device memory while the NEXT pass's probe kernels are queued (gs_tag_phase1_launch
+    # returns at once): what lets bench.py run the gather of pass i beside the probing of pass i + 1
+    import ctypes as C
+
+    L = _lib.lib()
+    _lib.check(L.gs_tag_phase1_launch(tab._h, dev._h))
+    again = comm.gather_hits(tab, dev, [len(whole)], 7)
+    assert np.array_equal(again["read"], whole["read"] + 7) and np.array_equal(again["pos"], whole["pos"]) and np.array_equal(again["payload"], whole["payload"])
+    has, last = C.c_uint32(0), C.c_uint32(0)
+    _lib.check(L.gs_tag_phase1_wait(tab._h, dev._h, C.byref(has), C.byref(last)))
+    assert has.value == 1
+    _lib.check(L.gs_tag_phase2(tab._h, dev._h, _lib.GS_NONE))
+    n = C.c_uint64(0)
+    _lib.check(L.gs_tag_finish(tab._h, dev._h, None, 0, C.byref(n), None, None))
+    assert n.value == len(whole)
+    got = comm.gather_hits(tab, dev, [len(whole)], 0)
+    assert np.array_equal(got, whole)
     # the phase-1 summaries over ncclAllGather (gs_comm_allgather_u64), and a failed pass reported by the gather itself
     assert comm.allgather_pairs(1, 0xFFFFFFFF) == [(1, 0xFFFFFFFF)]
     keys2, loc2 = np.append(keys, keys[:1] ^ np.uint64(1)), np.append(loc, np.uint32(_lib.GS_MISSING))
