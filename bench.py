@@ -487,30 +487,17 @@ def main():
         nb = len(batches)
         last = {"rows": 0, "raw": 0, "emitted": 0, "windows": 0, "tiles": 0, "fallback": 0}
         gathered = {"rows": None}
-        stream = engine.Stream(table, 0, 0, depth=3) if world == 1 else None
+        stream = engine.Stream(table, 0, 0, depth=3)  # (N > 1: for the no-exchange leg)
 
-        def step(keep_head=False, gather_to_host=False):
-            """One pass over all the rank's resident reads.  N = 1: the batches pipelined through gs_stream_submit_reads (the
-            carry goes from pass to pass on the device; every batch's rows are fetched to pinned host memory on the copy stream
-            while the next batch is probed).  N > 1: phase 1 of every batch, ONE exchange of the rank summaries, phase 2 with the
-            resolved carries, then the RCCL gather of every batch's rows into the root's device memory."""
+        def step_single(keep_head=False):
+            """The rank's resident batches through the streaming engine, no exchange with other ranks (the N = 1 step; at N > 1 the
+            reference point `no_exchange`: what the same ranks would do if they never talked)."""
             tot = dict.fromkeys(last, 0)
             head = None
-            if world == 1:
-                flying = 0
-                done = 0
-                for dr, _, _ in batches:
-                    if flying == 3:
-                        st_, hits, _, c = stream.next(copy=False)
-                        if keep_head and done == 0:
-                            head = hits.copy()
-                        done += 1
-                        flying -= 1
-                        for k_, v in (("rows", len(hits)), ("raw", c["raw_hits"]), ("emitted", c["emitted"]), ("windows", c["windows"]), ("tiles", c["tiles"]), ("fallback", c["fallback_tiles"])):
-                            tot[k_] += v
-                    stream.submit_reads(dr)
-                    flying += 1
-                while flying:
+            flying = 0
+            done = 0
+            for dr, _, _ in batches:
+                if flying == 3:
                     st_, hits, _, c = stream.next(copy=False)
                     if keep_head and done == 0:
                         head = hits.copy()
@@ -518,8 +505,27 @@ def main():
                     flying -= 1
                     for k_, v in (("rows", len(hits)), ("raw", c["raw_hits"]), ("emitted", c["emitted"]), ("windows", c["windows"]), ("tiles", c["tiles"]), ("fallback", c["fallback_tiles"])):
                         tot[k_] += v
-                last.update(tot)
-                return head
+                stream.submit_reads(dr)
+                flying += 1
+            while flying:
+                st_, hits, _, c = stream.next(copy=False)
+                if keep_head and done == 0:
+                    head = hits.copy()
+                done += 1
+                flying -= 1
+                for k_, v in (("rows", len(hits)), ("raw", c["raw_hits"]), ("emitted", c["emitted"]), ("windows", c["windows"]), ("tiles", c["tiles"]), ("fallback", c["fallback_tiles"])):
+                    tot[k_] += v
+            last.update(tot)
+            return head
+
+        def step(keep_head=False, gather_to_host=False):
+            """One pass over all the rank's resident reads.  N = 1: the batches pipelined through gs_stream_submit_reads (the
+            carry goes from pass to pass on the device; every batch's rows are fetched to pinned host memory on the copy stream
+            while the next batch is probed).  N > 1: phase 1 of every batch, ONE exchange of the rank summaries, phase 2 with the
+            resolved carries, then the RCCL gather of every batch's rows into the root's device memory."""
+            if world == 1:
+                return step_single(keep_head)
+            tot = dict.fromkeys(last, 0)
             # the probe kernels of every batch are queued first; while they run, the rows of the PREVIOUS pass (still in device
             # memory: phase 2 of this pass has not started) go to the root over xGMI -- the gather of pass i overlaps the probing
             # of pass i + 1, and the last pass's gather is flushed inside the timed region (flush_gathers below)
@@ -608,9 +614,22 @@ def main():
                 gather_check = bool(g is not None and sum(len(x) for x in g) == tot_rows)
                 log(f"gathered list: {sum(len(x) for x in g) if g is not None else None} rows of {tot_rows}: {gather_check}")
         L.gs_table_counters(table._h, C.byref(ctr))
+        solo = None
+        if world > 1:
+            # the reference point for the scaling of THIS workload: the same ranks, the same resident reads, no exchange and no gather
+            keep = dict(last)
+            step_single()
+            sync()
+            t2 = time.perf_counter()
+            for _ in range(2):
+                step_single()
+            sync()
+            solo = comm.all_max(time.perf_counter() - t2) / 2
+            last.update(keep)
+            log(f"{wname}: without exchange / gather: {total_bases / solo / 1e9:.1f} Gbase/s")
         res = {"w": w, "wname": wname, "shards": list(shards), "table": table, "batches": batches, "n_bases": n_bases, "total_bases": total_bases, "dt": dt,
                "steps": steps, "step_s": step_s, "n_sunks": n_sunks, "n_groups": n_groups, "sample": sample, "head": head,
-               "last": dict(last), "rlen": rlen_all, "n_launch": n_launch, "gather_check": gather_check, "ctr": ctr.as_dict(), "stream": stream}
+               "last": dict(last), "rlen": rlen_all, "n_launch": n_launch, "gather_check": gather_check, "ctr": ctr.as_dict(), "stream": stream, "solo": solo}
         return res
 
     def describe(res, headline):
@@ -635,6 +654,10 @@ def main():
             "unit": "bases/s",
             "ms_per_step": res["dt"] / steps * 1e3,
             "ms_per_step_spread": {"min": min(res["step_s"]) * 1e3, "median": float(np.median(res["step_s"])) * 1e3, "max": max(res["step_s"]) * 1e3},
+            **({"no_exchange": {"value": res["total_bases"] / res["solo"], "unit": "bases/s", "ms_per_step": res["solo"] * 1e3,
+                                "note": "the same ranks over the same resident reads WITHOUT the carry exchange and the hit gather (every rank's batches "
+                                        "through the one-GPU streaming engine, max over ranks): value / this = what the exchange + gather cost; "
+                                        "this / n_gpus = the one-GPU rate of this workload"}} if res.get("solo") else {}),
             "config": {"workload": (w["title"] if default_size else "REDUCED rehearsal (not the headline workload) of " + w["title"]) +
                                    f": {(a.genome_mb if a.genome_mb is not None else w['genome_mb']):g} Mb{' per haplotype' if w['kind'] == 'diploid' else ''} in 24 contigs, exact SUNK set, "
                                    f"{len(res['rlen'])} synthetic ONT reads per GPU, N50 {n50}, k={K}",
@@ -684,6 +707,8 @@ def main():
                # rank tags its own shard of the same size = weak scaling
                "scaling": "strong" if (wname == "diploid" and world > 1 and not a.shards) else "weak",
                "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": d["config"], "roofline": d["roofline"]}
+        if "no_exchange" in d:
+            out["no_exchange"] = d["no_exchange"]
         # ---- parity on the head of the stream + CPU baseline (outside the timed region) --------------------------
         sample = res["sample"]
         if sample is not None:
