@@ -1041,12 +1041,14 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
             // hot regions (header word 0 = kMzpOverflow | kMzpHot): no records, 15 filter words -- what looked like tags is none
             const unsigned long long hotb = ballot(q0.x > kMzpOverflow);
             if (hotb) {  // wave-uniform; rare outside variant-dominated assemblies
-                uint32_t wv = 0u;
+                uint32_t wv = 0u, wv2 = 0u;
+                const uint32_t fh2 = mzp_hot_second(fh);
                 if (__builtin_amdgcn_inverse_ballot_w64(hotb)) {
-                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(wv) : "v"(reg_a + 4u * mzp_hot_word(fh)) : "memory");
+                    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(wv), "=&v"(wv2) : "v"(reg_a + 4u * mzp_hot_word(fh)), "v"(reg_a + 4u * mzp_hot_word(fh2)) : "memory");
                 }
                 hitb &= ~hotb;
-                deferb = (deferb & ~hotb) | (ballot((wv >> mzp_hot_bit(fh)) & 1u) & hotb);
+                deferb = (deferb & ~hotb) | (ballot((wv >> mzp_hot_bit(fh)) & (wv2 >> mzp_hot_bit(fh2)) & 1u) & hotb);
             }
         } else
 #endif

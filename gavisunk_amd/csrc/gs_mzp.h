@@ -99,9 +99,11 @@ __host__ __device__ __forceinline__ void mzp_tag(uint64_t X, uint32_t p, int k, 
 // SUNKs at all.  The shift is the bit's distance from bit 31 (the lookup shifts it there and tests the sign).
 __host__ __device__ __forceinline__ uint32_t mzp_filter_hash(uint32_t tw, uint32_t fpw) { return (tw ^ fpw) * 0x9E3779B1u; }
 __host__ __device__ __forceinline__ uint32_t mzp_filter_shift(uint32_t tw, uint32_t fpw) { return mzp_filter_hash(tw, fpw) >> 27; }
-// hot regions: word (1..15) and bit of a window in the 480-bit filter
+// hot regions: word (1..15) and bit of a window in the 480-bit filter; every key sets TWO bits (h and mzp_hot_second(h)): with
+// the dozens of keys such a region has, two probes of 480 bits pass a third as many strangers as one
 __host__ __device__ __forceinline__ uint32_t mzp_hot_word(uint32_t h) { return 1u + (((h >> 27) * (uint32_t)kMzpHotWords) >> 5); }
 __host__ __device__ __forceinline__ uint32_t mzp_hot_bit(uint32_t h) { return (h >> 22) & 31u; }
+__host__ __device__ __forceinline__ uint32_t mzp_hot_second(uint32_t h) { return (h ^ (h >> 15)) * 0x85EBCA6Bu; }
 __host__ __device__ __forceinline__ uint64_t mzp_revcomp(uint64_t c, int k) {
     uint64_t r = 0;
     for (int i = 0; i < k; i++) {
@@ -190,8 +192,9 @@ __global__ void k_mzp_place(uint4 *regions, uint32_t *pay, int k, int m, int s, 
         const MzpProbe q = (ent[e] & 1ULL) ? mzp_probe_of(rc, c, k, m) : mzp_probe_of(c, rc, k, m);
         const uint32_t fpw = s ? ((uint32_t)q.y & fpmask) << (32 - s) : 0u;
         {
-            const uint32_t h = mzp_filter_hash(q.tw, fpw);
+            const uint32_t h = mzp_filter_hash(q.tw, fpw), h2 = mzp_hot_second(h);
             hotf[mzp_hot_word(h)] |= 1u << mzp_hot_bit(h);
+            hotf[mzp_hot_word(h2)] |= 1u << mzp_hot_bit(h2);
         }
         if (s && (loc[i] >> (32 - s))) {  // (a loc id that needs the fp's bits: not in this format)
             spill(i, 1, q.tw, fpw);

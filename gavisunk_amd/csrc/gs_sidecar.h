@@ -43,14 +43,14 @@ bool file_stamp(const char *path, FileStamp *out) {
 }
 
 struct SidecarHeader {
-    char magic[8];  // "GSSIDE06"
+    char magic[8];  // "GSSIDE07"
     uint32_t header_bytes, meta_bytes;
     FileStamp db, loc;
     uint64_t n_rows, names_bytes;
     uint32_t n_contigs, pad;
     TableMeta meta;
 };
-constexpr char kSidecarMagic[8] = {'G', 'S', 'S', 'I', 'D', 'E', '0', '6'};
+constexpr char kSidecarMagic[8] = {'G', 'S', 'S', 'I', 'D', 'E', '0', '7'};
 constexpr size_t kSidecarChunk = (size_t)64 << 20;
 
 struct FileCloser {
