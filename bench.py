@@ -185,11 +185,16 @@ def build_workload(a, w, device, rank, world, comm, shards):
             log(f"oracle sample: {ns} reads, {len(q)} distinct windows, {len(rows)} SUNKs among them ({time.perf_counter() - t0:.1f} s)")
         read0 += n
         rs.close()
+    contig_names = list(gen.names)
     gen.close()
     n_sunks, n_groups = (sunks.n, sunks.n_groups) if sunks is not None else (0, 0)
+    keep = None
     if sunks is not None:
-        sunks.close()
-    return table, batches, n_sunks, n_groups, sample
+        if getattr(a, "keep_sunks", False):
+            keep = (sunks, contig_names)  # (the device-resident stage-2/3 leg turns payloads into contig / start / ID through its arrays)
+        else:
+            sunks.close()
+    return table, batches, n_sunks, n_groups, sample, keep
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -248,6 +253,10 @@ def config2_leg(a, device):
            "engine_bases_per_s": n_bases / t_engine,
            "parity": {"against": "reference binary kmerpos_annot3 (tests/golden/config2_full/c2.sunkpos.gz)", "checked_reads": 10000,
                       "rows": len(want), "bit_exact": bool(got == want and st == 0 and same_hits(gh, hits.view(np.dtype([('read', '<u4'), ('pos', '<u4'), ('row', '<u4')]))))}}
+    try:
+        out["pair_stage"] = config2_chain(table, dev_reads, sunks, names, seqs, device)
+    except Exception as e:  # (a measurement leg must not cost the headline)
+        out["pair_stage"] = {"failed": repr(e)}
     if a.cli:
         out["cli"] = config2_cli(sunks, names, reads, n_bases, want)
     dev_reads.close()
@@ -435,6 +444,116 @@ def self_launch(n: int, script: str = None, args=None) -> int:
     return rc
 
 
+def chain_leg(table, batches, locrows, contig_names, device, names_sorted_like_stream=True):
+    """The device-resident second half over the hit list of the LAST pass of every resident batch (still in device memory):
+    rows gathered device to device -> gs_rowset_diag_filter -> gs_rowset_keep_filtered -> gs_rowset_bad_keys ->
+    gs_rowset_pair_stage.  Both haplotype roles of the bad-SUNK step are played by this one read set (every contig counts as
+    its own haplotype's).  -> timings, row counts, Mrow/s."""
+    from gavisunk_amd import _lib, engine
+
+    L = _lib.lib()
+    t = {}
+    n_reads = sum(len(b[2]) for b in batches)
+    rlen = np.concatenate([b[2] for b in batches])
+    t0 = time.perf_counter()
+    rs = engine.RowSet(device, 1 << 20)
+    for dr, r0, _ in batches:
+        rs.append_pass(table, dr, r0, locrows)
+    rows_in = rs.n
+    t["rows_from_hits"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, bc, bg, _, kept = rs.diag_filter(contig_names, np.ones(len(contig_names), np.uint8))
+    t["diag_filter"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rs.keep_filtered()
+    t["step2_compaction"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    key_hap = np.full(max(locrows.n_locs, 1), 3, np.uint8)
+    bad, meancov, d_bad = engine.RowSet.bad_keys(rs, rs, key_hap[: locrows.n_locs], keep_on_device=True)
+    t["bad_sunks"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    # (synthetic names are numbered so that their sorted order is the stream order: rank = read index)
+    res = rs.pair_stage(np.arange(n_reads, dtype=np.uint32), (rlen >= 10000).astype(np.uint8), d_key_bad=d_bad)
+    t["pair_stage"] = time.perf_counter() - t0
+    engine.free_device(d_bad, device)
+    rs.close()
+    total = sum(t.values())
+    c = res["counters"].tolist()
+    return {"rows_in": int(rows_in), "reads": int(n_reads), "seconds": {k_: round(v, 4) for k_, v in t.items()}, "seconds_total": round(total, 4),
+            "rows_per_s": rows_in / total, "reads_with_a_best_contig": int((bc != _lib.GS_NONE).sum()), "rows_after_diag_filter": int(kept),
+            "bad_sunk_groups": int(bad.sum()), "mean_coverage": meancov[0],
+            "pair_stage_counters": dict(zip(("rows_in", "not_bad", "in_reads_with_2_ids", "deduplicated", "in_long_reads", "read_groups", "tsv_rows"), c[:7])),
+            "tsv_rows": int(len(res["row_id"])), "validated_intervals": int(len(res["region_start"])),
+            "path": "hit list in HBM -> gs_rowset_append_pass -> gs_rowset_diag_filter -> gs_rowset_keep_filtered -> gs_rowset_bad_keys -> "
+                    "gs_rowset_pair_stage (csrc/gs_chain.hip): nothing but the final TSV / BED rows and per-read verdicts crosses PCIe"}
+
+
+def config2_chain(table, dev_reads, sunks, names, seqs, device):
+    """config 2 end to end through the device chain (the `pair_stage` key): tagger rows in HBM -> diag filter -> step 2 -> bad
+    SUNKs -> pair stage -> union.  Checked against the reference binary's own diag output on these inputs
+    (tests/golden/config2_full/c2.diag.gz) and against the oracle's restatement of the two Python scripts."""
+    from gavisunk_amd import _lib, engine
+    from oracle import oracle
+
+    class _Rows:
+        pass
+
+    L = _lib.lib()
+    _, loc = np.unique(sunks.group, return_inverse=True)
+    db = _Rows()
+    db.row_contig, db.row_start, db.row_group, db.row_loc = (np.zeros(len(sunks), np.uint32), sunks.start.astype(np.int64),
+                                                            sunks.group.astype(np.int64), loc.astype(np.uint32))
+    lr = engine.LocRows.from_db(db, device)
+    n_hits = C.c_uint64(0)
+    _lib.check(L.gs_tag_launch(table._h, dev_reads._h, _lib.GS_NONE))
+    _lib.check(L.gs_tag_finish(table._h, dev_reads._h, None, 0, C.byref(n_hits), None, None))
+    rlen = np.array([len(q) for q in seqs], dtype=np.int64)
+    order = np.argsort(np.array(names, dtype=object), kind="stable")
+    rank = np.empty(len(names), np.uint32)
+    rank[order] = np.arange(len(names), dtype=np.uint32)
+    best = None
+    for _ in range(3):  # (first round: first touch of the allocations)
+        t0 = time.perf_counter()
+        rs = engine.RowSet(device, n_hits.value)
+        rs.append_pass(table, dev_reads, 0, lr)
+        rows_in = rs.n
+        seg_name, bc, bg, bd, kept = rs.diag_filter(["ctg5M"], [1])
+        rs.keep_filtered()
+        bad, meancov, d_bad = engine.RowSet.bad_keys(rs, rs, np.full(lr.n_locs, 3, np.uint8), keep_on_device=True)
+        res = rs.pair_stage(rank, (rlen >= 10000).astype(np.uint8), d_key_bad=d_bad)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        step2 = rs.download()
+        engine.free_device(d_bad, device)
+        rs.close()
+    lr.close()
+    # ---- parity
+    diag = "".join(f"{names[n]}\tctg5M\t{g}\t{chr(d_)}\t{g}\n" for n, c_, g, d_ in zip(seg_name.tolist(), bc.tolist(), bg.tolist(), bd.tolist()) if c_ != _lib.GS_NONE)
+    want_diag = gzip.open(os.path.join(ROOT, "tests", "golden", "config2_full", "c2.diag.gz"), "rb").read().decode()
+    text2 = "".join(f"{names[n]}\t{p}\tctg5M\t{s_}\t{g}\n" for n, p, s_, g in zip(*(step2[k_].tolist() for k_ in ("name", "pos", "start", "id"))))
+    fai = "ctg5M\t5000000\n"
+    t1 = time.perf_counter()
+    ebad = oracle.badsunks(fai, fai, text2, text2)
+    gid = {}
+    for k_, g in zip(loc.tolist(), sunks.group.tolist()):
+        gid[k_] = g
+    got_bad = {f"ctg5M:{gid[int(k_)]}" for k_ in np.nonzero(bad)[0]}
+    rlen_text = "".join(f"{n}\t{l}\n" for n, l in zip(names, rlen.tolist()))
+    etsv, ebed = oracle.process_by_contig(text2, rlen_text, "".join(b_ + "\n" for b_ in sorted(ebad)))
+    t_oracle = time.perf_counter() - t1
+    tsv = "".join(f"{i}\t{names[n]}\n" for i, n in zip(res["row_id"].tolist(), res["row_name"].tolist()))
+    bed = "".join(f"ctg5M\t{s_}\t{e}\n" for s_, e in zip(res["region_start"].tolist(), res["region_end"].tolist()))
+    return {"workload": "config 2: the tagger's rows (still in HBM) -> diag_filter_v3 -> diag_filter_step2 -> badsunks -> process-by-contig, on the device (csrc/gs_chain.hip)",
+            "rows_in": int(rows_in), "reads": len(names), "seconds": round(best, 4), "rows_per_s": rows_in / best,
+            "rows_after_diag_filter": int(kept), "bad_sunk_groups": int(bad.sum()), "tsv_rows": int(len(res["row_id"])),
+            "validated_intervals": int(len(res["region_start"])),
+            "reference": {"process_by_contig_seconds": 34.0, "diag_filters_seconds": 0.16, "reads": 6504,
+                          "where": "BASELINE.md section 2: the reference's own script (pandas 2.x, graph_tool stand-in) and Nim binaries on config-2-scale inputs in the build container, one core"},
+            "oracle_seconds_same_inputs": round(t_oracle, 2),
+            "parity": {"diag_equals_reference_binary": bool(diag == want_diag), "bad_sunks_equal_oracle": bool(got_bad == ebad),
+                       "tsv_equals_oracle": bool(tsv == etsv), "bed_equals_oracle": bool(bed == ebed)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -452,6 +571,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity + CPU baseline)")
     ap.add_argument("--no-config2", action="store_true", help="skip the config-2 extra key")
     ap.add_argument("--no-engine", action="store_true", help="skip the streaming-engine leg")
+    ap.add_argument("--no-chain", action="store_true", help="skip the device-resident stage-2/3 leg (`pair_stage` key)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra workload key (N = 1: one diploid shard; N > 1: config-3 weak scaling)")
     ap.add_argument("--cli", action="store_true", help="(default now) config-2 leg: also time the command-line drop-in")
     ap.add_argument("--no-cli", action="store_true", help="config-2 leg without the command-line timing")
@@ -516,11 +636,12 @@ def main():
             else:
                 data_plane = "RCCL over xGMI (gs_table_broadcast, gs_comm_allgather_u64, gs_gather_hits)"
 
-    def run_workload(wname, shards, batches_per_shard, steps, warmup, want_sample):
+    def run_workload(wname, shards, batches_per_shard, steps, warmup, want_sample, want_chain=False):
         """Builds the workload, times `steps` passes, -> dict of raw results (rank 0: everything; others: timings only)."""
         w = dict(synth_gpu.WORKLOADS[wname])
         a.batches = batches_per_shard
-        table, batches, n_sunks, n_groups, sample = build_workload(a, w, device, rank, world, comm, shards)
+        a.keep_sunks = bool(want_chain)
+        table, batches, n_sunks, n_groups, sample, kept_sunks = build_workload(a, w, device, rank, world, comm, shards)
         if not want_sample:
             sample = None
         n_bases = int(sum(int(b[2].sum()) for b in batches))
@@ -646,7 +767,17 @@ def main():
             total_bases = n_bases
         log(f"{wname}: {steps} steps: {total_bases * steps / dt / 1e9:.1f} Gbase/s")
         # one more pass outside the timed region: the head batch's rows for the parity leg / the gathered list on the root
+        census = None
+        if hasattr(L, "gs_tuning_census"):  # (libgavisunk_tuning.so, GAVISUNK_LIB=...: what the region fetches of one pass find)
+            L.gs_tuning_census(device, None, 1)
         head = step(keep_head=True, gather_to_host=world > 1)
+        if hasattr(L, "gs_tuning_census"):
+            cz = (C.c_uint64 * 16)()
+            L.gs_tuning_census(device, cz, 0)
+            names = ["steps", "runs", "runs_with_hit", "runs_deferred_only", "runs_empty_region", "runs_mmer_absent", "runs_hot_region",
+                     "windows_deferred", "windows_hit", "windows"]
+            census = {n_: int(cz[i]) for i, n_ in enumerate(names)}
+            log(f"{wname} census of one pass: {census}")
         gather_check = None
         if world > 1:
             tot_rows = int(comm.all_sum(int(last["rows"])))
@@ -670,7 +801,7 @@ def main():
             log(f"{wname}: without exchange / gather: {total_bases / solo / 1e9:.1f} Gbase/s")
         res = {"w": w, "wname": wname, "shards": list(shards), "table": table, "batches": batches, "n_bases": n_bases, "total_bases": total_bases, "dt": dt,
                "steps": steps, "step_s": step_s, "n_sunks": n_sunks, "n_groups": n_groups, "sample": sample, "head": head,
-               "last": dict(last), "rlen": rlen_all, "n_launch": n_launch, "gather_check": gather_check, "ctr": ctr.as_dict(), "stream": stream, "solo": solo}
+               "last": dict(last), "rlen": rlen_all, "n_launch": n_launch, "gather_check": gather_check, "ctr": ctr.as_dict(), "stream": stream, "solo": solo, "census": census, "kept_sunks": kept_sunks}
         return res
 
     def describe(res, headline):
@@ -709,7 +840,8 @@ def main():
                        "h_raw": round(h_raw, 5), "h_emit": round(h_emit, 7), "tiles": last["tiles"],
                        "fallback_tiles": last["fallback"], "table_GiB": round(table.nbytes / 2**30, 2), "table_layout": table.layout,
                        "parallelism": f"read-sharded x{world}, table replicated", "data_plane": data_plane,
-                       "gathered_list_checked": res["gather_check"], "env_knobs": knobs},
+                       "gathered_list_checked": res["gather_check"], "env_knobs": knobs,
+                       **({"census_of_one_pass": res["census"]} if res.get("census") else {})},
             "roofline": {"bound": "hbm", "kernel": kernel_names(table.layout), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": tnote,
                          "basis": "algorithmic bytes (SURVEY.md 8d: 8.25 B/base + 16 B/raw hit + 12 B/emitted row) of ONE launch / average HIP-event time of one probe-kernel launch "
@@ -722,6 +854,8 @@ def main():
         return out
 
     def release(res):
+        if res.get("kept_sunks"):
+            res["kept_sunks"][0].close()
         if res.get("stream") is not None:
             res["stream"].close()
         for dr, _, _ in res["batches"]:
@@ -739,7 +873,7 @@ def main():
     else:
         shards = [rank]
         bps = a.batches or 8
-    res = run_workload(wname, shards, bps, a.steps, a.warmup, want_sample=True)
+    res = run_workload(wname, shards, bps, a.steps, a.warmup, want_sample=True, want_chain=(world == 1 and not a.no_chain))
 
     out = None
     if rank == 0:
@@ -789,6 +923,16 @@ def main():
                                    "per_core": rate / threads,
                                    "calibration": {"reference_binary_bases_per_s_per_core": 4.79e6, "where": "workflow/scripts/kmerpos_annot3 (the reference's Nim ELF) timed in the build container on config 2, tagging phase only (SURVEY.md section 6; the binary cannot travel to the GPU box)",
                                                    "port_over_reference_per_core": rate / threads / 4.79e6}}
+        if res.get("kept_sunks") and world == 1:
+            # the device-resident second half over this workload's own hit list (the rows of the last pass are still in HBM)
+            try:
+                lr = engine.LocRows.from_sunkset(res["kept_sunks"][0])
+                out["pair_stage"] = chain_leg(res["table"], res["batches"], lr, res["kept_sunks"][1], device)
+                out["pair_stage"]["workload"] = "the headline workload's own hit list (one pass over every resident batch)"
+                lr.close()
+                log(f"pair stage: {out['pair_stage']['rows_in']} rows in {out['pair_stage']['seconds_total']:.2f} s = {out['pair_stage']['rows_per_s'] / 1e6:.1f} Mrow/s")
+            except Exception as e:  # (a measurement leg must not cost the headline)
+                out["pair_stage"] = {"failed": repr(e)}
         if not a.no_engine and world == 1:
             try:
                 out.update(engine_leg(a, res["table"], res["batches"], device))

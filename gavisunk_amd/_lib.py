@@ -138,6 +138,45 @@ SIGNATURES = {
     "gs_sunkpos_n_contigs": (U32, [P]),
     "gs_sunkpos_contig_name": (C.c_char_p, [P, U32]),
     "gs_sunkpos_row_text": (P, [P, U64, C.POINTER(U32)]),
+    "gs_sunkpos_n_names": (U32, [P]),
+    "gs_sunkpos_row_name": (P, [P]),
+    "gs_sunkpos_name_rank": (P, [P]),
+    "gs_sunkpos_name": (C.c_char_p, [P, U32]),
+    "gs_sunkpos_names_long": (I, [P, C.c_char_p, C.c_int64, P]),
+    "gs_sunkpos_rows_bad": (I, [P, C.c_char_p, P]),
+    "gs_sunkpos_row_keys": (U32, [P, P, C.POINTER(P), C.POINTER(P)]),
+    "gs_tag_hits_device": (I, [P, P, C.POINTER(P), C.POINTER(U64)]),
+    "gs_locrows_create": (I, [I, U64, P, P, P, P, C.POINTER(P)]),
+    "gs_locrows_from_sunkset_dev": (I, [I, P, C.POINTER(P)]),
+    "gs_locrows_free": (None, [P]),
+    "gs_locrows_n_rows": (U64, [P]),
+    "gs_locrows_n_locs": (U32, [P]),
+    "gs_locrows_key_contig": (I, [P, P]),
+    "gs_rowset_create": (I, [I, U64, C.POINTER(P)]),
+    "gs_rowset_free": (None, [P]),
+    "gs_rowset_n": (U64, [P]),
+    "gs_rowset_append_pass": (I, [P, P, P, U32, P]),
+    "gs_rowset_append_host": (I, [P, U64, P, P, P, P, P, P]),
+    "gs_rowset_download": (I, [P, P, P, P, P, P, P]),
+    "gs_rowset_segments": (I, [P, C.POINTER(U32)]),
+    "gs_rowset_diag_filter": (I, [P, U32, C.POINTER(C.c_char_p), P, P, P, P, P, C.POINTER(U64)]),
+    "gs_rowset_keep_flags": (I, [P, P]),
+    "gs_rowset_keep_filtered": (I, [P]),
+    "gs_rowset_bad_keys": (I, [P, P, U32, P, P, P, C.POINTER(P)]),
+    "gs_device_free": (I, [I, P]),
+    "gs_rowset_pair_stage": (I, [P, P, P, U32, P, P, C.POINTER(P)]),
+    "gs_pairstage_free": (None, [P]),
+    "gs_pairstage_n_rows": (U64, [P]),
+    "gs_pairstage_row_contig": (P, [P]),
+    "gs_pairstage_row_name": (P, [P]),
+    "gs_pairstage_row_id": (P, [P]),
+    "gs_pairstage_n_regions": (U32, [P]),
+    "gs_pairstage_region_contig": (P, [P]),
+    "gs_pairstage_region_start": (P, [P]),
+    "gs_pairstage_region_end": (P, [P]),
+    "gs_pairstage_n_contigs_in": (U32, [P]),
+    "gs_pairstage_contigs_in": (P, [P]),
+    "gs_pairstage_counters": (P, [P]),
     "gs_diag_filter": (I, [I, P, P, P, P, P, P]),
     "gs_pair_component": (I, [I, U32, P, P, P, P, P, P]),
     "gs_key_histogram": (I, [I, U64, P, U32, P, P, P, U32]),

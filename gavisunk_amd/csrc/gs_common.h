@@ -43,6 +43,13 @@ int sort_keys_u64(const uint64_t *k_in, uint64_t *k_out, uint64_t n, void *strea
 int select_flagged_u32(const uint32_t *in, const uint8_t *flag, uint32_t *out, unsigned long long *d_count, uint64_t n, uint64_t *n_out,
                        void *stream);
 
+// the pair test / clean-up / largest component kernels over device arrays (gs_pair.hip); rows of a read = [d_off[r], d_off[r+1])
+int pair_component_device(uint32_t n_reads, uint64_t n_rows, const uint64_t *d_off, const int64_t *d_pos, const int64_t *d_start,
+                          const int64_t *d_id, uint32_t *d_outn, int64_t *d_out);
+// contig-wide union-find over device arrays (gs_pair.hip)
+int union_regions_device(uint64_t n_rows, const uint32_t *d_row_read, const uint32_t *d_row_vertex, uint32_t n_vertices,
+                         const int64_t *d_vertex_id, uint32_t *d_size, int64_t *d_min, int64_t *d_max);
+
 constexpr int kTileWindows = 2048;  // windows per tile = 64 lanes x 32 windows (one 64-bit word per lane)
 constexpr int kTileWords = 64;
 
@@ -75,4 +82,8 @@ struct gs_sunkpos {
     std::vector<uint64_t> row_text_off;  // n_rows + 1 offsets into `text`
     std::vector<char> text;              // rows back to back, '\0' after each
     std::vector<std::string> seg_names, contigs;
+    // the distinct names (built on demand, gs_sunkpos_n_names): first segment of every name, name id per segment / per row,
+    // rank of every name in sorted order; the distinct (contig, ID) pairs (gs_sunkpos_row_keys)
+    std::vector<uint32_t> names, name_of_seg, row_name, name_rank, key_contig;
+    std::vector<int64_t> key_id;
 };

@@ -1686,6 +1686,20 @@ int gs_device_synchronize(int device) {
     return GS_OK;
 }
 
+#ifdef GS_TUNING
+// (libgavisunk_tuning.so only; not in include/gavisunk.h) the census counters of k_probe_mz (gs_mz.h: g_mz_census) of `device`
+int gs_tuning_census(int device, uint64_t out[16], int reset) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (out) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mz_census), 16 * sizeof(uint64_t)));
+    if (reset) {
+        const uint64_t z[16] = {0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_mz_census), z, sizeof(z)));
+    }
+    return GS_OK;
+}
+#endif
+
 int gs_selftest_minimizer_rule(int device, int k, int m, uint64_t seed, uint32_t n_tiles, uint64_t *mismatches, uint32_t first_bad[4],
                                uint32_t lane_hist[64]) {
     if (!mismatches || !first_bad || k < 16 || k > 32 || m < 8 || m > k || m > 31 || k - m > 7 || !n_tiles || n_tiles > (1u << 20)) {
@@ -2403,6 +2417,23 @@ int gs_tag_hits_to_device(gs_table *t, gs_reads *r, void *dst, uint64_t cap, uin
     int rc;
     if ((rc = check_pair(t, r, "gs_tag_hits_to_device"))) return rc;
     return copy_hits(t, r, dst, cap, n_out, hipMemcpyDeviceToDevice);
+}
+
+int gs_tag_hits_device(gs_table *t, gs_reads *r, const void **d_hits, uint64_t *n_out) {
+    int rc;
+    if ((rc = check_pair(t, r, "gs_tag_hits_device"))) return rc;
+    if (!d_hits || !n_out) {
+        set_error("gs_tag_hits_device: null argument");
+        return GS_E_ARG;
+    }
+    if ((rc = settle(t, r))) return rc;
+    *d_hits = r->hits;
+    *n_out = r->ps.res_n;
+    if (r->ps.res_keyerr) {
+        set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
+        return GS_E_KEYERROR;
+    }
+    return GS_OK;
 }
 
 void gs_counters_reset(gs_table *t) {

@@ -17,6 +17,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 
 #include "gs_common.h"
 
@@ -896,6 +897,130 @@ const char *gs_sunkpos_row_text(const gs_sunkpos *s, uint64_t row, uint32_t *len
     if (row >= s->row_seg.size()) return nullptr;
     if (len) *len = (uint32_t)(s->row_text_off[row + 1] - s->row_text_off[row] - 1);
     return s->text.data() + s->row_text_off[row];
+}
+
+// ---- what the row-set functions (gs_chain.hip) need from a `.sunkpos` file beside its columns -------------------------------
+// The distinct read names in first-seen order: name id of every ROW, rank of every name in sorted (byte-wise = code-point) order
+// -- `groupby("rname")` iterates in that order (process-by-contig_lowmem_AR.py:135).  n_names and the arrays are built on the
+// first call and live as long as the handle.
+static void sunkpos_name_table(gs_sunkpos *s) {
+    if (!s->name_of_seg.empty() || s->seg_names.empty()) return;
+    std::unordered_map<std::string, uint32_t> ids;
+    s->name_of_seg.resize(s->seg_names.size());
+    for (size_t i = 0; i < s->seg_names.size(); i++) {
+        auto it = ids.find(s->seg_names[i]);
+        if (it == ids.end()) {
+            it = ids.emplace(s->seg_names[i], (uint32_t)s->names.size()).first;
+            s->names.push_back((uint32_t)i);  // (a name = the first segment that carries it)
+        }
+        s->name_of_seg[i] = it->second;
+    }
+    s->row_name.resize(s->row_seg.size());
+    for (size_t r = 0; r < s->row_seg.size(); r++) s->row_name[r] = s->name_of_seg[s->row_seg[r]];
+    std::vector<uint32_t> order(s->names.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return s->seg_names[s->names[a]] < s->seg_names[s->names[b]]; });
+    s->name_rank.resize(order.size());
+    for (size_t i = 0; i < order.size(); i++) s->name_rank[order[i]] = (uint32_t)i;
+}
+uint32_t gs_sunkpos_n_names(gs_sunkpos *s) {
+    sunkpos_name_table(s);
+    return (uint32_t)s->names.size();
+}
+const uint32_t *gs_sunkpos_row_name(gs_sunkpos *s) {
+    sunkpos_name_table(s);
+    return s->row_name.data();
+}
+const uint32_t *gs_sunkpos_name_rank(gs_sunkpos *s) {
+    sunkpos_name_table(s);
+    return s->name_rank.data();
+}
+const char *gs_sunkpos_name(gs_sunkpos *s, uint32_t name) {
+    sunkpos_name_table(s);
+    return name < s->names.size() ? s->seg_names[s->names[name]].c_str() : nullptr;
+}
+// name_long[n_names] <- 1 where the `.rlen` file (rows `rname \t len`) holds a row of that name with len >= minlen
+// (`lendf.query("len >= @minlen").index`, process-by-contig_lowmem_AR.py:106-108)
+int gs_sunkpos_names_long(gs_sunkpos *s, const char *rlen_path, int64_t minlen, uint8_t *name_long) {
+    if (!s || !rlen_path || !name_long) {
+        set_error("gs_sunkpos_names_long: null argument");
+        return GS_E_ARG;
+    }
+    sunkpos_name_table(s);
+    std::unordered_map<std::string, uint32_t> ids;
+    for (size_t i = 0; i < s->names.size(); i++) ids.emplace(s->seg_names[s->names[i]], (uint32_t)i);
+    std::fill(name_long, name_long + s->names.size(), 0);
+    LineReader r(rlen_path);
+    if (!r.ok()) {
+        set_error("cannot open the file %s", rlen_path);
+        return GS_E_IO;
+    }
+    std::string line, nm;
+    while (r.next(line)) {
+        const size_t t = line.find('\t');
+        if (t == std::string::npos) continue;
+        size_t t2 = line.find('\t', t + 1);
+        if (t2 == std::string::npos) t2 = line.size();
+        int64_t len;
+        if (!parse_i64(line.data() + t + 1, line.data() + t2, len)) continue;
+        if (len < minlen) continue;
+        nm.assign(line, 0, t);
+        auto it = ids.find(nm);
+        if (it != ids.end()) name_long[it->second] = 1;
+    }
+    return GS_OK;
+}
+// row_bad[n_rows] <- 1 where the row's `chrom:ID` is a line of the bad-SUNK list (process-by-contig_lowmem_AR.py:66-72: the
+// script compares the strings chrom + ":" + str(ID))
+int gs_sunkpos_rows_bad(gs_sunkpos *s, const char *bad_path, uint8_t *row_bad) {
+    if (!s || !bad_path || !row_bad) {
+        set_error("gs_sunkpos_rows_bad: null argument");
+        return GS_E_ARG;
+    }
+    std::unordered_map<std::string, uint32_t> cid;
+    for (size_t c = 0; c < s->contigs.size(); c++) cid.emplace(s->contigs[c], (uint32_t)c);
+    std::unordered_set<uint64_t> bad;  // contig id << 40 ^ ID (IDs are contig coordinates: below 2^40)
+    LineReader r(bad_path);
+    if (!r.ok()) {
+        set_error("cannot open the file %s", bad_path);
+        return GS_E_IO;
+    }
+    std::string line, nm;
+    while (r.next(line)) {  // (`splitlines()`: the text of every line, CR and all, is an element; only exact strings can match)
+        const size_t t = line.rfind(':');
+        if (t == std::string::npos) continue;
+        int64_t id;
+        if (!parse_i64(line.data() + t + 1, line.data() + line.size(), id) || id < 0) continue;
+        if (std::to_string(id) != line.substr(t + 1)) continue;  // ("007" is not str(7))
+        nm.assign(line, 0, t);
+        auto it = cid.find(nm);
+        if (it != cid.end()) bad.insert(((uint64_t)it->second << 40) ^ (uint64_t)id);
+    }
+    const size_t n = s->row_seg.size();
+    for (size_t i = 0; i < n; i++)
+        row_bad[i] = (s->row_group[i] >= 0 && bad.count(((uint64_t)s->row_contig[i] << 40) ^ (uint64_t)s->row_group[i])) ? 1 : 0;
+    return GS_OK;
+}
+// dense ids of the rows' distinct (contig, ID) pairs, in first-seen order: row_key[n_rows]; the pair of key j =
+// key_contig[j], key_id[j] (valid until the next call / the handle's end).  -> number of keys
+uint32_t gs_sunkpos_row_keys(gs_sunkpos *s, uint32_t *row_key, const uint32_t **key_contig, const int64_t **key_id) {
+    std::unordered_map<uint64_t, uint32_t> ids;
+    s->key_contig.clear();
+    s->key_id.clear();
+    const size_t n = s->row_seg.size();
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t k = ((uint64_t)s->row_contig[i] << 40) ^ (uint64_t)s->row_group[i];
+        auto it = ids.find(k);
+        if (it == ids.end()) {
+            it = ids.emplace(k, (uint32_t)s->key_contig.size()).first;
+            s->key_contig.push_back(s->row_contig[i]);
+            s->key_id.push_back(s->row_group[i]);
+        }
+        row_key[i] = it->second;
+    }
+    if (key_contig) *key_contig = s->key_contig.data();
+    if (key_id) *key_id = s->key_id.data();
+    return (uint32_t)s->key_contig.size();
 }
 
 }  // extern "C"

@@ -564,6 +564,9 @@ constexpr int kMzListCap = GS_MZ_LIST_CAP;     // maybe-hits (hits and deferred 
 constexpr int kMzStreamDwords = 2 * (kTileWords + 3);  // a tile's bases as 32-bit pieces: 64 words + 2 the last windows reach into + 1 of padding
 constexpr int kMzFastCand = GS_MZ_FAST_CAND;   // candidates (location changes) of a tile before it is handed to the exact form
 static_assert(kMzListCap >= kMzCandLds, "the exact form borrows the hit list as its candidate buffer");
+#ifndef GS_MZ_DMA_AUX
+#define GS_MZ_DMA_AUX 0  // cache policy bits of the region fetches (A/B: 2 = nt, 1 = sc0, 16 = sc1)
+#endif
 #ifndef GS_MZ_WG_WAVES
 #define GS_MZ_WG_WAVES 4
 #endif
@@ -868,6 +871,14 @@ __global__ __launch_bounds__(64) void k_mz_rule_check(int k_rt, int m_rt, const 
     }
 }
 
+#ifdef GS_TUNING
+// (tuning build only: tools/probe_census.py) what the region fetches of k_probe_mz's place format find -- per step of a
+// non-big step: [0] steps, [1] runs (= region fetches), [2] runs in which some window hits, [3] runs without a hit in which some
+// window is deferred to the generic table, [4] runs whose region holds no record and no overflow mark at all, [5] runs whose
+// m-mer is absent (no record of the region carries its fp; hot regions not counted), [6] runs that meet a hot region,
+// [7] windows deferred, [8] windows that hit, [9] valid windows
+__device__ unsigned long long g_mz_census[16];
+#endif
 // KT / MT: k and m as compile-time constants (0 = take them from the table); FMT: slot format (mz_key_fmt)
 // PLACE: 0 = per-key slots; the place-record format of gs_mzp.h (FMT is then unused): 1 = m <= 15 (the minimiser's value and
 // orientation in one register), 2 = longer minimisers (k = 22 .. 27: two registers)
@@ -924,6 +935,9 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
     // (PLACE: fpT = the fp word (fp << (32 - s)), want = tag word | mask word << 32)
     uint32_t fpT[kMzStages], regoff[kMzStages], runreg[kMzStages], nruns[kMzStages];  // fpT: fingerprint in all four bytes, bit 31 of regoff: invalid lane
     uint64_t want[kMzStages];
+#ifdef GS_TUNING
+    unsigned long long leaders[kMzStages];
+#endif
     const MzLaneGeom geom = mz_lane_geom(lds_addr(&L.fd[0]), lds_addr(&L.rd[0]), lane, k);
     auto window = [&](int s) {
         if constexpr (RCW) return mz_window_rcw<PLACE>(geom, s, k, m, mmask);
@@ -948,9 +962,9 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
             const uint4 *src = mz.regions + (uint64_t)rr * kMzPieces + (lane % kMzPieces);
             if constexpr (kMzRunCap % (int)kRunsPerDma != 0) {  // (a slot that ends inside the last instruction's 16 runs: its other lanes stay out)
                 if (it < kMzDma - 1 || lane < (kMzRunCap % (int)kRunsPerDma) * kMzPieces)
-                    __builtin_amdgcn_global_load_lds(src, &L.cache[slot][it * 64], 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(src, &L.cache[slot][it * 64], 16, 0, GS_MZ_DMA_AUX);
             } else {
-                __builtin_amdgcn_global_load_lds(src, &L.cache[slot][it * 64], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(src, &L.cache[slot][it * 64], 16, 0, GS_MZ_DMA_AUX);
             }
         }
     };
@@ -992,6 +1006,9 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
         const uint32_t R = (uint32_t)__popcll(lb);
         // the leaders at or below this lane, less one = those among lanes 1 .. lane (v_mbcnt: the lanes below, of a mask)
         const uint32_t myrun = mbcnt(lb >> 1);
+#ifdef GS_TUNING
+        leaders[slot] = lb;
+#endif
         fpT[slot] = fpw;
         regoff[slot] = myrun * (uint32_t)(kMzWords * 8) | (valid ? 0u : 0x80000000u);  // byte offset of the run's region in the cache slot
         want[slot] = wantw;
@@ -1050,6 +1067,36 @@ __global__ __launch_bounds__(64 * kMzWaves, GS_MZ_MIN_WAVES) void k_probe_mz(MzV
                 hitb &= ~hotb;
                 deferb = (deferb & ~hotb) | (ballot((wv >> mzp_hot_bit(fh)) & (wv2 >> mzp_hot_bit(fh2)) & 1u) & hotb);
             }
+#ifdef GS_TUNING
+            if constexpr (!BIG) {
+                const unsigned long long validb = ballot(FULL || !(regoff[u] >> 31)), lb = leaders[u] & validb;
+                // this lane's run = lanes [lane, next leader): does any of them hit / get deferred
+                const unsigned long long above = lane == 63 ? 0ULL : (leaders[u] & ~((2ULL << lane) - 1ULL));
+                const int nxt = above ? __ffsll(above) - 1 : 64;
+                const unsigned long long rmask = (nxt == 64 ? ~0ULL : ((1ULL << nxt) - 1ULL)) & ~((1ULL << lane) - 1ULL);
+                const bool run_hit = (hitb & rmask) != 0ULL, run_defer = (deferb & rmask) != 0ULL;
+                const uint32_t fpbits = fpT[u] >> (32 - mz.s);
+                const bool none = (q0.x | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w | q2.x) == 0u;
+                const bool present = (q0.z && (q2.y >> (32 - mz.s)) == fpbits) || (q0.w && (q2.z >> (32 - mz.s)) == fpbits) ||
+                                     (q1.x && (q2.w >> (32 - mz.s)) == fpbits) || (q1.y && (q3.x >> (32 - mz.s)) == fpbits) ||
+                                     (q1.z && (q3.y >> (32 - mz.s)) == fpbits) || (q1.w && (q3.z >> (32 - mz.s)) == fpbits) ||
+                                     (q2.x && (q3.w >> (32 - mz.s)) == fpbits);
+                const unsigned long long c2 = ballot(run_hit) & lb, c3 = ballot(!run_hit && run_defer) & lb, c4 = ballot(none) & lb,
+                                         c5 = ballot(!present) & lb & ~hotb, c6 = hotb & lb;
+                if (lane == 0) {
+                    atomicAdd(&g_mz_census[0], 1ULL);
+                    atomicAdd(&g_mz_census[1], (unsigned long long)__popcll(lb));
+                    atomicAdd(&g_mz_census[2], (unsigned long long)__popcll(c2));
+                    atomicAdd(&g_mz_census[3], (unsigned long long)__popcll(c3));
+                    atomicAdd(&g_mz_census[4], (unsigned long long)__popcll(c4));
+                    atomicAdd(&g_mz_census[5], (unsigned long long)__popcll(c5));
+                    atomicAdd(&g_mz_census[6], (unsigned long long)__popcll(c6));
+                    atomicAdd(&g_mz_census[7], (unsigned long long)__popcll(deferb));
+                    atomicAdd(&g_mz_census[8], (unsigned long long)__popcll(hitb));
+                    atomicAdd(&g_mz_census[9], (unsigned long long)__popcll(validb));
+                }
+            }
+#endif
         } else
 #endif
         {

@@ -13,6 +13,9 @@
 //                  vertex order (:189-198).  O(n^2 + E) work per read, spread over 256 threads.
 #include <hip/hip_runtime.h>
 
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -291,6 +294,107 @@ struct DevBuf {
 
 }  // namespace
 
+namespace {
+__global__ void k_widen_u32(const uint32_t *in, uint64_t *out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+}  // namespace
+
+// The three kernels over arrays that already are in device memory (gs_chain.hip: the device-resident second half of the
+// engine; gs_pair_component below: the host-array form).  d_out_n[n_reads], d_out_ids[n_rows]; synchronous.  The reads are
+// taken in chunks whose pair lists (at most n (n - 1) / 2 surviving pairs per read of n rows) stay below kMaxChunkPairs: a
+// genome-scale hit list has ~1e10 pairs in all, a chunk's edge arrays a few GB.
+int gs::pair_component_device(uint32_t n_reads, uint64_t n_rows, const uint64_t *d_off, const int64_t *d_pos, const int64_t *d_start,
+                              const int64_t *d_id, uint32_t *d_outn, int64_t *d_out) {
+    if (!n_reads) return GS_OK;
+    constexpr uint64_t kMaxChunkPairs = 400000000ULL;
+    std::vector<uint64_t> off((size_t)n_reads + 1);
+    HIP_TRY(hipMemcpy(off.data(), d_off, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    DevBuf db;
+    int rc;
+    uint64_t *d_reoff, *d_rowe64, *d_scan;
+    uint32_t *d_rowe, *d_deg, *d_rank, *d_vert, *d_parent, *d_size, *d_app;
+    int64_t *d_gp;
+    uint8_t *d_orient, *d_any;
+    if ((rc = db.put(&d_rowe, (const uint32_t *)nullptr, n_rows + 1)) || (rc = db.put(&d_reoff, (const uint64_t *)nullptr, n_rows + 1)) ||
+        (rc = db.put(&d_orient, (const uint8_t *)nullptr, n_reads)) || (rc = db.put(&d_any, (const uint8_t *)nullptr, n_reads)) ||
+        (rc = db.put(&d_deg, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_rank, (const uint32_t *)nullptr, n_rows)) ||
+        (rc = db.put(&d_vert, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_parent, (const uint32_t *)nullptr, n_rows)) ||
+        (rc = db.put(&d_size, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_app, (const uint32_t *)nullptr, n_rows)) ||
+        (rc = db.put(&d_gp, (const int64_t *)nullptr, n_rows)))
+        return rc;
+    HIP_TRY(hipMemset(d_rowe, 0, (n_rows + 1) * sizeof(uint32_t)));
+    // chunk boundaries and the largest chunk (rows, for the scan buffers)
+    std::vector<uint32_t> cuts(1, 0);
+    uint64_t acc = 0, max_rows = 0;
+    for (uint32_t r = 0; r < n_reads; r++) {
+        const uint64_t n = off[r + 1] - off[r], pairs = n * (n ? n - 1 : 0) / 2;
+        if (acc && acc + pairs > kMaxChunkPairs) {
+            cuts.push_back(r);
+            acc = 0;
+        }
+        acc += pairs;
+    }
+    cuts.push_back(n_reads);
+    for (size_t c = 0; c + 1 < cuts.size(); c++) max_rows = std::max(max_rows, off[cuts[c + 1]] - off[cuts[c]]);
+    if ((rc = db.put(&d_rowe64, (const uint64_t *)nullptr, max_rows + 1)) || (rc = db.put(&d_scan, (const uint64_t *)nullptr, max_rows + 1))) return rc;
+    size_t tb = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_rowe64, d_scan, (uint64_t)0, (size_t)max_rows + 1, rocprim::plus<uint64_t>()));
+    void *d_tmp;
+    if ((rc = db.put((uint8_t **)&d_tmp, (const uint8_t *)nullptr, tb))) return rc;
+    uint32_t *d_ei = nullptr, *d_ej = nullptr;
+    uint8_t *d_bad = nullptr;
+    uint64_t edge_cap = 0;
+    auto free_edges = [&]() {
+        if (d_ei) (void)hipFree(d_ei);
+        if (d_ej) (void)hipFree(d_ej);
+        if (d_bad) (void)hipFree(d_bad);
+        d_ei = d_ej = nullptr;
+        d_bad = nullptr;
+    };
+    for (size_t c = 0; c + 1 < cuts.size(); c++) {
+        const uint32_t r0 = cuts[c], nr = cuts[c + 1] - r0;
+        const uint64_t lo = off[r0], rows = off[cuts[c + 1]] - lo;
+        hipLaunchKernelGGL(k_pair_count, dim3(nr), dim3(kPairThreads), 0, 0, d_off + r0, d_pos, d_start, d_rowe, d_orient + r0, d_any + r0);
+        // surviving pairs per row -> their offsets in the chunk's edge list (exclusive scan, on the device)
+        hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, 0, d_rowe + lo, d_rowe64, rows);
+        hipError_t e = hipMemsetAsync(d_rowe64 + rows, 0, sizeof(uint64_t), 0);
+        size_t tb2 = tb;
+        if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp, tb2, d_rowe64, d_scan, (uint64_t)0, (size_t)rows + 1, rocprim::plus<uint64_t>());
+        if (e == hipSuccess) e = hipMemcpyAsync(d_reoff + lo, d_scan, (rows + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, 0);
+        uint64_t n_edges = 0;
+        if (e == hipSuccess) e = hipMemcpy(&n_edges, d_scan + rows, sizeof(uint64_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            free_edges();
+            set_error("gs_pair_component: %s", hipGetErrorString(e));
+            return GS_E_NODEVICE;
+        }
+        if (n_edges > edge_cap) {
+            free_edges();
+            edge_cap = std::max<uint64_t>(n_edges, 1024);
+            if (hipMalloc((void **)&d_ei, edge_cap * 4) != hipSuccess || hipMalloc((void **)&d_ej, edge_cap * 4) != hipSuccess ||
+                hipMalloc((void **)&d_bad, edge_cap) != hipSuccess) {
+                free_edges();
+                set_error("gs_pair_component: device allocation of %llu pairs failed", (unsigned long long)edge_cap);
+                return GS_E_NOMEM;
+            }
+        }
+        hipLaunchKernelGGL(k_pair_edges, dim3(nr), dim3(kPairThreads), 0, 0, d_off + r0, d_pos, d_start, d_orient + r0, d_reoff, d_ei, d_ej);
+        hipLaunchKernelGGL(k_pair_graph, dim3(nr), dim3(kGraphThreads), 0, 0, nr, d_off + r0, d_pos, d_id, d_any + r0, d_reoff,
+                           d_ei, d_ej, d_bad, d_deg, d_rank, d_vert, d_parent, d_size, d_app, d_gp, d_out, d_outn + r0);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            free_edges();
+            set_error("gs_pair_component: %s", hipGetErrorString(e));
+            return GS_E_NODEVICE;
+        }
+    }
+    free_edges();
+    return GS_OK;
+}
+
 extern "C" int gs_pair_component(int device, uint32_t n_reads, const uint64_t *read_off, const int64_t *pos,
                                  const int64_t *start, const int64_t *id, uint32_t *out_n, int64_t *out_ids) {
     if (!read_off || !out_n || (n_reads && read_off[n_reads] && (!pos || !start || !id || !out_ids))) {
@@ -306,38 +410,14 @@ extern "C" int gs_pair_component(int device, uint32_t n_reads, const uint64_t *r
     const uint64_t n_rows = read_off[n_reads];
     DevBuf db;
     int rc;
-    uint64_t *d_off, *d_reoff;
+    uint64_t *d_off;
     int64_t *d_pos, *d_start, *d_id, *d_out;
-    uint32_t *d_rowe, *d_outn, *d_deg, *d_rank, *d_vert, *d_parent, *d_size, *d_app;
-    int64_t *d_gp;
-    uint8_t *d_orient, *d_any;
+    uint32_t *d_outn;
     if ((rc = db.put(&d_off, read_off, (uint64_t)n_reads + 1)) || (rc = db.put(&d_pos, pos, n_rows)) ||
         (rc = db.put(&d_start, start, n_rows)) || (rc = db.put(&d_id, id, n_rows)) ||
-        (rc = db.put(&d_rowe, (const uint32_t *)nullptr, n_rows + 1)) || (rc = db.put(&d_orient, (const uint8_t *)nullptr, n_reads)) ||
-        (rc = db.put(&d_any, (const uint8_t *)nullptr, n_reads)))
+        (rc = db.put(&d_out, (const int64_t *)nullptr, n_rows)) || (rc = db.put(&d_outn, (const uint32_t *)nullptr, n_reads)))
         return rc;
-    hipLaunchKernelGGL(k_pair_count, dim3(n_reads), dim3(kPairThreads), 0, 0, d_off, d_pos, d_start, d_rowe, d_orient, d_any);
-    HIP_TRY(hipGetLastError());
-    std::vector<uint32_t> rowe(n_rows + 1, 0);
-    if (n_rows) HIP_TRY(hipMemcpy(rowe.data(), d_rowe, n_rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    std::vector<uint64_t> reoff(n_rows + 1, 0);
-    for (uint64_t i = 0; i < n_rows; i++) reoff[i + 1] = reoff[i] + rowe[i];
-    const uint64_t n_edges = reoff[n_rows];
-    uint32_t *d_ei, *d_ej;
-    uint8_t *d_bad;
-    if ((rc = db.put(&d_reoff, reoff.data(), n_rows + 1)) || (rc = db.put(&d_ei, (const uint32_t *)nullptr, n_edges)) ||
-        (rc = db.put(&d_ej, (const uint32_t *)nullptr, n_edges)) || (rc = db.put(&d_bad, (const uint8_t *)nullptr, n_edges)) ||
-        (rc = db.put(&d_deg, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_rank, (const uint32_t *)nullptr, n_rows)) ||
-        (rc = db.put(&d_vert, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_parent, (const uint32_t *)nullptr, n_rows)) ||
-        (rc = db.put(&d_size, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_app, (const uint32_t *)nullptr, n_rows)) ||
-        (rc = db.put(&d_gp, (const int64_t *)nullptr, n_rows)) || (rc = db.put(&d_out, (const int64_t *)nullptr, n_rows)) ||
-        (rc = db.put(&d_outn, (const uint32_t *)nullptr, n_reads)))
-        return rc;
-    hipLaunchKernelGGL(k_pair_edges, dim3(n_reads), dim3(kPairThreads), 0, 0, d_off, d_pos, d_start, d_orient, d_reoff, d_ei, d_ej);
-    hipLaunchKernelGGL(k_pair_graph, dim3(n_reads), dim3(kGraphThreads), 0, 0, n_reads, d_off, d_pos, d_id, d_any, d_reoff,
-                       d_ei, d_ej, d_bad, d_deg, d_rank, d_vert, d_parent, d_size, d_app, d_gp, d_out, d_outn);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = gs::pair_component_device(n_reads, n_rows, d_off, d_pos, d_start, d_id, d_outn, d_out))) return rc;
     HIP_TRY(hipMemcpy(out_n, d_outn, n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (n_rows) HIP_TRY(hipMemcpy(out_ids, d_out, n_rows * sizeof(int64_t), hipMemcpyDeviceToHost));
     return GS_OK;
@@ -437,6 +517,27 @@ __global__ void k_uf_stats(uint32_t *parent, const long long *vertex_id, uint32_
 }
 }  // namespace
 
+// device arrays in, device arrays out (comp_* of n_vertices entries each); synchronous
+int gs::union_regions_device(uint64_t n_rows, const uint32_t *d_rr, const uint32_t *d_rv, uint32_t n_vertices, const int64_t *d_vid,
+                             uint32_t *d_size, int64_t *d_min, int64_t *d_max) {
+    if (!n_vertices) return GS_OK;
+    DevBuf db;
+    int rc;
+    uint32_t *d_parent;
+    if ((rc = db.put(&d_parent, (const uint32_t *)nullptr, n_vertices))) return rc;
+    HIP_TRY(hipMemset(d_size, 0, n_vertices * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(d_min, 0x7F, n_vertices * sizeof(long long)));  // 0x7F7F...: above every ID
+    HIP_TRY(hipMemset(d_max, 0x80, n_vertices * sizeof(long long)));  // 0x8080...: below every ID
+    hipLaunchKernelGGL(k_uf_init, dim3((n_vertices + 255) / 256), dim3(256), 0, 0, d_parent, n_vertices);
+    if (n_rows > 1)
+        hipLaunchKernelGGL(k_uf_union, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, 0, d_parent, d_rv, d_rr, n_rows);
+    hipLaunchKernelGGL(k_uf_stats, dim3((n_vertices + 255) / 256), dim3(256), 0, 0, d_parent, (const long long *)d_vid, n_vertices, d_size,
+                       (long long *)d_min, (long long *)d_max);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return GS_OK;
+}
+
 extern "C" int gs_union_regions(int device, uint64_t n_rows, const uint32_t *row_read, const uint32_t *row_vertex,
                                 uint32_t n_vertices, const int64_t *vertex_id, uint32_t *comp_size, int64_t *comp_min,
                                 int64_t *comp_max) {
@@ -452,24 +553,16 @@ extern "C" int gs_union_regions(int device, uint64_t n_rows, const uint32_t *row
     HIP_TRY(hipSetDevice(device));
     DevBuf db;
     int rc;
-    uint32_t *d_rr, *d_rv, *d_parent, *d_size;
-    long long *d_vid, *d_min, *d_max;
+    uint32_t *d_rr, *d_rv, *d_size;
+    int64_t *d_vid, *d_min, *d_max;
     if ((rc = db.put(&d_rr, row_read, n_rows)) || (rc = db.put(&d_rv, row_vertex, n_rows)) ||
-        (rc = db.put(&d_parent, (const uint32_t *)nullptr, n_vertices)) || (rc = db.put(&d_size, (const uint32_t *)nullptr, n_vertices)) ||
-        (rc = db.put(&d_vid, (const long long *)vertex_id, n_vertices)) || (rc = db.put(&d_min, (const long long *)nullptr, n_vertices)) ||
-        (rc = db.put(&d_max, (const long long *)nullptr, n_vertices)))
+        (rc = db.put(&d_size, (const uint32_t *)nullptr, n_vertices)) ||
+        (rc = db.put(&d_vid, vertex_id, n_vertices)) || (rc = db.put(&d_min, (const int64_t *)nullptr, n_vertices)) ||
+        (rc = db.put(&d_max, (const int64_t *)nullptr, n_vertices)))
         return rc;
-    HIP_TRY(hipMemset(d_size, 0, n_vertices * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(d_min, 0x7F, n_vertices * sizeof(long long)));  // 0x7F7F...: above every ID
-    HIP_TRY(hipMemset(d_max, 0x80, n_vertices * sizeof(long long)));  // 0x8080...: below every ID
-    hipLaunchKernelGGL(k_uf_init, dim3((n_vertices + 255) / 256), dim3(256), 0, 0, d_parent, n_vertices);
-    if (n_rows > 1)
-        hipLaunchKernelGGL(k_uf_union, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, 0, d_parent, d_rv, d_rr, n_rows);
-    hipLaunchKernelGGL(k_uf_stats, dim3((n_vertices + 255) / 256), dim3(256), 0, 0, d_parent, d_vid, n_vertices, d_size, d_min, d_max);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = gs::union_regions_device(n_rows, d_rr, d_rv, n_vertices, d_vid, d_size, d_min, d_max))) return rc;
     HIP_TRY(hipMemcpy(comp_size, d_size, n_vertices * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(comp_min, d_min, n_vertices * sizeof(long long), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(comp_max, d_max, n_vertices * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(comp_min, d_min, n_vertices * sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(comp_max, d_max, n_vertices * sizeof(int64_t), hipMemcpyDeviceToHost));
     return GS_OK;
 }

@@ -1,7 +1,8 @@
 """Drop-in for GAVISUNK's `workflow/scripts/diag_filter_v3 <sunkpos> <fai>` > stdout (rule
 diag_filter_step, workflow/rules/tagONT.smk:92; source workflow/src/diag_filter_v3.nim): one line
 `rname \\t bestcontig \\t N \\t dir \\t N` per read whose best contig of this haplotype has N > 1
-distinct SUNK groups on the median diagonal.  The statistics run on the GPU (gs_diag_filter)."""
+distinct SUNK groups on the median diagonal.  A thin user of the device-resident chain: the rows are parsed natively,
+uploaded once, and the whole filter (Table slot order included) runs on the GPU (gs_rowset_diag_filter)."""
 from __future__ import annotations
 
 import os
@@ -12,13 +13,16 @@ from . import _lib, engine
 
 def run(sunkpos: str, fai: str, out=None, device: int = 0) -> int:
     out = out or sys.stdout
+    L = _lib.lib()
     with open(fai) as fh:
-        contigs = [ln.split("\t")[0].rstrip("\n") for ln in fh if ln.strip()]
+        contigs = {ln.split("\t")[0].rstrip("\n") for ln in fh if ln.strip()}
     sp = engine.SunkPos(sunkpos)
-    bc, bg, bd, _ = engine.diag_filter(sp, contigs, device)
-    for seg in range(sp.n_segs):
-        if bc[seg] != _lib.GS_NONE:
-            out.write(f"{sp.seg_name(seg)}\t{sp.contigs[bc[seg]]}\t{bg[seg]}\t{chr(bd[seg])}\t{bg[seg]}\n")
+    rs = engine.RowSet.from_sunkpos(sp, device)
+    seg_name, bc, bg, bd, _ = rs.diag_filter(sp.contigs, [1 if c in contigs else 0 for c in sp.contigs])
+    rs.close()
+    none = _lib.GS_NONE
+    out.write("".join(f"{L.gs_sunkpos_name(sp._h, n).decode()}\t{sp.contigs[c]}\t{g}\t{chr(d)}\t{g}\n"
+                      for n, c, g, d in zip(seg_name.tolist(), bc.tolist(), bg.tolist(), bd.tolist()) if c != none))
     sp.close()
     return 0
 

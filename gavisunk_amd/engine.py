@@ -507,6 +507,165 @@ def diag_filter(sp: SunkPos, fai_contigs, device: int = 0):
     return bc[: sp.n_segs], bg[: sp.n_segs], bd[: sp.n_segs], keep[: sp.n_rows]
 
 
+# ---------------------------------------------------------------------------------------------------
+# The device-resident second half (csrc/gs_chain.hip): rows -> diagonal filter -> bad SUNKs -> pair stage
+# ---------------------------------------------------------------------------------------------------
+class LocRows:
+    """kmer.loc rows in device memory (gs_locrows): payload of a hit -> chrom / start / ID / dense `chrom:ID` key."""
+
+    def __init__(self, h, device: int, keepalive=None):
+        self._h, self.device, self._keep = h, device, keepalive
+        self.n_locs = lib().gs_locrows_n_locs(h)
+
+    @classmethod
+    def from_db(cls, db: "SunkDB", device: int = 0) -> "LocRows":
+        h = C.c_void_p()
+        rc_, rs_, rg_, rl_ = (np.ascontiguousarray(db.row_contig, np.uint32), np.ascontiguousarray(db.row_start, np.int64),
+                              np.ascontiguousarray(db.row_group, np.int64), np.ascontiguousarray(db.row_loc, np.uint32))
+        check(lib().gs_locrows_create(device, len(rc_), rc_.ctypes.data, rs_.ctypes.data, rg_.ctypes.data, rl_.ctypes.data, C.byref(h)))
+        return cls(h, device)
+
+    @classmethod
+    def from_sunkset(cls, sunks: "DeviceSunkSet") -> "LocRows":
+        h = C.c_void_p()
+        check(lib().gs_locrows_from_sunkset_dev(sunks.device, sunks._h, C.byref(h)))
+        return cls(h, sunks.device, keepalive=sunks)  # (borrows the set's device arrays)
+
+    def key_contig(self) -> np.ndarray:
+        out = np.zeros(max(self.n_locs, 1), np.uint32)
+        check(lib().gs_locrows_key_contig(self._h, out.ctypes.data))
+        return out[: self.n_locs]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_locrows_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class RowSet:
+    """`.sunkpos` rows as arrays in device memory (gs_rowset), from tagging passes (device to device) or from a parsed file."""
+
+    def __init__(self, device: int = 0, cap_hint: int = 0):
+        h = C.c_void_p()
+        check(lib().gs_rowset_create(device, cap_hint, C.byref(h)))
+        self._h, self.device = h, device
+
+    @property
+    def n(self) -> int:
+        return lib().gs_rowset_n(self._h)
+
+    def append_pass(self, table: "DeviceTable", reads: "DeviceReads", name_base: int, locrows: LocRows) -> None:
+        check(lib().gs_rowset_append_pass(self._h, table._h, reads._h, name_base, locrows._h))
+
+    def append_host(self, name, pos, contig, start, ident, key=None) -> None:
+        cols = [np.ascontiguousarray(a, np.uint32) for a in (name, pos, contig, start, ident)]
+        k = np.ascontiguousarray(key, np.uint32) if key is not None else None
+        check(lib().gs_rowset_append_host(self._h, len(cols[0]), *[c.ctypes.data for c in cols], k.ctypes.data if k is not None else None))
+
+    @classmethod
+    def from_sunkpos(cls, sp: "SunkPos", device: int = 0, keys: bool = False, contig=None):
+        """The rows of a parsed `.sunkpos` file; name ids = the file's distinct names in first-seen order.  keys=True also numbers
+        the distinct (chrom, ID) pairs -> (row set, row_key, key_contig, key_id) (keys are uploaded by the caller: append order).
+        contig: a replacement for the contig column (process-by-contig groups by read name only)."""
+        L = lib()
+        n_names = L.gs_sunkpos_n_names(sp._h)
+        row_name = _view(L.gs_sunkpos_row_name(sp._h), sp.n_rows, np.uint32)
+        rs = cls(device, sp.n_rows)
+        kc = ki = None
+        key = None
+        if keys:
+            key = np.zeros(max(sp.n_rows, 1), np.uint32)
+            pc, pi = C.c_void_p(), C.c_void_p()
+            nk = L.gs_sunkpos_row_keys(sp._h, key.ctypes.data, C.byref(pc), C.byref(pi))
+            kc, ki = _view(pc.value, nk, np.uint32).copy(), _view(pi.value, nk, np.int64).copy()
+            key = key[: sp.n_rows]
+        for col in (sp.row_pos, sp.row_start, sp.row_group):  # (uint32 like the script's dtypes, process-by-contig_lowmem_AR.py:60)
+            if len(col) and (int(col.min()) < 0 or int(col.max()) > 0xFFFFFFFF):
+                raise ValueError("a .sunkpos column does not fit uint32 (pos / start / ID are contig coordinates)")
+        rs.append_host(row_name, sp.row_pos.astype(np.uint32), sp.row_contig if contig is None else contig, sp.row_start.astype(np.uint32),
+                       sp.row_group.astype(np.uint32), key)
+        rs.n_names = n_names
+        return (rs, kc, ki) if keys else rs
+
+    def download(self):
+        n = self.n
+        cols = [np.zeros(max(n, 1), np.uint32) for _ in range(6)]
+        check(lib().gs_rowset_download(self._h, *[c.ctypes.data for c in cols]))
+        return dict(zip(("name", "pos", "contig", "start", "id", "key"), (c[:n] for c in cols)))
+
+    def n_segs(self) -> int:
+        ns = C.c_uint32(0)
+        check(lib().gs_rowset_segments(self._h, C.byref(ns)))
+        return ns.value
+
+    def diag_filter(self, contig_names: Sequence[str], in_fai):
+        """diag_filter_v3 over the rows, on the device -> (seg_name, best_contig, best_good, best_dir, rows kept)."""
+        ns = self.n_segs()
+        arr = (C.c_char_p * max(len(contig_names), 1))(*[c.encode() for c in contig_names])
+        in_fai = np.ascontiguousarray(np.concatenate([np.asarray(in_fai, np.uint8), [0]]), np.uint8)
+        sn, bc, bg = (np.zeros(max(ns, 1), np.uint32) for _ in range(3))
+        bd = np.zeros(max(ns, 1), np.uint8)
+        kept = C.c_uint64(0)
+        check(lib().gs_rowset_diag_filter(self._h, len(contig_names), arr, in_fai.ctypes.data, sn.ctypes.data, bc.ctypes.data,
+                                          bg.ctypes.data, bd.ctypes.data, C.byref(kept)))
+        return sn[:ns], bc[:ns], bg[:ns], bd[:ns], kept.value
+
+    def keep_flags(self) -> np.ndarray:
+        out = np.zeros(max(self.n, 1), np.uint8)
+        check(lib().gs_rowset_keep_flags(self._h, out.ctypes.data))
+        return out[: self.n]
+
+    def keep_filtered(self) -> None:
+        check(lib().gs_rowset_keep_filtered(self._h))
+
+    @staticmethod
+    def bad_keys(hap1: "RowSet", hap2: "RowSet", key_hap: np.ndarray, keep_on_device: bool = False):
+        """badsunks_AR.py over both haplotypes' filtered rows -> (bad[n_keys] uint8, [meancov1, meancov2], device pointer or None)."""
+        key_hap = np.ascontiguousarray(key_hap, np.uint8)
+        bad = np.zeros(max(len(key_hap), 1), np.uint8)
+        mc = (C.c_uint32 * 2)()
+        d = C.c_void_p()
+        check(lib().gs_rowset_bad_keys(hap1._h, hap2._h, len(key_hap), key_hap.ctypes.data, bad.ctypes.data, mc,
+                                       C.byref(d) if keep_on_device else None))
+        return bad[: len(key_hap)], [int(mc[0]), int(mc[1])], (d.value if keep_on_device else None)
+
+    def pair_stage(self, name_rank, name_long, d_key_bad=None, row_bad=None):
+        """process-by-contig over the rows -> dict(row_contig, row_name, row_id, region_contig, region_start, region_end, contigs_in, counters)."""
+        L = lib()
+        name_rank = np.ascontiguousarray(name_rank, np.uint32)
+        name_long = np.ascontiguousarray(name_long, np.uint8)
+        rb = np.ascontiguousarray(row_bad, np.uint8) if row_bad is not None else None
+        h = C.c_void_p()
+        check(L.gs_rowset_pair_stage(self._h, d_key_bad, rb.ctypes.data if rb is not None else None, len(name_rank),
+                                     name_rank.ctypes.data if len(name_rank) else None, name_long.ctypes.data if len(name_long) else None, C.byref(h)))
+        try:
+            t, nr, nc = L.gs_pairstage_n_rows(h), L.gs_pairstage_n_regions(h), L.gs_pairstage_n_contigs_in(h)
+            out = {"row_contig": _view(L.gs_pairstage_row_contig(h), t, np.uint32).copy(), "row_name": _view(L.gs_pairstage_row_name(h), t, np.uint32).copy(),
+                   "row_id": _view(L.gs_pairstage_row_id(h), t, np.int64).copy(),
+                   "region_contig": _view(L.gs_pairstage_region_contig(h), nr, np.uint32).copy(),
+                   "region_start": _view(L.gs_pairstage_region_start(h), nr, np.int64).copy(),
+                   "region_end": _view(L.gs_pairstage_region_end(h), nr, np.int64).copy(),
+                   "contigs_in": _view(L.gs_pairstage_contigs_in(h), nc, np.uint32).copy(),
+                   "counters": _view(L.gs_pairstage_counters(h), 8, np.uint64).copy()}
+        finally:
+            L.gs_pairstage_free(h)
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_rowset_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def free_device(ptr, device: int = 0) -> None:
+    if ptr:
+        check(lib().gs_device_free(device, ptr))
+
+
 def define_sunks(contigs, k: int, device: int = 0):
     """GPU SUNK definition (gs_sunks_define).
     contigs: [(name, ascii bytes)] of both haplotypes -> synth.SunkSet-like arrays in kmer.loc order."""

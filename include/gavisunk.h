@@ -356,6 +356,20 @@ const char *gs_sunkpos_contig_name(const gs_sunkpos *s, uint32_t contig);
 /* the text of row i (without newline), for step 2's verbatim copy-through */
 const char *gs_sunkpos_row_text(const gs_sunkpos *s, uint64_t row, uint32_t *len);
 
+/* What the row-set functions below need from a `.sunkpos` file beside its columns (all host side, native):
+ *   the distinct read names in first-seen order -- name id of every row, rank of every name in sorted order (what
+ *   `groupby("rname")` iterates in, process-by-contig_lowmem_AR.py:135), the name's text;
+ *   gs_sunkpos_names_long  name_long[n_names] <- 1 where the `.rlen` file has a row of that name with len >= minlen (:106-108)
+ *   gs_sunkpos_rows_bad    row_bad[n_rows] <- 1 where the row's `chrom:ID` is a line of the bad-SUNK list (:66-72)
+ *   gs_sunkpos_row_keys    dense ids of the rows' distinct (chrom, ID) pairs (first-seen order) -> number of keys */
+uint32_t gs_sunkpos_n_names(gs_sunkpos *s);
+const uint32_t *gs_sunkpos_row_name(gs_sunkpos *s);
+const uint32_t *gs_sunkpos_name_rank(gs_sunkpos *s);
+const char *gs_sunkpos_name(gs_sunkpos *s, uint32_t name);
+int gs_sunkpos_names_long(gs_sunkpos *s, const char *rlen_path, int64_t minlen, uint8_t *name_long);
+int gs_sunkpos_rows_bad(gs_sunkpos *s, const char *bad_path, uint8_t *row_bad);
+uint32_t gs_sunkpos_row_keys(gs_sunkpos *s, uint32_t *row_key, const uint32_t **key_contig, const int64_t **key_id);
+
 /* Per segment (read): the contig with the most distinct SUNK groups within 2500 bp of the median
  * diagonal, trying `pos+start` ("-") then `start-pos` ("+") per contig; ties go to the contig
  * with fewer hits, then to the first contig in the slot order of Nim's Table[string, ...]
@@ -447,6 +461,85 @@ int gs_copy_to_host(int device, void *dst, const void *d_src, uint64_t bytes);
 int gs_union_regions(int device, uint64_t n_rows, const uint32_t *row_read, const uint32_t *row_vertex,
                      uint32_t n_vertices, const int64_t *vertex_id, uint32_t *comp_size, int64_t *comp_min,
                      int64_t *comp_max);
+
+
+/* ------------------------------------------------------------------------------------------
+ * The device-resident second half of the engine: hit list (HBM) -> rows -> diagonal filter -> bad-SUNK histogram -> the
+ * file-level filtering and the pair stage of process-by-contig -> contig-wide union, without leaving the device.  The file
+ * drop-ins above (diag_filter_v3, badsunks, process-by-contig) run the same functions over rows parsed from text.
+ * ---------------------------------------------------------------------------------------- */
+
+/* The rows of the last pass over `r` where they lie in DEVICE memory (gs_hit[*n_out], stream order); valid until the next
+ * pass over `r`.  What kmerpos_annot3.nim:93 prints, before any text exists. */
+int gs_tag_hits_device(gs_table *t, gs_reads *r, const void **d_hits, uint64_t *n_out);
+
+/* kmer.loc rows in device memory: what turns a hit's payload (the loc row) into `chrom, start, ID` and the dense id of
+ * `chrom:ID` (kmerpos_annot3.nim:44-69 keeps them in `coords`).  From the host arrays of a gs_sunkdb (row_contig / row_start /
+ * row_group / row_loc), or straight from a device-resident SUNK set (borrows its arrays: the set must outlive the handle). */
+typedef struct gs_locrows gs_locrows;
+int gs_locrows_create(int device, uint64_t n_rows, const uint32_t *row_contig, const int64_t *row_start, const int64_t *row_group,
+                      const uint32_t *row_loc, gs_locrows **out);
+int gs_locrows_from_sunkset_dev(int device, const gs_sunkset_dev *s, gs_locrows **out);
+void gs_locrows_free(gs_locrows *lr);
+uint64_t gs_locrows_n_rows(const gs_locrows *lr);
+uint32_t gs_locrows_n_locs(const gs_locrows *lr);
+/* contig of every dense (chrom, ID) key: key_contig[gs_locrows_n_locs] (GS_NONE where no row carries the key) */
+int gs_locrows_key_contig(const gs_locrows *lr, uint32_t *key_contig);
+
+/* `.sunkpos` rows (`rname \t pos \t chrom \t start \t ID`, kmerpos_annot3.nim:93) as arrays in device memory, file order:
+ * name = id of the read name (equal names = equal ids), pos, contig id, start, ID, key = dense id of `chrom:ID`
+ * (all uint32: the Python stage reads them as such, process-by-contig_lowmem_AR.py:60).
+ *   gs_rowset_append_pass  the rows of the last pass over `r`, device to device (name id = name_base + gs_hit.read)
+ *   gs_rowset_append_host  rows parsed from a file (key may be NULL: then no function that needs keys can run) */
+typedef struct gs_rowset gs_rowset;
+int gs_rowset_create(int device, uint64_t cap_hint, gs_rowset **out);
+void gs_rowset_free(gs_rowset *rs);
+uint64_t gs_rowset_n(const gs_rowset *rs);
+int gs_rowset_append_pass(gs_rowset *rs, gs_table *t, gs_reads *r, uint32_t name_base, const gs_locrows *lr);
+int gs_rowset_append_host(gs_rowset *rs, uint64_t n, const uint32_t *name, const uint32_t *pos, const uint32_t *contig,
+                          const uint32_t *start, const uint32_t *id, const uint32_t *key);
+/* any destination may be NULL */
+int gs_rowset_download(const gs_rowset *rs, uint32_t *name, uint32_t *pos, uint32_t *contig, uint32_t *start, uint32_t *id, uint32_t *key);
+/* segments = runs of consecutive rows with one name: the reads of diag_filter_v3.nim:64 */
+int gs_rowset_segments(gs_rowset *rs, uint32_t *n_segs);
+/* diag_filter_v3.nim:63-229 over the row set, everything on the device -- rows sorted by (read, contig), the slot order of Nim's
+ * Table[string, ...] (capacity carried from read to read as a running maximum; a read that makes the table grow is replayed
+ * exactly), statistics per (read, contig), the selection per read.  contig_names[n_contigs] (the Table hashes the names),
+ * in_fai[n_contigs].  Host outputs, n_segs entries each, any may be NULL: seg_name (name id), best_contig (GS_NONE: the read
+ * prints nothing), best_good, best_dir ('-' / '+').  Every row gets its verdict (diag_filter_step2.nim:45-64). */
+int gs_rowset_diag_filter(gs_rowset *rs, uint32_t n_contigs, const char *const *contig_names, const uint8_t *in_fai, uint32_t *seg_name,
+                          uint32_t *best_contig, uint32_t *best_good, uint8_t *best_dir, uint64_t *n_kept);
+int gs_rowset_keep_flags(const gs_rowset *rs, uint8_t *keep);
+/* diag_filter_step2: drop the rows the filter did not keep (in place, order preserved) */
+int gs_rowset_keep_filtered(gs_rowset *rs);
+/* badsunks_AR.py:20-103 over the two haplotypes' filtered row sets.  key_hap[n_keys]: bit 0 = the key's contig is in hap1's
+ * fai, bit 1 = in hap2's.  bad_host[n_keys] (may be NULL) and *d_bad (may be NULL; device flags, gs_device_free) <- the union
+ * of the four bad sets; meancov[h] = the script's "mean coverage" (mode of the reads per SUNK group on the haplotype's own contigs). */
+int gs_rowset_bad_keys(const gs_rowset *hap1, const gs_rowset *hap2, uint32_t n_keys, const uint8_t *key_hap, uint8_t *bad_host,
+                       uint32_t meancov[2], void **d_bad);
+int gs_device_free(int device, void *p);
+/* process-by-contig_lowmem_AR.py:50-260 over a row set (rows of several contigs are handled contig by contig, like the
+ * workflow's per-contig files): bad SUNKs dropped (d_key_bad: device flags per key, and / or row_bad: host flags per row),
+ * reads with >= 2 distinct IDs, sort by (name, start), exact duplicates, reads >= 10 kb (name_long[n_names]), then per read the
+ * pair test / orientation / multi-position clean-up / largest component (gs_pair_component's kernels), the `ID \t rname` rows in
+ * sorted-name order (name_rank[n_names]) and the contig-wide union (gs_union_regions' kernels) -> validated intervals. */
+typedef struct gs_pairstage gs_pairstage;
+int gs_rowset_pair_stage(const gs_rowset *rs, const void *d_key_bad, const uint8_t *row_bad, uint32_t n_names, const uint32_t *name_rank,
+                         const uint8_t *name_long, gs_pairstage **out);
+void gs_pairstage_free(gs_pairstage *ps);
+uint64_t gs_pairstage_n_rows(const gs_pairstage *ps);            /* TSV rows, contig by contig (ascending id), reads in name order */
+const uint32_t *gs_pairstage_row_contig(const gs_pairstage *ps);
+const uint32_t *gs_pairstage_row_name(const gs_pairstage *ps);
+const int64_t *gs_pairstage_row_id(const gs_pairstage *ps);
+uint32_t gs_pairstage_n_regions(const gs_pairstage *ps);         /* BED rows, by (contig, start) */
+const uint32_t *gs_pairstage_region_contig(const gs_pairstage *ps);
+const int64_t *gs_pairstage_region_start(const gs_pairstage *ps);
+const int64_t *gs_pairstage_region_end(const gs_pairstage *ps);
+uint32_t gs_pairstage_n_contigs_in(const gs_pairstage *ps);      /* distinct contigs of the input rows (a contig without output
+                                                                    still gets its one-line file, :92-94,202-204) */
+const uint32_t *gs_pairstage_contigs_in(const gs_pairstage *ps);
+/* rows in | not bad | in reads with >= 2 IDs | after de-duplication | in reads >= 10 kb | read groups | TSV rows | 0 */
+const uint64_t *gs_pairstage_counters(const gs_pairstage *ps);
 
 #ifdef __cplusplus
 }

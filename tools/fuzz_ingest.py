@@ -46,44 +46,37 @@ def make(rng):
     return text
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    t0, rounds, refused, blocks_seen = time.time(), 0, 0, 0
-    d = tempfile.mkdtemp(prefix="gs_fuzz_ingest_")
-    path = os.path.join(d, "f")
-    while time.time() - t0 < budget:
-        rng = np.random.default_rng(seed)
-        text = make(rng)
-        if not text:
-            seed += 1
-            continue
-        open(path, "wb").write(text)
-        hn, hl, hbatch = [], [], []
-        for b in engine.read_batches(path):
-            hn += b.names
-            hl += b.len.tolist()
-            hbatch.append(b)
-        dn, dl, dreads, ok = [], [], [], True
-        for blk in engine.text_blocks(path, int(rng.choice([1 << 30, 1 << 16, 4096, 300]))):
-            blocks_seen += 1
-            try:
-                r = engine.DeviceReads.from_text(blk, K)
-            except _lib.GsError as e:
-                assert e.status == _lib.GS_E_IRREGULAR, e
-                ok = False
-                break
-            dn += r.names
-            dl += r.len.tolist()
-            dreads.append(r)
+def one_file(seed, path):
+    """One seeded file through both parsers -> "ok", "refused" (irregular: the host parser's job) -- or an AssertionError."""
+    rng = np.random.default_rng(seed)
+    text = make(rng)
+    if not text:
+        return "empty", 0
+    open(path, "wb").write(text)
+    blocks_seen = 0
+    hn, hl, hbatch = [], [], []
+    for b in engine.read_batches(path):
+        hn += b.names
+        hl += b.len.tolist()
+        hbatch.append(b)
+    dn, dl, dreads, ok = [], [], [], True
+    for blk in engine.text_blocks(path, int(rng.choice([1 << 30, 1 << 16, 4096, 300]))):
+        blocks_seen += 1
+        try:
+            r = engine.DeviceReads.from_text(blk, K)
+        except _lib.GsError as e:
+            assert e.status == _lib.GS_E_IRREGULAR, e
+            ok = False
+            break
+        dn += r.names
+        dl += r.len.tolist()
+        dreads.append(r)
+    try:
         if ok:
             assert dn == hn and dl == hl, (seed, len(dn), len(hn))
             # the bases: a table of this file's own k-mers; hit lists of both paths must be identical
             if sum(hl) >= K:
                 from oracle import oracle
-                seqs = []
-                for b in hbatch:
-                    pass
                 keys = np.unique(np.concatenate([oracle.canonical_windows(bytes(s), K) for s in _seqs_of(text)]))[:200000]
                 tab = engine.DeviceTable(K, keys, (np.arange(len(keys)) % 977).astype(np.uint32), np.arange(len(keys), dtype=np.uint32))
                 carry, hh, base = _lib.GS_NONE, [], 0
@@ -99,14 +92,28 @@ def main():
                     dh.append(h)
                 assert carry == carry2 and np.array_equal(np.concatenate(hh), np.concatenate(dh)), seed
                 tab.close()
-        else:
-            refused += 1
+    finally:
         for r in dreads:
             r.close()
         for b in hbatch:
             b.close()
-        rounds += 1
+    return ("ok" if ok else "refused"), blocks_seen
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0, rounds, refused, blocks_seen = time.time(), 0, 0, 0
+    d = tempfile.mkdtemp(prefix="gs_fuzz_ingest_")
+    path = os.path.join(d, "f")
+    while time.time() - t0 < budget:
+        what, nb = one_file(seed, path)
         seed += 1
+        if what == "empty":
+            continue
+        blocks_seen += nb
+        refused += what == "refused"
+        rounds += 1
     print(f"OK: {rounds} files (seeds up to {seed - 1}), {refused} refused as irregular, {blocks_seen} blocks")
     return 0
 

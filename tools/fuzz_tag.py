@@ -96,21 +96,24 @@ def tag(layout, keys, loc, seqs, cuts):
     return np.concatenate(parts), carry, raw, win, name
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    t0, rounds, names = time.time(), 0, {}
-    while time.time() - t0 < budget:
-        keys, loc, seqs, env = draw(seed)
-        for k in ("GAVISUNK_COMPACT_QB",):
-            os.environ.pop(k, None)
-        os.environ.update(env)
+def one_round(seed, hot=None, verbose=False):
+    """One seeded round: every layout against the first one, small rounds against the oracle too.  hot: GAVISUNK_MZ_HOT for the
+    round (None: the library's own rule; 0: never a hot region; n: regions with n misfits become hot).
+    -> (ok, message, {layout name: 1})"""
+    keys, loc, seqs, env = draw(seed)
+    for k in ("GAVISUNK_COMPACT_QB", "GAVISUNK_MZ_HOT"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    if hot is not None:
+        os.environ["GAVISUNK_MZ_HOT"] = str(hot)
+    names = {}
+    try:
         rng = np.random.default_rng(seed + 7)
         n = len(seqs)
         cuts = [0, n] if rng.random() < 0.5 else sorted({0, n, *(int(x) for x in rng.integers(0, n + 1, 3))})
         ref = None
         for layout in LAYOUTS:
-            if os.environ.get("FUZZ_VERBOSE"):  # which (seed, layout) a GPU fault belongs to
+            if verbose:  # which (seed, layout) a GPU fault belongs to
                 print(f"seed {seed} k {K} layout {layout} keys {len(keys)} reads {len(seqs)} env {env} cuts {cuts}", flush=True)
             got = tag(layout, keys, loc, seqs, cuts if layout != "generic" else [0, n])
             names[got[4]] = names.get(got[4], 0) + 1
@@ -119,9 +122,8 @@ def main():
             else:
                 ok = np.array_equal(got[0], ref[0]) and got[1:4] == ref[1:4]
                 if not ok:
-                    print(f"MISMATCH seed {seed} k {K} layout {layout} ({got[4]}) vs {ref[4]}: rows {len(got[0])} / {len(ref[0])}, "
-                          f"carry {got[1]} / {ref[1]}, raw {got[2]} / {ref[2]}, env {env}, cuts {cuts}", flush=True)
-                    return 1
+                    return False, (f"MISMATCH seed {seed} k {K} layout {layout} ({got[4]}) vs {ref[4]}: rows {len(got[0])} / {len(ref[0])}, "
+                                   f"carry {got[1]} / {ref[1]}, raw {got[2]} / {ref[2]}, env {env}, hot {hot}, cuts {cuts}"), names
         if ref[3] < 3_000_000:  # the oracle too
             t = oracle.Table(K, keys, keys, np.zeros(len(keys), np.uint32), loc.astype(np.int64))
             buf, off = oracle.concat_reads(seqs)
@@ -130,8 +132,24 @@ def main():
                   and np.array_equal(oh["pos"], ref[0]["pos"]) and np.array_equal(oh["row"], ref[0]["payload"])
                   and octr["raw_hits"] == ref[2] and octr["windows"] == ref[3])
             if not ok:
-                print(f"ORACLE MISMATCH seed {seed} k {K}: rows {len(oh)} / {len(ref[0])}, env {env}", flush=True)
-                return 1
+                return False, f"ORACLE MISMATCH seed {seed} k {K}: rows {len(oh)} / {len(ref[0])}, env {env}, hot {hot}", names
+        return True, "", names
+    finally:
+        for k in ("GAVISUNK_COMPACT_QB", "GAVISUNK_MZ_HOT", "GAVISUNK_TABLE"):
+            os.environ.pop(k, None)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0, rounds, names = time.time(), 0, {}
+    while time.time() - t0 < budget:
+        ok, msg, seen = one_round(seed, hot=(None, 0, 3)[seed % 3], verbose=bool(os.environ.get("FUZZ_VERBOSE")))
+        for k_, v in seen.items():
+            names[k_] = names.get(k_, 0) + v
+        if not ok:
+            print(msg, flush=True)
+            return 1
         rounds += 1
         seed += 1
         if rounds % 10 == 0:
