@@ -66,6 +66,14 @@ SIGNATURES = {
     "gs_batch_len": (P, [P]),
     "gs_batch_name": (C.c_char_p, [P, U32]),
     "gs_batch_from_ascii": (I, [P, P, U32, C.POINTER(P)]),
+    "gs_gz_open": (I, [C.c_char_p, I, C.POINTER(P)]),
+    "gs_gz_read": (I, [P, U64, P, U64, C.POINTER(P), C.POINTER(U64)]),
+    "gs_gz_free_buffer": (None, [P]),
+    "gs_gz_at_end": (I, [P]),
+    "gs_gz_mode": (C.c_char_p, [P]),
+    "gs_gz_pieces": (U64, [P, C.POINTER(U64)]),
+    "gs_gz_close": (None, [P]),
+    "gs_text_record_cut": (U64, [P, U64]),
     "gs_table_create": (I, [I, I, U64, P, P, P, C.POINTER(P)]),
     "gs_table_create_device": (I, [I, I, U64, P, P, P, C.POINTER(P)]),
     "gs_table_destroy": (None, [P]),

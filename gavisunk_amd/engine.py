@@ -156,10 +156,57 @@ def read_batches(path: str, max_bases: int = 1 << 30, max_reads: int = 1 << 22) 
         lib().gs_fastx_close(fx)
 
 
+class _NativeBuffer:
+    """Bytes the native library handed over (gs_gz_read): freed when the last view of them goes."""
+
+    def __init__(self, ptr: int, n: int):
+        self.ptr, self.n = ptr, n
+
+    def view(self, lo: int, hi: int):
+        arr = (C.c_ubyte * max(hi - lo, 0)).from_address(self.ptr + lo)
+        arr._gs_owner = self  # (the array -- and every memoryview / numpy array made from it -- keeps the buffer alive)
+        return memoryview(arr).cast("B")
+
+    def __del__(self):
+        if self.ptr:
+            lib().gs_gz_free_buffer(self.ptr)
+            self.ptr = 0
+
+
+def gz_text_blocks(path: str, max_bytes: int = 1 << 30, threads: int = 0):
+    """The inflated text of a gzip-compressed FASTA / FASTQ file in blocks of whole records: inflated by the native parallel
+    reader (csrc/gs_inflate.cpp: several threads, block starts found in the compressed stream, CRC checked), cut where
+    gs_text_record_cut says a record ends.  Raises GsError(GS_E_IO) where zlib would fail too."""
+    L = lib()
+    z = C.c_void_p()
+    check(L.gs_gz_open(path.encode(), threads, C.byref(z)))
+    try:
+        rem = b""
+        while True:
+            p, n = C.c_void_p(), C.c_uint64(0)
+            check(L.gs_gz_read(z, max_bytes - len(rem) if max_bytes > len(rem) else max_bytes, rem, len(rem), C.byref(p), C.byref(n)))
+            buf = _NativeBuffer(p.value or 0, n.value)
+            if n.value == len(rem) and L.gs_gz_at_end(z):  # end of file: what is left is the last block
+                if n.value:
+                    yield buf.view(0, n.value)
+                return
+            cut = n.value if L.gs_gz_at_end(z) else L.gs_text_record_cut(p, n.value)
+            if cut <= 0:  # (a record longer than a block: grow)
+                rem = bytes(buf.view(0, n.value))
+                continue
+            rem = bytes(buf.view(cut, n.value))
+            yield buf.view(0, cut)
+            if L.gs_gz_at_end(z) and not rem:
+                return
+    finally:
+        L.gs_gz_close(z)
+
+
 def text_blocks(path: str, max_bytes: int = 1 << 30) -> Iterator[bytes]:
     """The (decompressed) text of a FASTA / FASTQ file in blocks of whole records, for DeviceReads.from_text: FASTA blocks end
     before a line that starts with '>', FASTQ blocks after a multiple of four lines (the regular four-line form; anything
-    else is refused by gs_reads_from_text and read by the host parser instead)."""
+    else is refused by gs_reads_from_text and read by the host parser instead).  `.gz` files are inflated by the native
+    parallel reader (gz_text_blocks); GAVISUNK_GZ=python keeps Python's gzip module (one zlib thread) instead."""
     import gzip
 
     import mmap
@@ -170,6 +217,9 @@ def text_blocks(path: str, max_bytes: int = 1 << 30) -> Iterator[bytes]:
         if not gz and 0 < size <= max_bytes:  # one block: the file's pages as they are (no copy on the host at all)
             yield mmap.mmap(probe.fileno(), 0, access=mmap.ACCESS_READ)  # (unmapped when its last user lets go of it)
             return
+    if gz and os.environ.get("GAVISUNK_GZ", "native") != "python":
+        yield from gz_text_blocks(path, max_bytes)
+        return
     f = gzip.open(path, "rb") if gz else open(path, "rb")
     try:
         rem = b""

@@ -107,6 +107,25 @@ const char *gs_batch_name(const gs_batch *b, uint32_t read);
  * Packing applies the `encode` table above. */
 int gs_batch_from_ascii(const uint8_t *seq, const uint64_t *off, uint32_t n_reads, gs_batch **out);
 
+/* Parallel gzip inflation (csrc/gs_inflate.cpp) for the `.fq.gz` files rule SUNK_annot is given (tagONT.smk:17,36; the
+ * reference reads them through zlib inside `readfq`, kmerpos_annot3.nim:85).  Workers find deflate block starts in their piece
+ * of the compressed file, decode with the unknown 32 KiB window kept symbolic, and the pieces are chained from the true start of
+ * the stream (only proven block boundaries are used); CRC-32 and size of every member are checked.  Any gzip file works
+ * (multi-member, stored / fixed blocks: those decode on one thread); a damaged file fails with GS_E_IO where zlib fails.
+ *   gs_gz_open    threads = 0: one per hardware thread (at most 32; GAVISUNK_GZ_THREADS overrides)
+ *   gs_gz_read    `prefix` (what the caller carried over from the stretch before: an unfinished record), then at least `want`
+ *                 new bytes unless the file ends first.  *data is handed over: free it with gs_gz_free_buffer.
+ *   gs_text_record_cut   where a block of FASTA / four-line FASTQ text can be cut so that it holds whole records */
+typedef struct gs_gzfile gs_gzfile;
+int gs_gz_open(const char *path, int threads, gs_gzfile **out);
+int gs_gz_read(gs_gzfile *z, uint64_t want, const uint8_t *prefix, uint64_t prefix_len, uint8_t **data, uint64_t *n);
+void gs_gz_free_buffer(uint8_t *p);
+int gs_gz_at_end(const gs_gzfile *z);
+const char *gs_gz_mode(const gs_gzfile *z);
+uint64_t gs_gz_pieces(const gs_gzfile *z, uint64_t *dropped);
+void gs_gz_close(gs_gzfile *z);
+uint64_t gs_text_record_cut(const uint8_t *text, uint64_t n);
+
 /* ------------------------------------------------------------------------------------------
  * Device side.
  * ---------------------------------------------------------------------------------------- */

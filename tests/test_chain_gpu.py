@@ -136,7 +136,7 @@ def _rows_with_many_contigs(rng, n_contigs_big):
     """Reads whose hits spread over 2 .. n_contigs_big contigs, with ties in (good, hit count) between contigs -- the slot order of
     Nim's Table decides, its capacity grows at the big reads and stays grown for the reads after them."""
     rows = []
-    contigs = [f"ctg{j:03d}_{int(rng.integers(0, 10**5))}" for j in range(n_contigs_big + 40)]
+    contigs = [f"ctg{j:03d}_{int(rng.integers(0, 10**5))}" for j in range(max(n_contigs_big, 90) + 40)]
     for r in range(60):
         nc = n_contigs_big if r in (20, 41) else (90 if r == 30 else int(rng.integers(2, 9)))
         mine = rng.choice(len(contigs), size=nc, replace=False)
