@@ -326,6 +326,11 @@ def cli_large_leg(a, device):
         sunks.write_files(gen.names, f"{d}/db", f"{d}/loc")
         rng = np.random.default_rng(31)
         rs = synth_gpu.ReadSet(gen, synth_gpu.lognormal_lengths(rng, 4000, median=32000.0), seed=31000)
+        big = None
+        if not a.no_cli_genome_scale and shutil.disk_usage("/tmp").free > 64 << 30:
+            # >= 1e10 bases of reads for the genome-scale run below (measurement (iii) at scale), written as rule split_ONT writes
+            # them: `seqtk seq -F '#'` FASTQ, gzip members one after the other (tagONT.smk:17; compressed by 16 threads here)
+            big = synth_gpu.ReadSet(gen, synth_gpu.lognormal_lengths(rng, 250_000, median=32000.0), seed=31001)
         gen.close()
         with open(f"{d}/reads.fa", "wb") as f:
             for i, sq in enumerate(rs.host_reads(0, rs.n_reads)):
@@ -333,6 +338,22 @@ def cli_large_leg(a, device):
         n_bases, n_keys = rs.n_bases, sunks.n
         rs.close()
         sunks.close()
+        big_bases = 0
+        if big is not None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            t1 = time.perf_counter()
+            big_bases, nb = big.n_bases, big.n_reads
+
+            def member(lo):
+                hi = min(lo + 500, nb)
+                return gzip.compress(b"".join(b"@g%d\n" % (lo + j) + sq + b"\n+\n" + b"#" * len(sq) + b"\n" for j, sq in enumerate(big.host_reads(lo, hi))), 1)
+
+            with open(f"{d}/big.fq.gz", "wb") as f, ThreadPoolExecutor(16) as pool:
+                for blob in pool.map(member, range(0, nb, 500)):
+                    f.write(blob)
+            big.close()
+            log(f"genome-scale reads: {nb} reads, {big_bases} bases -> big.fq.gz {os.path.getsize(f'{d}/big.fq.gz') / 2**30:.2f} GiB ({time.perf_counter() - t1:.1f} s)")
         log(f"CLI at {n_keys} keys: files written ({time.perf_counter() - t0:.1f} s; db {os.path.getsize(f'{d}/db') / 2**30:.1f} GiB, loc {os.path.getsize(f'{d}/loc') / 2**30:.1f} GiB)")
 
         def run(tag):
@@ -346,11 +367,38 @@ def cli_large_leg(a, device):
         t_prep = time.perf_counter() - t1
         rc3, t_side = run("side")
         same = rc1 == rc2 == rc3 == 0 and open(f"{d}/out.plain", "rb").read() == open(f"{d}/out.side", "rb").read()
+        scale = None
+        if big_bases:
+            t1 = time.perf_counter()
+            rc4 = kmerpos_annot3.main([f"{d}/big.fq.gz", f"{d}/db", f"{d}/loc", f"{d}/out.big"])
+            t_big = time.perf_counter() - t1
+            tm = dict(kmerpos_annot3.last_timing)
+            rows_big = int(tm.pop("rows", 0))
+            # spot check: the first rows against a plain run over the head of the file's text (first member = first 500 reads)
+            head = gzip.GzipFile(fileobj=open(f"{d}/big.fq.gz", "rb")).read(20_000_000)
+            cut = head.rfind(b"\n@g")
+            open(f"{d}/head.fq", "wb").write(head[:cut + 1])
+            rc5 = kmerpos_annot3.main([f"{d}/head.fq", f"{d}/db", f"{d}/loc", f"{d}/out.head"])
+            hd = open(f"{d}/out.head", "rb").read()
+            last_name = hd[hd.rfind(b"\n", 0, len(hd) - 1) + 1:].split(b"\t")[0] if hd else b""
+            with open(f"{d}/out.big", "rb") as fb:
+                hb = fb.read(len(hd) + 4096)
+            # (the carry of the head run and of the full run agree up to the head's last read)
+            ok_head = rc4 == rc5 == 0 and len(hd) > 1000 and hb[:hd.rfind(b"\n" + last_name + b"\t") + 1] == hd[:hd.rfind(b"\n" + last_name + b"\t") + 1]
+            scale = {"read_bases": int(big_bases), "fq_gz_GiB": round(os.path.getsize(f"{d}/big.fq.gz") / 2**30, 2), "rows_out": rows_big,
+                     "sunkpos_MiB": round(os.path.getsize(f"{d}/out.big") / 2**20, 1), "seconds": round(t_big, 2), "cli_bases_per_s": big_bases / t_big,
+                     "seconds_by_phase": {k_: round(v, 2) for k_, v in tm.items()},
+                     "head_of_output_equals_a_run_over_the_head_of_the_file": bool(ok_head),
+                     "note": "`python -m gavisunk_amd.kmerpos_annot3 big.fq.gz db loc out` with the sidecar: multi-member .fq.gz (quals '#') inflated by the native parallel reader "
+                             "(gs_gz_*), text blocks copied to the device and parsed there, rows written natively (gs_rowwriter_*).  read_or_inflate_text and "
+                             "copy_text_to_device run on the reader thread beside the others; wait_for_reader is what the main thread waits for them"}
+
         res = {"keys": int(n_keys), "read_bases": int(n_bases), "rows_out": open(f"{d}/out.plain", "rb").read().count(b"\n"),
                "parse_and_build_every_run": {"seconds": round(t_plain, 2), "cli_bases_per_s": n_bases / t_plain},
                "prepare_once": {"seconds": round(t_prep, 2), "sidecar_GiB": round(os.path.getsize(f"{d}/loc.gsidx") / 2**30, 2)},
                "with_sidecar": {"seconds": round(t_side, 2), "cli_bases_per_s": n_bases / t_side},
                "same_bytes": bool(same),
+               **({"cli_genome_scale": scale} if scale else {}),
                "note": "`python -m gavisunk_amd.kmerpos_annot3 reads.fa db loc out` in a warm process on a 200 Mb surrogate's files (the reference parses db and loc on every "
                        "run, once per scatter chunk: kmerpos_annot3.nim:20-72, tagONT.smk:19-37); with_sidecar = after `--prepare db loc` (parsed location rows + built table in "
                        "loc.gsidx, used only while its fingerprints of db and loc hold)"}
@@ -575,6 +623,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra workload key (N = 1: one diploid shard; N > 1: config-3 weak scaling)")
     ap.add_argument("--cli", action="store_true", help="(default now) config-2 leg: also time the command-line drop-in")
     ap.add_argument("--no-cli", action="store_true", help="config-2 leg without the command-line timing")
+    ap.add_argument("--no-cli-genome-scale", action="store_true", help="skip the >= 1e10-base .fq.gz run of the command-line timing")
     ap.add_argument("--no-cli-large", action="store_true", help="skip the command-line timing at 1e8 keys (files of a 200 Mb surrogate, with / without the sidecar)")
     a = ap.parse_args()
     a.cli = not a.no_cli
@@ -964,8 +1013,10 @@ def main():
             if a.cli and not a.no_cli_large and a.workload == "auto" and a.genome_mb is None:
                 try:
                     out["cli_1e8_keys"] = cli_large_leg(a, device)
+                    if "cli_genome_scale" in out["cli_1e8_keys"]:
+                        out["cli_genome_scale"] = out["cli_1e8_keys"].pop("cli_genome_scale")
                 except Exception as e:  # (a measurement leg must not cost the headline)
-                    out["cli_1e8_keys"] = {"failed": str(e)}
+                    out["cli_1e8_keys"] = {"failed": repr(e)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:

@@ -805,6 +805,125 @@ int gs_diag_filter_step2_files(const char *sunkpos_path, const char *diag_path, 
 
 }  // extern "C"
 
+// ------------------------------------------------------------------------------------- output rows
+// `name \t i \t chrom \t start \t group \n` (kmerpos_annot3.nim:93), formatted and written natively: a genome-scale pass emits
+// 1e7 .. 1e8 rows, far beyond what a per-row Python format survives.
+struct gs_rowwriter {
+    FILE *f = nullptr;
+    std::vector<char> buf;
+    uint64_t rows = 0;
+    bool flush() {
+        if (buf.empty()) return true;
+        const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        buf.clear();
+        return ok;
+    }
+};
+static inline char *put_u64(char *p, uint64_t v) {
+    char tmp[24];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+static inline char *put_i64(char *p, int64_t v) {
+    if (v < 0) {
+        *p++ = '-';
+        return put_u64(p, (uint64_t)(-(v + 1)) + 1u);
+    }
+    return put_u64(p, (uint64_t)v);
+}
+
+extern "C" {
+
+int gs_rowwriter_open(const char *path, gs_rowwriter **out) {
+    if (!path || !out) {
+        set_error("gs_rowwriter_open: null argument");
+        return GS_E_ARG;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        set_error("cannot create the file %s", path);
+        return GS_E_IO;
+    }
+    gs_rowwriter *w = new gs_rowwriter;
+    w->f = f;
+    w->buf.reserve(8u << 20);
+    *out = w;
+    return GS_OK;
+}
+// n rows of one batch: read names from (names_base + name_off[read], name_len[read]) -- the text block a device-parsed batch came
+// from (gs_textindex_*) -- or, when name_off is NULL, from `batch` (gs_batch_name)
+int gs_rowwriter_rows(gs_rowwriter *w, const gs_hit *hits, uint64_t n, const gs_sunkdb *db, const uint8_t *names_base,
+                      const uint64_t *name_off, const uint32_t *name_len, const gs_batch *batch) {
+    if (!w || !db || (n && !hits) || (!name_off && !batch) || (name_off && (!names_base || !name_len))) {
+        set_error("gs_rowwriter_rows: null argument");
+        return GS_E_ARG;
+    }
+    const uint64_t n_rows = db->row_contig.size();
+    for (uint64_t i = 0; i < n; i++) {
+        const gs_hit h = hits[i];
+        if (h.payload >= n_rows) {
+            set_error("gs_rowwriter_rows: payload %u is no loc row", h.payload);
+            return GS_E_ARG;
+        }
+        const char *nm;
+        size_t nl;
+        if (name_off) {
+            nm = reinterpret_cast<const char *>(names_base) + name_off[h.read];
+            nl = name_len[h.read];
+        } else {
+            if (h.read >= batch->len.size()) {
+                set_error("gs_rowwriter_rows: read %u is not in the batch", h.read);
+                return GS_E_ARG;
+            }
+            nm = batch->names.data() + batch->name_off[h.read];
+            nl = strlen(nm);
+        }
+        const std::string &cn = db->contigs[db->row_contig[h.payload]];
+        const size_t o = w->buf.size();
+        w->buf.resize(o + nl + cn.size() + 80);
+        char *p = w->buf.data() + o;
+        memcpy(p, nm, nl);
+        p += nl;
+        *p++ = '\t';
+        p = put_u64(p, h.pos);
+        *p++ = '\t';
+        memcpy(p, cn.data(), cn.size());
+        p += cn.size();
+        *p++ = '\t';
+        p = put_i64(p, db->row_start[h.payload]);
+        *p++ = '\t';
+        p = put_i64(p, db->row_group[h.payload]);
+        *p++ = '\n';
+        w->buf.resize((size_t)(p - w->buf.data()));
+        if (w->buf.size() > (7u << 20) && !w->flush()) {
+            set_error("gs_rowwriter_rows: write failed");
+            return GS_E_IO;
+        }
+    }
+    w->rows += n;
+    return GS_OK;
+}
+// flushes and closes; *rows_out = rows written
+int gs_rowwriter_close(gs_rowwriter *w, uint64_t *rows_out) {
+    if (!w) return GS_OK;
+    bool ok = w->flush();
+    ok = fclose(w->f) == 0 && ok;
+    if (rows_out) *rows_out = w->rows;
+    delete w;
+    if (!ok) {
+        set_error("gs_rowwriter_close: write failed");
+        return GS_E_IO;
+    }
+    return GS_OK;
+}
+
+}  // extern "C"
+
 // ------------------------------------------------------------------------------------- sunkpos
 extern "C" {
 

@@ -174,29 +174,48 @@ class _NativeBuffer:
 
 
 def gz_text_blocks(path: str, max_bytes: int = 1 << 30, threads: int = 0):
-    """The inflated text of a gzip-compressed FASTA / FASTQ file in blocks of whole records: inflated by the native parallel
-    reader (csrc/gs_inflate.cpp: several threads, block starts found in the compressed stream, CRC checked), cut where
-    gs_text_record_cut says a record ends.  Raises GsError(GS_E_IO) where zlib would fail too."""
+    """The inflated text of a gzip-compressed FASTA / FASTQ file in blocks of whole records of about max_bytes: inflated by the
+    native parallel reader (csrc/gs_inflate.cpp: several threads, block starts found in the compressed stream, CRC checked),
+    cut where gs_text_record_cut says a record ends.  Large blocks are views of the reader's buffers (no copy); small ones are
+    bytes.  Raises GsError(GS_E_IO) where zlib would fail too."""
     L = lib()
     z = C.c_void_p()
     check(L.gs_gz_open(path.encode(), threads, C.byref(z)))
+
+    def piece(buf, lo, hi):
+        v = buf.view(lo, hi)
+        return v if hi - lo >= (1 << 24) else bytes(v)
+
     try:
         rem = b""
         while True:
             p, n = C.c_void_p(), C.c_uint64(0)
             check(L.gs_gz_read(z, max_bytes - len(rem) if max_bytes > len(rem) else max_bytes, rem, len(rem), C.byref(p), C.byref(n)))
-            buf = _NativeBuffer(p.value or 0, n.value)
-            if n.value == len(rem) and L.gs_gz_at_end(z):  # end of file: what is left is the last block
-                if n.value:
-                    yield buf.view(0, n.value)
+            buf, n, at_end = _NativeBuffer(p.value or 0, n.value), n.value, bool(L.gs_gz_at_end(z))
+            if n == len(rem) and at_end:  # end of file: what is left is the last block
+                if n:
+                    yield piece(buf, 0, n)
                 return
-            cut = n.value if L.gs_gz_at_end(z) else L.gs_text_record_cut(p, n.value)
-            if cut <= 0:  # (a record longer than a block: grow)
-                rem = bytes(buf.view(0, n.value))
-                continue
-            rem = bytes(buf.view(cut, n.value))
-            yield buf.view(0, cut)
-            if L.gs_gz_at_end(z) and not rem:
+            off = 0
+            while n - off > max_bytes:  # (a read delivers whole groups of pieces: more than one block's worth)
+                w, cut = max_bytes, 0
+                while True:
+                    cut = L.gs_text_record_cut(buf.ptr + off, w)
+                    if cut or w >= n - off:
+                        break
+                    w = min(2 * w, n - off)  # a record longer than a block: grow
+                if not cut:
+                    break
+                yield piece(buf, off, off + cut)
+                off += cut
+            cut = n - off if at_end else L.gs_text_record_cut(buf.ptr + off, n - off)
+            if cut:
+                yield piece(buf, off, off + cut)
+            rem = bytes(buf.view(off + cut, n))
+            if at_end and not rem:
+                return
+            if at_end:  # (text after the last record end of a file that is over: the last block)
+                yield rem
                 return
     finally:
         L.gs_gz_close(z)
@@ -363,14 +382,24 @@ class DeviceReads:
         self = cls.__new__(cls)
         self._h, self.k, self.device = h, k, device
         n = L.gs_textindex_n_reads(ix)
-        no = _view(L.gs_textindex_name_off(ix), n, np.uint64).tolist()
-        nl = _view(L.gs_textindex_name_len(ix), n, np.uint32).tolist()
+        # (the names stay where they are in the text: a genome-scale batch has 1e6 of them, and the row writer takes them from there)
+        self._name_off = _view(L.gs_textindex_name_off(ix), n, np.uint64).copy()
+        self._name_len = _view(L.gs_textindex_name_len(ix), n, np.uint32).copy()
+        self._text = text
+        self._names = None
         self.len = _view(L.gs_textindex_len(ix), n, np.uint32).copy()
-        self.names = [bytes(text[o:o + l]).decode() for o, l in zip(no, nl)]
         L.gs_textindex_free(ix)
         self.n_reads, self.n_bases = n, int(self.len.sum())
         self.n_windows = L.gs_reads_n_windows(h)
         return self
+
+    @property
+    def names(self) -> List[str]:
+        """Read names, file order (made on first use)."""
+        if getattr(self, "_names", None) is None:
+            text = self._text
+            self._names = [bytes(text[o:o + l]).decode() for o, l in zip(self._name_off.tolist(), self._name_len.tolist())]
+        return self._names
 
     @classmethod
     def from_text(cls, text: bytes, k: int, device: int = 0) -> "DeviceReads":
@@ -510,6 +539,43 @@ def format_sunkpos(hits: np.ndarray, names: Sequence[str], db: SunkDB) -> str:
     return "".join(f"{names[r]}\t{p}\t{cn[c]}\t{s}\t{g}\n"
                    for r, p, c, s, g in zip(hits["read"].tolist(), hits["pos"].tolist(), contig.tolist(),
                                             start.tolist(), group.tolist()))
+
+
+class RowWriter:
+    """The tagger's output file, written natively (gs_rowwriter_*): `name \\t i \\t chrom \\t start \\t group` per emitted hit."""
+
+    def __init__(self, path: str):
+        h = C.c_void_p()
+        check(lib().gs_rowwriter_open(path.encode(), C.byref(h)))
+        self._h = h
+
+    def write(self, hits: np.ndarray, reads, db: "SunkDB") -> None:
+        """hits of one batch; reads: the DeviceReads (parsed on the device: names taken from its text block) or the ReadBatch
+        (host parser) they index into."""
+        if not len(hits):
+            return
+        hits = np.ascontiguousarray(hits)
+        if getattr(reads, "_name_off", None) is not None:
+            base = np.frombuffer(reads._text, dtype=np.uint8)
+            check(lib().gs_rowwriter_rows(self._h, hits.ctypes.data, len(hits), db._h, base.ctypes.data, reads._name_off.ctypes.data,
+                                          reads._name_len.ctypes.data, None))
+        else:
+            check(lib().gs_rowwriter_rows(self._h, hits.ctypes.data, len(hits), db._h, None, None, None, reads._h))
+
+    def close(self) -> int:
+        n = C.c_uint64(0)
+        if getattr(self, "_h", None):
+            h, self._h = self._h, None
+            check(lib().gs_rowwriter_close(h, C.byref(n)))
+        return n.value
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    __del__ = close
 
 
 class SunkPos:

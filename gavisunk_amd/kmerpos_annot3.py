@@ -29,7 +29,19 @@ import queue
 import sys
 import threading
 
+import time
+
 from . import _lib, engine
+
+# seconds of the last run() by phase (inflate / read of the text, copy to the device, record parse on the device, tagging,
+# formatting + writing the rows, waiting for the reader thread); what bench.py's `cli_genome_scale` key reports
+last_timing: dict = {}
+
+
+def _tick(key: str, t0: float) -> float:
+    t1 = time.perf_counter()
+    last_timing[key] = last_timing.get(key, 0.0) + (t1 - t0)
+    return t1
 
 
 class _Prefetch:
@@ -57,8 +69,21 @@ class _Prefetch:
 
     def _work(self, path, max_bases):
         try:
-            src = (engine.StagedText(t, self._device) for t in engine.text_blocks(path, max_bases)) if self._text else \
-                engine.read_batches(path, max_bases=max_bases)
+            if self._text:
+                def staged():
+                    it = engine.text_blocks(path, max_bases)
+                    while True:
+                        t0 = time.perf_counter()
+                        t = next(it, None)
+                        t0 = _tick("read_or_inflate_text", t0)
+                        if t is None:
+                            return
+                        st = engine.StagedText(t, self._device)
+                        _tick("copy_text_to_device", t0)
+                        yield st
+                src = staged()
+            else:
+                src = engine.read_batches(path, max_bases=max_bases)
             for b in src:
                 if not self._put(b):
                     b.close()
@@ -92,8 +117,14 @@ def _tag_text_blocks(blocks, db, table, ofile: str, device: int):
     """The reads file as text blocks parsed on the GPU (gs_reads_from_text).  -> exit code, or None
     when the text is outside the regular FASTA / FASTQ subset the device parser takes (nothing useful is written then)."""
     carry = _lib.GS_NONE
-    with open(ofile, "w") as out:
-        for staged in blocks:
+    with engine.RowWriter(ofile) as out:  # (rows formatted and written natively: gs_rowwriter_rows)
+        it = iter(blocks)
+        while True:
+            t0 = time.perf_counter()
+            staged = next(it, None)
+            t0 = _tick("wait_for_reader", t0)
+            if staged is None:
+                break
             try:
                 dev = engine.DeviceReads.from_staged(staged, db.k)
             except _lib.GsError as e:
@@ -102,9 +133,13 @@ def _tag_text_blocks(blocks, db, table, ofile: str, device: int):
                     return None
                 raise
             staged.close()
+            t0 = _tick("parse_records_on_device", t0)
             st, hits, carry, _ = engine.tag(table, dev, carry)
-            out.write(engine.format_sunkpos(hits, dev.names, db))
+            t0 = _tick("tag", t0)
+            out.write(hits, dev, db)
+            last_timing["rows"] = last_timing.get("rows", 0) + len(hits)
             dev.close()
+            _tick("write_rows", t0)
             if st == _lib.GS_E_KEYERROR:
                 sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
                 return 1
@@ -118,13 +153,13 @@ def _tag_host_batches(batches, db, table, ofile: str, batch_bases: int) -> int:
     it = iter(batches)
     first = next(it, None)
     second = next(it, None) if first is not None else None
-    with open(ofile, "w") as out:
+    with engine.RowWriter(ofile) as out:
         if first is None:
             return 0
         if second is None:
             dev = engine.DeviceReads(first, db.k, table.device)
             st, hits, _, _ = engine.tag(table, dev)
-            out.write(engine.format_sunkpos(hits, first.names, db))
+            out.write(hits, first, db)
             dev.close()
             first.close()
             if st == _lib.GS_E_KEYERROR:
@@ -141,7 +176,7 @@ def _tag_host_batches(batches, db, table, ofile: str, batch_bases: int) -> int:
             while len(pending) > upto:
                 st, hits, _, _ = stream.next(copy=False)
                 b, dev = pending.pop(0)
-                out.write(engine.format_sunkpos(hits, b.names, db))
+                out.write(hits, b, db)
                 if dev is not None:
                     dev.close()
                 b.close()
@@ -179,6 +214,8 @@ def _tag_host_batches(batches, db, table, ofile: str, batch_bases: int) -> int:
 
 def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_bases: int = 1 << 31) -> int:
     host_parse = os.environ.get("GAVISUNK_PARSE", "device") == "host"
+    last_timing.clear()
+    t_run = time.perf_counter()
     batches = _Prefetch(reads, batch_bases) if host_parse else None
     blocks = None if host_parse else _Prefetch(reads, min(batch_bases, 1 << 30), text=True, device=device)  # (read and copied meanwhile)
     try:
@@ -193,10 +230,12 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
         return 1
     sys.stderr.write("FINISHED READING KMERS\n")
     sys.stderr.write("FINISHED READING LOCS\n")
+    t_run = _tick("load_db_and_loc", t_run)
     if pre is not None:
         db, table = pre
     else:
         table = engine.DeviceTable.from_db(db, device)
+        _tick("build_table", t_run)
         if os.environ.get("GAVISUNK_WRITE_SIDECAR") == "1":
             try:
                 engine.write_sidecar(db, table, kmers, locs)

@@ -292,6 +292,15 @@ void gs_table_counters(const gs_table *t, gs_counters *out);
 int gs_reads_copy_words(const gs_reads *r, uint64_t word_lo, uint64_t n_words, uint64_t *dst);
 
 
+/* The output file: rows `name \t i \t chrom \t start \t group \n` (kmerpos_annot3.nim:93) formatted and written natively.
+ * Names of a batch come from the text block a device-parsed batch was made from (names_base + name_off[read], name_len[read]:
+ * gs_textindex_name_off / _name_len) or, with name_off = NULL, from a host-parsed `batch`. */
+typedef struct gs_rowwriter gs_rowwriter;
+int gs_rowwriter_open(const char *path, gs_rowwriter **out);
+int gs_rowwriter_rows(gs_rowwriter *w, const gs_hit *hits, uint64_t n, const gs_sunkdb *db, const uint8_t *names_base,
+                      const uint64_t *name_off, const uint32_t *name_len, const gs_batch *batch);
+int gs_rowwriter_close(gs_rowwriter *w, uint64_t *rows_out);
+
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU: read-sharded tagging, the SUNK table replicated.  One process per GPU; the data plane is
  * RCCL over xGMI, inside the library.  The reference has no counterpart (its parallelism is Snakemake's per-chunk scatter,

@@ -29,26 +29,50 @@ def one_pass(table, reads, carry=_lib.GS_NONE):
     return engine._view(vp.value, n.value, engine.HIT_DTYPE).copy(), c_out.value, ctr.as_dict()
 
 
-def oracle_slice(sunks, rs, k, lo, hi, prev_loc):
-    """Oracle over reads [lo, hi) with the sub-table of SUNKs that occur in them -> (hits, global rows of the sub-table, counters)."""
+def _windows_of(seqs, k):
+    """distinct canonical window codes of the reads, 250 reads at a time on a few threads (the C helper and NumPy's sort both run
+    without the GIL): a slice of thousands of reads has 1e8 windows"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def part(a):
+        return np.unique(np.concatenate([oracle.canonical_windows(s if len(s) >= k else s + b"A" * (k - len(s)), k) for s in seqs[a:a + 250]]))
+
+    with ThreadPoolExecutor(8) as pool:
+        parts = list(pool.map(part, range(0, len(seqs), 250)))
+    return np.unique(np.concatenate(parts))
+
+
+def oracle_slice_inputs(sunks, rs, k, lo, hi, prev_loc):
+    """What the oracle needs for reads [lo, hi): the reads, the sub-table of SUNKs that occur in them (rows of the full set found
+    by a set-membership kernel of the bench-support library), the row standing for the carried location group."""
     seqs = rs.host_reads(lo, hi)
-    q = np.unique(np.concatenate([oracle.canonical_windows(s if len(s) >= k else s + b"A" * (k - len(s)), k) for s in seqs]))
+    q = _windows_of(seqs, k)
     L = _lib.lib()
     rows = synth_gpu.select_rows(0, L.gs_sunkset_dev_code(sunks._h), sunks.n, q)
     code = synth_gpu.gather(0, L.gs_sunkset_dev_code(sunks._h), np.uint64, rows)
     pos = synth_gpu.gather(0, L.gs_sunkset_dev_pos(sunks._h), np.uint64, rows)
     grp = synth_gpu.gather(0, L.gs_sunkset_dev_group(sunks._h), np.uint32, rows)
     loc = synth_gpu.gather(0, L.gs_sunkset_dev_loc(sunks._h), np.uint32, rows)
-    t = oracle.Table(k, code, code, (pos >> np.uint64(32)).astype(np.uint32), grp.astype(np.int64))
     prev_row = oracle.NONE
     if prev_loc != _lib.GS_NONE:  # any row of that location group: the oracle compares (contig, group)
         w = np.nonzero(loc == prev_loc)[0]
         if len(w):  # (a carried group without a SUNK in this slice cannot suppress anything here)
             prev_row = int(w[0])
+    return seqs, rows, code, pos, grp, prev_row
+
+
+def oracle_slice_run(k, inputs):
+    """-> (hits, global rows of the sub-table, counters); a C call that releases the GIL: slices run side by side"""
+    seqs, rows, code, pos, grp, prev_row = inputs
+    t = oracle.Table(k, code, code, (pos >> np.uint64(32)).astype(np.uint32), grp.astype(np.int64))
     buf, off = oracle.concat_reads(seqs)
-    rc, oh, _, octr = t.tag(buf, off, prev_row=prev_row, cap=1 << 24)
+    rc, oh, _, octr = t.tag(buf, off, prev_row=prev_row, cap=max(1 << 20, int(off[-1]) // 8))
     assert rc == 0
     return oh, rows, octr
+
+
+def oracle_slice(sunks, rs, k, lo, hi, prev_loc):
+    return oracle_slice_run(k, oracle_slice_inputs(sunks, rs, k, lo, hi, prev_loc))
 
 
 def full_size_checks(table, reads, rs, sunks, k, cuts, slices, min_rows, min_slice_rows, hit_rate=(0.1, 0.4)):
@@ -91,14 +115,22 @@ def full_size_checks(table, reads, rs, sunks, k, cuts, slices, min_rows, min_sli
     assert cuts[0] == 0 and cuts[-1] == n_reads and cr == carry and raw == c["raw_hits"] and np.array_equal(parts, whole)
     del parts
 
-    # slices of the stream against the oracle
+    # slices of the stream against the oracle (>= 1 % of the reads in all): the GPU-side preparation of every slice first, then
+    # the oracle over all of them on a few host threads
+    from concurrent.futures import ThreadPoolExecutor
+
+    inputs = []
     for lo, hi in slices:
         prev = _lib.GS_NONE
         if lo:
             dr = engine.device_reads_from_device_ascii(rs.ptr, rs.off[: lo + 1], k)
             _, prev, _ = one_pass(table, dr)
             dr.close()
-        oh, rows, octr = oracle_slice(sunks, rs, k, lo, hi, prev)
+        inputs.append(oracle_slice_inputs(sunks, rs, k, lo, hi, prev))
+    with ThreadPoolExecutor(8) as pool:
+        results = list(pool.map(lambda x: oracle_slice_run(k, x), inputs))
+    del inputs
+    for (lo, hi), (oh, rows, octr) in zip(slices, results):
         mine = whole[(whole["read"] >= lo) & (whole["read"] < hi)]
         assert len(mine) == len(oh) > min_slice_rows
         assert np.array_equal(mine["read"] - lo, oh["read"]) and np.array_equal(mine["pos"], oh["pos"])

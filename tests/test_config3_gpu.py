@@ -24,7 +24,8 @@ def test_config3_full_size():
         assert table.layout.startswith("minimizer-hbm") and sunks.n > 1_000_000_000 and rs.n_bases > 3.5e10
         n = W["reads"]
         full_size_checks(table, reads, rs, sunks, K, cuts=[0, 1, 300_000, 300_001, 999_000, n],
-                         slices=((0, 600), (500_000, 500_300), (n - 200, n)), min_rows=1_000_000, min_slice_rows=1000)
+                         slices=((0, 2500), (125_000, 126_000), (250_000, 251_000), (375_000, 376_000), (500_000, 501_500), (625_000, 626_000),
+                                 (750_000, 751_000), (n - 2000, n)), min_rows=1_000_000, min_slice_rows=1000)
     finally:
         reads.close()
         table.close()

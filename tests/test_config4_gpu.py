@@ -29,7 +29,7 @@ def test_other_sunk_lengths_full_size(k):
         assert sunks.n > 800_000_000 and rs.n_bases > 3.5e10 and synth_gpu.n50(rs.off[1:] - rs.off[:-1]) > 95_000
         n = W["reads"]
         full_size_checks(table, reads, rs, sunks, k, cuts=[0, 1, 150_000, 150_001, 499_000, n],
-                         slices=((0, 300), (250_000, 250_150), (n - 100, n)), min_rows=1_000_000, min_slice_rows=300,
+                         slices=((0, 1500), (125_000, 126_000), (250_000, 251_000), (375_000, 376_000), (n - 1000, n)), min_rows=1_000_000, min_slice_rows=300,
                          hit_rate=(0.05, 0.4))
     finally:
         reads.close()

@@ -33,7 +33,7 @@ def test_diploid_shard_full_size():
         assert table.layout.startswith("minimizer-hbm") and rs.n_bases > 1.4e10
         n = W["reads"]
         whole, carry, c = full_size_checks(table, reads, rs, sunks, K, cuts=[0, 1, 100_000, 100_001, 366_000, n],
-                                           slices=((0, 1500), (180_000, 181_000), (n - 800, n)), min_rows=1_000_000,
+                                           slices=((0, 1500), (90_000, 90_500), (180_000, 181_000), (270_000, 270_500), (n - 800, n)), min_rows=1_000_000,
                                            min_slice_rows=1000, hit_rate=(0.005, 0.2))
         # rows from both haplotypes (contigs 0..23 = hap 1, 24..47 = hap 2)
         L = _lib.lib()
