@@ -78,14 +78,15 @@ def source_hash() -> str:
 
 def traffic_for(workload_key: str):
     """HBM bytes per launch from a separate rocprofv3 --pmc run (never collected inside the bench); quoted only for the
-    exact workload and kernel sources they were measured on (profiles/r03/traffic.json)."""
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r03", "traffic.json")))
-        e = tj[workload_key]
-        if e.get("source_hash") == source_hash():
-            return e["hbm_bytes_per_launch"], e.get("note")
-    except (OSError, KeyError, ValueError):
-        pass
+    exact workload and kernel sources they were measured on (profiles/r04/traffic.json: one entry per GPU workload)."""
+    for rnd in ("r04", "r03"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
+            e = tj[workload_key]
+            if e.get("source_hash") == source_hash():
+                return e["hbm_bytes_per_launch"], e.get("note")
+        except (OSError, KeyError, ValueError):
+            pass
     return None, None
 
 
@@ -613,6 +614,8 @@ def main():
     ap.add_argument("--genome-mb", type=float, default=None, help="assembly size in Mb per haplotype (default: the workload's own)")
     ap.add_argument("--shards", type=int, default=None, help="diploid: read shards per rank (default 8 / ranks at N > 1, 1 at N = 1)")
     ap.add_argument("--batches", type=int, default=None, help="resident device batches per shard (default 8)")
+    ap.add_argument("--group-len", type=int, default=0, help="haploid workloads: an interspersed 44-base element every N bases of unique sequence, so that "
+                    "location groups are ~N SUNKs long (the default surrogate: ~12 000); a surrogate-realism sweep, not the headline")
     ap.add_argument("--k", type=int, default=20, help="SUNK length (headline: 20; 21 / 25 = BASELINE.json configs[4])")
     ap.add_argument("--check-reads", type=int, default=1000, help="reads of the stream the oracle walks for the parity leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-time budget of the CPU baseline sample")
@@ -688,6 +691,9 @@ def main():
     def run_workload(wname, shards, batches_per_shard, steps, warmup, want_sample, want_chain=False):
         """Builds the workload, times `steps` passes, -> dict of raw results (rank 0: everything; others: timings only)."""
         w = dict(synth_gpu.WORKLOADS[wname])
+        if a.group_len and w["kind"] == "haploid":
+            w["group_len"] = a.group_len
+            w["title"] += f" with an interspersed element every {a.group_len} bases (location groups of ~{a.group_len} SUNKs)"
         a.batches = batches_per_shard
         a.keep_sunks = bool(want_chain)
         table, batches, n_sunks, n_groups, sample, kept_sunks = build_workload(a, w, device, rank, world, comm, shards)
@@ -866,7 +872,7 @@ def main():
         pass_step_s = c["total_ms"] / launches / 1e3 * len(res["batches"])
         bpb = alg_bytes_per_base(h_raw, h_emit)
         achieved = n_bases * bpb / probe_step_s / 1e9
-        default_size = a.genome_mb is None and a.reads is None
+        default_size = a.genome_mb is None and a.reads is None and not a.group_len
         wkey = f"{res['wname']}:k{K}:{'full' if default_size else 'reduced'}"
         traffic, tnote = traffic_for(wkey) if world == 1 else (None, None)
         n50 = synth_gpu.n50(res["rlen"]) if len(res["rlen"]) else 0
@@ -989,7 +995,7 @@ def main():
                 out["engine_note"] = f"engine leg failed: {e}"
     release(res)
     # ---- the other genome-scale workload as an extra key --------------------------------------------------------------
-    if not a.no_extra and a.workload == "auto" and K == 20 and a.genome_mb is None and a.reads is None:
+    if not a.no_extra and a.workload == "auto" and K == 20 and a.genome_mb is None and a.reads is None and not a.group_len:
         if world == 1:
             ex = run_workload("diploid", [0], 8, max(3, a.steps // 2), 1, want_sample=False)
             if rank == 0:

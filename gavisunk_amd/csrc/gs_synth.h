@@ -12,7 +12,7 @@ const char *gs_synth_last_error(void);
 void gs_synth_free(int device, void *d);
 /* ASCII assembly of n_bases: uniform ACGT, slots of family_len bases are repeat-family copies with probability repeat_fraction */
 int gs_synth_genome(int device, uint64_t seed, uint64_t n_bases, double repeat_fraction, uint32_t n_families, uint32_t family_len,
-                    void **d_ascii_out);
+                    uint32_t break_period, void **d_ascii_out);
 /* diploid assembly (BASELINE.json configs[3]): hap 1 then hap 2, n_bases_per_hap each, both descended from the assembly
  * gs_synth_genome makes from the same arguments; the haplotypes differ at a fraction `snp` of the sites, and a fraction `spec`
  * of each haplotype's slots of spec_len bases is sequence found nowhere else */

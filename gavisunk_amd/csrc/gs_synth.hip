@@ -44,22 +44,31 @@ __device__ __forceinline__ uint8_t ascii_of(uint32_t c) { return (uint8_t)("ACGT
 __device__ __forceinline__ uint8_t complement(uint8_t b) { return b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : 'A'; }
 
 // base i of the (ancestral) assembly: a pure function of (seed, i)
-__device__ __forceinline__ uint32_t ancestor_base(uint64_t i, uint64_t seed, uint32_t family_len, uint32_t n_families, uint32_t repeat_thr) {
+// break_period > 0: unique sequence is interrupted every break_period bases by a 44-base interspersed element (one of 32, the
+// same bases wherever it lands): its 25 windows are no SUNKs, a gap longer than k, so the run of SUNKs -- the location group
+// (workflow/rules/defineSUNKs.smk:124-126: one group per merged interval) -- ends there.  0: groups as long as the unique slots.
+constexpr uint32_t kBreakLen = 44;
+__device__ __forceinline__ uint32_t ancestor_base(uint64_t i, uint64_t seed, uint32_t family_len, uint32_t n_families, uint32_t repeat_thr,
+                                                  uint32_t break_period = 0) {
     const uint64_t slot = i / family_len;
     const uint64_t hs = mix64(seed ^ (slot * 0xD1B54A32D192ED03ULL) ^ 0xABCDEF);
     uint64_t h;
     if ((uint32_t)hs < repeat_thr) {  // a repeat slot: base (i mod family_len) of family (hs >> 32) mod n_families
         const uint64_t fam = (hs >> 32) % n_families;
         h = mix64(seed ^ 0x5EED0FFA ^ ((fam << 32) | (i % family_len)));
+    } else if (break_period && i % break_period < kBreakLen) {
+        const uint64_t elem = mix64(seed ^ 0xB4EA ^ (i / break_period)) & 31u;
+        h = mix64(seed ^ 0xE1E3 ^ ((elem << 32) | (i % break_period)));
     } else {
         h = mix64(seed ^ (i * 0x9E3779B97F4A7C15ULL));
     }
     return (uint32_t)(h >> 13) & 3u;
 }
 
-__global__ void k_genome(uint8_t *out, uint64_t n, uint64_t seed, uint32_t family_len, uint32_t n_families, uint32_t repeat_thr) {
+__global__ void k_genome(uint8_t *out, uint64_t n, uint64_t seed, uint32_t family_len, uint32_t n_families, uint32_t repeat_thr,
+                         uint32_t break_period) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        out[i] = ascii_of(ancestor_base(i, seed, family_len, n_families, repeat_thr));
+        out[i] = ascii_of(ancestor_base(i, seed, family_len, n_families, repeat_thr, break_period));
 }
 
 // BASELINE.json configs[3] (cfg 4): haplotype `hap` (0 / 1) of a diploid assembly -- both descend from
@@ -166,7 +175,7 @@ void gs_synth_free(int device, void *d) {
 }
 
 int gs_synth_genome(int device, uint64_t seed, uint64_t n_bases, double repeat_fraction, uint32_t n_families, uint32_t family_len,
-                    void **d_ascii_out) {
+                    uint32_t break_period, void **d_ascii_out) {
     if (!d_ascii_out || !n_bases || !n_families || !family_len || repeat_fraction < 0 || repeat_fraction > 1) {
         snprintf(g_err, sizeof g_err, "gs_synth_genome: bad argument");
         return -1;
@@ -175,7 +184,7 @@ int gs_synth_genome(int device, uint64_t seed, uint64_t n_bases, double repeat_f
     uint8_t *d = nullptr;
     SY_TRY(hipMalloc((void **)&d, n_bases + 64));
     const uint32_t thr = (uint32_t)(repeat_fraction * 4294967295.0);
-    hipLaunchKernelGGL(k_genome, dim3(8192), dim3(256), 0, 0, d, n_bases, seed, family_len, n_families, thr);
+    hipLaunchKernelGGL(k_genome, dim3(8192), dim3(256), 0, 0, d, n_bases, seed, family_len, n_families, thr, break_period);
     SY_TRY(hipGetLastError());
     SY_TRY(hipDeviceSynchronize());
     *d_ascii_out = d;

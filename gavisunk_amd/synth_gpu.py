@@ -32,7 +32,7 @@ def lib() -> C.CDLL:
         L.gs_synth_last_error.restype = C.c_char_p
         L.gs_synth_free.argtypes = [I, P]
         L.gs_synth_free.restype = None
-        L.gs_synth_genome.argtypes = [I, U64, U64, D, U32, U32, C.POINTER(P)]
+        L.gs_synth_genome.argtypes = [I, U64, U64, D, U32, U32, U32, C.POINTER(P)]
         L.gs_synth_diploid.argtypes = [I, U64, U64, D, U32, U32, D, D, U32, C.POINTER(P)]
         L.gs_synth_reads.argtypes = [I, U64, P, U32, P, P, P, D, D, D, C.POINTER(P), P]
         L.gs_synth_select_rows.argtypes = [I, P, U64, P, U64, P, U64, C.POINTER(U64)]
@@ -60,7 +60,9 @@ class Genome:
     1..22, X, Y roughly); slots of `family_len` bases are exact repeat-family copies with probability `repeat_fraction`."""
 
     def __init__(self, total_bases: int, n_contigs: int = 24, repeat_fraction: float = 0.5, n_families: int = 64,
-                 family_len: int = 6000, seed: int = 30, device: int = 0):
+                 family_len: int = 6000, seed: int = 30, device: int = 0, break_period: int = 0):
+        """break_period > 0: a 44-base interspersed element every break_period bases of unique sequence, so that the runs of SUNKs
+        -- the location groups -- are about that long instead of as long as the unique slots (12 000 on average)."""
         wts = np.linspace(2.0, 0.5, n_contigs)
         lens = np.maximum((wts / wts.sum() * total_bases).astype(np.int64), 1000)
         self.off = np.zeros(n_contigs + 1, dtype=np.uint64)
@@ -68,7 +70,7 @@ class Genome:
         self.names = [f"ctg{i + 1}" for i in range(n_contigs)]
         self.device = device
         p = P()
-        _check(lib().gs_synth_genome(device, seed, int(self.off[-1]), repeat_fraction, n_families, family_len, C.byref(p)))
+        _check(lib().gs_synth_genome(device, seed, int(self.off[-1]), repeat_fraction, n_families, family_len, break_period, C.byref(p)))
         self.ptr = p.value
 
     @property
@@ -202,7 +204,8 @@ def make_genome(w: dict, genome_mb: float | None = None, device: int = 0) -> Gen
     if w["kind"] == "diploid":
         return DiploidGenome(int(mb * 1e6), n_contigs=24, repeat_fraction=w["repeat_fraction"], snp=w["snp"], spec=w["spec"],
                              spec_len=w["spec_len"], seed=w["seed"], device=device)
-    return Genome(int(mb * 1e6), n_contigs=24, repeat_fraction=w["repeat_fraction"], seed=w["seed"], device=device)
+    return Genome(int(mb * 1e6), n_contigs=24, repeat_fraction=w["repeat_fraction"], seed=w["seed"], device=device,
+                  break_period=int(w.get("group_len", 0)))
 
 
 def make_reads(w: dict, gen: Genome, n_reads: int | None = None, shard: int = 0) -> ReadSet:
