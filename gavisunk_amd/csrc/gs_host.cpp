@@ -16,6 +16,10 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -305,6 +309,203 @@ static bool parse_i64(const char *b, const char *e, int64_t &v) {
     return true;
 }
 
+
+// ---- the location table parsed by several threads (a plain file of some size: mapped, cut at line ends) ----------------------
+// Every thread parses its stretch into arrays of its own, numbering contig names and (contig, group) pairs locally in
+// first-seen order; the merge walks the threads in file order, so the global numbering is the one a single pass gives.
+// -> 0 done, 1 a malformed line (*err_line = its 1-based number), -1 not applicable (gzip, small, cannot map): the caller's
+// line-by-line loop then reads the file.
+struct LocPart {
+    std::vector<uint32_t> cid, pid;  // per row: local contig id, local (contig, group) pair id
+    std::vector<int64_t> start, group;
+    std::vector<uint64_t> code;
+    std::vector<std::string> contigs;                   // local contigs, first-seen order
+    std::vector<std::pair<uint32_t, int64_t>> pairs;    // local (local contig, group) pairs, first-seen order
+    uint64_t lines = 0, err_line = 0;
+    bool err = false;
+};
+struct PairHash64 {
+    size_t operator()(const std::pair<uint32_t, int64_t> &p) const {
+        return std::hash<uint64_t>()(((uint64_t)p.first << 40) ^ (uint64_t)p.second * 0x9E3779B97F4A7C15ULL);
+    }
+};
+static void parse_loc_part(const char *b, const char *e, LocPart &o) {
+    std::unordered_map<std::string, uint32_t> contig_id;
+    std::unordered_map<std::pair<uint32_t, int64_t>, uint32_t, PairHash64> pairmap;
+    std::string name;
+    bool have_last = false;
+    uint32_t last_cid = 0, last_pid = 0;
+    int64_t last_group = 0;
+    const size_t guess = (size_t)(e - b) / 40 + 16;
+    o.cid.reserve(guess), o.pid.reserve(guess), o.start.reserve(guess), o.group.reserve(guess), o.code.reserve(guess);
+    while (b < e) {
+        const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
+        const char *le = nl ? nl : e;
+        const char *next = nl ? nl + 1 : e;
+        o.lines++;
+        if (le > b && le[-1] == '\r') le--;
+        if (le == b) {
+            b = next;
+            continue;
+        }
+        const char *f[4], *fe[4];
+        int nf = 0;
+        const char *s0 = b;
+        for (const char *q = b;; q++) {
+            if (q == le || *q == '\t') {
+                if (nf < 4) {
+                    f[nf] = s0;
+                    fe[nf] = q;
+                }
+                nf++;
+                s0 = q + 1;
+                if (q == le) break;
+            }
+        }
+        int64_t start, group;
+        if (nf < 4 || !parse_i64(f[1], fe[1], start) || !parse_i64(f[3], fe[3], group)) {
+            o.err = true;
+            o.err_line = o.lines;
+            return;
+        }
+        uint32_t cid;
+        const size_t nlen = (size_t)(fe[0] - f[0]);
+        if (have_last && nlen == name.size() && !memcmp(name.data(), f[0], nlen)) {
+            cid = last_cid;
+        } else {
+            name.assign(f[0], nlen);
+            auto it = contig_id.find(name);
+            if (it == contig_id.end()) {
+                cid = (uint32_t)o.contigs.size();
+                contig_id.emplace(name, cid);
+                o.contigs.push_back(name);
+            } else {
+                cid = it->second;
+            }
+        }
+        uint32_t pid;
+        if (have_last && cid == last_cid && group == last_group) {
+            pid = last_pid;
+        } else {
+            auto key = std::make_pair(cid, group);
+            auto lt = pairmap.find(key);
+            if (lt == pairmap.end()) {
+                pid = (uint32_t)o.pairs.size();
+                pairmap.emplace(key, pid);
+                o.pairs.push_back(key);
+            } else {
+                pid = lt->second;
+            }
+        }
+        have_last = true;
+        last_cid = cid;
+        last_group = group;
+        last_pid = pid;
+        o.cid.push_back(cid);
+        o.pid.push_back(pid);
+        o.start.push_back(start);
+        o.group.push_back(group);
+        o.code.push_back(encode_kmer(f[2], (size_t)(fe[2] - f[2])));
+        b = next;
+    }
+}
+static int parse_loc_parallel(const char *path, gs_sunkdb *d, std::vector<uint64_t> &row_code, uint64_t *err_line) {
+    if (getenv("GAVISUNK_LOC_THREADS") && atoi(getenv("GAVISUNK_LOC_THREADS")) <= 1) return -1;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < (4 << 20)) {
+        close(fd);
+        return -1;
+    }
+    const size_t n = (size_t)st.st_size;
+    void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return -1;
+    const char *p = static_cast<const char *>(m);
+    if ((unsigned char)p[0] == 0x1f && (unsigned char)p[1] == 0x8b) {  // gzip: the line reader inflates it
+        munmap(m, n);
+        return -1;
+    }
+    unsigned T = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("GAVISUNK_LOC_THREADS")) T = (unsigned)std::max(1, atoi(e));
+    T = (unsigned)std::min<size_t>(T, n >> 20);
+    std::vector<size_t> cut(T + 1, n);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; t++) {  // the first line start at or after n t / T
+        size_t q = n * t / T;
+        if (q < cut[t - 1]) q = cut[t - 1];
+        const char *nl = q < n ? (const char *)memchr(p + q, '\n', n - q) : nullptr;
+        cut[t] = nl ? (size_t)(nl - p) + 1 : n;
+    }
+    std::vector<LocPart> parts(T);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; t++) pool.emplace_back([&, t]() { parse_loc_part(p + cut[t], p + cut[t + 1], parts[t]); });
+        parse_loc_part(p + cut[0], p + cut[1], parts[0]);
+        for (auto &th : pool) th.join();
+    }
+    munmap(m, n);
+    uint64_t lines_before = 0;
+    for (unsigned t = 0; t < T; t++) {
+        if (parts[t].err) {
+            *err_line = lines_before + parts[t].err_line;
+            return 1;
+        }
+        lines_before += parts[t].lines;
+    }
+    // merge, in file order: global contig ids, then global (contig, group) ids
+    std::unordered_map<std::string, uint32_t> contig_id;
+    std::unordered_map<std::pair<uint32_t, int64_t>, uint32_t, PairHash64> locmap;
+    std::vector<std::vector<uint32_t>> cmap(T), pmap(T);
+    std::vector<size_t> row0(T + 1, 0);
+    for (unsigned t = 0; t < T; t++) {
+        LocPart &o = parts[t];
+        cmap[t].resize(o.contigs.size());
+        for (size_t c = 0; c < o.contigs.size(); c++) {
+            auto it = contig_id.find(o.contigs[c]);
+            if (it == contig_id.end()) {
+                it = contig_id.emplace(o.contigs[c], (uint32_t)d->contigs.size()).first;
+                d->contigs.push_back(o.contigs[c]);
+            }
+            cmap[t][c] = it->second;
+        }
+        pmap[t].resize(o.pairs.size());
+        for (size_t q = 0; q < o.pairs.size(); q++) {
+            const auto key = std::make_pair(cmap[t][o.pairs[q].first], o.pairs[q].second);
+            auto it = locmap.find(key);
+            if (it == locmap.end()) it = locmap.emplace(key, (uint32_t)locmap.size()).first;
+            pmap[t][q] = it->second;
+        }
+        row0[t + 1] = row0[t] + o.cid.size();
+    }
+    const size_t nrows = row0[T];
+    d->row_contig.resize(nrows);
+    d->row_start.resize(nrows);
+    d->row_group.resize(nrows);
+    d->row_loc.resize(nrows);
+    row_code.resize(nrows);
+    {
+        auto place = [&](unsigned t) {
+            const LocPart &o = parts[t];
+            const size_t b = row0[t];
+            for (size_t i = 0; i < o.cid.size(); i++) {
+                d->row_contig[b + i] = cmap[t][o.cid[i]];
+                d->row_loc[b + i] = pmap[t][o.pid[i]];
+            }
+            if (!o.cid.empty()) {
+                memcpy(d->row_start.data() + b, o.start.data(), o.start.size() * sizeof(int64_t));
+                memcpy(d->row_group.data() + b, o.group.data(), o.group.size() * sizeof(int64_t));
+                memcpy(row_code.data() + b, o.code.data(), o.code.size() * sizeof(uint64_t));
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; t++) pool.emplace_back(place, t);
+        place(0);
+        for (auto &th : pool) th.join();
+    }
+    return 0;
+}
 }  // namespace gs
 
 using namespace gs;
@@ -395,7 +596,17 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
     CodeMap rowmap[kMapParts];
     auto map_part = [](uint64_t code) { return (unsigned)((code * 0xD6E8FEB86659FD93ULL) >> 61); };
     std::vector<uint64_t> row_code;
-    {
+    uint64_t par_err_line = 0;
+    const int par = parse_loc_parallel(loc_path, d, row_code, &par_err_line);
+    if (par == 1) {
+        db_thread.join();
+        const int rc = db_rc != GS_OK ? db_error()
+                                      : (set_error("%s:%llu: expected `chrom<TAB>start<TAB>kmer<TAB>group`", loc_path, (unsigned long long)par_err_line),
+                                         GS_E_IO);
+        delete d;
+        return rc;
+    }
+    if (par < 0) {
         LineReader r(loc_path);
         if (!r.ok()) {
             db_thread.join();

@@ -70,14 +70,38 @@ class _Prefetch:
     def _work(self, path, max_bases):
         try:
             if self._text:
+                # two stages of their own: the text of block i + 1 is read / inflated (native threads, no GIL) while block i is
+                # copied to the device
+                tq: queue.Queue = queue.Queue(maxsize=1)
+
+                def inflate():
+                    try:
+                        it = engine.text_blocks(path, max_bases)
+                        while not self._stop.is_set():
+                            t0 = time.perf_counter()
+                            t = next(it, None)
+                            _tick("read_or_inflate_text", t0)
+                            while not self._stop.is_set():
+                                try:
+                                    tq.put(t, timeout=0.1)
+                                    break
+                                except queue.Full:
+                                    pass
+                            if t is None:
+                                return
+                    except BaseException as e:
+                        tq.put(e)
+
+                threading.Thread(target=inflate, daemon=True).start()
+
                 def staged():
-                    it = engine.text_blocks(path, max_bases)
                     while True:
-                        t0 = time.perf_counter()
-                        t = next(it, None)
-                        t0 = _tick("read_or_inflate_text", t0)
+                        t = tq.get()
                         if t is None:
                             return
+                        if isinstance(t, BaseException):
+                            raise t
+                        t0 = time.perf_counter()
                         st = engine.StagedText(t, self._device)
                         _tick("copy_text_to_device", t0)
                         yield st
