@@ -241,3 +241,52 @@ def test_diag_filter_step2_command_line_writes_stdout(golden):
     p = subprocess.run([sys.executable, "-m", "gavisunk_amd.diag_filter_step2", c.path(run["sunkpos"]), c.path(run["out"])],
                        cwd=root, capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and p.stdout == c.text(run["out2"])
+
+
+def test_loc_table_parsed_by_several_threads_equals_one_thread(tmp_path, monkeypatch):
+    """gs_sunkdb_load reads a plain location table of some size with several threads (stretches cut at line ends, contig and
+    (contig, group) numbering merged in file order): every array equals the single-thread result, CRLF / empty lines / duplicate
+    k-mers (last row wins) included, and a malformed line is reported with the same line number."""
+    import random
+
+    from gavisunk_amd import _lib, engine
+
+    rnd = random.Random(3)
+    lines = []
+    for i in range(160_000):
+        c = f"ctg{rnd.randint(0, 30)}"
+        s = rnd.randint(0, 10**7)
+        lines.append(f"{c}\t{s}\t{''.join(rnd.choice('ACGT') for _ in range(20))}\t{s // 500 * 500}" + ("\r" if i % 7 == 0 else ""))
+        if i % 1000 == 0:
+            lines.append("")
+    lines += lines[100:200]  # duplicate k-mers: the later row wins
+    (tmp_path / "loc").write_text("\n".join(lines) + "\n")
+    (tmp_path / "db").write_text("\n".join(ln.split("\t")[2] for ln in lines[::3] if ln) + "\n")
+    assert (tmp_path / "loc").stat().st_size > (4 << 20)
+
+    def load(threads, loc="loc"):
+        if threads:
+            monkeypatch.setenv("GAVISUNK_LOC_THREADS", str(threads))
+        else:
+            monkeypatch.delenv("GAVISUNK_LOC_THREADS", raising=False)
+        db = engine.SunkDB(str(tmp_path / "db"), str(tmp_path / loc))
+        out = {k: np.array(getattr(db, k)) for k in ("keys", "key_row", "key_loc", "row_contig", "row_start", "row_group", "row_loc")}
+        out["contigs"] = list(db.contigs)
+        db.close()
+        return out
+
+    one = load(1)
+    for threads in (0, 3, 7):
+        got = load(threads)
+        assert got["contigs"] == one["contigs"]
+        for k in one:
+            if k != "contigs":
+                assert np.array_equal(got[k], one[k]), (threads, k)
+    assert len(one["row_contig"]) == 160_100 and len(one["contigs"]) == 31
+    (tmp_path / "loc_bad").write_text("\n".join(lines[:120_000]) + "\nbad line here\n" + "\n".join(lines[120_000:]) + "\n")
+    msgs = []
+    for threads in (1, 0):
+        with pytest.raises(_lib.GsError) as e:
+            load(threads, "loc_bad")
+        msgs.append(e.value.msg)
+    assert msgs[0] == msgs[1] and ":120001:" in msgs[0]
