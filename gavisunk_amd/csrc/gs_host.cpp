@@ -409,6 +409,72 @@ static void parse_loc_part(const char *b, const char *e, LocPart &o) {
         b = next;
     }
 }
+// the k-mer list (one k-mer per line) parsed by several threads: -> false when not applicable (gzip, small, cannot map)
+static bool parse_db_parallel(const char *path, std::vector<uint64_t> &codes, int &k) {
+    if (getenv("GAVISUNK_LOC_THREADS") && atoi(getenv("GAVISUNK_LOC_THREADS")) <= 1) return false;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < (4 << 20)) {
+        close(fd);
+        return false;
+    }
+    const size_t n = (size_t)st.st_size;
+    void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return false;
+    const char *p = static_cast<const char *>(m);
+    if ((unsigned char)p[0] == 0x1f && (unsigned char)p[1] == 0x8b) {
+        munmap(m, n);
+        return false;
+    }
+    unsigned T = std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));  // (the location table is parsed beside this)
+    if (const char *e = getenv("GAVISUNK_LOC_THREADS")) T = (unsigned)std::max(1, atoi(e));
+    T = (unsigned)std::min<size_t>(T, n >> 20);
+    std::vector<size_t> cut(T + 1, n);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; t++) {
+        size_t q = std::max(n * t / T, cut[t - 1]);
+        const char *nl = q < n ? (const char *)memchr(p + q, '\n', n - q) : nullptr;
+        cut[t] = nl ? (size_t)(nl - p) + 1 : n;
+    }
+    std::vector<std::vector<uint64_t>> parts(T);
+    auto work = [&](unsigned t) {
+        const char *b = p + cut[t], *e = p + cut[t + 1];
+        parts[t].reserve((size_t)(e - b) / 16 + 16);
+        while (b < e) {  // every line is a k-mer, the empty ones too (the reference encodes whatever `lines` yields)
+            const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
+            const char *le = nl ? nl : e;
+            const char *next = nl ? nl + 1 : e;
+            if (le > b && le[-1] == '\r') le--;
+            parts[t].push_back(encode_kmer(b, (size_t)(le - b)));
+            b = next;
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; t++) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+    }
+    {  // k = len(first line), kmerpos_annot3.nim:28-38
+        const char *nl = (const char *)memchr(p, '\n', n);
+        const char *le = nl ? nl : p + n;
+        if (le > p && le[-1] == '\r') le--;
+        k = (int)(le - p);
+    }
+    munmap(m, n);
+    size_t total = 0;
+    for (auto &v : parts) total += v.size();
+    codes.resize(total);
+    size_t o = 0;
+    for (auto &v : parts) {
+        if (!v.empty()) memcpy(codes.data() + o, v.data(), v.size() * sizeof(uint64_t));
+        o += v.size();
+    }
+    return true;
+}
+
 static int parse_loc_parallel(const char *path, gs_sunkdb *d, std::vector<uint64_t> &row_code, uint64_t *err_line) {
     if (getenv("GAVISUNK_LOC_THREADS") && atoi(getenv("GAVISUNK_LOC_THREADS")) <= 1) return -1;
     const int fd = open(path, O_RDONLY);
@@ -534,19 +600,21 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
         std::string l;
         std::vector<uint64_t> codes;  // local while growing: the two threads must not share cache lines of *d
         int k = 0;
-        LineReader r(db_path);
-        if (!r.ok()) {
-            db_open = false;
-            db_rc = GS_E_IO;
-            return;
-        }
-        bool first = true;
-        while (r.next(l)) {
-            if (first) {  // k = len(first line), kmerpos_annot3.nim:28-38
-                k = (int)l.size();
-                first = false;
+        if (!parse_db_parallel(db_path, codes, k)) {
+            LineReader r(db_path);
+            if (!r.ok()) {
+                db_open = false;
+                db_rc = GS_E_IO;
+                return;
             }
-            codes.push_back(encode_kmer(l.data(), l.size()));
+            bool first = true;
+            while (r.next(l)) {
+                if (first) {  // k = len(first line), kmerpos_annot3.nim:28-38
+                    k = (int)l.size();
+                    first = false;
+                }
+                codes.push_back(encode_kmer(l.data(), l.size()));
+            }
         }
         // a k-mer listed twice is one key (the reference's HashSet): keep first occurrences, in file order.  The hashing
         // is split over threads by hash class, like the row map below.

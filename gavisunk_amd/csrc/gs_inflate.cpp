@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -527,6 +528,78 @@ uint32_t crc32_of(const uint8_t *p, size_t n) {
 
 }  // namespace
 
+namespace {
+// The text buffers handed to the caller come back through gs_gz_free_buffer: a few of them are kept for the next read instead
+// of going back to the allocator (a 1 GiB block returned to the system is a quarter of a million page faults when the next one
+// is written, taken by many threads at once).
+struct BufPool {
+    std::mutex m;
+    struct E {
+        uint8_t *p;
+        size_t cap;
+    };
+    std::vector<E> idle;
+    std::vector<E> live;
+    uint8_t *get(size_t want, size_t *cap) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].cap >= want && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+            if (best < idle.size()) {
+                E e = idle[best];
+                idle.erase(idle.begin() + (long)best);
+                live.push_back(e);
+                *cap = e.cap;
+                return e.p;
+            }
+        }
+        uint8_t *p = static_cast<uint8_t *>(malloc(std::max<size_t>(want, 64)));
+        if (!p) throw std::bad_alloc();
+        std::lock_guard<std::mutex> lk(m);
+        live.push_back(E{p, std::max<size_t>(want, 64)});
+        *cap = std::max<size_t>(want, 64);
+        return p;
+    }
+    void put(uint8_t *p) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(m);
+        for (size_t i = 0; i < live.size(); i++)
+            if (live[i].p == p) {
+                E e = live[i];
+                live.erase(live.begin() + (long)i);
+                if (idle.size() < 3 && e.cap >= ((size_t)16 << 20)) idle.push_back(e);
+                else free(e.p);
+                return;
+            }
+        free(p);  // (not one of ours)
+    }
+};
+BufPool &pool() {
+    static BufPool *p = new BufPool;  // (never destroyed: buffers may be returned during interpreter shutdown)
+    return *p;
+}
+struct OutBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~OutBuf() { pool().put(p); }
+    void reserve(size_t want) {
+        if (want <= cap) return;
+        size_t c = 0;
+        uint8_t *q = pool().get(want, &c);
+        if (n) memcpy(q, p, n);
+        pool().put(p);
+        p = q;
+        cap = c;
+    }
+    void grow_for(size_t extra) {
+        if (n + extra > cap) reserve(std::max(cap + cap / 2, n + extra + 4096));
+    }
+    size_t size() const { return n; }
+    uint8_t *data() { return p; }
+};
+}  // namespace
+
 struct gs_gzfile {
     int fd = -1;
     const uint8_t *data = nullptr;
@@ -538,7 +611,7 @@ struct gs_gzfile {
     // the member that is open at next_bit: crc / size so far
     uint32_t run_crc = 0;
     uint64_t run_size = 0;
-    RawVec<uint8_t> out;            // the text handed out last
+    OutBuf out;                     // the text being made for the caller
     std::vector<Piece> pool;        // the workers' symbol buffers, reused from group to group
     std::string mode, err;
     uint64_t pieces_used = 0, pieces_dropped = 0;
@@ -852,7 +925,7 @@ int gs_gz_read(gs_gzfile *z, uint64_t want, const uint8_t *prefix, uint64_t pref
     z->out.n = z->out.cap = 0;
     return GS_OK;
 }
-void gs_gz_free_buffer(uint8_t *p) { free(p); }
+void gs_gz_free_buffer(uint8_t *p) { pool().put(p); }
 int gs_gz_at_end(const gs_gzfile *z) { return z && z->at_end ? 1 : 0; }
 
 // Where a block of FASTA / FASTQ text can be cut so that it holds whole records (what the on-device record parser takes,
