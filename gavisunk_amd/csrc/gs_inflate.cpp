@@ -211,6 +211,91 @@ struct BlockCodes {
     Huff lit, dist;
 };
 
+// The symbols of a Huffman block with the reader's state in registers: one branch-free refill per symbol (after it at least 56
+// bits are at hand: a literal/length code, its extra bits, a distance code and its extra bits are at most 48), no capacity test
+// per symbol (the caller guarantees room for `budget` symbols and 8 readable bytes at `in_safe`), matches copied four symbols
+// at a time.  -> 1 end of block, 0 stop (input or output margin reached: the careful loop goes on), -1 invalid data.
+inline int fast_symbols(const BlockCodes &bc, Bits &b, uint16_t *&o, uint16_t *o_stop) {
+    const uint8_t *base = b.p, *in = base + b.byte;
+    const uint8_t *in_safe = b.n >= 16 ? base + b.n - 16 : base;
+    uint64_t buf = b.buf;
+    int cnt = b.cnt;
+    const uint32_t *lt = bc.lit.t.data(), *dt = bc.dist.t.data();
+    const int lp = bc.lit.primary, dp = bc.dist.primary;
+    const uint32_t lmask = (1u << lp) - 1u, dmask = (1u << dp) - 1u;
+    uint16_t *w = o;
+    int rc = 0;
+    while (in < in_safe && w < o_stop) {
+        uint64_t x;
+        memcpy(&x, in, 8);
+        buf |= x << cnt;
+        in += (63 - cnt) >> 3;
+        cnt |= 56;
+        uint32_t e = lt[(uint32_t)buf & lmask];
+        if (e & 32u) {
+            buf >>= lp;
+            cnt -= lp;
+            e = lt[(e >> 16) + ((uint32_t)buf & ((1u << ((e >> 8) & 15u)) - 1u))];
+        }
+        const int l = (int)(e & 31u);
+        if (!l) {
+            rc = -1;
+            break;
+        }
+        buf >>= l;
+        cnt -= l;
+        int s = (int)(e >> 16);
+        if (s < 256) {
+            *w++ = (uint16_t)s;
+            continue;
+        }
+        if (s == 256) {
+            rc = 1;
+            break;
+        }
+        s -= 257;
+        if (s >= 29) {
+            rc = -1;
+            break;
+        }
+        const int xl = kLenExtra[s];
+        const uint32_t len = kLenBase[s] + ((uint32_t)buf & ((1u << xl) - 1u));
+        buf >>= xl;
+        cnt -= xl;
+        uint32_t d = dt[(uint32_t)buf & dmask];
+        if (d & 32u) {
+            buf >>= dp;
+            cnt -= dp;
+            d = dt[(d >> 16) + ((uint32_t)buf & ((1u << ((d >> 8) & 15u)) - 1u))];
+        }
+        const int dl = (int)(d & 31u);
+        const int ds = (int)(d >> 16);
+        if (!dl || ds >= 30) {
+            rc = -1;
+            break;
+        }
+        buf >>= dl;
+        cnt -= dl;
+        const int xd = kDistExtra[ds];
+        const uint32_t dist = kDistBase[ds] + ((uint32_t)buf & ((1u << xd) - 1u));
+        buf >>= xd;
+        cnt -= xd;
+        const uint16_t *r = w - dist;  // (behind the 32768 markers a distance never reaches before the buffer)
+        if (dist >= 4) {
+            for (uint32_t i = 0; i < len; i += 4) memcpy(w + i, r + i, 8);  // (up to 3 symbols of slack past the match: the margin holds them)
+        } else {
+            for (uint32_t i = 0; i < len; i++) w[i] = r[i];
+        }
+        w += len;
+    }
+    o = w;
+    // hand the state back in the careful reader's form (no stray bits above cnt)
+    b.byte = (size_t)(in - base);
+    b.cnt = cnt;
+    b.buf = cnt >= 64 ? buf : (buf & ((1ULL << cnt) - 1ULL));
+    return rc;
+}
+
 // the header of a dynamic block (after its 3 header bits) -> codes; false = not a valid header
 bool read_dynamic_header(Bits &b, BlockCodes &bc) {
     b.refill();
@@ -392,6 +477,19 @@ bool decode_blocks(const uint8_t *data, size_t n, Bits &b, Piece &pc, const std:
             }
             for (;;) {
                 if (out.n + 300 > out.cap) out.grow_for(300);
+                if (out.cap - out.n > 1024 && b.byte + 32 < b.n && !bc->dist.t.empty()) {
+                    // the fast loop, while there is room for a few hundred symbols and input to spare
+                    uint16_t *o = out.p + out.n;
+                    const int rc = fast_symbols(*bc, b, o, out.p + out.cap - 300);
+                    out.n = (size_t)(o - out.p);
+                    if (rc < 0) {
+                        pc.err = "invalid code";
+                        return false;
+                    }
+                    if (rc == 1) break;
+                    if (out.n + 300 > out.cap) out.grow_for(out.cap);  // (the output margin stopped it: double the buffer)
+                    if (b.byte + 32 < b.n) continue;
+                }
                 int s = bc->lit.decode(b);
                 if (s < 256) {
                     if (s < 0) {
@@ -615,6 +713,7 @@ struct gs_gzfile {
     std::vector<Piece> pool;        // the workers' symbol buffers, reused from group to group
     std::string mode, err;
     uint64_t pieces_used = 0, pieces_dropped = 0;
+    uint64_t bytes_in = 0, bytes_out = 0;  // compressed bytes consumed / text produced so far (the expansion ratio)
 };
 
 namespace {
@@ -906,12 +1005,22 @@ int gs_gz_read(gs_gzfile *z, uint64_t want, const uint8_t *prefix, uint64_t pref
         size_t piece = (size_t)2 << 20;
         if (const char *e = getenv("GAVISUNK_GZ_PIECE_KB")) piece = (size_t)std::max(16, atoi(e)) << 10;  // (test knob: small groups)
         while (!z->at_end && z->out.size() - prefix_len < want) {
-            // enough pieces for every thread, a few more so that short pieces do not leave threads idle
-            if (!inflate_group(z, piece, (size_t)z->threads * 2)) {
+            // enough pieces for every thread, a few more so that short pieces do not leave threads idle -- fewer when the caller
+            // asks for little (the first blocks of a file: the sooner they are out, the sooner the copy to the device and the
+            // parser start beside the inflation of the rest), judged by the expansion seen so far
+            const double ratio = z->bytes_in > ((uint64_t)1 << 20) ? std::max(1.0, (double)z->bytes_out / (double)z->bytes_in) : 4.0;
+            const uint64_t missing = want - (z->out.size() - prefix_len);
+            size_t pieces = (size_t)((double)missing / ((double)piece * ratio)) + 1;
+            pieces = std::max<size_t>(std::min<size_t>(pieces, (size_t)z->threads * 2), std::max(1, z->threads / 2));
+            const uint64_t bit0 = z->next_bit;
+            const size_t out0 = z->out.size();
+            if (!inflate_group(z, piece, pieces)) {
                 z->failed = true;
                 set_error("gs_gz_read: %s", z->err.c_str());
                 return GS_E_IO;
             }
+            z->bytes_in += (z->next_bit - bit0) >> 3;
+            z->bytes_out += z->out.size() - out0;
         }
     } catch (const std::bad_alloc &) {
         z->failed = true;

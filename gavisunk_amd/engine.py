@@ -188,9 +188,11 @@ def gz_text_blocks(path: str, max_bytes: int = 1 << 30, threads: int = 0):
 
     try:
         rem = b""
+        want = min(max_bytes, 64 << 20)  # the first blocks are small (copy and parser start early), then they double up to max_bytes
         while True:
             p, n = C.c_void_p(), C.c_uint64(0)
-            check(L.gs_gz_read(z, max_bytes - len(rem) if max_bytes > len(rem) else max_bytes, rem, len(rem), C.byref(p), C.byref(n)))
+            check(L.gs_gz_read(z, want - len(rem) if want > len(rem) else want, rem, len(rem), C.byref(p), C.byref(n)))
+            want = min(2 * want, max_bytes)
             buf, n, at_end = _NativeBuffer(p.value or 0, n.value), n.value, bool(L.gs_gz_at_end(z))
             if n == len(rem) and at_end:  # end of file: what is left is the last block
                 if n:
