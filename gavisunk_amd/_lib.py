@@ -77,6 +77,8 @@ SIGNATURES = {
     "gs_gz_pieces": (U64, [P, C.POINTER(U64)]),
     "gs_gz_close": (None, [P]),
     "gs_text_record_cut": (U64, [P, U64]),
+    "gs_gz_newlines": (U64, [P]),
+    "gs_text_record_cut_counted": (U64, [P, U64, U64]),
     "gs_table_create": (I, [I, I, U64, P, P, P, C.POINTER(P)]),
     "gs_table_create_device": (I, [I, I, U64, P, P, P, C.POINTER(P)]),
     "gs_table_destroy": (None, [P]),

@@ -714,6 +714,7 @@ struct gs_gzfile {
     std::string mode, err;
     uint64_t pieces_used = 0, pieces_dropped = 0;
     uint64_t bytes_in = 0, bytes_out = 0;  // compressed bytes consumed / text produced so far (the expansion ratio)
+    uint64_t newlines = 0;                 // '\n' bytes among the NEW bytes of the stretch made last (counted while they are written)
 };
 
 namespace {
@@ -843,6 +844,7 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
             w[j] = v;
         }
     }
+    std::atomic<uint64_t> newlines{0};
     const size_t base = z->out.size();
     z->out.grow_for(out_off[chain.size()]);
     z->out.n = base + out_off[chain.size()];
@@ -858,15 +860,20 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                 const size_t m = pc.n_out();
                 uint8_t *o = z->out.data() + base + out_off[c];
                 const uint8_t *w = win[c].data();
+                uint64_t nl = 0;
                 for (size_t k = 0; k < m; k++) {
                     const uint16_t v = s[k];
-                    o[k] = v < kMarker ? (uint8_t)v : w[v - kMarker];
+                    const uint8_t byte = v < kMarker ? (uint8_t)v : w[v - kMarker];
+                    o[k] = byte;
+                    nl += byte == '\n';
                 }
+                newlines.fetch_add(nl, std::memory_order_relaxed);
             }
         };
         for (int t = 0; t < z->threads && (size_t)t < chain.size(); t++) th.emplace_back(work);
         for (auto &t : th) t.join();
     }
+    z->newlines += newlines.load();
     if (dbg) fprintf(stderr, "[gz] resolve + narrow %.3f s\n", now() - t0), t0 = now();
     // ---- members that ended inside this group: CRC-32 and ISIZE
     {
@@ -930,6 +937,8 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
 }  // namespace
 
 extern "C" {
+
+uint64_t gs_text_record_cut(const uint8_t *t, uint64_t n);
 
 // Opens a gzip file for parallel inflation with `threads` workers (0: the machine's hardware threads, at most 32).
 // GS_E_IO: cannot be opened / mapped, or does not start with a gzip member.
@@ -998,6 +1007,7 @@ int gs_gz_read(gs_gzfile *z, uint64_t want, const uint8_t *prefix, uint64_t pref
         const uint64_t left = (uint64_t)z->n - (z->next_bit >> 3);
         z->out.reserve((size_t)(prefix_len + std::min<uint64_t>(want + ((uint64_t)64 << 20), left * 8 + ((uint64_t)1 << 20))));
         z->out.n = 0;
+        z->newlines = 0;
         if (prefix_len) {
             memcpy(z->out.p, prefix, (size_t)prefix_len);
             z->out.n = (size_t)prefix_len;
@@ -1035,6 +1045,21 @@ int gs_gz_read(gs_gzfile *z, uint64_t want, const uint8_t *prefix, uint64_t pref
     return GS_OK;
 }
 void gs_gz_free_buffer(uint8_t *p) { pool().put(p); }
+// '\n' bytes among the new bytes (the prefix not counted) of the stretch gs_gz_read returned last
+uint64_t gs_gz_newlines(const gs_gzfile *z) { return z ? z->newlines : 0; }
+// gs_text_record_cut for a caller that already knows how many '\n' the text holds (the reader counts them while it writes)
+uint64_t gs_text_record_cut_counted(const uint8_t *t, uint64_t n, uint64_t n_newlines) {
+    if (!t || !n) return 0;
+    if (t[0] == '>') return gs_text_record_cut(t, n);  // (a backward search from the end: cheap)
+    if (n_newlines < 4) return 0;
+    uint64_t cut = n;
+    for (uint64_t k = 0; k < n_newlines % 4 + 1; k++) {
+        const void *q = cut ? memrchr(t, '\n', (size_t)cut) : nullptr;
+        if (!q) return 0;
+        cut = (uint64_t)(static_cast<const uint8_t *>(q) - t);
+    }
+    return cut + 1;
+}
 int gs_gz_at_end(const gs_gzfile *z) { return z && z->at_end ? 1 : 0; }
 
 // Where a block of FASTA / FASTQ text can be cut so that it holds whole records (what the on-device record parser takes,

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include <rocprim/device/device_scan.hpp>
@@ -163,7 +164,50 @@ struct gs_textstage {
     uint8_t *d_text = nullptr;
     uint32_t n = 0;
     uint8_t first = 0;
+    size_t cap = 0;
 };
+
+namespace {
+// Device buffers of staged text blocks are kept for the next block instead of being freed: hipFree / hipMalloc synchronise the
+// whole device, and in the command-line pipeline one thread stages block i + 1 while another parses and tags block i -- each
+// would wait for the other's work at every allocation.  (A block is released only after its parse has finished: the caller's
+// contract, and gs_reads_from_staged_text ends with a device synchronisation.)
+struct StageCache {
+    std::mutex m;
+    struct E {
+        int device;
+        uint8_t *p;
+        size_t cap;
+    };
+    std::vector<E> idle;
+    uint8_t *get(int device, size_t want, size_t *cap) {
+        std::lock_guard<std::mutex> lk(m);
+        size_t best = idle.size();
+        for (size_t i = 0; i < idle.size(); i++)
+            if (idle[i].device == device && idle[i].cap >= want && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+        if (best == idle.size()) return nullptr;
+        E e = idle[best];
+        idle.erase(idle.begin() + (long)best);
+        *cap = e.cap;
+        return e.p;
+    }
+    void put(int device, uint8_t *p, size_t cap) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (idle.size() < 3 && cap >= ((size_t)32 << 20)) {
+                idle.push_back(E{device, p, cap});
+                return;
+            }
+        }
+        (void)hipSetDevice(device);
+        (void)hipFree(p);
+    }
+};
+StageCache &stage_cache() {
+    static StageCache *c = new StageCache;
+    return *c;
+}
+}  // namespace
 
 int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstage **out) {
     if (!out || (!text && n_bytes)) {
@@ -185,10 +229,14 @@ int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstag
     st->n = (uint32_t)n_bytes;
     st->first = n_bytes ? text[0] : 0;
     const size_t n = st->n;
-    if (hipMalloc(reinterpret_cast<void **>(&st->d_text), std::max<size_t>(n, 1)) != hipSuccess) {
-        delete st;
-        set_error("gs_text_stage: out of device memory (%zu bytes)", n);
-        return GS_E_NOMEM;
+    st->d_text = stage_cache().get(device, n, &st->cap);
+    if (!st->d_text) {
+        st->cap = std::max<size_t>(n + n / 8, 1);  // (a little room: the next block of a file is about this long)
+        if (hipMalloc(reinterpret_cast<void **>(&st->d_text), st->cap) != hipSuccess) {
+            delete st;
+            set_error("gs_text_stage: out of device memory (%zu bytes)", n);
+            return GS_E_NOMEM;
+        }
     }
     // the text through two small pinned buffers on a stream of its own (a pageable copy of a few hundred MB makes the runtime
     // pin the whole range first); callable from a second thread while the first one loads the SUNK table
@@ -197,30 +245,32 @@ int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstag
         uint8_t *h[2] = {nullptr, nullptr};
         hipEvent_t ev[2] = {nullptr, nullptr};
         hipStream_t s = nullptr;
-        ~Stage() {
-            for (int i = 0; i < 2; i++) {
-                if (h[i]) (void)hipHostFree(h[i]);
-                if (ev[i]) (void)hipEventDestroy(ev[i]);
-            }
-            if (s) (void)hipStreamDestroy(s);
-        }
-    } sg;
+        // (never torn down: a thread's exit may come after the HIP runtime's; the process's end frees them)
+    };
+    // (one set per staging thread, made on its first block: creating and freeing pinned buffers and streams synchronises the device)
+    static thread_local Stage sg;
     auto fail = [&](hipError_t e) {
         set_error("gs_text_stage: %s", hipGetErrorString(e));
         (void)hipFree(st->d_text);
         delete st;
         return GS_E_NODEVICE;
     };
-    hipError_t e = hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking);
-    for (int i = 0; i < 2 && e == hipSuccess; i++) {
-        e = hipHostMalloc(reinterpret_cast<void **>(&sg.h[i]), kStage, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&sg.ev[i], hipEventDisableTiming);
+    hipError_t e = hipSuccess;
+    if (!sg.s) {
+        Stage ns;
+        e = hipStreamCreateWithFlags(&ns.s, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && e == hipSuccess; i++) {
+            e = hipHostMalloc(reinterpret_cast<void **>(&ns.h[i]), kStage, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ns.ev[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return fail(e);
+        sg = ns;
     }
-    if (e != hipSuccess) return fail(e);
     int b = 0;
     for (size_t o = 0; o < n; o += kStage, b ^= 1) {
         const size_t len = std::min(kStage, n - o);
         if (o >= 2 * kStage && (e = hipEventSynchronize(sg.ev[b])) != hipSuccess) return fail(e);  // this buffer's last copy has left it
+        // (a call ends with a stream synchronisation: at o < 2 kStage both buffers are free)
         memcpy(sg.h[b], text + o, len);
         if ((e = hipMemcpyAsync(st->d_text + o, sg.h[b], len, hipMemcpyHostToDevice, sg.s)) != hipSuccess) return fail(e);
         if ((e = hipEventRecord(sg.ev[b], sg.s)) != hipSuccess) return fail(e);
@@ -232,8 +282,7 @@ int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstag
 
 void gs_text_stage_free(gs_textstage *st) {
     if (!st) return;
-    (void)hipSetDevice(st->device);
-    (void)hipFree(st->d_text);
+    if (st->d_text) stage_cache().put(st->device, st->d_text, st->cap);
     delete st;
 }
 

@@ -199,7 +199,18 @@ def gz_text_blocks(path: str, max_bytes: int = 1 << 30, threads: int = 0):
                     yield piece(buf, 0, n)
                 return
             off = 0
-            while n - off > max_bytes:  # (a read delivers whole groups of pieces: more than one block's worth)
+            nl = L.gs_gz_newlines(z) + rem.count(b"\n")  # (counted by the reader while it wrote the bytes: no pass over the text here)
+            if n <= 2 * max_bytes:  # the usual case: one block, cut where the last whole record ends
+                cut = n if at_end else L.gs_text_record_cut_counted(buf.ptr, n, nl)
+                if cut:
+                    yield piece(buf, 0, cut)
+                rem = bytes(buf.view(cut, n))
+                if at_end:
+                    if rem:
+                        yield rem
+                    return
+                continue
+            while n - off > max_bytes:  # (a read that delivered far more than a block's worth)
                 w, cut = max_bytes, 0
                 while True:
                     cut = L.gs_text_record_cut(buf.ptr + off, w)

@@ -125,6 +125,10 @@ const char *gs_gz_mode(const gs_gzfile *z);
 uint64_t gs_gz_pieces(const gs_gzfile *z, uint64_t *dropped);
 void gs_gz_close(gs_gzfile *z);
 uint64_t gs_text_record_cut(const uint8_t *text, uint64_t n);
+/* '\n' bytes among the new bytes (the prefix not counted) of the stretch gs_gz_read returned last: counted while they are written */
+uint64_t gs_gz_newlines(const gs_gzfile *z);
+/* gs_text_record_cut when the number of '\n' in the text is known already (no pass over the text) */
+uint64_t gs_text_record_cut_counted(const uint8_t *text, uint64_t n, uint64_t n_newlines);
 
 /* ------------------------------------------------------------------------------------------
  * Device side.

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Phase times of the native parallel gzip reader (csrc/gs_inflate.cpp) on a genome-scale-like `.fq.gz` (multi-member, quals '#'),
+by thread count.  CPU only (run it on the GPU box for that box's host cores).  usage: gz_time.py [GB of text, default 6]"""
+import ctypes as C
+import gzip
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gavisunk_amd import _lib  # noqa: E402
+
+gb = float(sys.argv[1]) if len(sys.argv) > 1 else 6.0
+path = "/tmp/gz_time.fq.gz"
+n_members = int(gb * 1e9 / 40e6)
+lut = np.frombuffer(b"ACGT", np.uint8)
+
+
+def member(i):
+    rng = np.random.default_rng(i)
+    out = []
+    for j in range(500):
+        ln = int(rng.integers(20000, 60000))
+        out.append(b"@m%d_%d\n" % (i, j) + lut[rng.integers(0, 4, ln, dtype=np.uint8)].tobytes() + b"\n+\n" + b"#" * ln + b"\n")
+    return gzip.compress(b"".join(out), 1)
+
+
+t0 = time.time()
+with open(path, "wb") as f, ThreadPoolExecutor(16) as pool:
+    for blob in pool.map(member, range(n_members)):
+        f.write(blob)
+print(f"{path}: {os.path.getsize(path) / 2**30:.2f} GiB in {n_members} members ({time.time() - t0:.0f} s); hardware threads {os.cpu_count()}, "
+      f"affinity {len(os.sched_getaffinity(0))}", flush=True)
+L = _lib.lib()
+for threads in (8, 16, 32):
+    for dbg in (False, True):
+        if dbg:
+            os.environ["GAVISUNK_GZ_DEBUG"] = "1"
+        else:
+            os.environ.pop("GAVISUNK_GZ_DEBUG", None)
+        z = C.c_void_p()
+        _lib.check(L.gs_gz_open(path.encode(), threads, C.byref(z)))
+        t0 = time.time()
+        total = 0
+        while True:
+            p, n = C.c_void_p(), C.c_uint64(0)
+            _lib.check(L.gs_gz_read(z, 1 << 30, None, 0, C.byref(p), C.byref(n)))
+            total += n.value
+            L.gs_gz_free_buffer(p)
+            if not n.value or L.gs_gz_at_end(z):
+                break
+        dt = time.time() - t0
+        L.gs_gz_close(z)
+        if not dbg:
+            print(f"threads {threads:2d}: {total / 1e9:.2f} GB of text in {dt:.2f} s = {total / dt / 1e9:.2f} GB/s", flush=True)
+os.unlink(path)
