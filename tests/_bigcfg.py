@@ -136,3 +136,52 @@ def full_size_checks(table, reads, rs, sunks, k, cuts, slices, min_rows, min_sli
         assert np.array_equal(mine["read"] - lo, oh["read"]) and np.array_equal(mine["pos"], oh["pos"])
         assert np.array_equal(mine["payload"], rows[oh["row"]])
     return whole, carry, c
+
+
+def chain_slice_check(table, reads, rs, sunks, contig_names, n_slice, k):
+    """The device-resident second half (csrc/gs_chain.hip) over the WHOLE hit list of a pass, checked on the reads [0, n_slice)
+    against the oracle's restatements: diag_filter_v3 lines, and -- with the bad-SUNK flags the device computed over the whole
+    set -- the per-read `ID \\t rname` rows of process-by-contig, contig by contig (a read's rows depend on its own hits and on
+    the bad set only; the BED is contig-wide and is not compared on a slice)."""
+    lr = engine.LocRows.from_sunkset(sunks)
+    one_pass(table, reads)
+    rows = engine.RowSet(0, 1 << 20)
+    rows.append_pass(table, reads, 0, lr)
+    n_reads = rs.n_reads
+    rlen = (rs.off[1:] - rs.off[:-1]).astype(np.int64)
+    raw = rows.download()
+    assert rows.n == len(raw["name"]) > 1_000_000 and np.all(np.diff(raw["name"].astype(np.int64)) >= 0)
+
+    def text_of(cols, mask):
+        return "".join(f"r{n:07d}\t{p}\t{contig_names[c]}\t{s}\t{g}\n" for n, p, c, s, g in
+                       zip(*(cols[x][mask].tolist() for x in ("name", "pos", "contig", "start", "id"))))
+
+    seg_name, bc, bg, bd, kept = rows.diag_filter(contig_names, np.ones(len(contig_names), np.uint8))
+    exp = oracle.diag_filter_v3(oracle.parse_sunkpos(text_of(raw, raw["name"] < n_slice)), contig_names)
+    sm = seg_name < n_slice
+    got = "".join(f"r{n:07d}\t{contig_names[c]}\t{g}\t{chr(d)}\t{g}\n" for n, c, g, d in
+                  zip(seg_name[sm].tolist(), bc[sm].tolist(), bg[sm].tolist(), bd[sm].tolist()) if c != _lib.GS_NONE)
+    assert got == exp and exp.count("\n") > n_slice // 4
+    del raw
+    rows.keep_filtered()
+    assert rows.n == kept
+    f = rows.download()
+    bad, meancov, d_bad = engine.RowSet.bad_keys(rows, rows, np.full(lr.n_locs, 3, np.uint8), keep_on_device=True)
+    res = rows.pair_stage(np.arange(n_reads, dtype=np.uint32), (rlen >= 10000).astype(np.uint8), d_key_bad=d_bad)
+    engine.free_device(d_bad)
+    fm = f["name"] < n_slice
+    rlen_text = "".join(f"r{i:07d}\t{int(rlen[i])}\n" for i in range(n_slice))
+    checked = 0
+    for c in np.unique(f["contig"][fm]).tolist():
+        m = fm & (f["contig"] == c)
+        bm = m & (bad[f["key"]] != 0)
+        bad_text = "".join(sorted({f"{contig_names[c]}:{g}\n" for g in f["id"][bm].tolist()}))
+        etsv, _ = oracle.process_by_contig(text_of(f, m), rlen_text, bad_text)
+        rm = (res["row_contig"] == c) & (res["row_name"] < n_slice)
+        tsv = "".join(f"{i}\tr{n:07d}\n" for i, n in zip(res["row_id"][rm].tolist(), res["row_name"][rm].tolist()))
+        assert (tsv or f"{contig_names[c]}\n") == etsv, contig_names[c]
+        checked += tsv.count("\n")
+    assert checked > n_slice // 8
+    rows.close()
+    lr.close()
+    return int(kept), int(len(res["row_id"])), int(len(res["region_start"]))

@@ -9,7 +9,7 @@ space.  What is checked, and why that way: tests/_bigcfg.py."""
 import numpy as np
 import pytest
 
-from _bigcfg import full_size_checks
+from _bigcfg import chain_slice_check, full_size_checks
 from gavisunk_amd import _lib, engine, synth_gpu
 
 pytestmark = pytest.mark.gpu
@@ -27,6 +27,7 @@ def test_diploid_shard_full_size():
     assert int(pos[0] >> np.uint64(32)) == 0 and sunks.n > 100_000_000 and sunks.n_groups > (1 << 21)
     table = sunks.table()
     rs = synth_gpu.make_reads(W, gen)
+    contig_names = list(gen.names)
     gen.close()
     reads = engine.device_reads_from_device_ascii(rs.ptr, rs.off, K)
     try:
@@ -39,6 +40,9 @@ def test_diploid_shard_full_size():
         L = _lib.lib()
         ctg = synth_gpu.gather(0, L.gs_sunkset_dev_pos(sunks._h), np.uint64, whole["payload"][: 1 << 20]) >> np.uint64(32)
         assert (ctg < 24).any() and (ctg >= 24).any()
+        # the device-resident second half over the shard's whole hit list (48 contigs, 3e6 location groups); its head against the oracle
+        kept, tsv_rows, regions = chain_slice_check(table, reads, rs, sunks, contig_names, 400, K)
+        assert kept > 1_000_000 and tsv_rows > 10_000
     finally:
         reads.close()
         table.close()
