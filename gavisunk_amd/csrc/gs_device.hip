@@ -34,6 +34,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -988,6 +989,7 @@ struct PassState {
     Agg *d_totals = nullptr;  // [0] scan A grand total, [1] scan B grand total
     uint32_t *d_complex_n = nullptr;
     bool pass_pending = false;
+    mutable bool was_chained_to = false;  // some later pass took (or may still take) its carry from this batch's device memory
     const gs_table *table = nullptr;      // of the pending / settled pass
     const struct gs_reads *after = nullptr;  // the batch whose pass hands its carry to this one on the device (or NULL)
     uint32_t last_carry_in = GS_NONE;
@@ -1020,6 +1022,11 @@ struct gs_reads {
     std::vector<uint32_t> read_tile0_host;               // first tile of every read
     TileDesc *tile_desc = nullptr;     // [n_tiles]
     PassState ps;
+    // what the arrays hold room for (reads_alloc); a complete handle whose pass has settled is kept for the next batch of
+    // its size instead of being freed (reads_pool below)
+    uint64_t cap_words = 0, cap_tiles = 0;
+    uint32_t cap_reads = 0;
+    bool complete = false;
 };
 
 namespace {
@@ -1156,8 +1163,10 @@ int launch_phase2(gs_table *t, gs_reads *r, uint32_t carry_in, const gs_reads *a
     HIP_TRY(hipSetDevice(t->device));
     r->ps.last_carry_in = carry_in;
     r->ps.after = after;
-    if (after)
+    if (after) {
+        after->ps.was_chained_to = true;  // (its device memory is read by this pass: such a handle is never recycled, only freed behind a device synchronisation)
         hipLaunchKernelGGL(k_chain_carry, dim3(1), dim3(1), 0, t->stream, (const Agg *)after->ps.d_totals, r->ps.d_carry_in);
+    }
     else
         HIP_TRY(hipMemcpyAsync(r->ps.d_carry_in, &r->ps.last_carry_in, sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
     int rc;
@@ -1918,9 +1927,42 @@ __global__ void k_tile_index(const uint64_t *__restrict__ read_word_off, const u
     tdesc[t] = TileDesc{read_word_off[lo] + (uint64_t)q * kTileWords, read_nwin[lo] - q * kTileWindows, lo};
 }
 
+// Batch handles that were destroyed with nothing in flight wait here for the next batch that fits them: a batch owns ~22 device
+// arrays, a pinned mirror of its hit list, pinned status blocks and four events, and every hipFree / hipHostFree / hipMalloc
+// synchronises the whole device -- in the command-line pipeline that means waiting for the copy of the NEXT block, which another
+// thread has in flight.  A file is tagged block after block, the blocks alike: from the third block on nothing is allocated.
+struct ReadsPool {
+    std::mutex m;
+    std::vector<gs_reads *> idle;
+};
+static ReadsPool &reads_pool() {
+    static ReadsPool *p = new ReadsPool;  // (never torn down: the HIP runtime may be gone before static destructors run)
+    return *p;
+}
+static void reads_free_now(gs_reads *r);
+
 // every device array of a batch, for up to cap_words packed words, cap_reads reads, cap_tiles tiles
 static int reads_alloc(int device, int k, uint64_t cap_words, uint32_t cap_reads, uint64_t cap_tiles, uint64_t cand_rows, gs_reads **out) {
     HIP_TRY(hipSetDevice(device));
+    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>(cand_rows, 0xFFFFFFFFull);
+    {
+        ReadsPool &pool = reads_pool();
+        std::lock_guard<std::mutex> lk(pool.m);
+        size_t best = pool.idle.size();
+        for (size_t i = 0; i < pool.idle.size(); i++) {
+            const gs_reads *c = pool.idle[i];
+            if (c->device == device && c->cap_words >= cap_words && c->cap_reads >= cap_reads && c->cap_tiles >= cap_tiles && c->cand_cap >= cand_cap &&
+                c->cap_words <= 2 * cap_words + (1u << 20) && (best == pool.idle.size() || c->cap_words < pool.idle[best]->cap_words))
+                best = i;
+        }
+        if (best < pool.idle.size()) {
+            gs_reads *r = pool.idle[best];
+            pool.idle.erase(pool.idle.begin() + (long)best);
+            r->k = k;
+            *out = r;
+            return GS_OK;
+        }
+    }
     auto *r = new gs_reads();
     std::unique_ptr<gs_reads, void (*)(gs_reads *)> guard(r, gs_reads_destroy);
     r->device = device;
@@ -1940,7 +1982,11 @@ static int reads_alloc(int device, int k, uint64_t cap_words, uint32_t cap_reads
         (rc = dev_alloc(&ta.emit_prefix, cap_tiles)))
         return rc;
     if ((rc = dev_alloc(&r->block_agg, (cap_tiles + kScanBlock - 1) / kScanBlock))) return rc;
-    if ((rc = ensure_out_buffers(r, (uint32_t)std::min<uint64_t>(cand_rows, 0xFFFFFFFFull)))) return rc;
+    if ((rc = ensure_out_buffers(r, cand_cap))) return rc;
+    r->cap_words = cap_words;
+    r->cap_reads = cap_reads;
+    r->cap_tiles = cap_tiles;
+    r->complete = true;
     *out = guard.release();
     return GS_OK;
 }
@@ -2156,6 +2202,37 @@ int gs_reads_from_device_ascii(int device, const void *d_seq, const uint64_t *of
 
 void gs_reads_destroy(gs_reads *r) {
     if (!r) return;
+    // a complete handle with nothing in flight (its last pass settled, or it never had one) goes to the pool
+    if (r->complete && !r->ps.pass_pending && !r->ps.was_chained_to && !r->d_seed && !getenv("GAVISUNK_NO_READS_POOL")) {
+        r->n_reads = r->n_tiles = 0;
+        r->n_bases = r->n_windows = r->n_words = 0;
+        r->n_scan_blocks = 0;
+        r->seed_tiles.clear();
+        r->read_tile0_host.clear();
+        r->ps.table = nullptr;
+        r->ps.after = nullptr;
+        r->ps.last_carry_in = GS_NONE;
+        r->ps.settled = false;
+        r->ps.res_n = 0;
+        r->ps.res_carry = GS_NONE;
+        r->ps.res_keyerr = false;
+        ReadsPool &pool = reads_pool();
+        gs_reads *evict = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(pool.m);
+            pool.idle.push_back(r);
+            if (pool.idle.size() > 3) {  // (the oldest goes)
+                evict = pool.idle.front();
+                pool.idle.erase(pool.idle.begin());
+            }
+        }
+        if (evict) reads_free_now(evict);
+        return;
+    }
+    reads_free_now(r);
+}
+
+static void reads_free_now(gs_reads *r) {
     (void)hipSetDevice(r->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(r->words);

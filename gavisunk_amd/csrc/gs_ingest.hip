@@ -45,16 +45,56 @@ struct gs_textindex {
 
 namespace {
 
-struct DevMem {  // frees what it was given when it goes out of scope
-    std::vector<void *> p;
+// The parser's temporaries come out of ONE device arena that is kept from call to call (a file is parsed block after block, the
+// blocks alike): fifteen hipMalloc / hipFree per block synchronise the device fifteen times, each waiting for whatever another
+// thread has in flight (the command line stages the next block meanwhile).  What does not fit is allocated on the side and
+// makes the arena larger for the next call.  One parse at a time holds the arena (a lock for the call's duration).
+struct ParseArena {
+    std::mutex m;
+    int device = -1;
+    uint8_t *base = nullptr;
+    size_t cap = 0, want = 0;
+};
+ParseArena &parse_arena() {
+    static ParseArena *a = new ParseArena;
+    return *a;
+}
+struct DevMem {  // bump allocation from the arena; side allocations are freed when it goes out of scope
+    std::vector<void *> side;
+    std::unique_lock<std::mutex> lk;
+    ParseArena *ar = nullptr;
+    size_t used = 0, asked = 0;
+    explicit DevMem(int device) : lk(parse_arena().m), ar(&parse_arena()) {
+        if (ar->base && (ar->device != device || ar->want > ar->cap)) {  // (idle here: nobody else holds it)
+            (void)hipFree(ar->base);
+            ar->base = nullptr;
+            ar->cap = 0;
+        }
+        if (!ar->base && ar->want) {
+            void *q = nullptr;
+            if (hipMalloc(&q, ar->want + ar->want / 8) == hipSuccess) {
+                ar->base = static_cast<uint8_t *>(q);
+                ar->cap = ar->want + ar->want / 8;
+                ar->device = device;
+            }
+        }
+    }
     ~DevMem() {
-        for (void *q : p) (void)hipFree(q);
+        for (void *q : side) (void)hipFree(q);
+        ar->want = std::max(ar->want, asked);
     }
     template <typename T>
     hipError_t get(T **out, size_t n) {
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        asked += bytes;
+        if (ar->base && used + bytes <= ar->cap) {
+            *out = reinterpret_cast<T *>(ar->base + used);
+            used += bytes;
+            return hipSuccess;
+        }
         void *q = nullptr;
-        hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
-        if (e == hipSuccess) p.push_back(q);
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e == hipSuccess) side.push_back(q);
         *out = static_cast<T *>(q);
         return e;
     }
@@ -310,7 +350,7 @@ int gs_reads_from_staged_text(const gs_textstage *stage, int k, gs_reads **out, 
         t_last = t;
     };
     const bool fastq = stage->first == '@';
-    DevMem mem;
+    DevMem mem(device);
     const uint8_t *d_text = stage->d_text;
     uint8_t *d_flag, *d_c0, *d_hdr, *d_seq;
     uint32_t *d_ls, *d_llen, *d_seqbytes, *d_base, *d_scalars, *d_hdr_line, *d_name_off, *d_name_len, *d_rec_off;
