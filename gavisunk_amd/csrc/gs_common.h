@@ -50,6 +50,11 @@ int pair_component_device(uint32_t n_reads, uint64_t n_rows, const uint64_t *d_o
 int union_regions_device(uint64_t n_rows, const uint32_t *d_row_read, const uint32_t *d_row_vertex, uint32_t n_vertices,
                          const int64_t *d_vertex_id, uint32_t *d_size, int64_t *d_min, int64_t *d_max);
 
+// (gs_device.hip, for the on-device record parser of gs_ingest.hip) gs_reads_from_device_ascii for bases that kernels on the
+// NULL stream wrote: waits for that stream only, takes its n_reads + 1 words of scratch from the caller
+int reads_from_parsed_text(int device, const void *d_seq, const uint64_t *off, uint32_t n_reads, int k, uint64_t *d_boff_scratch,
+                           gs_reads **out);
+
 constexpr int kTileWindows = 2048;  // windows per tile = 64 lanes x 32 windows (one 64-bit word per lane)
 constexpr int kTileWords = 64;
 

@@ -2139,8 +2139,11 @@ __global__ void k_pack_reads(const uint8_t *seq, const uint64_t *byte_off, const
 }
 
 // shared by the two ASCII entry points: index + allocations, then the packing kernel over a device copy of the bases
+// d_boff_scratch != NULL (the on-device record parser, whose kernels all ran on the null stream): n_reads + 1 words of device
+// memory to put the offsets in, and the call waits for the NULL STREAM only -- a device-wide synchronisation (and every hipMalloc
+// / hipFree is one) would wait for the copy of the NEXT text block, which another thread of the command line has in flight
 static int reads_from_ascii(int device, const uint8_t *seq, bool seq_on_device, const uint64_t *off, uint32_t n_reads, int k,
-                            gs_reads **out, const char *who) {
+                            gs_reads **out, const char *who, uint64_t *d_boff_scratch = nullptr) {
     if (!out || (n_reads && (!off || (off[n_reads] && !seq)))) {
         set_error("%s: bad argument", who);
         return GS_E_ARG;
@@ -2163,10 +2166,10 @@ static int reads_from_ascii(int device, const uint8_t *seq, bool seq_on_device, 
     std::unique_ptr<gs_reads, void (*)(gs_reads *)> guard(*out, gs_reads_destroy);
     *out = nullptr;
     uint8_t *d_seq = nullptr;
-    uint64_t *d_boff = nullptr;
+    uint64_t *d_boff = d_boff_scratch;
     const uint64_t nbytes = off[n_reads];
     if (!seq_on_device && (rc = dev_alloc(&d_seq, nbytes))) return rc;
-    if ((rc = dev_alloc(&d_boff, (uint64_t)n_reads + 1))) {
+    if (!d_boff_scratch && (rc = dev_alloc(&d_boff, (uint64_t)n_reads + 1))) {
         (void)hipFree(d_seq);
         return rc;
     }
@@ -2176,10 +2179,10 @@ static int reads_from_ascii(int device, const uint8_t *seq, bool seq_on_device, 
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, 0, seq_on_device ? seq : d_seq, d_boff,
                            guard->read_word_off, n_reads, n_words, guard->words);
-        e = hipDeviceSynchronize();
+        e = d_boff_scratch ? hipStreamSynchronize(nullptr) : hipDeviceSynchronize();
     }
-    (void)hipFree(d_seq);
-    (void)hipFree(d_boff);
+    if (d_seq) (void)hipFree(d_seq);
+    if (!d_boff_scratch) (void)hipFree(d_boff);
     if (e != hipSuccess) {
         set_error("%s: %s", who, hipGetErrorString(e));
         return GS_E_NODEVICE;
@@ -2198,6 +2201,13 @@ int gs_reads_from_device_ascii(int device, const void *d_seq, const uint64_t *of
         HIP_TRY(hipDeviceSynchronize());  // the bases may have been written on another stream
     }
     return reads_from_ascii(device, static_cast<const uint8_t *>(d_seq), true, off, n_reads, k, out, "gs_reads_from_device_ascii");
+}
+
+// (gs_ingest.hip) the bases were written by kernels on the null stream; d_boff_scratch: n_reads + 1 words of device memory
+int gs::reads_from_parsed_text(int device, const void *d_seq, const uint64_t *off, uint32_t n_reads, int k, uint64_t *d_boff_scratch,
+                               gs_reads **out) {
+    HIP_TRY(hipSetDevice(device));
+    return reads_from_ascii(device, static_cast<const uint8_t *>(d_seq), true, off, n_reads, k, out, "gs_reads_from_text", d_boff_scratch);
 }
 
 void gs_reads_destroy(gs_reads *r) {

@@ -162,8 +162,9 @@ def _tag_text_blocks(blocks, db, table, ofile: str, device: int):
             t0 = _tick("tag", t0)
             out.write(hits, dev, db)
             last_timing["rows"] = last_timing.get("rows", 0) + len(hits)
+            t0 = _tick("write_rows", t0)
             dev.close()
-            _tick("write_rows", t0)
+            _tick("release_batch", t0)
             if st == _lib.GS_E_KEYERROR:
                 sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
                 return 1
