@@ -2203,12 +2203,14 @@ int gs_reads_from_device_ascii(int device, const void *d_seq, const uint64_t *of
     return reads_from_ascii(device, static_cast<const uint8_t *>(d_seq), true, off, n_reads, k, out, "gs_reads_from_device_ascii");
 }
 
+}  // extern "C"
 // (gs_ingest.hip) the bases were written by kernels on the null stream; d_boff_scratch: n_reads + 1 words of device memory
 int gs::reads_from_parsed_text(int device, const void *d_seq, const uint64_t *off, uint32_t n_reads, int k, uint64_t *d_boff_scratch,
                                gs_reads **out) {
     HIP_TRY(hipSetDevice(device));
     return reads_from_ascii(device, static_cast<const uint8_t *>(d_seq), true, off, n_reads, k, out, "gs_reads_from_text", d_boff_scratch);
 }
+extern "C" {
 
 void gs_reads_destroy(gs_reads *r) {
     if (!r) return;

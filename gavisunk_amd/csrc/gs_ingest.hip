@@ -445,7 +445,7 @@ int gs_reads_from_staged_text(const gs_textstage *stage, int k, gs_reads **out, 
     for (uint32_t r = 0; r < n_rec; r++) ix->len[r] = (uint32_t)(off[r + 1] - off[r]);
     uint64_t *d_boff;
     HIP_TRY(mem.get(&d_boff, (size_t)n_rec + 1));
-    const int rc = reads_from_parsed_text(device, d_seq, off.data(), n_rec, k, d_boff, out);  // (waits for the null stream: every kernel above ran there)
+    const int rc = gs::reads_from_parsed_text(device, d_seq, off.data(), n_rec, k, d_boff, out);  // (waits for the null stream: every kernel above ran there)
     lap("index copies, pack");
     if (rc != GS_OK) {
         delete ix;
