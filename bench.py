@@ -638,6 +638,7 @@ def main():
     ap.add_argument("--no-config2", action="store_true", help="skip the config-2 extra key")
     ap.add_argument("--no-engine", action="store_true", help="skip the streaming-engine leg")
     ap.add_argument("--no-chain", action="store_true", help="skip the device-resident stage-2/3 leg (`pair_stage` key)")
+    ap.add_argument("--rehearse-extra", action="store_true", help="run the extra workload key even on a reduced (--genome-mb / --reads) rehearsal")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra workload key (N = 1: one diploid shard; N > 1: config-3 weak scaling)")
     ap.add_argument("--cli", action="store_true", help="(default now) config-2 leg: also time the command-line drop-in")
     ap.add_argument("--no-cli", action="store_true", help="config-2 leg without the command-line timing")
@@ -1010,7 +1011,7 @@ def main():
                 out["engine_note"] = f"engine leg failed: {e}"
     release(res)
     # ---- the other genome-scale workload as an extra key --------------------------------------------------------------
-    if not a.no_extra and a.workload == "auto" and K == 20 and a.genome_mb is None and a.reads is None and not a.group_len:
+    if not a.no_extra and a.workload == "auto" and K == 20 and ((a.genome_mb is None and a.reads is None) or a.rehearse_extra) and not a.group_len:
         if world == 1:
             ex = run_workload("diploid", [0], 8, max(3, a.steps // 2), 1, want_sample=False)
             if rank == 0:
