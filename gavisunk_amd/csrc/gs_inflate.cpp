@@ -30,6 +30,9 @@
 #include <vector>
 #include <chrono>
 
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -247,6 +250,19 @@ inline int fast_symbols(const BlockCodes &bc, Bits &b, uint16_t *&o, uint16_t *o
         int s = (int)(e >> 16);
         if (s < 256) {
             *w++ = (uint16_t)s;
+            // up to two more literals from the bits already at hand (three codes are at most 45 of the >= 56 bits)
+            uint32_t e2 = lt[(uint32_t)buf & lmask];
+            if (!(e2 & 32u) && (e2 >> 16) < 256u && (e2 & 31u)) {
+                buf >>= (e2 & 31u);
+                cnt -= (int)(e2 & 31u);
+                *w++ = (uint16_t)(e2 >> 16);
+                e2 = lt[(uint32_t)buf & lmask];
+                if (!(e2 & 32u) && (e2 >> 16) < 256u && (e2 & 31u)) {
+                    buf >>= (e2 & 31u);
+                    cnt -= (int)(e2 & 31u);
+                    *w++ = (uint16_t)(e2 >> 16);
+                }
+            }
             continue;
         }
         if (s == 256) {
@@ -880,7 +896,29 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                 uint8_t *o = z->out.data() + base + out_off[c];
                 const uint8_t *w = win[c].data();
                 uint64_t nl = 0;
-                for (size_t k = 0; k < m; k++) {
+                size_t k = 0;
+#if defined(__SSE2__)
+                // sixteen symbols at a time while none of them is a marker (all but the first stretch of a piece): pack to bytes,
+                // count the newlines by compare + mask
+                const __m128i hi = _mm_set1_epi16((short)0xFF00), nlv = _mm_set1_epi8('\n');
+                for (; k + 16 <= m; k += 16) {
+                    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k));
+                    const __m128i b2 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k + 8));
+                    if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(_mm_or_si128(a, b2), hi), _mm_setzero_si128())) != 0xFFFF) {
+                        for (size_t j = k; j < k + 16; j++) {  // a marker among them: one by one
+                            const uint16_t v = s[j];
+                            const uint8_t byte = v < kMarker ? (uint8_t)v : w[v - kMarker];
+                            o[j] = byte;
+                            nl += byte == '\n';
+                        }
+                        continue;
+                    }
+                    const __m128i bytes = _mm_packus_epi16(a, b2);
+                    _mm_storeu_si128(reinterpret_cast<__m128i *>(o + k), bytes);
+                    nl += (uint64_t)__builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(bytes, nlv)));
+                }
+#endif
+                for (; k < m; k++) {
                     const uint16_t v = s[k];
                     const uint8_t byte = v < kMarker ? (uint8_t)v : w[v - kMarker];
                     o[k] = byte;
