@@ -17,6 +17,7 @@
 #include <rocprim/functional.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -308,7 +309,8 @@ __global__ void k_widen_u32(const uint32_t *in, uint64_t *out, uint64_t n) {
 int gs::pair_component_device(uint32_t n_reads, uint64_t n_rows, const uint64_t *d_off, const int64_t *d_pos, const int64_t *d_start,
                               const int64_t *d_id, uint32_t *d_outn, int64_t *d_out) {
     if (!n_reads) return GS_OK;
-    constexpr uint64_t kMaxChunkPairs = 400000000ULL;
+    uint64_t kMaxChunkPairs = 400000000ULL;
+    if (const char *e = getenv("GAVISUNK_PAIR_CHUNK")) kMaxChunkPairs = (uint64_t)std::max(1, atoi(e));  // (test knob: many small chunks)
     std::vector<uint64_t> off((size_t)n_reads + 1);
     HIP_TRY(hipMemcpy(off.data(), d_off, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     DevBuf db;

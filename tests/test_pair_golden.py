@@ -70,9 +70,15 @@ def test_tie_census_of_the_goldens():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [None, "2000"])
 @pytest.mark.parametrize("case", CASES)
-def test_gpu_stub_matches_reference_script(case, tmp_path):
+def test_gpu_stub_matches_reference_script(case, chunk, tmp_path, monkeypatch):
+    """chunk: the pair kernels take the reads in chunks of at most that many candidate pairs (a genome-scale hit list has 1e10 of
+    them): the goldens once in one chunk, once in dozens."""
     from gavisunk_amd import process_by_contig
+
+    if chunk:
+        monkeypatch.setenv("GAVISUNK_PAIR_CHUNK", chunk)
 
     for d, c in _items(case):
         t = c["tag"]
