@@ -670,6 +670,29 @@ int sort_by(uint64_t *key, uint32_t *idx, uint64_t n, int bits, Dev &db) {
     return GS_OK;
 }
 
+// every v[i] < bound?  (ids that index caller-sized arrays: a wrong count must fail loudly, not read out of bounds)
+__global__ void k_any_ge(const uint32_t *v, uint64_t n, uint32_t bound, uint32_t *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && v[i] >= bound) atomicOr(flag, 1u);
+}
+int check_ids_below(const uint32_t *d_ids, uint64_t n, uint32_t bound, const char *what) {
+    if (!n) return GS_OK;
+    uint32_t *d_flag = nullptr, h = 0;
+    HIP_TRY(hipMalloc((void **)&d_flag, sizeof(uint32_t)));
+    hipError_t e = hipMemset(d_flag, 0, sizeof(uint32_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_any_ge, dim3(blocks_of(n)), dim3(256), 0, 0, d_ids, n, bound, d_flag);
+        e = hipMemcpy(&h, d_flag, sizeof h, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_flag);
+    HIP_TRY(e);
+    if (h) {
+        set_error("%s: a row's id is not below %u", what, bound);
+        return GS_E_ARG;
+    }
+    return GS_OK;
+}
+
 int compute_segments(gs_rowset *rs) {
     if (rs->seg_n == rs->n && rs->seg) return GS_OK;
     rowset_drop_derived(rs);
@@ -894,6 +917,7 @@ int gs_rowset_diag_filter(gs_rowset *rs, uint32_t n_contigs, const char *const *
         return GS_E_ARG;
     }
     GS_TRY(check_device(rs->device, "gs_rowset_diag_filter"));
+    GS_TRY(check_ids_below(rs->contig, rs->n, n_contigs, "gs_rowset_diag_filter: contig"));
     GS_TRY(compute_segments(rs));
     const uint64_t n = rs->n;
     const uint32_t n_segs = rs->n_segs;
@@ -1054,6 +1078,8 @@ int gs_rowset_bad_keys(const gs_rowset *hap1, const gs_rowset *hap2, uint32_t n_
         return GS_E_ARG;
     }
     GS_TRY(check_device(hap1->device, "gs_rowset_bad_keys"));
+    GS_TRY(check_ids_below(hap1->key, hap1->n, n_keys, "gs_rowset_bad_keys: key"));
+    GS_TRY(check_ids_below(hap2->key, hap2->n, n_keys, "gs_rowset_bad_keys: key"));
     Dev db;
     uint8_t *d_hap, *d_bad = nullptr;
     uint32_t *d_count, *d_hist;
@@ -1144,6 +1170,7 @@ int gs_rowset_pair_stage(const gs_rowset *rs, const void *d_key_bad, const uint8
         return GS_E_ARG;
     }
     GS_TRY(check_device(rs->device, "gs_rowset_pair_stage"));
+    GS_TRY(check_ids_below(rs->name, rs->n, n_names, "gs_rowset_pair_stage: name"));
     gs_pairstage *ps = new gs_pairstage;
     struct Guard {
         gs_pairstage *p;

@@ -205,3 +205,23 @@ def test_pair_stage_prefilters_on_the_device(tmp_path):
     etsv, ebed = oracle.process_by_contig(text, "".join(rl), bad)
     assert (tmp_path / "o.tsv").read_text() == etsv and etsv.count("\n") > 100
     assert ((tmp_path / "o.bed").read_text() if (tmp_path / "o.bed").exists() else "") == ebed
+
+
+def test_ids_out_of_range_fail_loudly():
+    """Row ids index caller-sized arrays (contig names, keys, name ranks): a count that is too small is an error, not an
+    out-of-bounds read on the device."""
+    rs = engine.RowSet()
+    z = np.zeros(4, np.uint32)
+    rs.append_host(np.array([0, 0, 1, 5], np.uint32), z, np.array([0, 1, 2, 2], np.uint32), z, z, np.array([0, 1, 2, 9], np.uint32))
+    with pytest.raises(_lib.GsError) as e:
+        rs.diag_filter(["a", "b"], [1, 1])  # contig id 2 with two names
+    assert e.value.status == _lib.GS_E_ARG
+    with pytest.raises(_lib.GsError) as e:
+        engine.RowSet.bad_keys(rs, rs, np.full(5, 3, np.uint8))  # key 9 with five keys
+    assert e.value.status == _lib.GS_E_ARG
+    with pytest.raises(_lib.GsError) as e:
+        rs.pair_stage(np.arange(3, dtype=np.uint32), np.ones(3, np.uint8))  # name 5 with three names
+    assert e.value.status == _lib.GS_E_ARG
+    seg_name, bc, bg, bd, kept = rs.diag_filter(["a", "b", "c"], [1, 1, 1])  # the right count works
+    assert len(seg_name) == 3
+    rs.close()
