@@ -144,10 +144,12 @@ def build_workload(a, w, device, rank, world, comm, shards):
     log(f"assembly surrogate: {gen.n_bases} bases in {len(gen.off) - 1} contigs ({time.perf_counter() - t0:.1f} s)")
     replicate = comm is not None and comm.rccl is not None
     sunks = table = None
-    if rank == 0 or not replicate:
+    if rank == 0 or not replicate or getattr(a, "keep_sunks", False):
+        # (the sharded second half turns payloads into contig / start / ID through the SUNK set's own arrays: every rank defines it)
         t0 = time.perf_counter()
         sunks = engine.DeviceSunkSet(gen.ptr, gen.off, K, device)
         log(f"exact SUNK set: {sunks.n} keys in {sunks.n_groups} groups ({time.perf_counter() - t0:.1f} s, gs_sunks_define_device)")
+    if rank == 0 or not replicate:
         t0 = time.perf_counter()
         table = sunks.table()
         log(f"table: {table.layout} | {table.nbytes / 2**30:.1f} GiB ({time.perf_counter() - t0:.1f} s)")
@@ -552,6 +554,41 @@ def chain_leg(table, batches, locrows, contig_names, device, names_sorted_like_s
                     "gs_rowset_pair_stage (csrc/gs_chain.hip): nothing but the final TSV / BED rows and per-read verdicts crosses PCIe"}
 
 
+def sharded_chain_leg(comm, table, batches, locrows, contig_names, device, read_lo):
+    """The second half at N > 1 (`--sharded-chain`): every rank runs the device chain over ITS hit lists (they never leave their
+    GPU); the Table capacity by all-gather, the reads-per-SUNK counters by all-reduce, the TSV rows merged on rank 0
+    (gavisunk_amd.dist.sharded_second_half).  Timed between barriers, max over ranks.  -> dict on rank 0, None elsewhere."""
+    from gavisunk_amd import _lib, engine
+    from gavisunk_amd import dist as gdist
+
+    L = _lib.lib()
+    n_local = sum(len(b[2]) for b in batches)
+    rlen = np.concatenate([b[2] for b in batches])
+    comm.barrier()
+    _lib.check(L.gs_device_synchronize(device))
+    t0 = time.perf_counter()
+    rs = engine.RowSet(device, 1 << 20)
+    for dr, r0, _ in batches:
+        rs.append_pass(table, dr, r0, locrows)
+    rows_in = rs.n
+    key_hap = np.full(max(locrows.n_locs, 1), 3, np.uint8)[: locrows.n_locs]
+    # (synthetic names are numbered so that their sorted order is the stream order: global rank = global read index)
+    local, merged = gdist.sharded_second_half(comm, rs, contig_names, np.ones(len(contig_names), np.uint8), key_hap,
+                                              (read_lo + np.arange(n_local)).astype(np.uint32), (rlen >= 10000).astype(np.uint8), read_lo)
+    _lib.check(L.gs_device_synchronize(device))
+    dt = comm.all_max(time.perf_counter() - t0)
+    rs.close()
+    rows_all = int(comm.all_sum(int(rows_in)))
+    kept_all = int(comm.all_sum(int(local["rows_kept"])))
+    if merged is None:
+        return None
+    return {"rows_in": rows_all, "ranks": comm.world, "seconds_total": round(dt, 4), "rows_per_s": rows_all / dt, "rows_after_diag_filter": kept_all,
+            "bad_sunk_groups": int(local["bad"].sum()), "mean_coverage": local["meancov"][0], "tsv_rows": int(len(merged["row_id"])),
+            "validated_intervals": int(len(merged["region_start"])),
+            "path": "per rank: hit list in HBM -> rows -> diag filter -> step 2 -> bad SUNKs -> pair stage (csrc/gs_chain.hip); across ranks: Table "
+                    "capacity (all-gather, 8 B), reads per SUNK (all-reduce, n_keys x 4 B), TSV rows to the root (20 B per row) + union there"}
+
+
 def config2_chain(table, dev_reads, sunks, names, seqs, device):
     """config 2 end to end through the device chain (the `pair_stage` key): tagger rows in HBM -> diag filter -> step 2 -> bad
     SUNKs -> pair stage -> union.  Checked against the reference binary's own diag output on these inputs
@@ -638,6 +675,9 @@ def main():
     ap.add_argument("--no-config2", action="store_true", help="skip the config-2 extra key")
     ap.add_argument("--no-engine", action="store_true", help="skip the streaming-engine leg")
     ap.add_argument("--no-chain", action="store_true", help="skip the device-resident stage-2/3 leg (`pair_stage` key)")
+    ap.add_argument("--sharded-chain", action="store_true",
+                    help="N > 1: also run the read-sharded second half (dist.sharded_second_half: every rank filters and pair-tests its own hit list, "
+                         "counters by all-reduce, TSV rows merged on the root) -> `pair_stage` key; every rank then defines the SUNK set itself")
     ap.add_argument("--rehearse-extra", action="store_true", help="run the extra workload key even on a reduced (--genome-mb / --reads) rehearsal")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra workload key (N = 1: one diploid shard; N > 1: config-3 weak scaling)")
     ap.add_argument("--cli", action="store_true", help="(default now) config-2 leg: also time the command-line drop-in")
@@ -944,7 +984,13 @@ def main():
     else:
         shards = [rank]
         bps = a.batches or 8
-    res = run_workload(wname, shards, bps, a.steps, a.warmup, want_sample=True, want_chain=(world == 1 and not a.no_chain))
+    res = run_workload(wname, shards, bps, a.steps, a.warmup, want_sample=True,
+                       want_chain=((world == 1 and not a.no_chain) or (world > 1 and a.sharded_chain)))
+    sharded = None
+    if world > 1 and a.sharded_chain and res.get("kept_sunks"):
+        lr = engine.LocRows.from_sunkset(res["kept_sunks"][0])
+        sharded = sharded_chain_leg(comm, res["table"], res["batches"], lr, res["kept_sunks"][1], device, rank * len(res["rlen"]))
+        lr.close()
 
     out = None
     if rank == 0:
@@ -1004,6 +1050,10 @@ def main():
                 log(f"pair stage: {out['pair_stage']['rows_in']} rows in {out['pair_stage']['seconds_total']:.2f} s = {out['pair_stage']['rows_per_s'] / 1e6:.1f} Mrow/s")
             except Exception as e:  # (a measurement leg must not cost the headline)
                 out["pair_stage"] = {"failed": repr(e)}
+        if sharded is not None:
+            out["pair_stage"] = sharded
+            out["pair_stage"]["workload"] = "every rank's own hit list of the headline workload (read-sharded second half)"
+            log(f"sharded pair stage: {sharded['rows_in']} rows on {world} ranks in {sharded['seconds_total']:.2f} s = {sharded['rows_per_s'] / 1e6:.1f} Mrow/s")
         if not a.no_engine and world == 1:
             try:
                 out.update(engine_leg(a, res["table"], res["batches"], device))

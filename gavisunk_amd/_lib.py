@@ -132,6 +132,9 @@ SIGNATURES = {
     "gs_sidecar_write": (I, [C.c_char_p, P, P, C.c_char_p, C.c_char_p]),
     "gs_sidecar_open": (I, [C.c_char_p, C.c_char_p, C.c_char_p, I, C.POINTER(P), C.POINTER(P)]),
     "gs_comm_allgather_u64": (I, [P, P, U32, P]),
+    "gs_comm_allreduce_u32": (I, [P, P, U64]),
+    "gs_comm_reduce_u32": (I, [P, P, U64]),
+    "gs_comm_gatherv_host": (I, [P, I, P, U64, I, C.POINTER(P), P]),
     "gs_comm_destroy": (None, [P]),
     "gs_table_broadcast": (I, [P, I, P, C.POINTER(P)]),
     "gs_gather_hits": (I, [P, I, P, P, U32, P, U64, C.POINTER(U64)]),
@@ -175,8 +178,13 @@ SIGNATURES = {
     "gs_rowset_diag_filter": (I, [P, U32, C.POINTER(C.c_char_p), P, P, P, P, P, C.POINTER(U64)]),
     "gs_rowset_keep_flags": (I, [P, P]),
     "gs_rowset_keep_filtered": (I, [P]),
+    "gs_rowset_diag_filter_from": (I, [P, U32, C.POINTER(C.c_char_p), P, U32, P, P, P, P, C.POINTER(U64), C.POINTER(U32)]),
     "gs_rowset_bad_keys": (I, [P, P, U32, P, P, P, C.POINTER(P)]),
+    "gs_rowset_bad_keys_reduced": (I, [P, P, U32, P, P, P, P, P, C.POINTER(P)]),
     "gs_device_free": (I, [I, P]),
+    "gs_device_copy_to_host": (I, [I, P, P, U64]),
+    "gs_device_copy_from_host": (I, [I, P, P, U64]),
+    "gs_pairstage_from_rows": (I, [I, U64, P, P, P, U32, P, C.POINTER(P)]),
     "gs_rowset_pair_stage": (I, [P, P, P, U32, P, P, C.POINTER(P)]),
     "gs_pairstage_free": (None, [P]),
     "gs_pairstage_n_rows": (U64, [P]),

@@ -161,6 +161,9 @@ int check_device(int device, const char *who) {
         return GS_E_NODEVICE;
     }
     HIP_TRY(hipSetDevice(device));
+    // rocprim returns whatever hipGetLastError holds after its launches: an error another library left behind on this thread (RCCL
+    // probes host pointers with hipPointerGetAttributes, which records "invalid argument") must not fail the next scan
+    (void)hipGetLastError();
     return GS_OK;
 }
 
@@ -313,10 +316,10 @@ __global__ void k_seg_need(const uint32_t *seg_pair_off, uint32_t n_segs, uint32
 // A read that makes it grow is listed in grow_list and replayed exactly by k_slots_grow.
 __global__ void k_slots(uint32_t n_segs, const uint32_t *seg_pair_off, const uint32_t *need, const uint32_t *need_prefmax,
                         const uint64_t *pair_off, const uint64_t *pair_key, const uint32_t *rows_sorted, const uint32_t *chash,
-                        uint32_t *pair_slot, uint32_t *grow_list, uint32_t *grow_count, uint32_t grow_cap) {
+                        uint32_t *pair_slot, uint32_t *grow_list, uint32_t *grow_count, uint32_t grow_cap, uint32_t cap0) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_segs) return;
-    const uint32_t cap_before = s ? max(64u, need_prefmax[s - 1]) : 64u;
+    const uint32_t cap_before = s ? max(cap0, need_prefmax[s - 1]) : cap0;
     const uint32_t p0 = seg_pair_off[s], p1 = seg_pair_off[s + 1];
     if (need[s] > cap_before) {
         const uint32_t g = atomicAdd(grow_count, 1u);
@@ -353,11 +356,12 @@ __global__ void k_slots(uint32_t n_segs, const uint32_t *seg_pair_off, const uin
 // exact replay of a growing Table (one thread per such read; scratch: 4 arrays of the final capacity)
 __global__ void k_slots_grow(uint32_t n_grow, const uint32_t *grow_list, const uint64_t *scratch_off, uint32_t *scratch,
                              const uint32_t *seg_pair_off, const uint32_t *need_prefmax, const uint64_t *pair_off,
-                             const uint64_t *pair_key, const uint32_t *rows_sorted, const uint32_t *chash, uint32_t *pair_slot) {
+                             const uint64_t *pair_key, const uint32_t *rows_sorted, const uint32_t *chash, uint32_t *pair_slot,
+                             uint32_t cap0) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_grow) return;
     const uint32_t s = grow_list[g];
-    uint32_t n = s ? max(64u, need_prefmax[s - 1]) : 64u;
+    uint32_t n = s ? max(cap0, need_prefmax[s - 1]) : cap0;
     const uint32_t p0 = seg_pair_off[s], p1 = seg_pair_off[s + 1];
     const uint32_t capf = max(n, nim_cap_for(p1 - p0));
     uint32_t *key = scratch + scratch_off[g], *hc = key + capf, *nk = hc + capf, *nh = nk + capf;
@@ -646,6 +650,10 @@ __global__ void k_lookup_vertex(const uint64_t *vk, uint64_t n, const uint64_t *
     }
     row_vertex[i] = lo;
 }
+__global__ void k_pack_u32x2(const uint32_t *hi, const uint32_t *lo, uint64_t n, uint64_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint64_t)hi[i] << 32 | lo[i];
+}
 __global__ void k_widen(const uint32_t *in, uint64_t *out, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i];
@@ -710,6 +718,68 @@ int compute_segments(gs_rowset *rs) {
     return GS_OK;
 }
 
+
+// process-by-contig_lowmem_AR.py:219-260 over T output rows in device memory (contig, ID, group = the read the row belongs to; a
+// read's rows are adjacent): vertices = distinct (contig, ID), an edge between consecutive rows of a read, components with more
+// than two SUNKs -> [min, max] per contig.  Commutative over reads: the rows of several ranks, concatenated, give the union of
+// the whole run (gs_pairstage_from_rows).
+int union_of_rows(Dev &db, uint64_t T, const uint32_t *d_oc, const int64_t *d_oi, const uint32_t *d_og, gs_pairstage *ps) {
+    uint64_t *d_vk, *d_vs, *d_uniq;
+    uint32_t *d_vh, *d_vi, *d_rv, *d_size;
+    int64_t *d_vid, *d_min, *d_max;
+    GS_TRY(db.get(&d_vk, T));
+    GS_TRY(db.get(&d_vs, T));
+    hipLaunchKernelGGL(k_vertex_key, dim3(blocks_of(T)), dim3(256), 0, 0, d_oc, d_oi, T, d_vk);
+    GS_TRY(sort_keys_u64(d_vk, d_vs, T, nullptr));
+    GS_TRY(db.get(&d_vh, T));
+    GS_TRY(db.get(&d_vi, T));
+    hipLaunchKernelGGL(k_head_u64, dim3(blocks_of(T)), dim3(256), 0, 0, d_vs, T, d_vh);
+    GS_TRY(inclusive_scan(d_vh, d_vi, T, rocprim::plus<uint32_t>()));
+    uint32_t nv = 0;
+    HIP_TRY(hipMemcpy(&nv, d_vi + T - 1, 4, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_dec, dim3(blocks_of(T)), dim3(256), 0, 0, d_vi, T);
+    GS_TRY(db.get(&d_uniq, nv));
+    GS_TRY(db.get(&d_vid, nv));
+    hipLaunchKernelGGL(k_unique_fill, dim3(blocks_of(T)), dim3(256), 0, 0, d_vs, d_vh, d_vi, T, d_uniq, d_vid);
+    GS_TRY(db.get(&d_rv, T));
+    hipLaunchKernelGGL(k_lookup_vertex, dim3(blocks_of(T)), dim3(256), 0, 0, d_vk, T, d_uniq, nv, d_rv);
+    GS_TRY(db.get(&d_size, nv));
+    GS_TRY(db.get(&d_min, nv));
+    GS_TRY(db.get(&d_max, nv));
+    HIP_TRY(hipDeviceSynchronize());
+    GS_TRY(union_regions_device(T, d_og, d_rv, nv, d_vid, d_size, d_min, d_max));
+    uint8_t *d_rf;
+    uint32_t *d_rsel;
+    GS_TRY(db.get(&d_rf, nv));
+    GS_TRY(db.get(&d_rsel, nv));
+    hipLaunchKernelGGL(k_region_flag, dim3(blocks_of(nv)), dim3(256), 0, 0, d_size, nv, d_rf);
+    uint64_t nr = 0;
+    GS_TRY(select_indices(d_rf, d_rsel, nv, &nr));
+    if (nr) {
+        std::vector<uint32_t> sel(nr);
+        std::vector<uint64_t> uq(nv);
+        std::vector<int64_t> mn(nv), mx(nv);
+        HIP_TRY(hipMemcpy(sel.data(), d_rsel, nr * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(uq.data(), d_uniq, (size_t)nv * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(mn.data(), d_min, (size_t)nv * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(mx.data(), d_max, (size_t)nv * 8, hipMemcpyDeviceToHost));
+        struct Reg {
+            uint32_t c;
+            int64_t s, e;
+        };
+        std::vector<Reg> regs;
+        for (uint32_t v : sel) regs.push_back(Reg{(uint32_t)(uq[v] >> 32), mn[v], mx[v]});
+        std::sort(regs.begin(), regs.end(), [](const Reg &a, const Reg &b) {  // `sort_values(by='start')` per contig (:254); (start, end) as the stub always wrote
+            return a.c != b.c ? a.c < b.c : (a.s != b.s ? a.s < b.s : a.e < b.e);
+        });
+        for (const Reg &r : regs) {
+            ps->region_contig.push_back(r.c);
+            ps->region_start.push_back(r.s);
+            ps->region_end.push_back(r.e);
+        }
+    }
+    return GS_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -912,10 +982,18 @@ int gs_rowset_segments(gs_rowset *rs, uint32_t *n_segs) {
 //   seg_name = name id of the segment's rows; best_contig = contig id or GS_NONE (prints nothing); best_good; best_dir
 int gs_rowset_diag_filter(gs_rowset *rs, uint32_t n_contigs, const char *const *contig_names, const uint8_t *in_fai, uint32_t *seg_name,
                           uint32_t *best_contig, uint32_t *best_good, uint8_t *best_dir, uint64_t *n_kept) {
-    if (!rs || !contig_names || !in_fai) {
-        set_error("gs_rowset_diag_filter: null argument");
+    return gs_rowset_diag_filter_from(rs, n_contigs, contig_names, in_fai, 64, seg_name, best_contig, best_good, best_dir, n_kept, nullptr);
+}
+
+int gs_rowset_diag_filter_from(gs_rowset *rs, uint32_t n_contigs, const char *const *contig_names, const uint8_t *in_fai, uint32_t cap_in,
+                               uint32_t *seg_name, uint32_t *best_contig, uint32_t *best_good, uint8_t *best_dir, uint64_t *n_kept,
+                               uint32_t *cap_out) {
+    if (!rs || !contig_names || !in_fai || cap_in < 64 || (cap_in & (cap_in - 1))) {
+        set_error("gs_rowset_diag_filter: bad argument (cap_in = the Table capacity carried in: a power of two >= 64)");
         return GS_E_ARG;
     }
+    const uint32_t cap0 = cap_in;
+    if (cap_out) *cap_out = cap0;
     GS_TRY(check_device(rs->device, "gs_rowset_diag_filter"));
     GS_TRY(check_ids_below(rs->contig, rs->n, n_contigs, "gs_rowset_diag_filter: contig"));
     GS_TRY(compute_segments(rs));
@@ -971,7 +1049,12 @@ int gs_rowset_diag_filter(gs_rowset *rs, uint32_t n_contigs, const char *const *
     GS_TRY(db.get(&d_grow_n, 1));
     HIP_TRY(hipMemset(d_grow_n, 0, sizeof(uint32_t)));
     hipLaunchKernelGGL(k_slots, dim3(blocks_of(n_segs, 128)), dim3(128), 0, 0, n_segs, d_seg_pair_off, d_need, d_prefmax, d_pair_off,
-                       d_pair_key, d_rows, d_chash, d_slot, d_grow, d_grow_n, grow_cap);
+                       d_pair_key, d_rows, d_chash, d_slot, d_grow, d_grow_n, grow_cap, cap0);
+    if (cap_out) {  // the capacity the Table leaves this row set with
+        uint32_t last = 0;
+        HIP_TRY(hipMemcpy(&last, d_prefmax + n_segs - 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        *cap_out = std::max(cap0, last);
+    }
     uint32_t n_grow = 0;
     HIP_TRY(hipMemcpy(&n_grow, d_grow_n, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (n_grow > grow_cap) {
@@ -986,7 +1069,7 @@ int gs_rowset_diag_filter(gs_rowset *rs, uint32_t n_contigs, const char *const *
         std::vector<uint64_t> so(n_grow + 1, 0);
         for (uint32_t g = 0; g < n_grow; g++) {
             const uint32_t s = gl[g];
-            const uint32_t capf = std::max(need[s], s ? std::max(64u, pm[s - 1]) : 64u);
+            const uint32_t capf = std::max(need[s], s ? std::max(cap0, pm[s - 1]) : cap0);
             so[g + 1] = so[g] + 4ULL * capf;
         }
         uint64_t *d_so;
@@ -994,7 +1077,7 @@ int gs_rowset_diag_filter(gs_rowset *rs, uint32_t n_contigs, const char *const *
         GS_TRY(db.put(&d_so, so.data(), so.size()));
         GS_TRY(db.get(&d_scr, so[n_grow]));
         hipLaunchKernelGGL(k_slots_grow, dim3(blocks_of(n_grow, 64)), dim3(64), 0, 0, n_grow, d_grow, d_so, d_scr, d_seg_pair_off, d_prefmax,
-                           d_pair_off, d_pair_key, d_rows, d_chash, d_slot);
+                           d_pair_off, d_pair_key, d_rows, d_chash, d_slot, cap0);
     }
     // statistics per (read, contig), selection per read, verdict per row
     int64_t *d_sa, *d_sb;
@@ -1073,6 +1156,11 @@ int gs_rowset_keep_filtered(gs_rowset *rs) {
 // "mean coverage" of haplotype h (mode of the reads per SUNK group on its own contigs, smallest on ties).
 int gs_rowset_bad_keys(const gs_rowset *hap1, const gs_rowset *hap2, uint32_t n_keys, const uint8_t *key_hap, uint8_t *bad_host,
                        uint32_t meancov[2], void **d_bad_out) {
+    return gs_rowset_bad_keys_reduced(hap1, hap2, n_keys, key_hap, nullptr, nullptr, bad_host, meancov, d_bad_out);
+}
+
+int gs_rowset_bad_keys_reduced(const gs_rowset *hap1, const gs_rowset *hap2, uint32_t n_keys, const uint8_t *key_hap, gs_reduce_u32_fn reduce,
+                               void *reduce_ctx, uint8_t *bad_host, uint32_t meancov[2], void **d_bad_out) {
     if (!hap1 || !hap2 || !key_hap || !n_keys || !hap1->has_key || !hap2->has_key || hap1->device != hap2->device) {
         set_error("gs_rowset_bad_keys: bad argument (both row sets need keys and one device)");
         return GS_E_ARG;
@@ -1097,6 +1185,10 @@ int gs_rowset_bad_keys(const gs_rowset *hap1, const gs_rowset *hap2, uint32_t n_
         hipError_t e = hipMemset(d_count, 0, (size_t)n_keys * 4);
         if (e == hipSuccess) e = hipMemset(d_hist, 0, hist_len * 4);
         if (e == hipSuccess && rs->n) hipLaunchKernelGGL(k_count_keys, dim3(blocks_of(rs->n)), dim3(256), 0, 0, rs->key, rs->n, d_count);
+        if (e == hipSuccess && reduce) {  // reads sharded over ranks: the counts of all of them (one sum per haplotype)
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess && (rc = reduce(reduce_ctx, d_count, n_keys)) != GS_OK) break;
+        }
         if (e == hipSuccess) hipLaunchKernelGGL(k_hist_counts, dim3(blocks_of(n_keys)), dim3(256), 0, 0, d_count, d_hap, bit, n_keys, d_hist, hist_len);
         if (e == hipSuccess) e = hipMemcpy(hist.data(), d_hist, hist_len * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
@@ -1330,62 +1422,50 @@ int gs_rowset_pair_stage(const gs_rowset *rs, const void *d_key_bad, const uint8
     HIP_TRY(hipMemcpy(ps->row_contig.data(), d_oc, T * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ps->row_name.data(), d_on, T * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ps->row_id.data(), d_oi, T * 8, hipMemcpyDeviceToHost));
-    // 6. contig-wide union of the reads' ID sets (:219-260): vertices = distinct (contig, ID), an edge between consecutive rows of a read
-    uint64_t *d_vk, *d_vs, *d_uniq;
-    uint32_t *d_vh, *d_vi, *d_rv, *d_size;
-    int64_t *d_vid, *d_min, *d_max;
-    GS_TRY(db.get(&d_vk, T));
-    GS_TRY(db.get(&d_vs, T));
-    hipLaunchKernelGGL(k_vertex_key, dim3(blocks_of(T)), dim3(256), 0, 0, d_oc, d_oi, T, d_vk);
-    GS_TRY(sort_keys_u64(d_vk, d_vs, T, nullptr));
-    GS_TRY(db.get(&d_vh, T));
-    GS_TRY(db.get(&d_vi, T));
-    hipLaunchKernelGGL(k_head_u64, dim3(blocks_of(T)), dim3(256), 0, 0, d_vs, T, d_vh);
-    GS_TRY(inclusive_scan(d_vh, d_vi, T, rocprim::plus<uint32_t>()));
-    uint32_t nv = 0;
-    HIP_TRY(hipMemcpy(&nv, d_vi + T - 1, 4, hipMemcpyDeviceToHost));
-    hipLaunchKernelGGL(k_dec, dim3(blocks_of(T)), dim3(256), 0, 0, d_vi, T);
-    GS_TRY(db.get(&d_uniq, nv));
-    GS_TRY(db.get(&d_vid, nv));
-    hipLaunchKernelGGL(k_unique_fill, dim3(blocks_of(T)), dim3(256), 0, 0, d_vs, d_vh, d_vi, T, d_uniq, d_vid);
-    GS_TRY(db.get(&d_rv, T));
-    hipLaunchKernelGGL(k_lookup_vertex, dim3(blocks_of(T)), dim3(256), 0, 0, d_vk, T, d_uniq, nv, d_rv);
-    GS_TRY(db.get(&d_size, nv));
-    GS_TRY(db.get(&d_min, nv));
-    GS_TRY(db.get(&d_max, nv));
-    HIP_TRY(hipDeviceSynchronize());
-    GS_TRY(union_regions_device(T, d_og, d_rv, nv, d_vid, d_size, d_min, d_max));
-    uint8_t *d_rf;
-    uint32_t *d_rsel;
-    GS_TRY(db.get(&d_rf, nv));
-    GS_TRY(db.get(&d_rsel, nv));
-    hipLaunchKernelGGL(k_region_flag, dim3(blocks_of(nv)), dim3(256), 0, 0, d_size, nv, d_rf);
-    uint64_t nr = 0;
-    GS_TRY(select_indices(d_rf, d_rsel, nv, &nr));
-    if (nr) {
-        std::vector<uint32_t> sel(nr);
-        std::vector<uint64_t> uq(nv);
-        std::vector<int64_t> mn(nv), mx(nv);
-        HIP_TRY(hipMemcpy(sel.data(), d_rsel, nr * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(uq.data(), d_uniq, (size_t)nv * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(mn.data(), d_min, (size_t)nv * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(mx.data(), d_max, (size_t)nv * 8, hipMemcpyDeviceToHost));
-        struct Reg {
-            uint32_t c;
-            int64_t s, e;
-        };
-        std::vector<Reg> regs;
-        for (uint32_t v : sel) regs.push_back(Reg{(uint32_t)(uq[v] >> 32), mn[v], mx[v]});
-        std::sort(regs.begin(), regs.end(), [](const Reg &a, const Reg &b) {  // `sort_values(by='start')` per contig (:254); (start, end) as the stub always wrote
-            return a.c != b.c ? a.c < b.c : (a.s != b.s ? a.s < b.s : a.e < b.e);
-        });
-        for (const Reg &r : regs) {
-            ps->region_contig.push_back(r.c);
-            ps->region_start.push_back(r.s);
-            ps->region_end.push_back(r.e);
-        }
-    }
+    // 6. contig-wide union of the reads' ID sets (:219-260)
+    GS_TRY(union_of_rows(db, T, d_oc, d_oi, d_og, ps));
     ps->counters[6] = T;
+    *out = ps;
+    guard.p = nullptr;
+    return GS_OK;
+}
+
+// The last step of a read-sharded run on its root: the TSV rows of all ranks (sorted by contig, then by the reads' name order;
+// a read's rows adjacent and in the order its rank wrote them) -> the same result object a one-GPU run gives: rows as handed in,
+// the validated intervals from the contig-wide union over ALL of them.
+int gs_pairstage_from_rows(int device, uint64_t n_rows, const uint32_t *row_contig, const uint32_t *row_name, const int64_t *row_id,
+                           uint32_t n_contigs_in, const uint32_t *contigs_in, gs_pairstage **out) {
+    if (!out || (n_rows && (!row_contig || !row_name || !row_id)) || (n_contigs_in && !contigs_in)) {
+        set_error("gs_pairstage_from_rows: null argument");
+        return GS_E_ARG;
+    }
+    GS_TRY(check_device(device, "gs_pairstage_from_rows"));
+    gs_pairstage *ps = new gs_pairstage;
+    struct Guard {
+        gs_pairstage *p;
+        ~Guard() { delete p; }
+    } guard{ps};
+    ps->contigs_in.assign(contigs_in, contigs_in + n_contigs_in);
+    ps->row_contig.assign(row_contig, row_contig + n_rows);
+    ps->row_name.assign(row_name, row_name + n_rows);
+    ps->row_id.assign(row_id, row_id + n_rows);
+    ps->counters[6] = n_rows;
+    if (n_rows) {
+        Dev db;
+        uint32_t *d_oc, *d_on, *d_head, *d_og;
+        int64_t *d_oi;
+        uint64_t *d_gk;
+        GS_TRY(db.put(&d_oc, row_contig, n_rows));
+        GS_TRY(db.put(&d_on, row_name, n_rows));
+        GS_TRY(db.put(&d_oi, row_id, n_rows));
+        GS_TRY(db.get(&d_gk, n_rows));
+        GS_TRY(db.get(&d_head, n_rows));
+        GS_TRY(db.get(&d_og, n_rows));
+        hipLaunchKernelGGL(k_pack_u32x2, dim3(blocks_of(n_rows)), dim3(256), 0, 0, d_oc, d_on, n_rows, d_gk);
+        hipLaunchKernelGGL(k_head_u64, dim3(blocks_of(n_rows)), dim3(256), 0, 0, d_gk, n_rows, d_head);
+        GS_TRY(inclusive_scan(d_head, d_og, n_rows, rocprim::plus<uint32_t>()));  // (group numbers from 1: only equality matters)
+        GS_TRY(union_of_rows(db, n_rows, d_oc, d_oi, d_og, ps));
+    }
     *out = ps;
     guard.p = nullptr;
     return GS_OK;

@@ -40,6 +40,7 @@ struct Rccl {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -61,12 +62,13 @@ Rccl *rccl() {
             GS_RCCL_SYM(GetErrorString);
             GS_RCCL_SYM(Broadcast);
             GS_RCCL_SYM(AllGather);
+            GS_RCCL_SYM(AllReduce);
             GS_RCCL_SYM(Send);
             GS_RCCL_SYM(Recv);
             GS_RCCL_SYM(GroupStart);
             GS_RCCL_SYM(GroupEnd);
 #undef GS_RCCL_SYM
-            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GetErrorString || !r.Broadcast || !r.AllGather || !r.Send ||
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GetErrorString || !r.Broadcast || !r.AllGather || !r.AllReduce || !r.Send ||
                 !r.Recv || !r.GroupStart || !r.GroupEnd)
                 r.so = nullptr;
         }
@@ -181,6 +183,7 @@ int comm_agree(Rccl *R, gs_comm *c, int mine, int *agreed) {
     std::vector<unsigned long long> all((size_t)c->nranks);
     HIP_TRY(hipMemcpyAsync(all.data(), c->d_meta, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipGetLastError();  // (see gs_gather_hits)
     *agreed = 0;
     for (int i = 0; i < c->nranks; i++)
         if ((long long)all[i] != 0) {
@@ -245,6 +248,7 @@ int gs_comm_init(int device, int nranks, int rank, const void *unique_id, gs_com
     NCCL_TRY(R->CommInitRank(&c->comm, nranks, id, rank));
     int rc;
     if ((rc = dev_alloc(&c->d_meta, (uint64_t)4 * nranks))) return rc;
+    (void)hipGetLastError();  // (see gs_gather_hits)
     *out = guard.release();
     return GS_OK;
 }
@@ -306,6 +310,7 @@ int gs_table_broadcast(gs_comm *c, int root, gs_table *mine, gs_table **out) {
             NCCL_TRY(R->Broadcast(b + o, b + o, std::min<size_t>(piece, a.bytes - o), ncclUint8, root, c->comm, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipGetLastError();  // (see gs_gather_hits)
     if (!is_root) guard.release();
     *out = t;
     return GS_OK;
@@ -358,6 +363,7 @@ int gs_comm_allgather_u64(gs_comm *c, const uint64_t *mine, uint32_t n, uint64_t
     if (c->nranks > 1) NCCL_TRY(R->AllGather(seg, c->d_meta, n, ncclUint64, c->comm, c->stream));
     HIP_TRY(hipMemcpyAsync(out, c->d_meta, (size_t)n * c->nranks * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipGetLastError();  // (see gs_gather_hits)
     return GS_OK;
 }
 
@@ -434,6 +440,9 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
         NCCL_TRY(R->Send(r->hits, (size_t)r->ps.res_n * sizeof(gs_hit), ncclUint8, root, c->comm, c->stream));
     }
     if (n > 1) NCCL_TRY(R->GroupEnd());
+    // (RCCL probes pointers with hipPointerGetAttributes and leaves "invalid argument" in this thread's last-error slot: dropped
+    // here, so that the check after OUR kernels below, and rocprim's own checks in later calls, see only our errors)
+    (void)hipGetLastError();
     if (is_root) {
         uint64_t at = 0;
         for (int i = 0; i < n; i++) {  // shard-local read indices -> indices in the whole input
@@ -493,6 +502,137 @@ int gs_gather_device(gs_comm *c, const void **d_out, uint64_t *n_out) {
     }
     if (d_out) *d_out = c->d_gather;
     if (n_out) *n_out = c->gather_n;
+    return GS_OK;
+}
+
+// ---- the second half of a read-sharded run (csrc/gs_chain.hip; SURVEY.md section 8e: "pair-distance stage: shard by read") ----
+// Every rank filters and pair-tests its OWN rows; two things are not local.  The bad-SUNK histogram counts reads per SUNK over
+// all reads (badsunks_AR.py:20-46): one in-place sum of the per-key counters (n_keys x 4 bytes) per haplotype.  The contig-wide
+// union joins the reads' ID sets (process-by-contig_lowmem_AR.py:219-260): the TSV rows of every rank -- 16 bytes per row, 10^-2
+// of the hit list -- go to the root, which merges them (gs_pairstage_from_rows).  The hit lists themselves never leave their GPU.
+int gs_comm_allreduce_u32(gs_comm *c, void *d_buf, uint64_t n) {
+    if (!c || (n && !d_buf)) {
+        set_error("gs_comm_allreduce_u32: bad argument");
+        return GS_E_ARG;
+    }
+    Rccl *R = rccl();
+    if (!R) return GS_E_NODEVICE;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t piece = (uint64_t)1 << 28;  // 1 GiB of counters per collective
+    for (uint64_t o = 0; o < n; o += piece) {
+        uint32_t *b = static_cast<uint32_t *>(d_buf) + o;
+        NCCL_TRY(R->AllReduce(b, b, (size_t)std::min(piece, n - o), ncclUint32, ncclSum, c->comm, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipGetLastError();  // (RCCL's own pointer probes leave "invalid argument" behind: not ours, and rocprim would report it)
+    return GS_OK;
+}
+// the same as a gs_reduce_u32_fn (gs_rowset_bad_keys_reduced): ctx = the communicator
+int gs_comm_reduce_u32(void *ctx, void *d_buf, uint64_t n) { return gs_comm_allreduce_u32(static_cast<gs_comm *>(ctx), d_buf, n); }
+
+// Variable-size gather of host bytes to the root: (size, status) of every rank by ncclAllGather -- a rank whose step failed says
+// so here and every rank returns its code before anything is sent --, then grouped ncclSend / ncclRecv of exactly the bytes
+// each rank has, staged through device memory on both sides.  sizes[nranks] on every rank; *out (root only; pinned: gs_host_free) = the
+// ranks' bytes back to back in rank order.
+int gs_comm_gatherv_host(gs_comm *c, int root, const void *mine, uint64_t nbytes, int status, void **out, uint64_t *sizes) {
+    if (!c || root < 0 || root >= c->nranks || (nbytes && !mine) || !sizes || (c->rank == root && !out)) {
+        set_error("gs_comm_gatherv_host: bad argument");
+        return GS_E_ARG;
+    }
+    if (out) *out = nullptr;
+    Rccl *R = rccl();
+    if (!R) return GS_E_NODEVICE;
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = c->nranks;
+    const bool is_root = c->rank == root;
+    const unsigned long long meta_mine[2] = {status ? 0ull : (unsigned long long)nbytes, (unsigned long long)(long long)status};
+    HIP_TRY(hipMemcpyAsync(c->d_meta + 2 * c->rank, meta_mine, sizeof meta_mine, hipMemcpyHostToDevice, c->stream));
+    if (n > 1) NCCL_TRY(R->AllGather(c->d_meta + 2 * c->rank, c->d_meta, 2, ncclUint64, c->comm, c->stream));
+    std::vector<unsigned long long> meta((size_t)2 * n);
+    HIP_TRY(hipMemcpyAsync(meta.data(), c->d_meta, meta.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        sizes[i] = meta[2 * i];
+        total += meta[2 * i];
+    }
+    for (int i = 0; i < n; i++)
+        if ((long long)meta[2 * i + 1] != 0) {
+            const int code = (int)(long long)meta[2 * i + 1];
+            if (i != c->rank) set_error("gs_comm_gatherv_host: the step of rank %d failed (status %d)", i, code);
+            return code;
+        }
+    // staging buffers, then one more agreement (nobody sends to a root that cannot receive)
+    const uint64_t my_bytes = meta[2 * c->rank];
+    uint8_t *d_stage = nullptr;
+    int st = dev_alloc(&d_stage, std::max<uint64_t>(is_root ? total : my_bytes, 16));
+    DevBufs tmp;
+    if (!st) tmp.p.push_back(d_stage);
+    void *host = nullptr;
+    if (!st && is_root && hipHostMalloc(&host, std::max<uint64_t>(total, 1), hipHostMallocDefault) != hipSuccess) {
+        set_error("gs_comm_gatherv_host: out of pinned host memory (%llu bytes)", (unsigned long long)total);
+        host = nullptr;
+        st = GS_E_NOMEM;
+    }
+    int agreed = 0, rc;
+    if ((rc = comm_agree(R, c, st, &agreed))) {
+        gs_host_free(host);
+        return rc;
+    }
+    if (agreed) {
+        if (!st) set_error("gs_comm_gatherv_host: another rank could not allocate its buffer (status %d)", agreed);
+        gs_host_free(host);
+        return agreed;
+    }
+    uint64_t my_at = 0;
+    for (int i = 0; i < c->rank; i++) my_at += meta[2 * i];
+    uint8_t *d_mine = is_root ? d_stage + my_at : d_stage;
+    hipError_t e = my_bytes ? hipMemcpyAsync(d_mine, mine, my_bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    ncclResult_t nr = ncclSuccess;
+    if (e == hipSuccess && n > 1) {
+        nr = R->GroupStart();
+        if (is_root) {
+            uint64_t at = 0;
+            for (int i = 0; i < n && nr == ncclSuccess; i++) {
+                if (i != root && meta[2 * i]) nr = R->Recv(d_stage + at, (size_t)meta[2 * i], ncclUint8, i, c->comm, c->stream);
+                at += meta[2 * i];
+            }
+        } else if (my_bytes && nr == ncclSuccess) {
+            nr = R->Send(d_stage, (size_t)my_bytes, ncclUint8, root, c->comm, c->stream);
+        }
+        const ncclResult_t ge = R->GroupEnd();
+        if (nr == ncclSuccess) nr = ge;
+    }
+    if (e == hipSuccess && nr == ncclSuccess && is_root && total) e = hipMemcpyAsync(host, d_stage, total, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess || nr != ncclSuccess) {
+        set_error("gs_comm_gatherv_host: %s", e != hipSuccess ? hipGetErrorString(e) : R->GetErrorString(nr));
+        gs_host_free(host);
+        return GS_E_NODEVICE;
+    }
+    if (is_root) *out = host;
+    (void)hipGetLastError();
+    return GS_OK;
+}
+
+// plain copies between host memory and device pointers this library handed out (the counters of gs_rowset_bad_keys_reduced when
+// the caller's data plane is not RCCL: tests with several processes on one GPU)
+int gs_device_copy_to_host(int device, void *host, const void *d_src, uint64_t nbytes) {
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_device_copy_to_host: HIP device %d not available", device);
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    if (nbytes) HIP_TRY(hipMemcpy(host, d_src, nbytes, hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+int gs_device_copy_from_host(int device, void *d_dst, const void *host, uint64_t nbytes) {
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_device_copy_from_host: HIP device %d not available", device);
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    if (nbytes) HIP_TRY(hipMemcpy(d_dst, host, nbytes, hipMemcpyHostToDevice));
     return GS_OK;
 }
 

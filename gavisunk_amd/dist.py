@@ -14,15 +14,27 @@ reads; so the path has exactly one exchange step:
   gather   per-rank hit buffers (12 B per output row) are concatenated on rank 0 in shard order (gs_gather_hits: counts and
            statuses by ncclAllGather, rows by grouped send / receive of exactly their size).
 
-Nothing here computes on the CPU: the tagging itself is engine.DeviceTable / engine.DeviceReads.
+The SECOND half shards the same way ("pair-distance stage: shard by read"): every rank runs the device
+chain (csrc/gs_chain.hip) over the rows of its OWN reads -- the hit lists never leave their GPU -- and three things cross ranks:
+
+  capacity   the slot order of diag_filter_v3's Table depends on its capacity, which persists from read to read: one all_gather of
+             the capacity each shard leaves (4 bytes), and a shard whose predecessors grew the Table past 64 slots runs again
+  counters   the bad-SUNK histogram counts reads per SUNK over ALL reads: one all_reduce (sum) of n_keys x 4 bytes per haplotype
+  TSV rows   the pair stage's output rows (20 bytes each, ~1e-2 of the hit list) go to the root, which merges them in name
+             order and runs the contig-wide union over all of them (gs_pairstage_from_rows)
+
+Nothing here computes on the CPU: the tagging itself is engine.DeviceTable / engine.DeviceReads, the filters engine.RowSet.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Sequence, Tuple
 
 import numpy as np
 
 from ._lib import GS_NONE
+
+ROW_DTYPE = np.dtype([("contig", "<u4"), ("name", "<u4"), ("rank", "<u4"), ("id", "<i8")], align=False)  # a TSV row on its way to the root
 
 
 def shard_bounds(n_reads: int, world: int, rank: int) -> Tuple[int, int]:
@@ -136,9 +148,126 @@ class Comm:
         self.dist.gather(padded, None, dst=dst)
         return None
 
+    # ---- the two exchanges of the second half -----------------------------------------------------------------
+    def reducer(self):
+        """(function pointer, context) for engine.RowSet.bad_keys(reduce=): the reads-per-SUNK counters of all ranks summed in
+        place -- ncclAllReduce inside the library on the RCCL data plane; device -> host -> gloo all_reduce -> device otherwise."""
+        if self.rccl is not None:
+            return self.rccl.reducer()
+        import torch
+
+        from ._lib import lib
+
+        def cb(_ctx, d_ptr, n):
+            try:
+                host = np.zeros(max(int(n), 1), np.uint32)
+                if lib().gs_device_copy_to_host(self.device, host.ctypes.data, d_ptr, int(n) * 4):
+                    return -1
+                t = torch.from_numpy(host.astype(np.int64))
+                self.dist.all_reduce(t)
+                host[:] = t.numpy().astype(np.uint32)
+                return lib().gs_device_copy_from_host(self.device, d_ptr, host.ctypes.data, int(n) * 4)
+            except Exception:  # (an exception cannot cross the C frame)
+                return -1
+
+        self._reduce_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)(cb)  # (kept alive by the communicator)
+        return C.cast(self._reduce_cb, C.c_void_p), None
+
+    def gatherv(self, data: np.ndarray, status: int = 0, dst: int = 0):
+        """Every rank's bytes on rank dst as a list of uint8 arrays in rank order (None elsewhere); a non-zero status on any rank
+        makes every rank raise.  RCCL: gs_comm_gatherv_host; gloo: sizes first, then a padded gather."""
+        if self.rccl is not None:
+            return self.rccl.gatherv(data, status, dst)
+        import torch
+
+        from ._lib import GsError
+
+        data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        meta = self._all_gather_i64([0 if status else len(data), status])
+        for r, (_, code) in enumerate(meta):
+            if code:
+                raise GsError(int(code), f"the step of rank {r} failed")
+        sizes = [m[0] for m in meta]
+        padded = torch.zeros(max(max(sizes), 1), dtype=torch.uint8)
+        padded[: len(data)] = torch.from_numpy(data.copy())
+        if self.rank == dst:
+            bufs = [torch.empty_like(padded) for _ in range(self.world)]
+            self.dist.gather(padded, bufs, dst=dst)
+            return [b[:c].numpy().copy() for b, c in zip(bufs, sizes)]
+        self.dist.gather(padded, None, dst=dst)
+        return None
+
     def close(self):
         if self.rccl is not None:
             self.rccl.close()
             self.rccl = None
         self.dist.barrier()
         self.dist.destroy_process_group()
+
+
+def carried_capacity(caps: Sequence[int], rank: int) -> int:
+    """The capacity of diag_filter_v3's Table before the first read of `rank`: the largest any earlier shard left (64 = fresh)."""
+    return max([64] + [int(c) for c in caps[:rank]])
+
+
+def sharded_second_half(comm: Comm, rows, contig_names, in_fai, key_hap, name_grank, name_long, read_offset: int, other_hap=None,
+                        dst: int = 0):
+    """Diagonal filter -> step 2 -> bad SUNKs -> process-by-contig (pair test, component) over THIS rank's rows on its GPU, the
+    contig-wide union on rank dst (module docstring).  rows: engine.RowSet of this rank's reads, name ids = read index in the shard;
+    name_grank[n_local]: position of each of them in the sorted order of ALL read names (`groupby("rname")`);
+    name_long[n_local]: the read is >= 10 kb; read_offset: index of the shard's first read in the whole input; other_hap: the
+    other haplotype's row set of the same reads (bad SUNKs count both; default: `rows` stands for both, as bench.py has it).
+    -> (local, merged): local = this rank's diag verdicts and bad-SUNK flags; merged (rank dst only, else None) = the dict
+    engine.RowSet.pair_stage returns on one GPU over all reads, `row_name` = index of the read in the whole input."""
+    from . import engine
+    from ._lib import GsError
+
+    status, err = 0, None
+    diag = None
+    cap = 64
+    try:
+        *diag, kept, cap = rows.diag_filter(contig_names, in_fai, want_cap=True)
+    except GsError as e:
+        status, err = e.status, e
+    meta = comm.exchange_summaries(cap, status & 0xFFFFFFFF)  # (the capacity travels with the status: a failed rank fails all)
+    for r, (_, code) in enumerate(meta):
+        if code:
+            raise err if err is not None else GsError(int(code) - (1 << 32), f"the diagonal filter of rank {r} failed")
+    cap_in = carried_capacity([m[0] for m in meta], comm.rank)
+    if cap_in > 64:  # (a read with more than 43 distinct contigs somewhere before this shard: rare, and exact either way)
+        *diag, kept, _ = rows.diag_filter(contig_names, in_fai, cap_in=cap_in, want_cap=True)
+    rows.keep_filtered()
+    bad, meancov, d_bad = engine.RowSet.bad_keys(rows, other_hap if other_hap is not None else rows, key_hap, keep_on_device=True,
+                                                 reduce=comm.reducer())
+    res = None
+    try:
+        res = rows.pair_stage(name_grank, name_long, d_key_bad=d_bad)
+    except GsError as e:
+        status, err = e.status, e
+    finally:
+        engine.free_device(d_bad, rows.device)
+    # this rank's TSV rows (read index in the whole input, global name rank) and its input contigs, in one message
+    t = len(res["row_id"]) if res is not None else 0
+    rec = np.zeros(t, ROW_DTYPE)
+    ci = np.zeros(0, np.uint32)
+    if t or res is not None:
+        ci = res["contigs_in"].astype(np.uint32)
+        rec["contig"], rec["name"], rec["id"] = res["row_contig"], res["row_name"] + np.uint32(read_offset), res["row_id"]
+        rec["rank"] = np.asarray(name_grank, np.uint32)[res["row_name"]]
+    blob = np.concatenate([np.array([len(ci)], np.uint32).view(np.uint8), ci.view(np.uint8), rec.view(np.uint8).reshape(-1)])
+    parts = comm.gatherv(blob, status, dst)
+    if err is not None:
+        raise err
+    local = {"diag": diag, "rows_kept": kept, "bad": bad, "meancov": meancov, "cap_in": cap_in, "counters": res["counters"]}
+    if parts is None:
+        return local, None
+    cis, recs = [], []
+    for b in parts:
+        nci = int(b[:4].view(np.uint32)[0])
+        cis.append(b[4:4 + 4 * nci].view(np.uint32))
+        recs.append(b[4 + 4 * nci:].view(ROW_DTYPE))
+    allrec = np.concatenate(recs)
+    order = np.lexsort((allrec["rank"], allrec["contig"]))  # stable: a read's rows stay in the order its rank wrote them
+    allrec = allrec[order]
+    merged = engine.pairstage_from_rows(allrec["contig"], allrec["name"], allrec["id"], np.unique(np.concatenate(cis)), rows.device)
+    return local, merged

@@ -729,16 +729,20 @@ class RowSet:
         check(lib().gs_rowset_segments(self._h, C.byref(ns)))
         return ns.value
 
-    def diag_filter(self, contig_names: Sequence[str], in_fai):
-        """diag_filter_v3 over the rows, on the device -> (seg_name, best_contig, best_good, best_dir, rows kept)."""
+    def diag_filter(self, contig_names: Sequence[str], in_fai, cap_in: int = 64, want_cap: bool = False):
+        """diag_filter_v3 over the rows, on the device -> (seg_name, best_contig, best_good, best_dir, rows kept).
+        cap_in / want_cap: one shard of a read-sharded run (gs_rowset_diag_filter_from): the Table capacity the reads before this
+        shard leave behind, and (sixth value) the one this shard leaves."""
         ns = self.n_segs()
         arr = (C.c_char_p * max(len(contig_names), 1))(*[c.encode() for c in contig_names])
         in_fai = np.ascontiguousarray(np.concatenate([np.asarray(in_fai, np.uint8), [0]]), np.uint8)
         sn, bc, bg = (np.zeros(max(ns, 1), np.uint32) for _ in range(3))
         bd = np.zeros(max(ns, 1), np.uint8)
-        kept = C.c_uint64(0)
-        check(lib().gs_rowset_diag_filter(self._h, len(contig_names), arr, in_fai.ctypes.data, sn.ctypes.data, bc.ctypes.data,
-                                          bg.ctypes.data, bd.ctypes.data, C.byref(kept)))
+        kept, cap_out = C.c_uint64(0), C.c_uint32(0)
+        check(lib().gs_rowset_diag_filter_from(self._h, len(contig_names), arr, in_fai.ctypes.data, cap_in, sn.ctypes.data, bc.ctypes.data,
+                                               bg.ctypes.data, bd.ctypes.data, C.byref(kept), C.byref(cap_out)))
+        if want_cap:
+            return sn[:ns], bc[:ns], bg[:ns], bd[:ns], kept.value, cap_out.value
         return sn[:ns], bc[:ns], bg[:ns], bd[:ns], kept.value
 
     def keep_flags(self) -> np.ndarray:
@@ -750,14 +754,17 @@ class RowSet:
         check(lib().gs_rowset_keep_filtered(self._h))
 
     @staticmethod
-    def bad_keys(hap1: "RowSet", hap2: "RowSet", key_hap: np.ndarray, keep_on_device: bool = False):
-        """badsunks_AR.py over both haplotypes' filtered rows -> (bad[n_keys] uint8, [meancov1, meancov2], device pointer or None)."""
+    def bad_keys(hap1: "RowSet", hap2: "RowSet", key_hap: np.ndarray, keep_on_device: bool = False, reduce=None):
+        """badsunks_AR.py over both haplotypes' filtered rows -> (bad[n_keys] uint8, [meancov1, meancov2], device pointer or None).
+        reduce: (function pointer, context) of a gs_reduce_u32_fn -- the reads-per-SUNK counters summed over the ranks of a
+        read-sharded run (dist.Comm.reducer())."""
         key_hap = np.ascontiguousarray(key_hap, np.uint8)
         bad = np.zeros(max(len(key_hap), 1), np.uint8)
         mc = (C.c_uint32 * 2)()
         d = C.c_void_p()
-        check(lib().gs_rowset_bad_keys(hap1._h, hap2._h, len(key_hap), key_hap.ctypes.data, bad.ctypes.data, mc,
-                                       C.byref(d) if keep_on_device else None))
+        fn, ctx = reduce if reduce is not None else (None, None)
+        check(lib().gs_rowset_bad_keys_reduced(hap1._h, hap2._h, len(key_hap), key_hap.ctypes.data, fn, ctx, bad.ctypes.data, mc,
+                                               C.byref(d) if keep_on_device else None))
         return bad[: len(key_hap)], [int(mc[0]), int(mc[1])], (d.value if keep_on_device else None)
 
     def pair_stage(self, name_rank, name_long, d_key_bad=None, row_bad=None):
@@ -769,18 +776,7 @@ class RowSet:
         h = C.c_void_p()
         check(L.gs_rowset_pair_stage(self._h, d_key_bad, rb.ctypes.data if rb is not None else None, len(name_rank),
                                      name_rank.ctypes.data if len(name_rank) else None, name_long.ctypes.data if len(name_long) else None, C.byref(h)))
-        try:
-            t, nr, nc = L.gs_pairstage_n_rows(h), L.gs_pairstage_n_regions(h), L.gs_pairstage_n_contigs_in(h)
-            out = {"row_contig": _view(L.gs_pairstage_row_contig(h), t, np.uint32).copy(), "row_name": _view(L.gs_pairstage_row_name(h), t, np.uint32).copy(),
-                   "row_id": _view(L.gs_pairstage_row_id(h), t, np.int64).copy(),
-                   "region_contig": _view(L.gs_pairstage_region_contig(h), nr, np.uint32).copy(),
-                   "region_start": _view(L.gs_pairstage_region_start(h), nr, np.int64).copy(),
-                   "region_end": _view(L.gs_pairstage_region_end(h), nr, np.int64).copy(),
-                   "contigs_in": _view(L.gs_pairstage_contigs_in(h), nc, np.uint32).copy(),
-                   "counters": _view(L.gs_pairstage_counters(h), 8, np.uint64).copy()}
-        finally:
-            L.gs_pairstage_free(h)
-        return out
+        return _pairstage_result(h)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -788,6 +784,35 @@ class RowSet:
             self._h = None
 
     __del__ = close
+
+
+def _pairstage_result(h):
+    L = lib()
+    try:
+        t, nr, nc = L.gs_pairstage_n_rows(h), L.gs_pairstage_n_regions(h), L.gs_pairstage_n_contigs_in(h)
+        out = {"row_contig": _view(L.gs_pairstage_row_contig(h), t, np.uint32).copy(), "row_name": _view(L.gs_pairstage_row_name(h), t, np.uint32).copy(),
+               "row_id": _view(L.gs_pairstage_row_id(h), t, np.int64).copy(),
+               "region_contig": _view(L.gs_pairstage_region_contig(h), nr, np.uint32).copy(),
+               "region_start": _view(L.gs_pairstage_region_start(h), nr, np.int64).copy(),
+               "region_end": _view(L.gs_pairstage_region_end(h), nr, np.int64).copy(),
+               "contigs_in": _view(L.gs_pairstage_contigs_in(h), nc, np.uint32).copy(),
+               "counters": _view(L.gs_pairstage_counters(h), 8, np.uint64).copy()}
+    finally:
+        L.gs_pairstage_free(h)
+    return out
+
+
+def pairstage_from_rows(row_contig, row_name, row_id, contigs_in, device: int = 0):
+    """gs_pairstage_from_rows: the root of a read-sharded run merges the TSV rows of all ranks (sorted by contig, then by the reads'
+    name order) -> the dict RowSet.pair_stage gives on one GPU: rows as handed in, intervals from the union over all of them."""
+    rc = np.ascontiguousarray(row_contig, np.uint32)
+    rn = np.ascontiguousarray(row_name, np.uint32)
+    ri = np.ascontiguousarray(row_id, np.int64)
+    ci = np.ascontiguousarray(contigs_in, np.uint32)
+    h = C.c_void_p()
+    check(lib().gs_pairstage_from_rows(device, len(rc), rc.ctypes.data if len(rc) else None, rn.ctypes.data if len(rc) else None,
+                                       ri.ctypes.data if len(rc) else None, len(ci), ci.ctypes.data if len(ci) else None, C.byref(h)))
+    return _pairstage_result(h)
 
 
 def free_device(ptr, device: int = 0) -> None:

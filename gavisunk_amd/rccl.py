@@ -54,6 +54,28 @@ class RcclComm:
         check(lib().gs_gather_view(self._h, C.byref(vp), None))  # pinned host memory of the library: no further copy
         return engine._view(vp.value, n.value, engine.HIT_DTYPE)
 
+    def reducer(self):
+        """(function pointer, context) of gs_comm_reduce_u32: what engine.RowSet.bad_keys(reduce=) takes -- one ncclAllReduce of the
+        reads-per-SUNK counters per haplotype."""
+        return C.cast(lib().gs_comm_reduce_u32, C.c_void_p), self._h
+
+    def gatherv(self, data: np.ndarray, status: int = 0, dst: int = 0):
+        """gs_comm_gatherv_host: every rank's bytes on rank dst, as a list of uint8 arrays in rank order (None elsewhere); a rank
+        that passes a non-zero status makes every rank raise that error."""
+        data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        sizes = np.zeros(self.world, np.uint64)
+        out = C.c_void_p()
+        check(lib().gs_comm_gatherv_host(self._h, dst, data.ctypes.data if len(data) else None, len(data), status, C.byref(out), sizes.ctypes.data))
+        if self.rank != dst:
+            return None
+        try:
+            total = int(sizes.sum())
+            blob = engine._view(out.value, total, np.uint8).copy() if total else np.zeros(0, np.uint8)
+        finally:
+            lib().gs_host_free(out)
+        cuts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        return [blob[cuts[r]:cuts[r + 1]] for r in range(self.world)]
+
     def close(self):
         if getattr(self, "_h", None):
             lib().gs_comm_destroy(self._h)

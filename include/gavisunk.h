@@ -332,6 +332,15 @@ int gs_table_clone(const gs_table *src, gs_table **out);
 /* ncclAllGather of n (1 or 2) 64-bit words per rank on the library's stream: the phase-1 summaries {has a raw hit, loc of the
  * last one} of a read-sharded pass without a second transport.  out[rank * n + i], host. */
 int gs_comm_allgather_u64(gs_comm *c, const uint64_t *mine, uint32_t n, uint64_t *out);
+/* The two exchanges of a read-sharded SECOND half (every rank filters and pair-tests its own rows; the hit lists never leave
+ * their GPU): ncclAllReduce (sum, in place) of n uint32 counters in device memory -- the reads per SUNK of the bad-SUNK
+ * histogram; gs_comm_reduce_u32 is the same as a gs_reduce_u32_fn with ctx = the communicator -- and a variable-size gather of
+ * host bytes to the root (the ranks' TSV rows): sizes and a status word by ncclAllGather first (a failed rank fails all of them
+ * before anything is sent), then grouped ncclSend / ncclRecv of exactly each rank's bytes.  sizes[nranks] on every rank; *out
+ * (root only; gs_host_free) = the ranks' bytes back to back in rank order. */
+int gs_comm_allreduce_u32(gs_comm *c, void *d_buf, uint64_t n);
+int gs_comm_reduce_u32(void *ctx, void *d_buf, uint64_t n);
+int gs_comm_gatherv_host(gs_comm *c, int root, const void *mine, uint64_t nbytes, int status, void **out, uint64_t *sizes);
 /* After a finished pass on every rank: all ranks' emitted hits concatenated in the ROOT'S DEVICE MEMORY, in rank order, `read`
  * shifted by the rank's read_offset.  Counts and offsets travel by ncclAllGather, the rows by grouped ncclSend / ncclRecv of
  * exactly their size.  A rank whose pass failed (GS_E_KEYERROR: kmerpos_annot3.nim:90 is data-dependent, one shard meets it)
@@ -541,6 +550,13 @@ int gs_rowset_segments(gs_rowset *rs, uint32_t *n_segs);
  * prints nothing), best_good, best_dir ('-' / '+').  Every row gets its verdict (diag_filter_step2.nim:45-64). */
 int gs_rowset_diag_filter(gs_rowset *rs, uint32_t n_contigs, const char *const *contig_names, const uint8_t *in_fai, uint32_t *seg_name,
                           uint32_t *best_contig, uint32_t *best_good, uint8_t *best_dir, uint64_t *n_kept);
+/* The same for ONE shard of a read-sharded run: the Table's capacity is the only state diag_filter_v3
+ * carries from read to read (`clear()` keeps it, diag_filter_v3.nim:141), so a shard needs the capacity the reads BEFORE it
+ * leave behind: cap_in (a power of two >= 64; 64 = a fresh Table), and reports the one it leaves: *cap_out (may be NULL).
+ * Ranks run it with cap_in = 64, exchange cap_out, and the few whose predecessors grew the Table run it again. */
+int gs_rowset_diag_filter_from(gs_rowset *rs, uint32_t n_contigs, const char *const *contig_names, const uint8_t *in_fai, uint32_t cap_in,
+                               uint32_t *seg_name, uint32_t *best_contig, uint32_t *best_good, uint8_t *best_dir, uint64_t *n_kept,
+                               uint32_t *cap_out);
 int gs_rowset_keep_flags(const gs_rowset *rs, uint8_t *keep);
 /* diag_filter_step2: drop the rows the filter did not keep (in place, order preserved) */
 int gs_rowset_keep_filtered(gs_rowset *rs);
@@ -549,7 +565,16 @@ int gs_rowset_keep_filtered(gs_rowset *rs);
  * of the four bad sets; meancov[h] = the script's "mean coverage" (mode of the reads per SUNK group on the haplotype's own contigs). */
 int gs_rowset_bad_keys(const gs_rowset *hap1, const gs_rowset *hap2, uint32_t n_keys, const uint8_t *key_hap, uint8_t *bad_host,
                        uint32_t meancov[2], void **d_bad);
+/* The same when the reads are sharded over ranks: the reads-per-SUNK counters (badsunks_AR.py:33-36 counts over ALL reads) are
+ * summed over the ranks before the histogram -- `reduce(ctx, d_counts, n_keys)` is called once per haplotype with the uint32
+ * counters in device memory and returns with the sums in place on every rank (gs_comm_reduce_u32 with ctx = the communicator:
+ * one ncclAllReduce; NULL = one rank). */
+typedef int (*gs_reduce_u32_fn)(void *ctx, void *d_counts, uint64_t n);
+int gs_rowset_bad_keys_reduced(const gs_rowset *hap1, const gs_rowset *hap2, uint32_t n_keys, const uint8_t *key_hap, gs_reduce_u32_fn reduce,
+                               void *reduce_ctx, uint8_t *bad_host, uint32_t meancov[2], void **d_bad);
 int gs_device_free(int device, void *p);
+int gs_device_copy_to_host(int device, void *host, const void *d_src, uint64_t nbytes);
+int gs_device_copy_from_host(int device, void *d_dst, const void *host, uint64_t nbytes);
 /* process-by-contig_lowmem_AR.py:50-260 over a row set (rows of several contigs are handled contig by contig, like the
  * workflow's per-contig files): bad SUNKs dropped (d_key_bad: device flags per key, and / or row_bad: host flags per row),
  * reads with >= 2 distinct IDs, sort by (name, start), exact duplicates, reads >= 10 kb (name_long[n_names]), then per read the
@@ -558,6 +583,12 @@ int gs_device_free(int device, void *p);
 typedef struct gs_pairstage gs_pairstage;
 int gs_rowset_pair_stage(const gs_rowset *rs, const void *d_key_bad, const uint8_t *row_bad, uint32_t n_names, const uint32_t *name_rank,
                          const uint8_t *name_long, gs_pairstage **out);
+/* Root of a read-sharded run: the TSV rows of ALL ranks (sorted by contig, then by the reads' name order; a read's rows adjacent,
+ * in the order its rank produced them) -> the result a one-GPU run over all reads gives: the rows as handed in, the validated
+ * intervals from the contig-wide union over all of them (:219-260 is commutative over reads).  contigs_in: the union of the
+ * ranks' gs_pairstage_contigs_in. */
+int gs_pairstage_from_rows(int device, uint64_t n_rows, const uint32_t *row_contig, const uint32_t *row_name, const int64_t *row_id,
+                           uint32_t n_contigs_in, const uint32_t *contigs_in, gs_pairstage **out);
 void gs_pairstage_free(gs_pairstage *ps);
 uint64_t gs_pairstage_n_rows(const gs_pairstage *ps);            /* TSV rows, contig by contig (ascending id), reads in name order */
 const uint32_t *gs_pairstage_row_contig(const gs_pairstage *ps);

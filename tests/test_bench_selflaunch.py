@@ -39,7 +39,7 @@ def test_bench_gpus2_runs_by_itself_on_one_device():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome-mb", "40",
-                        "--reads", "3000", "--check-reads", "200", "--cpu-seconds", "1", "--rehearse-extra"],
+                        "--reads", "3000", "--check-reads", "200", "--cpu-seconds", "1", "--rehearse-extra", "--sharded-chain"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -51,3 +51,6 @@ def test_bench_gpus2_runs_by_itself_on_one_device():
     # the extra key of an N > 1 line: BASELINE.json configs[3] cut over the ranks (strong scaling), with its no-exchange reference
     e = d["diploid_strong"]
     assert e["scaling"] == "strong" and e["value"] > 0 and e["config"]["read_shards_per_gpu"] == 4 and e["no_exchange"]["value"] > 0
+    # --sharded-chain: the second half over both ranks' own hit lists, merged on rank 0
+    ps = d["pair_stage"]
+    assert ps["ranks"] == 2 and ps["rows_in"] > 10000 and ps["rows_after_diag_filter"] > 1000 and ps["tsv_rows"] > 100 and ps["validated_intervals"] > 0

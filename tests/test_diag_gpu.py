@@ -61,3 +61,23 @@ def test_random_rows_match_oracle(tmp_path):
     assert diag_filter_v3.run(str(p), str(fai), out=buf) == 0
     exp = oracle.diag_filter_v3(oracle.parse_sunkpos(text), contigs[:12])
     assert buf.getvalue() == exp and exp.count("\n") > 50
+
+
+def test_coordinates_outside_uint32_take_the_wide_path(tmp_path):
+    """diag_filter_v3.nim:148-150 parses pos / start / ID with parseInt: negative and > 2^32 values are legal input of the filter
+    (found by tools/fuzz_filters.py when the CLI moved to the uint32 row set)"""
+    rows = []
+    for r in range(40):
+        base = -2000 + 100 * r if r % 2 else (1 << 33) + 1000 * r
+        for i in range(12):
+            s = base + 300 * i + (7 if i % 5 else 2600)
+            rows.append((f"w{r}", 300 * i, "ctgA" if i % 4 else "ctgB", s, (s // 500) * 500))
+    text = "".join(f"{a}\t{b}\t{c}\t{d}\t{e}\n" for a, b, c, d, e in rows)
+    p = tmp_path / "w.sunkpos"
+    p.write_text(text)
+    fai = tmp_path / "w.fai"
+    fai.write_text("ctgA\t1\nctgB\t1\n")
+    buf = io.StringIO()
+    assert diag_filter_v3.run(str(p), str(fai), out=buf) == 0
+    exp = oracle.diag_filter_v3(oracle.parse_sunkpos(text), ["ctgA", "ctgB"])
+    assert buf.getvalue() == exp and exp.count("\n") >= 30

@@ -1,0 +1,178 @@
+"""The read-sharded SECOND half (gavisunk_amd.dist.sharded_second_half over csrc/gs_chain.hip; SURVEY.md section 8e: "pair-distance
+stage: shard by read; the contig-wide union is a merge"): 2 and 3 processes share the test box's one GPU (exchanges over gloo:
+RCCL refuses two ranks on one device), each runs diagonal filter -> step 2 -> bad SUNKs -> pair stage over the rows of its OWN
+reads, the root merges the TSV rows and runs the union -- and everything must equal ONE process over all rows: the diagonal
+filter's verdicts (the Table capacity carried across shard boundaries), the bad-SUNK flags (counters summed over ranks), the TSV
+rows and the validated intervals.  The same exchanges through the C-ABI's RCCL entry points run with one rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(seed, n_reads, big_at):
+    """Rows of n_reads reads: 6 "main" contigs carry SUNKs every ~1.5 kb and the reads cover them ~6-fold along a diagonal (the
+    bad-SUNK histogram has a mode, pairs of SUNKs pass the distance test, neighbouring reads share IDs for the union); 124 more
+    contigs give stray hits.  A third of the reads are TIES for the diagonal filter: the same number of hits, all good, on two
+    contigs -- the slot order of Nim's Table decides, i.e. the Table's capacity.  The reads in big_at hit 44-90 contigs: the
+    Table grows there and stays grown for every later read, on whichever rank it lives."""
+    rng = np.random.default_rng(seed)
+    contigs = [f"ctg{j:03d}_{int(rng.integers(0, 10**5))}" for j in range(130)]
+    n_main, clen = 6, 200_000
+    sunk_at = [np.sort(rng.choice(np.arange(1000, clen, 50), size=clen // 1500, replace=False)) for _ in range(n_main)]
+    name, pos, contig, start, ident, rlen = [], [], [], [], [], []
+    for r in range(n_reads):
+        per = []
+        tie = r % 3 == 1 and r not in big_at
+        c = int(rng.integers(0, n_main))
+        ln = int(rng.choice([4000, 12000, 30000, 30000]))
+        o = int(rng.integers(0, clen - ln))
+        mine = sunk_at[c][(sunk_at[c] >= o) & (sunk_at[c] < o + ln)]
+        if tie:
+            mine = mine[: int(rng.integers(2, 4))]
+        for s in mine.tolist():
+            per.append((s - o + 20, c, s, s))
+        others = rng.choice(np.arange(n_main, len(contigs)), size=int(rng.choice([44, 60, 90])) if r in big_at else (1 if tie else int(rng.integers(0, 4))),
+                            replace=False)
+        for c2 in others.tolist():
+            nh = len(mine) if tie else int(rng.choice([1, 1, 2, 3]))
+            base = int(rng.integers(10**4, 10**6))
+            for q in np.sort(rng.choice(np.arange(100, max(ln, 4000), 7), size=max(nh, 1), replace=False)).tolist():
+                per.append((q, c2, base + q, (base + q) // 500 * 500))
+        per.sort(key=lambda t: t[0])
+        for q, cc, s, g in per:
+            name.append(r), pos.append(q), contig.append(cc), start.append(s), ident.append(g)
+        rlen.append(ln)
+    cols = {k: np.array(v, np.uint32) for k, v in (("name", name), ("pos", pos), ("contig", contig), ("start", start), ("id", ident))}
+    # dense key of (contig, ID): what the tagger's loc id is
+    _, cols["key"] = np.unique(cols["contig"].astype(np.uint64) << np.uint64(32) | cols["id"], return_inverse=True)
+    cols["key"] = cols["key"].astype(np.uint32)
+    n_keys = int(cols["key"].max()) + 1
+    # read names sort differently from file order (`groupby("rname")` walks them sorted)
+    names = [f"r{int(x):06d}" for x in rng.permutation(10**5)[:n_reads]]
+    order = np.argsort(np.array(names, dtype=object), kind="stable")
+    grank = np.empty(n_reads, np.uint32)
+    grank[order] = np.arange(n_reads, dtype=np.uint32)
+    in_fai = np.array([0 if j % 9 == 7 else 1 for j in range(len(contigs))], np.uint8)
+    return contigs, in_fai, cols, n_keys, grank, (np.array(rlen) >= 10000).astype(np.uint8)
+
+
+CASE = dict(seed=515, n_reads=240, big_at=(31, 100, 170))
+
+
+def _single(device=0):
+    from gavisunk_amd import engine
+
+    contigs, in_fai, cols, n_keys, grank, long_ = _rows(**CASE)
+    rs = engine.RowSet(device)
+    rs.append_host(cols["name"], cols["pos"], cols["contig"], cols["start"], cols["id"], cols["key"])
+    seg_name, bc, bg, bd, kept = rs.diag_filter(contigs, in_fai)
+    rs.keep_filtered()
+    bad, meancov, d_bad = engine.RowSet.bad_keys(rs, rs, np.full(n_keys, 3, np.uint8), keep_on_device=True)
+    res = rs.pair_stage(grank, long_, d_key_bad=d_bad)
+    engine.free_device(d_bad, device)
+    rs.close()
+    return (seg_name, bc, bg, bd, kept), bad, meancov, res
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gavisunk_amd import dist as gdist
+    from gavisunk_amd import engine
+
+    comm = gdist.Comm(0, rccl=False)
+    contigs, in_fai, cols, n_keys, grank, long_ = _rows(**CASE)
+    lo, hi = gdist.shard_bounds(CASE["n_reads"], world, rank)
+    m = (cols["name"] >= lo) & (cols["name"] < hi)
+    rs = engine.RowSet(0)
+    rs.append_host(cols["name"][m] - np.uint32(lo), cols["pos"][m], cols["contig"][m], cols["start"][m], cols["id"][m], cols["key"][m])
+    local, merged = gdist.sharded_second_half(comm, rs, contigs, in_fai, np.full(n_keys, 3, np.uint8), grank[lo:hi], long_[lo:hi], lo)
+    rs.close()
+    seg_name, bc, bg, bd = local["diag"]
+    np.savez(f"{out_path}.{rank}.npz", seg_name=seg_name + np.uint32(lo), bc=bc, bg=bg, bd=bd, kept=local["rows_kept"], bad=local["bad"],
+             meancov=np.array(local["meancov"]), cap_in=local["cap_in"], **({f"m_{k}": v for k, v in merged.items()} if merged is not None else {}))
+    comm.close()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_second_half_equals_one_gpu(world, tmp_path):
+    out = str(tmp_path / "r")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    (seg_name, bc, bg, bd, kept), bad, meancov, res = _single()
+    parts = [np.load(f"{out}.{r}.npz") for r in range(world)]
+    # the diagonal filter's verdicts, shard after shard, equal the one-GPU run's -- with a grown Table carried into later shards
+    assert [int(p["cap_in"]) for p in parts][0] == 64 and max(int(p["cap_in"]) for p in parts) >= 128
+    assert np.array_equal(np.concatenate([p["seg_name"] for p in parts]), seg_name)
+    assert np.array_equal(np.concatenate([p["bc"] for p in parts]), bc) and np.array_equal(np.concatenate([p["bg"] for p in parts]), bg)
+    ok = bc != 0xFFFFFFFF
+    assert np.array_equal(np.concatenate([p["bd"] for p in parts])[ok], bd[ok]) and ok.sum() > 100
+    assert sum(int(p["kept"]) for p in parts) == kept
+    # bad SUNKs: every rank holds the flags of the whole run
+    for p in parts:
+        assert np.array_equal(p["bad"], bad) and p["meancov"].tolist() == meancov
+    assert 0 < bad.sum() < len(bad)
+    # TSV rows and validated intervals on the root
+    root = parts[0]
+    assert "m_row_id" in root.files and not any("m_row_id" in p.files for p in parts[1:])
+    for k in ("row_contig", "row_name", "row_id", "region_contig", "region_start", "region_end", "contigs_in"):
+        assert np.array_equal(root[f"m_{k}"], res[k]), k
+    assert len(res["row_id"]) > 200 and len(res["region_start"]) > 5
+
+
+def test_without_the_carried_capacity_the_verdicts_differ():
+    """The test above has teeth: a later shard filtered with a fresh 64-slot Table does NOT reproduce the one-GPU verdicts."""
+    from gavisunk_amd import engine
+
+    contigs, in_fai, cols, n_keys, grank, long_ = _rows(**CASE)
+    (seg_name, bc, bg, bd, kept), *_ = _single()
+    lo = 120
+    m = cols["name"] >= lo
+    outs = []
+    for cap_in in (64, 128):
+        rs = engine.RowSet(0)
+        rs.append_host(cols["name"][m] - np.uint32(lo), cols["pos"][m], cols["contig"][m], cols["start"][m], cols["id"][m], cols["key"][m])
+        outs.append(rs.diag_filter(contigs, in_fai, cap_in=cap_in, want_cap=True))
+        rs.close()
+    want = bc[seg_name >= lo]
+    assert np.array_equal(outs[1][1], want) and outs[1][5] == 128
+    assert not np.array_equal(outs[0][1], want)
+
+
+def test_rccl_exchanges_with_one_rank():
+    """gs_comm_allreduce_u32 / gs_comm_reduce_u32 / gs_comm_gatherv_host through RCCL with a one-rank communicator (all a one-GPU
+    box can start): the sharded second half over the RCCL data plane equals the plain chain."""
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from gavisunk_amd import dist as gdist
+        from gavisunk_amd import engine
+
+        comm = gdist.Comm(0, rccl=True)
+        contigs, in_fai, cols, n_keys, grank, long_ = _rows(**CASE)
+        rs = engine.RowSet(0)
+        rs.append_host(cols["name"], cols["pos"], cols["contig"], cols["start"], cols["id"], cols["key"])
+        local, merged = gdist.sharded_second_half(comm, rs, contigs, in_fai, np.full(n_keys, 3, np.uint8), grank, long_, 0)
+        rs.close()
+        got = comm.gatherv(np.arange(10, dtype=np.uint32))
+        assert len(got) == 1 and np.array_equal(got[0].view(np.uint32), np.arange(10, dtype=np.uint32))
+        comm.rccl.close()
+        comm.rccl = None
+    finally:
+        dist.destroy_process_group()
+    (seg_name, bc, bg, bd, kept), bad, meancov, res = _single()
+    assert np.array_equal(local["diag"][1], bc) and np.array_equal(local["bad"], bad) and local["meancov"] == meancov
+    for k in ("row_contig", "row_name", "row_id", "region_contig", "region_start", "region_end", "contigs_in"):
+        assert np.array_equal(merged[k], res[k]), k

@@ -44,3 +44,15 @@ def test_fuzz_ingest_files(tmp_path):
         what, _ = fuzz_ingest.one_file(seed, path)
         counts[what] += 1
     assert counts["ok"] >= 40, counts
+
+
+def test_fuzz_filter_rounds(tmp_path):
+    """tools/fuzz_filters.py: the file-level drop-ins (diag_filter_v3 + step 2, process-by-contig, badsunks: all users of the
+    device chain) and the SUNK definition against the oracle, 25 seeded rounds of each"""
+    import fuzz_filters
+
+    for seed in range(92000, 92025):
+        for name, fn in (("diag", fuzz_filters.fuzz_diag), ("pair", fuzz_filters.fuzz_pair), ("sunkdef", fuzz_filters.fuzz_sunkdef),
+                         ("badsunks", fuzz_filters.fuzz_badsunks)):
+            err = fn(seed, str(tmp_path))
+            assert err is None, (name, seed, err)
