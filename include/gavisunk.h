@@ -551,7 +551,7 @@ int gs_rowset_segments(gs_rowset *rs, uint32_t *n_segs);
 int gs_rowset_diag_filter(gs_rowset *rs, uint32_t n_contigs, const char *const *contig_names, const uint8_t *in_fai, uint32_t *seg_name,
                           uint32_t *best_contig, uint32_t *best_good, uint8_t *best_dir, uint64_t *n_kept);
 /* The same for ONE shard of a read-sharded run: the Table's capacity is the only state diag_filter_v3
- * carries from read to read (`clear()` keeps it, diag_filter_v3.nim:141), so a shard needs the capacity the reads BEFORE it
+ * carries from read to read (`clear()` keeps it, diag_filter_v3.nim:143), so a shard needs the capacity the reads BEFORE it
  * leave behind: cap_in (a power of two >= 64; 64 = a fresh Table), and reports the one it leaves: *cap_out (may be NULL).
  * Ranks run it with cap_in = 64, exchange cap_out, and the few whose predecessors grew the Table run it again. */
 int gs_rowset_diag_filter_from(gs_rowset *rs, uint32_t n_contigs, const char *const *contig_names, const uint8_t *in_fai, uint32_t cap_in,
