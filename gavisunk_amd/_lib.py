@@ -81,6 +81,7 @@ SIGNATURES = {
     "gs_text_record_cut_counted": (U64, [P, U64, U64]),
     "gs_table_create": (I, [I, I, U64, P, P, P, C.POINTER(P)]),
     "gs_table_create_device": (I, [I, I, U64, P, P, P, C.POINTER(P)]),
+    "gs_table_create_from_db": (I, [I, P, C.POINTER(P)]),
     "gs_table_destroy": (None, [P]),
     "gs_table_bytes": (U64, [P]),
     "gs_table_layout": (C.c_char_p, [P]),

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "gavisunk.h"
@@ -43,6 +44,10 @@ int sort_keys_u64(const uint64_t *k_in, uint64_t *k_out, uint64_t n, void *strea
 int select_flagged_u32(const uint32_t *in, const uint8_t *flag, uint32_t *out, unsigned long long *d_count, uint64_t n, uint64_t *n_out,
                        void *stream);
 
+// the join of a parsed <kmers.db> with its <kmer.loc> on the device (gs_sunkdef.hip): distinct db codes (sorted), per code the dense
+// (contig, group) id and the row of the LAST loc row that carries it, GS_MISSING where none does.  hipMalloc'ed outputs.
+int db_join_device(int device, const gs_sunkdb *db, uint64_t **d_keys, uint32_t **d_loc, uint32_t **d_payload, uint64_t *n_keys);
+
 // the pair test / clean-up / largest component kernels over device arrays (gs_pair.hip); rows of a read = [d_off[r], d_off[r+1])
 int pair_component_device(uint32_t n_reads, uint64_t n_rows, const uint64_t *d_off, const int64_t *d_pos, const int64_t *d_start,
                           const int64_t *d_id, uint32_t *d_outn, int64_t *d_out);
@@ -62,6 +67,14 @@ constexpr int kTileWords = 64;
 
 struct gs_sunkdb {
     int k = 0;
+    // what the parsers leave: every line of <kmers.db> (file order, duplicates included) and the k-mer of every loc row.  The join
+    // of the two -- distinct db codes, each with the LAST loc row that carries it (kmerpos_annot3.nim:68) -- is made where it is
+    // needed: on the device for the table (gs_table_create_from_db: sorts + a merge), on the host when a caller asks for the
+    // arrays below (gs_sunkdb_keys / _key_row / _key_loc: the first call pays for it)
+    std::vector<uint64_t> db_codes;
+    std::vector<uint64_t> row_code;
+    bool joined = false;
+    std::mutex join_mu;
     std::vector<uint64_t> keys;     // distinct db codes, first-seen order
     std::vector<uint32_t> key_row;  // winning loc row or GS_MISSING
     std::vector<uint32_t> key_loc;  // dense (contig, group) id or GS_MISSING

@@ -20,6 +20,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <functional>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -582,6 +583,84 @@ const char *gs_last_error(void) { return g_err.c_str(); }
 const char *gs_version(void) { return "gavisunk_amd 0.1 (gfx950)"; }
 
 // ------------------------------------------------------------------------------------- sunkdb
+// The join of the parsed k-mer list with the location table, on the host, for callers that ask for the key arrays (the table
+// itself is joined on the device: gs_table_create_from_db).  Distinct db codes in first-seen order (a k-mer listed twice is one
+// key: the reference's HashSet, kmerpos_annot3.nim:20-38), each with the LAST loc row that carries it (:68), GS_MISSING without
+// one.  The hashing is split over threads by hash class; rows stay in file order inside a class.
+static void join_host(gs_sunkdb *d) {
+    std::lock_guard<std::mutex> lock(d->join_mu);
+    if (d->joined) return;
+    constexpr unsigned kMapParts = 8;
+    auto map_part = [](uint64_t code) { return (unsigned)((code * 0xD6E8FEB86659FD93ULL) >> 61); };
+    auto run_parts = [&](size_t n, const std::function<void(unsigned)> &fn) {
+        if (n < (1u << 16)) {
+            for (unsigned p2 = 0; p2 < kMapParts; p2++) fn(p2);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned p2 = 1; p2 < kMapParts; p2++) pool.emplace_back(fn, p2);
+            fn(0);
+            for (auto &t : pool) t.join();
+        }
+    };
+    // distinct db codes, first occurrences, file order
+    std::vector<uint64_t> codes = std::move(d->db_codes);
+    const size_t n = codes.size();
+    std::vector<uint8_t> is_first(n, 0);
+    run_parts(n, [&](unsigned part) {
+        CodeMap seen;
+        seen.reserve(n / 8 + n / 32 + 16);
+        for (size_t i = 0; i < n; i++)
+            if (map_part(codes[i]) == part) {
+                bool fresh;
+                seen.at(codes[i], fresh);
+                is_first[i] = fresh;
+            }
+    });
+    size_t nk = 0;
+    for (size_t i = 0; i < n; i++)
+        if (is_first[i]) codes[nk++] = codes[i];
+    codes.resize(nk);
+    d->keys = std::move(codes);
+    // loc code -> last row with that code
+    CodeMap rowmap[kMapParts];
+    const std::vector<uint64_t> &row_code = d->row_code;
+    const size_t nrows = row_code.size();
+    run_parts(nrows, [&](unsigned part) {
+        CodeMap &m = rowmap[part];
+        m.reserve(nrows / kMapParts + nrows / (4 * kMapParts) + 16);
+        for (size_t i = 0; i < nrows; i++)
+            if (map_part(row_code[i]) == part) {
+                bool fresh;
+                m.at(row_code[i], fresh) = (uint32_t)i;  // later row overwrites (kmerpos_annot3.nim:68)
+            }
+    });
+    d->key_row.resize(nk);
+    d->key_loc.resize(nk);
+    auto join_range = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            uint32_t row;
+            if (rowmap[map_part(d->keys[i])].get(d->keys[i], row)) {
+                d->key_row[i] = row;
+                d->key_loc[i] = d->row_loc[row];
+            } else {
+                d->key_row[i] = GS_MISSING;
+                d->key_loc[i] = GS_MISSING;
+            }
+        }
+    };
+    const unsigned nthr = nk < (1u << 16) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthr; t++) pool.emplace_back(join_range, nk * t / nthr, nk * (t + 1) / nthr);
+    join_range(0, nk / nthr);
+    for (auto &t : pool) t.join();
+    std::vector<uint64_t>().swap(d->row_code);
+    d->joined = true;
+}
+static const gs_sunkdb *joined(const gs_sunkdb *db) {
+    if (!db->joined) join_host(const_cast<gs_sunkdb *>(db));
+    return db;
+}
+
 int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
     if (!db_path || !loc_path || !out) {
         set_error("gs_sunkdb_load: null argument");
@@ -616,34 +695,8 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
                 codes.push_back(encode_kmer(l.data(), l.size()));
             }
         }
-        // a k-mer listed twice is one key (the reference's HashSet): keep first occurrences, in file order.  The hashing
-        // is split over threads by hash class, like the row map below.
-        const size_t n = codes.size();
-        std::vector<uint8_t> is_first(n, 0);
-        auto mark = [&](unsigned part) {
-            CodeMap seen;
-            seen.reserve(n / 8 + n / 32 + 16);
-            for (size_t i = 0; i < n; i++)
-                if ((unsigned)((codes[i] * 0xD6E8FEB86659FD93ULL) >> 61) == part) {
-                    bool fresh;
-                    seen.at(codes[i], fresh);
-                    is_first[i] = fresh;
-                }
-        };
-        if (n < (1u << 16)) {
-            for (unsigned p2 = 0; p2 < 8; p2++) mark(p2);
-        } else {
-            std::vector<std::thread> pool;
-            for (unsigned p2 = 1; p2 < 8; p2++) pool.emplace_back(mark, p2);
-            mark(0);
-            for (auto &t : pool) t.join();
-        }
-        size_t nk = 0;
-        for (size_t i = 0; i < n; i++)
-            if (is_first[i]) codes[nk++] = codes[i];
-        codes.resize(nk);
         d->k = k;
-        d->keys = std::move(codes);
+        d->db_codes = std::move(codes);  // (duplicates and all: the join makes the key set)
         if (k < 1 || k > 32) db_rc = GS_E_ARG;
     });
     struct Joiner {  // the thread is joined on every way out
@@ -658,14 +711,10 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
         else set_error("%s: k = %d is outside 1..32 (2 bits per base in a uint64)", db_path, d->k);
         return db_rc;
     };
-    // loc code -> last row with that code.  The codes are collected while the text is parsed and hashed afterwards by
-    // several threads, each owning the codes of one hash class (rows stay in file order inside a class: last row wins).
-    constexpr unsigned kMapParts = 8;
-    CodeMap rowmap[kMapParts];
-    auto map_part = [](uint64_t code) { return (unsigned)((code * 0xD6E8FEB86659FD93ULL) >> 61); };
     std::vector<uint64_t> row_code;
     uint64_t par_err_line = 0;
     const int par = parse_loc_parallel(loc_path, d, row_code, &par_err_line);
+    const double t_parsed = tnow();
     if (par == 1) {
         db_thread.join();
         const int rc = db_rc != GS_OK ? db_error()
@@ -765,66 +814,27 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
             row_code.push_back(encode_kmer(f[2], fe[2] - f[2]));
         }
     }
-    {
-        const size_t nrows = row_code.size();
-        auto build = [&](unsigned part) {
-            CodeMap &m = rowmap[part];
-            m.reserve(nrows / kMapParts + nrows / (4 * kMapParts) + 16);
-            for (size_t i = 0; i < nrows; i++)
-                if (map_part(row_code[i]) == part) {
-                    bool fresh;
-                    m.at(row_code[i], fresh) = (uint32_t)i;  // later row overwrites (kmerpos_annot3.nim:68)
-                }
-        };
-        if (nrows < (1u << 16)) {
-            for (unsigned p2 = 0; p2 < kMapParts; p2++) build(p2);
-        } else {
-            std::vector<std::thread> pool;
-            for (unsigned p2 = 1; p2 < kMapParts; p2++) pool.emplace_back(build, p2);
-            build(0);
-            for (auto &t : pool) t.join();
-        }
-    }
     const double t_loc = tnow();
     db_thread.join();
-    const double t_db = tnow();
     if (db_rc != GS_OK) {
         const int rc = db_error();
         delete d;
         return rc;
     }
-    d->key_row.resize(d->keys.size());
-    d->key_loc.resize(d->keys.size());
-    auto join_range = [&](size_t lo, size_t hi) {
-        for (size_t i = lo; i < hi; i++) {
-            uint32_t row;
-            if (rowmap[map_part(d->keys[i])].get(d->keys[i], row)) {
-                d->key_row[i] = row;
-                d->key_loc[i] = d->row_loc[row];
-            } else {
-                d->key_row[i] = GS_MISSING;
-                d->key_loc[i] = GS_MISSING;
-            }
-        }
-    };
-    const size_t nk = d->keys.size();
-    const unsigned nthr = nk < (1u << 16) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nthr; t++) pool.emplace_back(join_range, nk * t / nthr, nk * (t + 1) / nthr);
-    join_range(0, nk / nthr);
-    for (auto &t : pool) t.join();
+    d->row_code = std::move(row_code);
     if (getenv("GAVISUNK_TIMING"))
-        fprintf(stderr, "[sunkdb] loc %.3f s, +db wait %.3f s, join %.3f s (%u threads)\n", t_loc - t_start, t_db - t_loc, tnow() - t_db, nthr);
+        fprintf(stderr, "[sunkdb] loc text %.3f s, +db wait %.3f s (the join is made by whoever needs it)\n", t_parsed - t_start, tnow() - t_loc);
     *out = d;
     return GS_OK;
 }
 
 void gs_sunkdb_free(gs_sunkdb *db) { delete db; }
 int gs_sunkdb_k(const gs_sunkdb *db) { return db->k; }
-uint64_t gs_sunkdb_n_keys(const gs_sunkdb *db) { return db->keys.size(); }
-const uint64_t *gs_sunkdb_keys(const gs_sunkdb *db) { return db->keys.data(); }
-const uint32_t *gs_sunkdb_key_row(const gs_sunkdb *db) { return db->key_row.data(); }
-const uint32_t *gs_sunkdb_key_loc(const gs_sunkdb *db) { return db->key_loc.data(); }
+// (the four below make the host join on first use; a handle from gs_sidecar_open has no keys: they live in its table)
+uint64_t gs_sunkdb_n_keys(const gs_sunkdb *db) { return joined(db)->keys.size(); }
+const uint64_t *gs_sunkdb_keys(const gs_sunkdb *db) { return joined(db)->keys.data(); }
+const uint32_t *gs_sunkdb_key_row(const gs_sunkdb *db) { return joined(db)->key_row.data(); }
+const uint32_t *gs_sunkdb_key_loc(const gs_sunkdb *db) { return joined(db)->key_loc.data(); }
 uint64_t gs_sunkdb_n_rows(const gs_sunkdb *db) { return db->row_contig.size(); }
 const uint32_t *gs_sunkdb_row_contig(const gs_sunkdb *db) { return db->row_contig.data(); }
 const int64_t *gs_sunkdb_row_start(const gs_sunkdb *db) { return db->row_start.data(); }

@@ -46,6 +46,12 @@ namespace {
         }                                                                                     \
     } while (0)
 
+#define GS_TRY(expr)                  \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != GS_OK) return _rc; \
+    } while (0)
+
 __device__ __forceinline__ int base_code(uint8_t c) {  // -1: not a nucleotide jellyfish counts
     switch (c) {
         case 'A': case 'a': return 0;
@@ -166,6 +172,139 @@ int gs::sort_keys_u64(const uint64_t *k_in, uint64_t *k_out, uint64_t n, void *s
         set_error("radix sort failed: %s", hipGetErrorString(e));
         return GS_E_NODEVICE;
     }
+    return GS_OK;
+}
+
+// ---- the join of <kmers.db> with <kmer.loc> on the device (what the reference builds as HashSet + Table on the host,
+// kmerpos_annot3.nim:20-72): sorts and a merge instead of 1e8 .. 1e9 hash-map inserts ----
+namespace {
+__global__ void k_dbj_iota(uint32_t *o, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = (uint32_t)i;
+}
+__global__ void k_dbj_tail(const uint64_t *k, uint64_t n, uint8_t *f) {  // 1 at the last entry of a run of equal codes
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = (i + 1 == n || k[i + 1] != k[i]) ? 1 : 0;
+}
+__global__ void k_dbj_head(const uint64_t *k, uint64_t n, uint8_t *f) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = (i == 0 || k[i - 1] != k[i]) ? 1 : 0;
+}
+__global__ void k_dbj_gather(const uint64_t *in, const uint32_t *idx, uint64_t n, uint64_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+// every distinct db code looked up among the distinct loc codes (both ascending): the row that wins and its location id
+__global__ void k_dbj_join(const uint64_t *keys, uint64_t nk, const uint64_t *lcode, const uint32_t *lrow, uint64_t nl, const uint32_t *row_loc,
+                           uint32_t *key_loc, uint32_t *key_row) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nk) return;
+    const uint64_t x = keys[i];
+    uint64_t lo = 0, hi = nl;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (lcode[mid] < x) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo < nl && lcode[lo] == x) {
+        key_row[i] = lrow[lo];
+        key_loc[i] = row_loc[lrow[lo]];
+    } else {
+        key_row[i] = GS_MISSING;  // a db k-mer without loc row: the reference's KeyError when a read meets it (kmerpos_annot3.nim:90)
+        key_loc[i] = GS_MISSING;
+    }
+}
+inline unsigned dbj_blocks(uint64_t n) { return (unsigned)std::max<uint64_t>((n + 255) / 256, 1); }
+}  // namespace
+
+int gs::db_join_device(int device, const gs_sunkdb *db, uint64_t **d_keys_out, uint32_t **d_loc_out, uint32_t **d_payload_out, uint64_t *n_keys) {
+    *d_keys_out = nullptr;
+    *d_loc_out = *d_payload_out = nullptr;
+    *n_keys = 0;
+    const uint64_t nd = db->db_codes.size(), nr = db->row_code.size();
+    if (nd > 0xFFFFFFF0ull || nr > 0xFFFFFFF0ull) {
+        set_error("gs_table_create_from_db: more than 2^32 rows");
+        return GS_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    if (!nd) return GS_OK;
+    const int bits = std::min(64, 2 * std::max(db->k, 1));
+    Bufs keep;  // what outlives the steps
+    unsigned long long *d_cnt = nullptr;
+    GS_TRY(keep.get(&d_cnt, 1));
+    // ---- loc side: distinct codes (ascending), each with its LAST row ----
+    uint64_t *d_lcode = nullptr;
+    uint32_t *d_lrow = nullptr, *d_rowloc = nullptr;
+    uint64_t nl = 0;
+    GS_TRY(keep.get(&d_rowloc, nr));
+    if (nr) {
+        HIP_TRY(hipMemcpy(d_rowloc, db->row_loc.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice));
+        Bufs tmp;
+        uint64_t *d_rc, *d_rc2;
+        uint32_t *d_ri, *d_ri2, *d_sel;
+        uint8_t *d_f;
+        GS_TRY(tmp.get(&d_rc, nr));
+        GS_TRY(tmp.get(&d_rc2, nr));
+        GS_TRY(tmp.get(&d_ri, nr));
+        GS_TRY(tmp.get(&d_ri2, nr));
+        GS_TRY(tmp.get(&d_f, nr));
+        GS_TRY(tmp.get(&d_sel, nr));
+        HIP_TRY(hipMemcpy(d_rc, db->row_code.data(), nr * sizeof(uint64_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_dbj_iota, dim3(dbj_blocks(nr)), dim3(256), 0, 0, d_ri, nr);
+        GS_TRY(sort_pairs_u64_u32(d_rc, d_rc2, d_ri, d_ri2, nr, bits, nullptr));  // stable: rows ascend inside a run of equal codes
+        hipLaunchKernelGGL(k_dbj_tail, dim3(dbj_blocks(nr)), dim3(256), 0, 0, d_rc2, nr, d_f);
+        GS_TRY(select_flagged_u32(d_ri2, d_f, d_sel, d_cnt, nr, &nl, nullptr));  // the last row of every code (kmerpos_annot3.nim:68)
+        GS_TRY(keep.get(&d_lcode, nl));
+        GS_TRY(keep.get(&d_lrow, nl));
+        HIP_TRY(hipMemcpy(d_lrow, d_sel, nl * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        hipLaunchKernelGGL(k_dbj_gather, dim3(dbj_blocks(nl)), dim3(256), 0, 0, d_rc, d_lrow, nl, d_lcode);  // (ascending: tails in sorted order)
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    // ---- db side: distinct codes (a k-mer listed twice is one key: the reference's HashSet) ----
+    uint64_t *d_keys = nullptr;
+    uint64_t nk = 0;
+    {
+        Bufs tmp;
+        uint64_t *d_dc, *d_dc2;
+        uint32_t *d_pos, *d_sel;
+        uint8_t *d_f;
+        GS_TRY(tmp.get(&d_dc, nd));
+        GS_TRY(tmp.get(&d_dc2, nd));
+        GS_TRY(tmp.get(&d_pos, nd));
+        GS_TRY(tmp.get(&d_sel, nd));
+        GS_TRY(tmp.get(&d_f, nd));
+        HIP_TRY(hipMemcpy(d_dc, db->db_codes.data(), nd * sizeof(uint64_t), hipMemcpyHostToDevice));
+        GS_TRY(sort_keys_u64(d_dc, d_dc2, nd, nullptr));
+        hipLaunchKernelGGL(k_dbj_head, dim3(dbj_blocks(nd)), dim3(256), 0, 0, d_dc2, nd, d_f);
+        hipLaunchKernelGGL(k_dbj_iota, dim3(dbj_blocks(nd)), dim3(256), 0, 0, d_pos, nd);
+        GS_TRY(select_flagged_u32(d_pos, d_f, d_sel, d_cnt, nd, &nk, nullptr));
+        HIP_TRY(hipMalloc((void **)&d_keys, std::max<uint64_t>(nk, 1) * sizeof(uint64_t)));
+        hipLaunchKernelGGL(k_dbj_gather, dim3(dbj_blocks(nk)), dim3(256), 0, 0, d_dc2, d_sel, nk, d_keys);
+        if (hipDeviceSynchronize() != hipSuccess) {
+            (void)hipFree(d_keys);
+            set_error("gs_table_create_from_db: the key sort failed");
+            return GS_E_NODEVICE;
+        }
+    }
+    // ---- the join ----
+    uint32_t *d_loc = nullptr, *d_pay = nullptr;
+    hipError_t e = hipMalloc((void **)&d_loc, std::max<uint64_t>(nk, 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_pay, std::max<uint64_t>(nk, 1) * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_dbj_join, dim3(dbj_blocks(nk)), dim3(256), 0, 0, d_keys, nk, d_lcode, d_lrow, nl, d_rowloc, d_loc, d_pay);
+        e = hipDeviceSynchronize();
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(d_keys);
+        (void)hipFree(d_loc);
+        (void)hipFree(d_pay);
+        set_error("gs_table_create_from_db: %s", hipGetErrorString(e));
+        return GS_E_NODEVICE;
+    }
+    *d_keys_out = d_keys;
+    *d_loc_out = d_loc;
+    *d_payload_out = d_pay;
+    *n_keys = nk;
     return GS_OK;
 }
 

@@ -37,15 +37,29 @@ class SunkDB:
         self._h = h
         L = lib()
         self.k = L.gs_sunkdb_k(h)
-        nk, nr = L.gs_sunkdb_n_keys(h), L.gs_sunkdb_n_rows(h)
-        self.keys = _view(L.gs_sunkdb_keys(h), nk, np.uint64)
-        self.key_row = _view(L.gs_sunkdb_key_row(h), nk, np.uint32)
-        self.key_loc = _view(L.gs_sunkdb_key_loc(h), nk, np.uint32)
+        nr = L.gs_sunkdb_n_rows(h)
         self.row_contig = _view(L.gs_sunkdb_row_contig(h), nr, np.uint32)
         self.row_start = _view(L.gs_sunkdb_row_start(h), nr, np.int64)
         self.row_group = _view(L.gs_sunkdb_row_group(h), nr, np.int64)
         self.row_loc = _view(L.gs_sunkdb_row_loc(h), nr, np.uint32)
         self.contigs = [L.gs_sunkdb_contig_name(h, i).decode() for i in range(L.gs_sunkdb_n_contigs(h))]
+
+    # the join of the k-mer list with the location table -- distinct k-mers, each with its winning loc row -- is made on the
+    # device for the table (DeviceTable.from_db: gs_table_create_from_db); these three make it on the host, on first use
+    @property
+    def keys(self) -> np.ndarray:
+        L = lib()
+        return _view(L.gs_sunkdb_keys(self._h), L.gs_sunkdb_n_keys(self._h), np.uint64)
+
+    @property
+    def key_row(self) -> np.ndarray:
+        L = lib()
+        return _view(L.gs_sunkdb_key_row(self._h), L.gs_sunkdb_n_keys(self._h), np.uint32)
+
+    @property
+    def key_loc(self) -> np.ndarray:
+        L = lib()
+        return _view(L.gs_sunkdb_key_loc(self._h), L.gs_sunkdb_n_keys(self._h), np.uint32)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -60,10 +74,7 @@ class SunkDB:
         self._h = h
         L = lib()
         self.k = L.gs_sunkdb_k(h)
-        nk, nr = L.gs_sunkdb_n_keys(h), L.gs_sunkdb_n_rows(h)
-        self.keys = _view(L.gs_sunkdb_keys(h), nk, np.uint64)
-        self.key_row = _view(L.gs_sunkdb_key_row(h), nk, np.uint32)
-        self.key_loc = _view(L.gs_sunkdb_key_loc(h), nk, np.uint32)
+        nr = L.gs_sunkdb_n_rows(h)
         self.row_contig = _view(L.gs_sunkdb_row_contig(h), nr, np.uint32)
         self.row_start = _view(L.gs_sunkdb_row_start(h), nr, np.int64)
         self.row_group = _view(L.gs_sunkdb_row_group(h), nr, np.int64)
@@ -313,7 +324,13 @@ class DeviceTable:
 
     @classmethod
     def from_db(cls, db: SunkDB, device: int = 0) -> "DeviceTable":
-        return cls(db.k, db.keys, db.key_loc, db.key_row, device)
+        """gs_table_create_from_db: the k-mer list joined with the location table on the device, the table built from that."""
+        h = C.c_void_p()
+        check(lib().gs_table_create_from_db(device, db._h, C.byref(h)))
+        t = cls.__new__(cls)
+        t._h, t.k, t.device = h, db.k, device
+        t.n = None  # (the number of distinct k-mers is the join's business: gs_sunkdb_n_keys makes it on the host)
+        return t
 
     def clone(self) -> "DeviceTable":
         """A second handle of the same table on its device (gs_table_clone: what a receiving rank of gs_table_broadcast does,

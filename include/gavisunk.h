@@ -149,6 +149,11 @@ int gs_table_create(int device, int k, uint64_t n, const uint64_t *keys, const u
  * payload[i] = i.  The arrays are read during the call only; the caller keeps owning them. */
 int gs_table_create_device(int device, int k, uint64_t n, const void *d_keys, const void *d_loc, const void *d_payload,
                            gs_table **out);
+/* The table of a parsed <kmers.db> + <kmer.loc> pair (gs_sunkdb_load), the join made on the device: distinct db k-mers (the
+ * reference's HashSet, kmerpos_annot3.nim:20-38), each with the LAST loc row that carries it (:68) -- two radix sorts and a merge
+ * instead of the reference's per-run hash-map inserts.  A db k-mer without loc row keeps loc = GS_MISSING (KeyError when a read
+ * meets it, :90). */
+int gs_table_create_from_db(int device, const gs_sunkdb *db, gs_table **out);
 void gs_table_destroy(gs_table *t);
 uint64_t gs_table_bytes(const gs_table *t);
 /* Human-readable description of the layout chosen for this table: "minimizer-hbm" (the default for k >= 16: 64-byte regions

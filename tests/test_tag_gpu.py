@@ -559,3 +559,59 @@ def test_deterministic_across_runs():
     a = _engine_hits(k, keys, loc, seqs)[1]
     b = _engine_hits(k, keys, loc, seqs)[1]
     assert a.tobytes() == b.tobytes()
+
+
+def test_table_from_db_joins_on_the_device(tmp_path):
+    """DeviceTable.from_db (gs_table_create_from_db: the k-mer list joined with the location table by sorts and a merge on the
+    device) against the host join of the same files (gs_sunkdb_keys / _key_row / _key_loc) and the oracle: k-mers listed twice in
+    <db>, loc rows that repeat a k-mer (the last row wins, kmerpos_annot3.nim:68), loc rows whose k-mer is not in <db>, a db k-mer
+    without loc row (KeyError when a read meets it, :90) -- in files big enough for the multi-threaded parsers."""
+    from gavisunk_amd import synth
+
+    k = 20
+    rng = np.random.default_rng(99)
+    g = rng.integers(0, 4, 400_000, dtype=np.uint8)
+    sunks = sunkdef.define_sunks([("c", synth.codes_to_ascii(g))], k)
+    n = len(sunks.code)
+    assert n > 300_000
+    bases = ((sunks.code[:, None] >> (2 * (k - 1 - np.arange(k, dtype=np.uint64)))[None, :]) & np.uint64(3)).astype(np.uint8)
+    canon = [row.tobytes() for row in np.frombuffer(b"ACGT", np.uint8)[bases]]  # the canonical spelling, as jellyfish / the loc table have it
+    dup_db = rng.integers(0, n, 5000)
+    missing = b"ACGTTGCATTGACCAGTAGC"
+    db_lines = [canon[i] for i in range(n)] + [canon[i] for i in dup_db.tolist()] + [missing]
+    order = rng.permutation(len(db_lines))
+    (tmp_path / "db").write_bytes(b"".join(db_lines[i] + b"\n" for i in order.tolist()))
+    rows = [(i, int(sunks.start[i]), int(sunks.group[i])) for i in range(n)]
+    rows += [(int(i), 7_000_000 + j, 9_000_000 + 1000 * (j % 7)) for j, i in enumerate(rng.integers(0, n, 3000).tolist())]  # repeats: the last one wins
+    stray = [(b"TTTTTTTTTTGGGGGGGGGG", 5, 5), (b"ACACACACACACACACACAC", 6, 6)]  # in <loc> only: no key
+    with open(tmp_path / "loc", "wb") as f:
+        for i, s, gr in rows:
+            f.write(b"c%d\t%d\t%s\t%d\n" % (s % 3, s, canon[i], gr))
+        for km, s, gr in stray:
+            f.write(b"c9\t%d\t%s\t%d\n" % (s, km, gr))
+    db = engine.SunkDB(str(tmp_path / "db"), str(tmp_path / "loc"))
+    t_dev = engine.DeviceTable.from_db(db)            # device join (nothing asked for the host arrays yet)
+    t_host = engine.DeviceTable(db.k, db.keys, db.key_loc, db.key_row)  # host join, built from its arrays
+    assert len(db.keys) == n + 1 and int((db.key_row == _lib.GS_MISSING).sum()) == 1
+    t_dev2 = engine.DeviceTable.from_db(db)           # (after the host join exists: built from it)
+    reads = [synth.codes_to_ascii(r) for r in synth.simulate_reads(rng, [g], synth.lognormal_lengths(rng, 40, median=6000, sigma=0.6, lo=50, hi=40000))]
+    outs = []
+    for t in (t_dev, t_host, t_dev2):
+        dev = engine.DeviceReads(engine.ReadBatch.from_ascii(reads), k)
+        st, hits, carry, ctr = engine.tag(t, dev)
+        outs.append((st, hits.copy(), carry, ctr["raw_hits"]))
+        dev.close()
+    assert outs[0][0] == 0 and len(outs[0][1]) > 500
+    for o in outs[1:]:
+        assert o[0] == 0 and np.array_equal(o[1], outs[0][1]) and o[2] == outs[0][2] and o[3] == outs[0][3]
+    # the winning rows are the LAST ones
+    payload_rows = set(outs[0][1]["payload"].tolist())
+    assert any(p >= n for p in payload_rows)
+    # a read over the k-mer that has no loc row: KeyError from both tables
+    for t in (t_dev, t_host):
+        dev = engine.DeviceReads(engine.ReadBatch.from_ascii([reads[0][:300] + missing + reads[1][:200]]), k)
+        assert engine.tag(t, dev)[0] == _lib.GS_E_KEYERROR
+        dev.close()
+    for t in (t_dev, t_host, t_dev2):
+        t.close()
+    db.close()
