@@ -308,6 +308,35 @@ int gs::db_join_device(int device, const gs_sunkdb *db, uint64_t **d_keys_out, u
     return GS_OK;
 }
 
+extern "C" {
+// The table of a parsed <kmers.db> + <kmer.loc> pair: the join (distinct db codes, each with the last loc row that carries it) is
+// made on the device (gs::db_join_device: two radix sorts and a merge) and feeds the build directly -- what the reference does
+// with 1e8 .. 1e9 HashSet / Table inserts per run (kmerpos_annot3.nim:20-72).  A handle whose host join exists already (somebody
+// asked for gs_sunkdb_keys) is built from that.
+int gs_table_create_from_db(int device, const gs_sunkdb *db, gs_table **out) {
+    if (!db || !out) {
+        set_error("gs_table_create_from_db: null argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    if (db->joined)
+        return gs_table_create(device, db->k, db->keys.size(), db->keys.data(), db->key_loc.data(), db->key_row.data(), out);
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_table_create_from_db: HIP device %d not available (%d devices) -- there is no CPU fallback", device, gs_device_count());
+        return GS_E_NODEVICE;
+    }
+    uint64_t *dk = nullptr;
+    uint32_t *dl = nullptr, *dp = nullptr;
+    uint64_t n = 0;
+    int rc = db_join_device(device, db, &dk, &dl, &dp, &n);
+    if (rc == GS_OK) rc = gs_table_create_device(device, db->k, n, dk, dl, dp, out);
+    (void)hipFree(dk);
+    (void)hipFree(dl);
+    (void)hipFree(dp);
+    return rc;
+}
+}  // extern "C"
+
 struct gs_sunkset_dev {
     int device = 0, k = 0;
     uint64_t n = 0, n_groups = 0;

@@ -100,6 +100,39 @@ def _worker(rank, world, port, out_path):
     comm.close()
 
 
+def _failing_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gavisunk_amd import _lib, engine
+    from gavisunk_amd import dist as gdist
+
+    comm = gdist.Comm(0, rccl=False)
+    contigs, in_fai, cols, n_keys, grank, long_ = _rows(**CASE)
+    lo, hi = gdist.shard_bounds(CASE["n_reads"], world, rank)
+    m = (cols["name"] >= lo) & (cols["name"] < hi)
+    rs = engine.RowSet(0)
+    rs.append_host(cols["name"][m] - np.uint32(lo), cols["pos"][m], cols["contig"][m], cols["start"][m], cols["id"][m], cols["key"][m])
+    code = 0
+    try:  # rank 1 names too few contigs: its diagonal filter fails (GS_E_ARG) -- and every rank must hear of it
+        gdist.sharded_second_half(comm, rs, contigs[:5] if rank == 1 else contigs, in_fai[:5] if rank == 1 else in_fai,
+                                  np.full(n_keys, 3, np.uint8), grank[lo:hi], long_[lo:hi], lo)
+    except _lib.GsError as e:
+        code = e.status
+    rs.close()
+    np.save(f"{out_path}.{rank}.npy", np.array([code]))
+    comm.close()
+
+
+def test_a_failed_rank_fails_all_ranks(tmp_path):
+    """A rank whose filter fails must not leave the others waiting in the next exchange: its status travels with the capacity, and
+    every rank raises."""
+    from gavisunk_amd import _lib
+
+    out = str(tmp_path / "st")
+    mp.spawn(_failing_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    assert [int(np.load(f"{out}.{r}.npy")[0]) for r in range(3)] == [_lib.GS_E_ARG] * 3
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

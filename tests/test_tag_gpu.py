@@ -615,3 +615,38 @@ def test_table_from_db_joins_on_the_device(tmp_path):
     for t in (t_dev, t_host, t_dev2):
         t.close()
     db.close()
+
+
+@pytest.mark.parametrize("k,seed", [(11, 1), (16, 2), (27, 3), (32, 4)])
+def test_table_from_db_small_files(tmp_path, k, seed):
+    """The same join through the single-threaded line readers (files below 4 MB), other k: random k-mer lists with repeats, loc
+    rows with repeats and strays; device join == host join, key for key."""
+    rng = np.random.default_rng(seed)
+    n = 3000
+    codes = np.unique(rng.integers(0, 1 << min(2 * k, 62), n, dtype=np.uint64))
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    spell = lambda c: lut[((np.uint64(c) >> (2 * (k - 1 - np.arange(k, dtype=np.uint64)))) & np.uint64(3)).astype(np.uint8)].tobytes()
+    words = [spell(c) for c in codes.tolist()]
+    db_lines = [words[i] for i in rng.integers(0, len(words), len(words) + 500).tolist()] + words[:50]
+    (tmp_path / "db").write_bytes(b"".join(w + b"\n" for w in db_lines))
+    with open(tmp_path / "loc", "wb") as f:
+        for j in range(4000):
+            w = words[int(rng.integers(0, len(words)))] if rng.random() < 0.9 else spell(int(rng.integers(0, 1 << min(2 * k, 62))))
+            f.write(b"ctg%d\t%d\t%s\t%d\n" % (j % 4, j * 3, w, (j // 40) * 100))
+    db = engine.SunkDB(str(tmp_path / "db"), str(tmp_path / "loc"))
+    t_dev = engine.DeviceTable.from_db(db)
+    t_host = engine.DeviceTable(db.k, db.keys, db.key_loc, db.key_row)
+    assert db.k == k and len(db.keys) == len(set(db_lines))
+    present = [w for w, r in zip([spell(c) for c in db.keys.tolist()], db.key_row.tolist()) if r != _lib.GS_MISSING]
+    reads = [b"".join(present[i] + b"N" for i in rng.integers(0, len(present), 30).tolist()) for _ in range(20)]
+    res = []
+    for t in (t_dev, t_host):
+        dev = engine.DeviceReads(engine.ReadBatch.from_ascii(reads), k)
+        st, hits, carry, ctr = engine.tag(t, dev)
+        res.append((st, hits.copy(), carry, ctr["raw_hits"]))
+        dev.close()
+        t.close()
+    # (at k = 11 a random window can be a db k-mer without loc row: the KeyError is part of what must agree)
+    assert res[0][0] == res[1][0] and res[0][0] in (0, _lib.GS_E_KEYERROR)
+    assert len(res[0][1]) > 20 and np.array_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
+    db.close()
