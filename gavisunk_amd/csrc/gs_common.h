@@ -5,7 +5,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <cstdlib>
 #include <mutex>
+#include <new>
+#include <utility>
 #include <vector>
 
 #include "gavisunk.h"
@@ -65,23 +68,64 @@ constexpr int kTileWords = 64;
 
 }  // namespace gs
 
+void gs_advise_huge(void *p, size_t bytes);  // madvise(MADV_HUGEPAGE) (gs_host.cpp)
+
+// std::vector for the row arrays of a parsed table (1e8 .. 1e9 entries each): resize() leaves the new elements uninitialised
+// (they are written right after, by several threads: no single-threaded zero fill, first touch in parallel), and allocations of
+// 4 MiB and more are 2 MiB-aligned and marked for transparent huge pages (a quarter of the page faults of 1e9 rows x 32 bytes)
+template <typename T>
+struct HugeAlloc {
+    using value_type = T;
+    HugeAlloc() = default;
+    template <typename U>
+    HugeAlloc(const HugeAlloc<U> &) {}
+    T *allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= ((size_t)4 << 20)) {
+            const size_t a = (size_t)2 << 20;
+            void *p = aligned_alloc(a, (bytes + a - 1) / a * a);
+            if (!p) throw std::bad_alloc();
+            gs_advise_huge(p, (bytes + a - 1) / a * a);
+            return static_cast<T *>(p);
+        }
+        void *p = malloc(bytes ? bytes : 1);
+        if (!p) throw std::bad_alloc();
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t) { free(p); }
+    template <typename U>
+    void construct(U *p) {
+        ::new ((void *)p) U;  // default-initialisation: nothing for the integer types this is used with
+    }
+    template <typename U, typename... A>
+    void construct(U *p, A &&...a) {
+        ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+    template <typename U>
+    bool operator==(const HugeAlloc<U> &) const { return true; }
+    template <typename U>
+    bool operator!=(const HugeAlloc<U> &) const { return false; }
+};
+template <typename T>
+using HugeVec = std::vector<T, HugeAlloc<T>>;
+
 struct gs_sunkdb {
     int k = 0;
     // what the parsers leave: every line of <kmers.db> (file order, duplicates included) and the k-mer of every loc row.  The join
     // of the two -- distinct db codes, each with the LAST loc row that carries it (kmerpos_annot3.nim:68) -- is made where it is
     // needed: on the device for the table (gs_table_create_from_db: sorts + a merge), on the host when a caller asks for the
     // arrays below (gs_sunkdb_keys / _key_row / _key_loc: the first call pays for it)
-    std::vector<uint64_t> db_codes;
-    std::vector<uint64_t> row_code;
+    HugeVec<uint64_t> db_codes;
+    HugeVec<uint64_t> row_code;
     bool joined = false;
     std::mutex join_mu;
     std::vector<uint64_t> keys;     // distinct db codes, first-seen order
     std::vector<uint32_t> key_row;  // winning loc row or GS_MISSING
     std::vector<uint32_t> key_loc;  // dense (contig, group) id or GS_MISSING
-    std::vector<uint32_t> row_contig;
-    std::vector<int64_t> row_start;
-    std::vector<int64_t> row_group;
-    std::vector<uint32_t> row_loc;
+    HugeVec<uint32_t> row_contig;
+    HugeVec<int64_t> row_start;
+    HugeVec<int64_t> row_group;
+    HugeVec<uint32_t> row_loc;
     std::vector<std::string> contigs;
 };
 

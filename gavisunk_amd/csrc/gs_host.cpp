@@ -26,6 +26,8 @@
 
 #include "gs_common.h"
 
+void gs_advise_huge(void *p, size_t bytes) { (void)madvise(p, bytes, MADV_HUGEPAGE); }
+
 namespace gs {
 
 static thread_local std::string g_err;
@@ -317,9 +319,9 @@ static bool parse_i64(const char *b, const char *e, int64_t &v) {
 // -> 0 done, 1 a malformed line (*err_line = its 1-based number), -1 not applicable (gzip, small, cannot map): the caller's
 // line-by-line loop then reads the file.
 struct LocPart {
-    std::vector<uint32_t> cid, pid;  // per row: local contig id, local (contig, group) pair id
-    std::vector<int64_t> start, group;
-    std::vector<uint64_t> code;
+    HugeVec<uint32_t> cid, pid;  // per row: local contig id, local (contig, group) pair id
+    HugeVec<int64_t> start, group;
+    HugeVec<uint64_t> code;
     std::vector<std::string> contigs;                   // local contigs, first-seen order
     std::vector<std::pair<uint32_t, int64_t>> pairs;    // local (local contig, group) pairs, first-seen order
     uint64_t lines = 0, err_line = 0;
@@ -411,7 +413,7 @@ static void parse_loc_part(const char *b, const char *e, LocPart &o) {
     }
 }
 // the k-mer list (one k-mer per line) parsed by several threads: -> false when not applicable (gzip, small, cannot map)
-static bool parse_db_parallel(const char *path, std::vector<uint64_t> &codes, int &k) {
+static bool parse_db_parallel(const char *path, HugeVec<uint64_t> &codes, int &k) {
     if (getenv("GAVISUNK_LOC_THREADS") && atoi(getenv("GAVISUNK_LOC_THREADS")) <= 1) return false;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return false;
@@ -439,7 +441,7 @@ static bool parse_db_parallel(const char *path, std::vector<uint64_t> &codes, in
         const char *nl = q < n ? (const char *)memchr(p + q, '\n', n - q) : nullptr;
         cut[t] = nl ? (size_t)(nl - p) + 1 : n;
     }
-    std::vector<std::vector<uint64_t>> parts(T);
+    std::vector<HugeVec<uint64_t>> parts(T);
     auto work = [&](unsigned t) {
         const char *b = p + cut[t], *e = p + cut[t + 1];
         parts[t].reserve((size_t)(e - b) / 16 + 16);
@@ -465,18 +467,23 @@ static bool parse_db_parallel(const char *path, std::vector<uint64_t> &codes, in
         k = (int)(le - p);
     }
     munmap(m, n);
-    size_t total = 0;
-    for (auto &v : parts) total += v.size();
-    codes.resize(total);
-    size_t o = 0;
-    for (auto &v : parts) {
-        if (!v.empty()) memcpy(codes.data() + o, v.data(), v.size() * sizeof(uint64_t));
-        o += v.size();
+    std::vector<size_t> at(T + 1, 0);
+    for (unsigned t = 0; t < T; t++) at[t + 1] = at[t] + parts[t].size();
+    codes.resize(at[T]);  // (uninitialised: every thread copies its part, and frees it)
+    {
+        auto place = [&](unsigned t) {
+            if (!parts[t].empty()) memcpy(codes.data() + at[t], parts[t].data(), parts[t].size() * sizeof(uint64_t));
+            HugeVec<uint64_t>().swap(parts[t]);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; t++) pool.emplace_back(place, t);
+        place(0);
+        for (auto &th : pool) th.join();
     }
     return true;
 }
 
-static int parse_loc_parallel(const char *path, gs_sunkdb *d, std::vector<uint64_t> &row_code, uint64_t *err_line) {
+static int parse_loc_parallel(const char *path, gs_sunkdb *d, HugeVec<uint64_t> &row_code, uint64_t *err_line) {
     if (getenv("GAVISUNK_LOC_THREADS") && atoi(getenv("GAVISUNK_LOC_THREADS")) <= 1) return -1;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return -1;
@@ -506,13 +513,17 @@ static int parse_loc_parallel(const char *path, gs_sunkdb *d, std::vector<uint64
         cut[t] = nl ? (size_t)(nl - p) + 1 : n;
     }
     std::vector<LocPart> parts(T);
+    auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = tnow();
     {
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < T; t++) pool.emplace_back([&, t]() { parse_loc_part(p + cut[t], p + cut[t + 1], parts[t]); });
         parse_loc_part(p + cut[0], p + cut[1], parts[0]);
         for (auto &th : pool) th.join();
     }
+    const double tp1 = tnow();
     munmap(m, n);
+    const double tp2 = tnow();
     uint64_t lines_before = 0;
     for (unsigned t = 0; t < T; t++) {
         if (parts[t].err) {
@@ -554,7 +565,7 @@ static int parse_loc_parallel(const char *path, gs_sunkdb *d, std::vector<uint64
     row_code.resize(nrows);
     {
         auto place = [&](unsigned t) {
-            const LocPart &o = parts[t];
+            LocPart &o = parts[t];
             const size_t b = row0[t];
             for (size_t i = 0; i < o.cid.size(); i++) {
                 d->row_contig[b + i] = cmap[t][o.cid[i]];
@@ -565,12 +576,15 @@ static int parse_loc_parallel(const char *path, gs_sunkdb *d, std::vector<uint64
                 memcpy(d->row_group.data() + b, o.group.data(), o.group.size() * sizeof(int64_t));
                 memcpy(row_code.data() + b, o.code.data(), o.code.size() * sizeof(uint64_t));
             }
+            parts[t] = LocPart();  // (640 MB per 2e7 rows go back to the system here, on this thread)
         };
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < T; t++) pool.emplace_back(place, t);
         place(0);
         for (auto &th : pool) th.join();
     }
+    if (getenv("GAVISUNK_TIMING"))
+        fprintf(stderr, "[sunkdb] loc: %u threads, parse %.3f s, munmap %.3f s, merge + place %.3f s\n", T, tp1 - tp0, tp2 - tp1, tnow() - tp2);
     return 0;
 }
 }  // namespace gs
@@ -603,7 +617,7 @@ static void join_host(gs_sunkdb *d) {
         }
     };
     // distinct db codes, first occurrences, file order
-    std::vector<uint64_t> codes = std::move(d->db_codes);
+    HugeVec<uint64_t> codes = std::move(d->db_codes);
     const size_t n = codes.size();
     std::vector<uint8_t> is_first(n, 0);
     run_parts(n, [&](unsigned part) {
@@ -619,11 +633,11 @@ static void join_host(gs_sunkdb *d) {
     size_t nk = 0;
     for (size_t i = 0; i < n; i++)
         if (is_first[i]) codes[nk++] = codes[i];
-    codes.resize(nk);
-    d->keys = std::move(codes);
+    d->keys.assign(codes.begin(), codes.begin() + nk);
+    HugeVec<uint64_t>().swap(codes);
     // loc code -> last row with that code
     CodeMap rowmap[kMapParts];
-    const std::vector<uint64_t> &row_code = d->row_code;
+    const HugeVec<uint64_t> &row_code = d->row_code;
     const size_t nrows = row_code.size();
     run_parts(nrows, [&](unsigned part) {
         CodeMap &m = rowmap[part];
@@ -653,7 +667,7 @@ static void join_host(gs_sunkdb *d) {
     for (unsigned t = 1; t < nthr; t++) pool.emplace_back(join_range, nk * t / nthr, nk * (t + 1) / nthr);
     join_range(0, nk / nthr);
     for (auto &t : pool) t.join();
-    std::vector<uint64_t>().swap(d->row_code);
+    HugeVec<uint64_t>().swap(d->row_code);
     d->joined = true;
 }
 static const gs_sunkdb *joined(const gs_sunkdb *db) {
@@ -677,7 +691,7 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
     bool db_open = true;
     std::thread db_thread([&]() {
         std::string l;
-        std::vector<uint64_t> codes;  // local while growing: the two threads must not share cache lines of *d
+        HugeVec<uint64_t> codes;  // local while growing: the two threads must not share cache lines of *d
         int k = 0;
         if (!parse_db_parallel(db_path, codes, k)) {
             LineReader r(db_path);
@@ -711,7 +725,7 @@ int gs_sunkdb_load(const char *db_path, const char *loc_path, gs_sunkdb **out) {
         else set_error("%s: k = %d is outside 1..32 (2 bits per base in a uint64)", db_path, d->k);
         return db_rc;
     };
-    std::vector<uint64_t> row_code;
+    HugeVec<uint64_t> row_code;
     uint64_t par_err_line = 0;
     const int par = parse_loc_parallel(loc_path, d, row_code, &par_err_line);
     const double t_parsed = tnow();
