@@ -9,7 +9,10 @@
 
 #include <sys/stat.h>
 
+#include <unistd.h>
+
 #include <cstdio>
+#include <thread>
 
 namespace {
 
@@ -52,6 +55,31 @@ struct SidecarHeader {
 };
 constexpr char kSidecarMagic[8] = {'G', 'S', 'S', 'I', 'D', 'E', '0', '7'};
 constexpr size_t kSidecarChunk = (size_t)64 << 20;
+
+// `bytes` of the file at `off` into dst, read by a few threads (pread: a 5 GiB sidecar comes from the page cache at the speed of
+// ONE memcpy otherwise)
+bool read_parallel(int fd, void *dst, size_t bytes, uint64_t off) {
+    const unsigned T = (unsigned)std::min<size_t>(8, std::max<size_t>(bytes >> 23, 1));
+    std::vector<char> okv(T, 1);
+    auto work = [&](unsigned t) {
+        size_t lo = bytes * t / T, hi = bytes * (t + 1) / T;
+        while (lo < hi) {
+            const ssize_t r = pread(fd, static_cast<char *>(dst) + lo, hi - lo, (off_t)(off + lo));
+            if (r <= 0) {
+                okv[t] = 0;
+                return;
+            }
+            lo += (size_t)r;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < T; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    for (char o : okv)
+        if (!o) return false;
+    return true;
+}
 
 struct FileCloser {
     FILE *f;
@@ -171,7 +199,12 @@ int gs_sidecar_open(const char *path, const char *db_path, const char *loc_path,
         o = e + 1;
     }
     ok = ok && db->contigs.size() == h.n_contigs;
-    auto get = [&](void *p, size_t bytes) { ok = ok && (!bytes || fread(p, bytes, 1, f) == 1); };
+    uint64_t at = ok ? (uint64_t)ftello(f) : 0;
+    const int fd = fileno(f);
+    auto get = [&](void *p, size_t bytes) {
+        ok = ok && (!bytes || read_parallel(fd, p, bytes, at));
+        at += bytes;
+    };
     if (ok) {
         db->row_contig.resize(h.n_rows);
         db->row_start.resize(h.n_rows);

@@ -142,33 +142,77 @@ def _tag_text_blocks(blocks, db, table, ofile: str, device: int):
     when the text is outside the regular FASTA / FASTQ subset the device parser takes (nothing useful is written then)."""
     carry = _lib.GS_NONE
     with engine.RowWriter(ofile) as out:  # (rows formatted and written natively: gs_rowwriter_rows)
-        it = iter(blocks)
-        while True:
-            t0 = time.perf_counter()
-            staged = next(it, None)
-            t0 = _tick("wait_for_reader", t0)
-            if staged is None:
-                break
-            try:
-                dev = engine.DeviceReads.from_staged(staged, db.k)
-            except _lib.GsError as e:
+        # the rows of block i are formatted and written by a second thread while block i + 1 is parsed and tagged (the hit list of a
+        # pass lives in pinned memory of ITS reads handle until that handle is closed: the main thread closes a block's handle only
+        # when the writer has handed it back)
+        todo: "queue.Queue" = queue.Queue(maxsize=2)
+        done: "queue.Queue" = queue.Queue()
+        failed = []
+
+        def writer():
+            while True:
+                item = todo.get()
+                if item is None:
+                    return
+                hits, dev = item
+                try:
+                    if not failed:
+                        t1 = time.perf_counter()
+                        out.write(hits, dev, db)
+                        _tick("write_rows", t1)
+                except BaseException as e:  # noqa: BLE001 (handed to the main thread)
+                    failed.append(e)
+                done.put(dev)
+
+        def close_done() -> None:
+            while True:
+                try:
+                    done.get_nowait().close()
+                except queue.Empty:
+                    return
+
+        wt = threading.Thread(target=writer, name="gavisunk-rows", daemon=True)
+        wt.start()
+        rc = 0
+        try:
+            it = iter(blocks)
+            while True:
+                t0 = time.perf_counter()
+                staged = next(it, None)
+                t0 = _tick("wait_for_reader", t0)
+                if staged is None:
+                    break
+                try:
+                    dev = engine.DeviceReads.from_staged(staged, db.k)
+                except _lib.GsError as e:
+                    staged.close()
+                    if e.status == _lib.GS_E_IRREGULAR:
+                        rc = None
+                        break
+                    raise
                 staged.close()
-                if e.status == _lib.GS_E_IRREGULAR:
-                    return None
-                raise
-            staged.close()
-            t0 = _tick("parse_records_on_device", t0)
-            st, hits, carry, _ = engine.tag(table, dev, carry)
-            t0 = _tick("tag", t0)
-            out.write(hits, dev, db)
-            last_timing["rows"] = last_timing.get("rows", 0) + len(hits)
-            t0 = _tick("write_rows", t0)
-            dev.close()
-            _tick("release_batch", t0)
-            if st == _lib.GS_E_KEYERROR:
-                sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
-                return 1
-    return 0
+                t0 = _tick("parse_records_on_device", t0)
+                st, hits, carry, _ = engine.tag(table, dev, carry)
+                t0 = _tick("tag", t0)
+                last_timing["rows"] = last_timing.get("rows", 0) + len(hits)
+                todo.put((hits, dev))
+                close_done()
+                _tick("release_batch", t0)
+                if failed:
+                    break
+                if st == _lib.GS_E_KEYERROR:
+                    sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
+                    rc = 1
+                    break
+        finally:
+            todo.put(None)
+            t0 = time.perf_counter()
+            wt.join()
+            _tick("wait_for_writer", t0)
+            close_done()
+        if failed:
+            raise failed[0]
+    return rc
 
 
 def _tag_host_batches(batches, db, table, ofile: str, batch_bases: int) -> int:
