@@ -35,7 +35,7 @@ with open(path, "wb") as f, ThreadPoolExecutor(16) as pool:
 print(f"{path}: {os.path.getsize(path) / 2**30:.2f} GiB in {n_members} members ({time.time() - t0:.0f} s); hardware threads {os.cpu_count()}, "
       f"affinity {len(os.sched_getaffinity(0))}", flush=True)
 L = _lib.lib()
-for threads, hold in ((8, 0), (16, 0), (32, 0), (32, 5), (32, 5)):
+for threads, hold in [(int(x), 0) for x in os.environ.get("GZ_TIME_THREADS", "").split(",") if x] or ((8, 0), (16, 0), (32, 0), (32, 5), (32, 5)):
     # hold: text blocks the consumer still holds when the next one is made (the command line holds up to 5: being inflated, queued,
     # being copied, queued, being parsed) -- those cannot come back from the reader's buffer pool
     z = C.c_void_p()
@@ -56,4 +56,5 @@ for threads, hold in ((8, 0), (16, 0), (32, 0), (32, 5), (32, 5)):
         L.gs_gz_free_buffer(p)
     L.gs_gz_close(z)
     print(f"threads {threads:2d}, {hold} blocks held: {total / 1e9:.2f} GB of text in {dt:.2f} s = {total / dt / 1e9:.2f} GB/s", flush=True)
-os.unlink(path)
+if not os.environ.get("GZ_TIME_KEEP"):
+    os.unlink(path)
