@@ -212,7 +212,92 @@ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13
 
 struct BlockCodes {
     Huff lit, dist;
+    // up to three LITERALS per lookup (sequence text: A C G T take 2 .. 3 bits each, so the primary table's 11 bits usually hold
+    // three of them): entry = three 16-bit symbols | bits to drop << 48 | count << 56; count 0 = take the one-symbol path.
+    // Empty when the block's literal codes are too long for it to pay (build_multi).
+    std::vector<uint64_t> multi;
+    // the two tables as the fast loop reads them: the symbol already turned into what it means --
+    //   bits 0..4 code length, bit 5 "subtable" (bits 8..11 its index bits, bits 16.. its offset), else bits 6..7 kind (0 literal,
+    //   1 length / distance, 2 end of block), bits 8..11 number of extra bits, bits 16..31 literal / base length / base distance
+    // -- so that a match costs two dependent table loads instead of four (kLenBase / kLenExtra / kDistBase / kDistExtra)
+    std::vector<uint32_t> flit, fdist;
 };
+
+// A prefix of a stream's next P bits decodes the same whatever follows it, so the second and third literal of an entry can be
+// looked up in the same table with the bits that are left, zero-padded: a code longer than those bits cannot come back as a
+// shorter one (the code is prefix-free).
+void build_multi(BlockCodes &bc) {
+    bc.multi.clear();
+    const int P = bc.lit.primary;
+    if (bc.lit.t.size() < ((size_t)1 << P)) return;
+    const uint32_t *lt = bc.lit.t.data();
+    // worth it when two literals fit the table's bits more often than not: at least two literal codes of <= 4 bits
+    int short_lits = 0;
+    for (uint32_t i = 0; i < 16u && short_lits < 2; i++) {
+        const uint32_t e = lt[i];
+        if (!(e & 32u) && (e & 31u) && (e & 31u) <= 4u && (e >> 16) < 256u && (i >> (e & 31u)) == 0u) short_lits++;
+    }
+    if (short_lits < 2) return;
+    bc.multi.resize((size_t)1 << P);
+    uint64_t *mt = bc.multi.data();
+    for (uint32_t i = 0; i < ((uint32_t)1 << P); i++) {
+        uint64_t m = 0;
+        const uint32_t e1 = lt[i];
+        const int l1 = (int)(e1 & 31u);
+        if (!(e1 & 32u) && l1 && (e1 >> 16) < 256u) {
+            uint32_t rest = i >> l1;
+            int avail = P - l1;
+            const uint32_t e2 = lt[rest];
+            const int l2 = (int)(e2 & 31u);
+            if (!(e2 & 32u) && l2 && l2 <= avail && (e2 >> 16) < 256u) {
+                uint64_t syms = (uint64_t)(e1 >> 16) | ((uint64_t)(e2 >> 16) << 16);
+                int cnt = 2, tot = l1 + l2;
+                rest >>= l2;
+                avail -= l2;
+                const uint32_t e3 = lt[rest];
+                const int l3 = (int)(e3 & 31u);
+                if (!(e3 & 32u) && l3 && l3 <= avail && (e3 >> 16) < 256u) {
+                    syms |= (uint64_t)(e3 >> 16) << 32;
+                    cnt = 3;
+                    tot += l3;
+                }
+                m = syms | ((uint64_t)tot << 48) | ((uint64_t)cnt << 56);
+            }
+        }
+        mt[i] = m;
+    }
+}
+
+void make_fast(BlockCodes &bc) {
+    const size_t P1 = (size_t)1 << bc.lit.primary, P2 = (size_t)1 << bc.dist.primary;
+    bc.flit.resize(bc.lit.t.size());
+    for (size_t i = 0; i < bc.lit.t.size(); i++) {
+        const uint32_t e = bc.lit.t[i];
+        uint32_t f = 0;
+        if (i < P1 && (e & 32u)) {
+            f = e;  // pointer to a subtable: as it is
+        } else if (e & 31u) {
+            const uint32_t s = e >> 16, l = e & 31u;
+            if (s < 256u) f = (s << 16) | l;
+            else if (s == 256u) f = (2u << 6) | l;
+            else if (s < 286u) f = ((uint32_t)kLenBase[s - 257] << 16) | ((uint32_t)kLenExtra[s - 257] << 8) | (1u << 6) | l;
+            // (286, 287: no valid length symbol -> 0 = invalid)
+        }
+        bc.flit[i] = f;
+    }
+    bc.fdist.resize(bc.dist.t.size());
+    for (size_t i = 0; i < bc.dist.t.size(); i++) {
+        const uint32_t e = bc.dist.t[i];
+        uint32_t f = 0;
+        if (i < P2 && (e & 32u)) {
+            f = e;
+        } else if (e & 31u) {
+            const uint32_t s = e >> 16, l = e & 31u;
+            if (s < 30u) f = ((uint32_t)kDistBase[s] << 16) | ((uint32_t)kDistExtra[s] << 8) | (1u << 6) | l;
+        }
+        bc.fdist[i] = f;
+    }
+}
 
 // The symbols of a Huffman block with the reader's state in registers: one branch-free refill per symbol (after it at least 56
 // bits are at hand: a literal/length code, its extra bits, a distance code and its extra bits are at most 48), no capacity test
@@ -223,17 +308,35 @@ inline int fast_symbols(const BlockCodes &bc, Bits &b, uint16_t *&o, uint16_t *o
     const uint8_t *in_safe = b.n >= 16 ? base + b.n - 16 : base;
     uint64_t buf = b.buf;
     int cnt = b.cnt;
-    const uint32_t *lt = bc.lit.t.data(), *dt = bc.dist.t.data();
+    const uint32_t *lt = bc.flit.data(), *dt = bc.fdist.data();
     const int lp = bc.lit.primary, dp = bc.dist.primary;
     const uint32_t lmask = (1u << lp) - 1u, dmask = (1u << dp) - 1u;
     uint16_t *w = o;
     int rc = 0;
+    const uint64_t *mt = bc.multi.empty() ? nullptr : bc.multi.data();
     while (in < in_safe && w < o_stop) {
         uint64_t x;
         memcpy(&x, in, 8);
         buf |= x << cnt;
         in += (63 - cnt) >> 3;
         cnt |= 56;
+        if (mt) {
+            // two or three literals per lookup, up to four lookups from the >= 56 bits at hand (11 bits each at most); the store
+            // writes four symbols, the fourth is overwritten by what comes next (the output margin holds it)
+            uint64_t m = mt[(uint32_t)buf & lmask];
+            if (m >> 56) {
+                int k = 0;
+                do {
+                    memcpy(w, &m, 8);
+                    w += m >> 56;
+                    const int l = (int)((m >> 48) & 255u);
+                    buf >>= l;
+                    cnt -= l;
+                    m = mt[(uint32_t)buf & lmask];
+                } while ((m >> 56) && ++k < 4);
+                continue;
+            }
+        }
         uint32_t e = lt[(uint32_t)buf & lmask];
         if (e & 32u) {
             buf >>= lp;
@@ -245,19 +348,19 @@ inline int fast_symbols(const BlockCodes &bc, Bits &b, uint16_t *&o, uint16_t *o
             rc = -1;
             break;
         }
-        buf >>= l;
-        cnt -= l;
-        int s = (int)(e >> 16);
-        if (s < 256) {
-            *w++ = (uint16_t)s;
+        const uint32_t kind = (e >> 6) & 3u;
+        if (kind == 0) {
+            buf >>= l;
+            cnt -= l;
+            *w++ = (uint16_t)(e >> 16);
             // up to two more literals from the bits already at hand (three codes are at most 45 of the >= 56 bits)
             uint32_t e2 = lt[(uint32_t)buf & lmask];
-            if (!(e2 & 32u) && (e2 >> 16) < 256u && (e2 & 31u)) {
+            if (!(e2 & (32u | 192u)) && (e2 & 31u)) {
                 buf >>= (e2 & 31u);
                 cnt -= (int)(e2 & 31u);
                 *w++ = (uint16_t)(e2 >> 16);
                 e2 = lt[(uint32_t)buf & lmask];
-                if (!(e2 & 32u) && (e2 >> 16) < 256u && (e2 & 31u)) {
+                if (!(e2 & (32u | 192u)) && (e2 & 31u)) {
                     buf >>= (e2 & 31u);
                     cnt -= (int)(e2 & 31u);
                     *w++ = (uint16_t)(e2 >> 16);
@@ -265,19 +368,17 @@ inline int fast_symbols(const BlockCodes &bc, Bits &b, uint16_t *&o, uint16_t *o
             }
             continue;
         }
-        if (s == 256) {
+        if (kind == 2) {
+            buf >>= l;
+            cnt -= l;
             rc = 1;
             break;
         }
-        s -= 257;
-        if (s >= 29) {
-            rc = -1;
-            break;
-        }
-        const int xl = kLenExtra[s];
-        const uint32_t len = kLenBase[s] + ((uint32_t)buf & ((1u << xl) - 1u));
-        buf >>= xl;
-        cnt -= xl;
+        // a match: base length + extra bits, then the distance the same way (at most 15 + 5 + 15 + 13 = 48 of the >= 56 bits)
+        const int xl = (int)((e >> 8) & 15u);
+        const uint32_t len = (e >> 16) + ((uint32_t)(buf >> l) & ((1u << xl) - 1u));
+        buf >>= l + xl;
+        cnt -= l + xl;
         uint32_t d = dt[(uint32_t)buf & dmask];
         if (d & 32u) {
             buf >>= dp;
@@ -285,17 +386,14 @@ inline int fast_symbols(const BlockCodes &bc, Bits &b, uint16_t *&o, uint16_t *o
             d = dt[(d >> 16) + ((uint32_t)buf & ((1u << ((d >> 8) & 15u)) - 1u))];
         }
         const int dl = (int)(d & 31u);
-        const int ds = (int)(d >> 16);
-        if (!dl || ds >= 30) {
+        if (!dl) {
             rc = -1;
             break;
         }
-        buf >>= dl;
-        cnt -= dl;
-        const int xd = kDistExtra[ds];
-        const uint32_t dist = kDistBase[ds] + ((uint32_t)buf & ((1u << xd) - 1u));
-        buf >>= xd;
-        cnt -= xd;
+        const int xd = (int)((d >> 8) & 15u);
+        const uint32_t dist = (d >> 16) + ((uint32_t)(buf >> dl) & ((1u << xd) - 1u));
+        buf >>= dl + xd;
+        cnt -= dl + xd;
         const uint16_t *r = w - dist;  // (behind the 32768 markers a distance never reaches before the buffer)
         if (dist >= 4) {
             for (uint32_t i = 0; i < len; i += 4) memcpy(w + i, r + i, 8);  // (up to 3 symbols of slack past the match: the margin holds them)
@@ -348,6 +446,7 @@ bool read_dynamic_header(Bits &b, BlockCodes &bc) {
     if (!lens[256]) return false;  // a block without an end-of-block code never ends
     if (!bc.lit.build(lens, hlit, 11, false)) return false;
     if (!bc.dist.build(lens + hlit, hdist, 8, true)) return false;
+    make_fast(bc);
     return true;
 }
 
@@ -363,6 +462,7 @@ const BlockCodes &fixed_codes() {
         uint8_t d[32];
         for (int i = 0; i < 32; i++) d[i] = 5;
         c.dist.build(d, 32, 8, true);  // (32 codes of 5 bits; 30 and 31 never occur in valid data and are refused by the decoder)
+        make_fast(c);
         return c;
     }();
     return bc;
@@ -449,6 +549,9 @@ size_t skip_gzip_header(const uint8_t *p, size_t n, size_t pos) {
     return q <= n ? q : 0;
 }
 
+bool g_prof = getenv("GAVISUNK_GZ_PROF") != nullptr;
+std::atomic<uint64_t> g_prof_cycles{0}, g_prof_blocks{0};
+
 // Decodes blocks from b's position.  `stops`: sorted bit positions of later pieces' starts: decoding ends at the first block
 // boundary that equals one of them (-> its index + 1 in *landed) and walks past those it misses.  Also ends at the end of
 // the file's last member.  `one_block`: decode exactly one block (the finder's trial).
@@ -495,9 +598,16 @@ bool decode_blocks(const uint8_t *data, size_t n, Bits &b, Piece &pc, const std:
             if (btype == 1) {
                 bc = &fixed_codes();
             } else {
+                const uint64_t tsc0 = g_prof ? __builtin_ia32_rdtsc() : 0;
                 if (!read_dynamic_header(b, dyn)) {
                     pc.err = "bad dynamic block header";
                     return false;
+                }
+                if (!one_block) build_multi(dyn);  // (the finder's trial blocks do without)
+                else dyn.multi.clear();
+                if (g_prof) {
+                    g_prof_cycles.fetch_add(__builtin_ia32_rdtsc() - tsc0, std::memory_order_relaxed);
+                    g_prof_blocks.fetch_add(1, std::memory_order_relaxed);
                 }
                 bc = &dyn;
             }
@@ -634,13 +744,13 @@ bool find_block(const uint8_t *data, size_t n, uint64_t from, uint64_t to, uint6
     return false;
 }
 
-uint32_t crc32_of(const uint8_t *p, size_t n) {
+// CRC-32 of p[0, n) continued from `c` (0 = a fresh one)
+uint32_t crc32_more(uint32_t c, const uint8_t *p, size_t n) {
     static uint32_t (*fast)(uint32_t, const void *, size_t) = [] {
         void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         return h ? (uint32_t(*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32") : nullptr;
     }();
-    if (fast) return fast(0, p, n);
-    uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
+    if (fast) return fast(c, p, n);
     while (n) {
         const uInt m = (uInt)std::min<size_t>(n, 1u << 30);
         c = (uint32_t)crc32(c, p, m);
@@ -834,6 +944,8 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
         for (auto &t : th) t.join();
     }
     if (dbg) fprintf(stderr, "[gz] decode %.3f s\n", now() - t0), t0 = now();
+    if (g_prof) fprintf(stderr, "[gz] block headers + tables: %llu blocks, %.1f kcycles each so far\n", (unsigned long long)g_prof_blocks.load(),
+                        g_prof_blocks.load() ? (double)g_prof_cycles.load() / (double)g_prof_blocks.load() / 1e3 : 0.0);
     // ---- chain: from piece 0 along the landings; in a group that is not the file's last, the chain must end ON a later piece's
     // start (the next group begins there); pieces after the last landing are decoded again by the next group
     std::vector<size_t> chain;
@@ -883,6 +995,13 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
     const size_t base = z->out.size();
     z->out.grow_for(out_off[chain.size()]);
     z->out.n = base + out_off[chain.size()];
+    // per piece: the CRC-32 of every stretch between member ends (a piece holds the tail of one member, whole members, the head
+    // of the next), taken tile by tile right behind the narrowing while the bytes are in the cache
+    struct SegCrc {
+        size_t len;
+        uint32_t crc;
+    };
+    std::vector<std::vector<SegCrc>> segs(chain.size());
     {
         std::vector<std::thread> th;
         std::atomic<size_t> nextc{0};
@@ -896,33 +1015,46 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                 uint8_t *o = z->out.data() + base + out_off[c];
                 const uint8_t *w = win[c].data();
                 uint64_t nl = 0;
-                size_t k = 0;
+                std::vector<SegCrc> &sg = segs[c];
+                size_t seg_lo = 0;
+                for (size_t mi = 0; mi <= pc.members.size(); mi++) {
+                    const size_t seg_hi = mi < pc.members.size() ? (size_t)pc.members[mi].out_pos : m;
+                    uint32_t crc = 0;
+                    for (size_t ta = seg_lo; ta < seg_hi;) {
+                        const size_t t1 = std::min(seg_hi, ta + ((size_t)1 << 17));
+                        size_t k = ta;
 #if defined(__SSE2__)
-                // sixteen symbols at a time while none of them is a marker (all but the first stretch of a piece): pack to bytes,
-                // count the newlines by compare + mask
-                const __m128i hi = _mm_set1_epi16((short)0xFF00), nlv = _mm_set1_epi8('\n');
-                for (; k + 16 <= m; k += 16) {
-                    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k));
-                    const __m128i b2 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k + 8));
-                    if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(_mm_or_si128(a, b2), hi), _mm_setzero_si128())) != 0xFFFF) {
-                        for (size_t j = k; j < k + 16; j++) {  // a marker among them: one by one
-                            const uint16_t v = s[j];
+                        // sixteen symbols at a time while none of them is a marker (all but the first stretch of a piece): pack to
+                        // bytes, count the newlines by compare + mask
+                        const __m128i hi = _mm_set1_epi16((short)0xFF00), nlv = _mm_set1_epi8('\n');
+                        for (; k + 16 <= t1; k += 16) {
+                            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k));
+                            const __m128i b2 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k + 8));
+                            if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(_mm_or_si128(a, b2), hi), _mm_setzero_si128())) != 0xFFFF) {
+                                for (size_t j = k; j < k + 16; j++) {  // a marker among them: one by one
+                                    const uint16_t v = s[j];
+                                    const uint8_t byte = v < kMarker ? (uint8_t)v : w[v - kMarker];
+                                    o[j] = byte;
+                                    nl += byte == '\n';
+                                }
+                                continue;
+                            }
+                            const __m128i bytes = _mm_packus_epi16(a, b2);
+                            _mm_storeu_si128(reinterpret_cast<__m128i *>(o + k), bytes);
+                            nl += (uint64_t)__builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(bytes, nlv)));
+                        }
+#endif
+                        for (; k < t1; k++) {
+                            const uint16_t v = s[k];
                             const uint8_t byte = v < kMarker ? (uint8_t)v : w[v - kMarker];
-                            o[j] = byte;
+                            o[k] = byte;
                             nl += byte == '\n';
                         }
-                        continue;
+                        crc = crc32_more(crc, o + ta, t1 - ta);
+                        ta = t1;
                     }
-                    const __m128i bytes = _mm_packus_epi16(a, b2);
-                    _mm_storeu_si128(reinterpret_cast<__m128i *>(o + k), bytes);
-                    nl += (uint64_t)__builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(bytes, nlv)));
-                }
-#endif
-                for (; k < m; k++) {
-                    const uint16_t v = s[k];
-                    const uint8_t byte = v < kMarker ? (uint8_t)v : w[v - kMarker];
-                    o[k] = byte;
-                    nl += byte == '\n';
+                    sg.push_back(SegCrc{seg_hi - seg_lo, crc});
+                    seg_lo = seg_hi;
                 }
                 newlines.fetch_add(nl, std::memory_order_relaxed);
             }
@@ -931,52 +1063,27 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
         for (auto &t : th) t.join();
     }
     z->newlines += newlines.load();
-    if (dbg) fprintf(stderr, "[gz] resolve + narrow %.3f s\n", now() - t0), t0 = now();
-    // ---- members that ended inside this group: CRC-32 and ISIZE
-    {
-        size_t seg_lo = base;  // first byte (in z->out) of the member that is open
-        for (size_t c = 0; c < chain.size(); c++) {
-            const Piece &pc = pcs[chain[c]];
-            for (const Piece::MemberEnd &me : pc.members) {
-                const size_t seg_hi = base + out_off[c] + (size_t)me.out_pos;
-                // CRC of [seg_lo, seg_hi) in parallel slices, combined behind the part of the member that earlier groups saw
-                const size_t len = seg_hi - seg_lo;
-                const size_t ns = std::max<size_t>(1, std::min<size_t>((size_t)z->threads, len >> 22));
-                std::vector<uint32_t> part(ns);
-                std::vector<std::thread> th;
-                for (size_t s = 0; s < ns; s++)
-                    th.emplace_back([&, s]() {
-                        const size_t a = seg_lo + len * s / ns, e = seg_lo + len * (s + 1) / ns;
-                        part[s] = crc32_of(z->out.data() + a, e - a);
-                    });
-                for (auto &t : th) t.join();
-                uint32_t crc = z->run_crc;
-                bool first = z->run_size == 0;
-                for (size_t s = 0; s < ns; s++) {
-                    const size_t a = seg_lo + len * s / ns, e = seg_lo + len * (s + 1) / ns;
-                    if (first) {
-                        crc = part[s];
-                        first = false;
-                    } else {
-                        crc = (uint32_t)crc32_combine(crc, part[s], (z_off_t)(e - a));
-                    }
-                }
-                if (first) crc = crc32_of(nullptr, 0);
-                const uint64_t size = z->run_size + len;
-                if (crc != me.crc || (uint32_t)size != me.isize) {
+    if (dbg) fprintf(stderr, "[gz] resolve + narrow + crc %.3f s\n", now() - t0), t0 = now();
+    // ---- members that ended inside this group: CRC-32 and ISIZE, combined from the stretches' values behind what earlier groups
+    // saw of the open member
+    for (size_t c = 0; c < chain.size(); c++) {
+        const Piece &pc = pcs[chain[c]];
+        for (size_t mi = 0; mi < segs[c].size(); mi++) {
+            const SegCrc &sg = segs[c][mi];
+            if (sg.len) {
+                z->run_crc = z->run_size ? (uint32_t)crc32_combine(z->run_crc, sg.crc, (z_off_t)sg.len) : sg.crc;
+                z->run_size += sg.len;
+            }
+            if (mi < pc.members.size()) {  // a member ends behind this stretch
+                const Piece::MemberEnd &me = pc.members[mi];
+                const uint32_t crc = z->run_size ? z->run_crc : 0u;
+                if (crc != me.crc || (uint32_t)z->run_size != me.isize) {
                     z->err = "gzip member fails its CRC-32 / size check";
                     return false;
                 }
                 z->run_crc = 0;
                 z->run_size = 0;
-                seg_lo = seg_hi;
             }
-        }
-        const size_t tail = z->out.size() - seg_lo;  // the open member's bytes so far
-        if (tail) {
-            const uint32_t c = crc32_of(z->out.data() + seg_lo, tail);
-            z->run_crc = z->run_size ? (uint32_t)crc32_combine(z->run_crc, c, (z_off_t)tail) : c;
-            z->run_size += tail;
         }
     }
     if (dbg) fprintf(stderr, "[gz] crc %.3f s\n", now() - t0), t0 = now();
