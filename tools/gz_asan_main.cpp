@@ -1,0 +1,65 @@
+// AddressSanitizer / UBSan driver of the native gzip reader (csrc/gs_inflate.cpp), CPU only: inflates a file through gs_gz_* and
+// compares the bytes with zlib's gzread.  Built and run by tools/gz_asan.sh (the GPU build cannot run under sanitizers).
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "gavisunk.h"
+
+int main(int argc, char **argv) {
+    if (argc < 4) {
+        fprintf(stderr, "usage: gz_asan_main file.gz threads want_bytes\n");
+        return 2;
+    }
+    const int threads = atoi(argv[2]);
+    const uint64_t want = strtoull(argv[3], nullptr, 10);
+    std::vector<uint8_t> ref;
+    {
+        gzFile g = gzopen(argv[1], "rb");
+        if (!g) return 2;
+        std::vector<uint8_t> buf(1 << 20);
+        int n;
+        while ((n = gzread(g, buf.data(), (unsigned)buf.size())) > 0) ref.insert(ref.end(), buf.begin(), buf.begin() + n);
+        const bool bad = n < 0;
+        gzclose(g);
+        if (bad) {
+            fprintf(stderr, "zlib refuses %s\n", argv[1]);
+            ref.clear();
+        }
+    }
+    gs_gzfile *z = nullptr;
+    if (gs_gz_open(argv[1], threads, &z) != GS_OK) {
+        fprintf(stderr, "open failed: %s\n", gs_last_error());
+        return 1;
+    }
+    std::vector<uint8_t> got;
+    uint64_t nl = 0;
+    for (;;) {
+        uint8_t *p = nullptr;
+        uint64_t n = 0;
+        const int rc = gs_gz_read(z, want, nullptr, 0, &p, &n);
+        if (rc != GS_OK) {
+            fprintf(stderr, "read failed (%d): %s\n", rc, gs_last_error());
+            gs_gz_close(z);
+            return 3;
+        }
+        got.insert(got.end(), p, p + n);
+        nl += gs_gz_newlines(z);  // (of the stretch just returned)
+        gs_gz_free_buffer(p);
+        if (!n || gs_gz_at_end(z)) break;
+    }
+    gs_gz_close(z);
+    uint64_t want_nl = 0;
+    for (uint8_t c : ref) want_nl += c == '\n';
+    if (got.size() != ref.size() || (!ref.empty() && memcmp(got.data(), ref.data(), ref.size()) != 0) || nl != want_nl) {
+        fprintf(stderr, "MISMATCH %s: %zu bytes against %zu, newlines %llu against %llu\n", argv[1], got.size(), ref.size(), (unsigned long long)nl,
+                (unsigned long long)want_nl);
+        return 4;
+    }
+    printf("ok %s: %zu bytes, %d threads, want %llu\n", argv[1], got.size(), threads, (unsigned long long)want);
+    return 0;
+}
