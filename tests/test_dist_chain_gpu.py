@@ -209,3 +209,96 @@ def test_rccl_exchanges_with_one_rank():
     assert np.array_equal(local["diag"][1], bc) and np.array_equal(local["bad"], bad) and local["meancov"] == meancov
     for k in ("row_contig", "row_name", "row_id", "region_contig", "region_start", "region_end", "contigs_in"):
         assert np.array_equal(merged[k], res[k]), k
+
+
+# ---- both halves sharded, from files: every rank tags its block of the reads (carry exchanged), gathers its rows device to device,
+# and runs the second half over them; rank 0's merged result must equal one process over the whole file ----
+def _files(tmp):
+    """A two-haplotype assembly (3 contigs each, shared ancestry, pasted repeats), its SUNK definition through the drop-in
+    (`define_sunks`: db + loc files), and 120 reads of haplotype 1."""
+    import test_chain_gpu as tc
+    from gavisunk_amd import define_sunks, synth
+
+    rng = np.random.default_rng(777)
+    haps = tc._assembly(rng, 3, 50_000)
+    for h in (0, 1):
+        (tmp / f"hap{h + 1}.fa").write_bytes(b"".join(b">%s\n%s\n" % (n.encode(), synth.codes_to_ascii(s)) for n, s in haps[h]))
+    assert define_sunks.main(["-k", "20", str(tmp / "hap1.fa"), str(tmp / "hap2.fa"), "--db", str(tmp / "db"), "--loc", str(tmp / "loc")]) == 0
+    lens = synth.lognormal_lengths(rng, 120, median=14000, sigma=0.5, lo=3000, hi=45000)
+    reads = [synth.codes_to_ascii(r) for r in synth.simulate_reads(rng, [s for _, s in haps[0]], lens)]
+    names = [f"read{int(x):05d}" for x in rng.permutation(10**4)[: len(reads)]]
+    np.save(tmp / "lens.npy", lens)
+    (tmp / "reads.txt").write_bytes(b"\n".join(reads))
+    (tmp / "names.txt").write_text("\n".join(names))
+
+
+def _load(tmp):
+    from gavisunk_amd import engine
+
+    db = engine.SunkDB(str(tmp / "db"), str(tmp / "loc"))
+    reads = (tmp / "reads.txt").read_bytes().split(b"\n")
+    names = (tmp / "names.txt").read_text().split("\n")
+    lens = np.load(tmp / "lens.npy")
+    order = np.argsort(np.array(names, dtype=object), kind="stable")
+    grank = np.empty(len(names), np.uint32)
+    grank[order] = np.arange(len(names), dtype=np.uint32)
+    table = engine.DeviceTable.from_db(db)
+    lr = engine.LocRows.from_db(db)
+    kc = lr.key_contig()
+    in_fai = np.array([1 if c.startswith("h1") else 0 for c in db.contigs], np.uint8)
+    key_hap = np.full(len(kc), 3, np.uint8)  # (this one read set plays both haplotypes' roles in the bad-SUNK step, as in bench.py)
+    return db, table, lr, reads, grank, (lens >= 10000).astype(np.uint8), in_fai, key_hap
+
+
+def _files_worker(rank, world, port, tmp_s, out_path):
+    import ctypes as C
+    import pathlib
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gavisunk_amd import _lib, engine
+    from gavisunk_amd import dist as gdist
+
+    L = _lib.lib()
+    comm = gdist.Comm(0, rccl=False)
+    db, table, lr, reads, grank, long_, in_fai, key_hap = _load(pathlib.Path(tmp_s))
+    lo, hi = gdist.shard_bounds(len(reads), world, rank)
+    dev = engine.DeviceReads(engine.ReadBatch.from_ascii(reads[lo:hi]), db.k)
+    has, last = C.c_uint32(0), C.c_uint32(0)
+    _lib.check(L.gs_tag_phase1(table._h, dev._h, C.byref(has), C.byref(last)))
+    summ = comm.exchange_summaries(has.value, last.value)
+    _lib.check(L.gs_tag_phase2(table._h, dev._h, gdist.resolve_carry(summ, rank)))
+    _lib.check(L.gs_tag_finish(table._h, dev._h, None, 0, None, None, None))
+    rs = engine.RowSet(0)
+    rs.append_pass(table, dev, 0, lr)  # name ids = read index inside the shard
+    local, merged = gdist.sharded_second_half(comm, rs, db.contigs, in_fai, key_hap, grank[lo:hi], long_[lo:hi], lo)
+    if merged is not None:
+        np.savez(out_path, bad=local["bad"], **merged)
+    for x in (rs, dev, lr, table, db):
+        x.close()
+    comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_both_halves_sharded_from_files(world, tmp_path):
+    from gavisunk_amd import engine
+
+    _files(tmp_path)
+    out = str(tmp_path / "merged.npz")
+    mp.spawn(_files_worker, args=(world, _free_port(), str(tmp_path), out), nprocs=world, join=True)
+    got = np.load(out)
+    db, table, lr, reads, grank, long_, in_fai, key_hap = _load(tmp_path)
+    dev = engine.DeviceReads(engine.ReadBatch.from_ascii(reads), db.k)
+    assert engine.tag(table, dev)[0] == 0
+    rs = engine.RowSet(0)
+    rs.append_pass(table, dev, 0, lr)
+    rs.diag_filter(db.contigs, in_fai)
+    rs.keep_filtered()
+    bad, _, d_bad = engine.RowSet.bad_keys(rs, rs, key_hap, keep_on_device=True)
+    res = rs.pair_stage(grank, long_, d_key_bad=d_bad)
+    engine.free_device(d_bad)
+    assert np.array_equal(got["bad"], bad) and len(res["row_id"]) > 100 and len(res["region_start"]) >= 3
+    for k in ("row_contig", "row_name", "row_id", "region_contig", "region_start", "region_end", "contigs_in"):
+        assert np.array_equal(got[k], res[k]), k
+    for x in (rs, dev, lr, table, db):
+        x.close()
