@@ -612,6 +612,10 @@ bool decode_blocks(const uint8_t *data, size_t n, Bits &b, Piece &pc, const std:
                 bc = &dyn;
             }
             for (;;) {
+                if (b.over) {  // (past the end the reader yields zeros, which may well be a literal's code: a cut file would never end)
+                    pc.err = "truncated stream";
+                    return false;
+                }
                 if (out.n + 300 > out.cap) out.grow_for(300);
                 if (out.cap - out.n > 1024 && b.byte + 32 < b.n && !bc->dist.t.empty()) {
                     // the fast loop, while there is room for a few hundred symbols and input to spare
@@ -885,6 +889,17 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
         pc.err.clear();
         pc.sym.n = 0;
     }
+    // (an exception must not leave a worker thread: it is reported by the calling thread after the join)
+    std::atomic<bool> oom{false};
+    auto guarded = [&oom](auto &fn) {
+        return [&oom, &fn]() {
+            try {
+                fn();
+            } catch (...) {
+                oom.store(true);
+            }
+        };
+    };
     const bool dbg = getenv("GAVISUNK_GZ_DEBUG") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
@@ -906,9 +921,10 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                 }
             }
         };
-        for (int t = 0; t < z->threads && (size_t)t + 1 < np; t++) th.emplace_back(work);
+        for (int t = 0; t < z->threads && (size_t)t + 1 < np; t++) th.emplace_back(guarded(work));
         for (auto &t : th) t.join();
     }
+    if (oom.load()) throw std::bad_alloc();
     if (dbg) fprintf(stderr, "[gz] find %.3f s\n", now() - t0), t0 = now();
     std::vector<uint64_t> stops;      // starts of the found pieces after the first, ascending
     std::vector<uint32_t> stop_piece;
@@ -940,9 +956,10 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                 pc.ok = decode_blocks(data, n, b, pc, &stops, fs, false, std::max<size_t>(piece_bytes * 32, (size_t)1 << 26));
             }
         };
-        for (int t = 0; t < z->threads && (size_t)t < np; t++) th.emplace_back(work);
+        for (int t = 0; t < z->threads && (size_t)t < np; t++) th.emplace_back(guarded(work));
         for (auto &t : th) t.join();
     }
+    if (oom.load()) throw std::bad_alloc();
     if (dbg) fprintf(stderr, "[gz] decode %.3f s\n", now() - t0), t0 = now();
     if (g_prof) fprintf(stderr, "[gz] block headers + tables: %llu blocks, %.1f kcycles each so far\n", (unsigned long long)g_prof_blocks.load(),
                         g_prof_blocks.load() ? (double)g_prof_cycles.load() / (double)g_prof_blocks.load() / 1e3 : 0.0);
@@ -1059,9 +1076,10 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                 newlines.fetch_add(nl, std::memory_order_relaxed);
             }
         };
-        for (int t = 0; t < z->threads && (size_t)t < chain.size(); t++) th.emplace_back(work);
+        for (int t = 0; t < z->threads && (size_t)t < chain.size(); t++) th.emplace_back(guarded(work));
         for (auto &t : th) t.join();
     }
+    if (oom.load()) throw std::bad_alloc();
     z->newlines += newlines.load();
     if (dbg) fprintf(stderr, "[gz] resolve + narrow + crc %.3f s\n", now() - t0), t0 = now();
     // ---- members that ended inside this group: CRC-32 and ISIZE, combined from the stretches' values behind what earlier groups

@@ -112,3 +112,25 @@ def test_text_blocks_of_a_gz_file_are_whole_records(tmp_path, fastq, monkeypatch
     assert b"".join(blocks) == fa and len(blocks) >= 2 and all(b[:1] == b">" for b in blocks)
     monkeypatch.setenv("GAVISUNK_GZ", "python")
     assert b"".join(bytes(b) for b in engine.text_blocks(path, 2_000_000)) == fa
+
+
+def test_fuzz_slice(tmp_path):
+    """A seeded slice of tools/fuzz_gz.py (content kinds x levels x strategies x flush patterns x members x threads x piece sizes,
+    one file in four damaged): zlib's bytes and newline counts, or an error where zlib refuses.  Seed 71 is the round's find: a
+    file cut inside a member whose zero padding decodes as a literal -- the careful loop used to produce output until memory ran
+    out; it reports a truncated stream now."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gz
+
+    old = os.environ.get("GAVISUNK_GZ_PIECE_KB")
+    try:
+        for seed in list(range(60, 85)) + list(range(400, 415)):
+            err = fuzz_gz.one_round(seed, str(tmp_path / "f.gz"))
+            assert err is None, err
+    finally:
+        if old is None:
+            os.environ.pop("GAVISUNK_GZ_PIECE_KB", None)
+        else:
+            os.environ["GAVISUNK_GZ_PIECE_KB"] = old
