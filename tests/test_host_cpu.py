@@ -290,3 +290,21 @@ def test_loc_table_parsed_by_several_threads_equals_one_thread(tmp_path, monkeyp
             load(threads, "loc_bad")
         msgs.append(e.value.msg)
     assert msgs[0] == msgs[1] and ":120001:" in msgs[0]
+
+
+def test_fuzz_tables_slice(tmp_path, monkeypatch):
+    """A seeded slice of tools/fuzz_tables.py: irregular and malformed k-mer lists / location tables through the multi-threaded
+    parsers (2, 5, default threads) and the single-threaded readers -- identical arrays, contig order, location ids, identical error
+    text -- and the host join against a dictionary."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_tables
+
+    monkeypatch.delenv("GAVISUNK_LOC_THREADS", raising=False)
+    try:
+        for seed in range(1, 25):
+            err = fuzz_tables.one_round(seed, str(tmp_path))
+            assert err is None, err
+    finally:
+        os.environ.pop("GAVISUNK_LOC_THREADS", None)
