@@ -374,10 +374,14 @@ def cli_large_leg(a, device):
             log(f"genome-scale reads: {nb} reads, {big_bases} bases -> big.fq.gz {os.path.getsize(f'{d}/big.fq.gz') / 2**30:.2f} GiB ({time.perf_counter() - t1:.1f} s)")
         log(f"CLI at {n_keys} keys: files written ({time.perf_counter() - t0:.1f} s; db {os.path.getsize(f'{d}/db') / 2**30:.1f} GiB, loc {os.path.getsize(f'{d}/loc') / 2**30:.1f} GiB)")
 
+        phases = {}
+
         def run(tag):
             t1 = time.perf_counter()
             rc = kmerpos_annot3.main([f"{d}/reads.fa", f"{d}/db", f"{d}/loc", f"{d}/out.{tag}"])
-            return rc, time.perf_counter() - t1
+            dt = time.perf_counter() - t1
+            phases[tag] = {k_: round(v, 3) for k_, v in kmerpos_annot3.last_timing.items() if k_ != "rows"}
+            return rc, dt
 
         rc1, t_plain = run("plain")
         t1 = time.perf_counter()
@@ -412,9 +416,9 @@ def cli_large_leg(a, device):
                              "copy_text_to_device run on the reader thread beside the others; wait_for_reader is what the main thread waits for them"}
 
         res = {"keys": int(n_keys), "read_bases": int(n_bases), "rows_out": open(f"{d}/out.plain", "rb").read().count(b"\n"),
-               "parse_and_build_every_run": {"seconds": round(t_plain, 2), "cli_bases_per_s": n_bases / t_plain},
+               "parse_and_build_every_run": {"seconds": round(t_plain, 2), "cli_bases_per_s": n_bases / t_plain, "seconds_by_phase": phases.get("plain")},
                "prepare_once": {"seconds": round(t_prep, 2), "sidecar_GiB": round(os.path.getsize(f"{d}/loc.gsidx") / 2**30, 2)},
-               "with_sidecar": {"seconds": round(t_side, 2), "cli_bases_per_s": n_bases / t_side},
+               "with_sidecar": {"seconds": round(t_side, 2), "cli_bases_per_s": n_bases / t_side, "seconds_by_phase": phases.get("side")},
                "same_bytes": bool(same),
                **({"cli_genome_scale": scale} if scale else {}),
                "note": "`python -m gavisunk_amd.kmerpos_annot3 reads.fa db loc out` in a warm process on a 200 Mb surrogate's files (the reference parses db and loc on every "

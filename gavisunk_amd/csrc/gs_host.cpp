@@ -26,7 +26,10 @@
 
 #include "gs_common.h"
 
-void gs_advise_huge(void *p, size_t bytes) { (void)madvise(p, bytes, MADV_HUGEPAGE); }
+void gs_advise_huge(void *p, size_t bytes) {
+    static const bool off = getenv("GAVISUNK_NO_THP") != nullptr;  // (experiment knob: huge-page faults compact memory when it is fragmented)
+    if (!off) (void)madvise(p, bytes, MADV_HUGEPAGE);
+}
 
 namespace gs {
 
@@ -326,21 +329,28 @@ struct LocPart {
     std::vector<std::pair<uint32_t, int64_t>> pairs;    // local (local contig, group) pairs, first-seen order
     uint64_t lines = 0, err_line = 0;
     bool err = false;
-};
-struct PairHash64 {
-    size_t operator()(const std::pair<uint32_t, int64_t> &p) const {
-        return std::hash<uint64_t>()(((uint64_t)p.first << 40) ^ (uint64_t)p.second * 0x9E3779B97F4A7C15ULL);
-    }
-};
-static void parse_loc_part(const char *b, const char *e, LocPart &o) {
+    // the parser's state (a part is read and parsed stretch by stretch)
+    struct PairHash64 {
+        size_t operator()(const std::pair<uint32_t, int64_t> &p) const {
+            return std::hash<uint64_t>()(((uint64_t)p.first << 40) ^ (uint64_t)p.second * 0x9E3779B97F4A7C15ULL);
+        }
+    };
     std::unordered_map<std::string, uint32_t> contig_id;
     std::unordered_map<std::pair<uint32_t, int64_t>, uint32_t, PairHash64> pairmap;
     std::string name;
     bool have_last = false;
     uint32_t last_cid = 0, last_pid = 0;
     int64_t last_group = 0;
-    const size_t guess = (size_t)(e - b) / 40 + 16;
-    o.cid.reserve(guess), o.pid.reserve(guess), o.start.reserve(guess), o.group.reserve(guess), o.code.reserve(guess);
+};
+using PairHash64 = LocPart::PairHash64;
+// whole lines [b, e) of the location table, appended to the part
+static void parse_loc_part(const char *b, const char *e, LocPart &o) {
+    auto &contig_id = o.contig_id;
+    auto &pairmap = o.pairmap;
+    std::string &name = o.name;
+    bool &have_last = o.have_last;
+    uint32_t &last_cid = o.last_cid, &last_pid = o.last_pid;
+    int64_t &last_group = o.last_group;
     while (b < e) {
         const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
         const char *le = nl ? nl : e;
@@ -412,6 +422,50 @@ static void parse_loc_part(const char *b, const char *e, LocPart &o) {
         b = next;
     }
 }
+
+// The bytes [lo, hi) of a file (hi = a line start or the end of the file), handed to `fn` in stretches of whole lines read with
+// pread into a buffer of the calling thread.  (A mapping of the file costs a page fault per 4 KiB touched, all of them under one
+// lock of the address space: with 16 threads on a 4 GiB table that was up to 1.3 s of a 0.3 s parse whenever the page cache held
+// the file in small pages.)
+template <typename Fn>
+static bool for_line_stretches(int fd, uint64_t lo, uint64_t hi, Fn &&fn) {
+    if (hi <= lo) return true;
+    std::vector<char> buf((size_t)4 << 20);
+    size_t have = 0;  // bytes of an unfinished line at the front of buf
+    uint64_t at = lo;
+    while (at < hi || have) {
+        if (at < hi) {
+            if (buf.size() - have < ((size_t)1 << 20)) buf.resize(buf.size() * 2);  // (a line longer than the buffer)
+            const size_t want = (size_t)std::min<uint64_t>(buf.size() - have, hi - at);
+            const ssize_t r = pread(fd, buf.data() + have, want, (off_t)at);
+            if (r <= 0) return false;
+            at += (uint64_t)r;
+            have += (size_t)r;
+        }
+        size_t usable = have;
+        if (at < hi) {  // more to come: up to the last line end in the buffer
+            const void *q = memrchr(buf.data(), '\n', have);
+            if (!q) continue;
+            usable = (size_t)(static_cast<const char *>(q) - buf.data()) + 1;
+        }
+        fn(buf.data(), buf.data() + usable);
+        memmove(buf.data(), buf.data() + usable, have - usable);
+        have -= usable;
+    }
+    return true;
+}
+// the first line start at or after `q` (or the end of the file), looked for with small reads
+static uint64_t next_line_start(int fd, uint64_t q, uint64_t n) {
+    char tmp[4096];
+    while (q < n) {
+        const ssize_t r = pread(fd, tmp, (size_t)std::min<uint64_t>(sizeof tmp, n - q), (off_t)q);
+        if (r <= 0) return n;
+        const void *nl = memchr(tmp, '\n', (size_t)r);
+        if (nl) return q + (uint64_t)(static_cast<const char *>(nl) - tmp) + 1;
+        q += (uint64_t)r;
+    }
+    return n;
+}
 // the k-mer list (one k-mer per line) parsed by several threads: -> false when not applicable (gzip, small, cannot map)
 static bool parse_db_parallel(const char *path, HugeVec<uint64_t> &codes, int &k) {
     if (getenv("GAVISUNK_LOC_THREADS") && atoi(getenv("GAVISUNK_LOC_THREADS")) <= 1) return false;
@@ -423,36 +477,32 @@ static bool parse_db_parallel(const char *path, HugeVec<uint64_t> &codes, int &k
         return false;
     }
     const size_t n = (size_t)st.st_size;
-    void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) return false;
-    const char *p = static_cast<const char *>(m);
-    if ((unsigned char)p[0] == 0x1f && (unsigned char)p[1] == 0x8b) {
-        munmap(m, n);
-        return false;
-    }
+    struct FdCloser {
+        int fd;
+        ~FdCloser() { close(fd); }
+    } fdc{fd};
+    unsigned char magic[2] = {0, 0};
+    if (pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b)) return false;
     unsigned T = std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));  // (the location table is parsed beside this)
     if (const char *e = getenv("GAVISUNK_LOC_THREADS")) T = (unsigned)std::max(1, atoi(e));
     T = (unsigned)std::min<size_t>(T, n >> 20);
-    std::vector<size_t> cut(T + 1, n);
+    std::vector<uint64_t> cut(T + 1, n);
     cut[0] = 0;
-    for (unsigned t = 1; t < T; t++) {
-        size_t q = std::max(n * t / T, cut[t - 1]);
-        const char *nl = q < n ? (const char *)memchr(p + q, '\n', n - q) : nullptr;
-        cut[t] = nl ? (size_t)(nl - p) + 1 : n;
-    }
+    for (unsigned t = 1; t < T; t++) cut[t] = next_line_start(fd, std::max<uint64_t>((uint64_t)n * t / T, cut[t - 1]), n);
     std::vector<HugeVec<uint64_t>> parts(T);
+    std::vector<char> okv(T, 1);
     auto work = [&](unsigned t) {
-        const char *b = p + cut[t], *e = p + cut[t + 1];
-        parts[t].reserve((size_t)(e - b) / 16 + 16);
-        while (b < e) {  // every line is a k-mer, the empty ones too (the reference encodes whatever `lines` yields)
-            const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
-            const char *le = nl ? nl : e;
-            const char *next = nl ? nl + 1 : e;
-            if (le > b && le[-1] == '\r') le--;
-            parts[t].push_back(encode_kmer(b, (size_t)(le - b)));
-            b = next;
-        }
+        parts[t].reserve((size_t)(cut[t + 1] - cut[t]) / 16 + 16);
+        okv[t] = for_line_stretches(fd, cut[t], cut[t + 1], [&](const char *b, const char *e) {
+            while (b < e) {  // every line is a k-mer, the empty ones too (the reference encodes whatever `lines` yields)
+                const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
+                const char *le = nl ? nl : e;
+                const char *next = nl ? nl + 1 : e;
+                if (le > b && le[-1] == '\r') le--;
+                parts[t].push_back(encode_kmer(b, (size_t)(le - b)));
+                b = next;
+            }
+        }) ? 1 : 0;
     };
     {
         std::vector<std::thread> pool;
@@ -460,13 +510,17 @@ static bool parse_db_parallel(const char *path, HugeVec<uint64_t> &codes, int &k
         work(0);
         for (auto &th : pool) th.join();
     }
+    for (char o : okv)
+        if (!o) return false;
     {  // k = len(first line), kmerpos_annot3.nim:28-38
-        const char *nl = (const char *)memchr(p, '\n', n);
-        const char *le = nl ? nl : p + n;
-        if (le > p && le[-1] == '\r') le--;
-        k = (int)(le - p);
+        char head[256];
+        const ssize_t r = pread(fd, head, sizeof head, 0);
+        const char *nl = r > 0 ? (const char *)memchr(head, '\n', (size_t)r) : nullptr;
+        if (!nl && (size_t)r == sizeof head) return false;  // (no k-mer is that long: let the line reader say what it is)
+        const char *le = nl ? nl : head + std::max<ssize_t>(r, 0);
+        if (le > head && le[-1] == '\r') le--;
+        k = (int)(le - head);
     }
-    munmap(m, n);
     std::vector<size_t> at(T + 1, 0);
     for (unsigned t = 0; t < T; t++) at[t + 1] = at[t] + parts[t].size();
     codes.resize(at[T]);  // (uninitialised: every thread copies its part, and frees it)
@@ -493,37 +547,40 @@ static int parse_loc_parallel(const char *path, gs_sunkdb *d, HugeVec<uint64_t> 
         return -1;
     }
     const size_t n = (size_t)st.st_size;
-    void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) return -1;
-    const char *p = static_cast<const char *>(m);
-    if ((unsigned char)p[0] == 0x1f && (unsigned char)p[1] == 0x8b) {  // gzip: the line reader inflates it
-        munmap(m, n);
-        return -1;
-    }
+    struct FdCloser {
+        int fd;
+        ~FdCloser() { close(fd); }
+    } fdc{fd};
+    unsigned char magic[2] = {0, 0};
+    if (pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b)) return -1;  // gzip: the line reader inflates it
     unsigned T = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("GAVISUNK_LOC_THREADS")) T = (unsigned)std::max(1, atoi(e));
     T = (unsigned)std::min<size_t>(T, n >> 20);
-    std::vector<size_t> cut(T + 1, n);
+    std::vector<uint64_t> cut(T + 1, n);
     cut[0] = 0;
-    for (unsigned t = 1; t < T; t++) {  // the first line start at or after n t / T
-        size_t q = n * t / T;
-        if (q < cut[t - 1]) q = cut[t - 1];
-        const char *nl = q < n ? (const char *)memchr(p + q, '\n', n - q) : nullptr;
-        cut[t] = nl ? (size_t)(nl - p) + 1 : n;
-    }
+    for (unsigned t = 1; t < T; t++) cut[t] = next_line_start(fd, std::max<uint64_t>((uint64_t)n * t / T, cut[t - 1]), n);  // the first line start at or after n t / T
     std::vector<LocPart> parts(T);
+    std::vector<char> okv(T, 1);
     auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tp0 = tnow();
     {
+        auto work = [&](unsigned t) {
+            LocPart &o = parts[t];
+            const size_t guess = (size_t)(cut[t + 1] - cut[t]) / 40 + 16;
+            o.cid.reserve(guess), o.pid.reserve(guess), o.start.reserve(guess), o.group.reserve(guess), o.code.reserve(guess);
+            okv[t] = for_line_stretches(fd, cut[t], cut[t + 1], [&](const char *b, const char *e) {
+                if (!o.err) parse_loc_part(b, e, o);
+            }) ? 1 : 0;
+        };
         std::vector<std::thread> pool;
-        for (unsigned t = 1; t < T; t++) pool.emplace_back([&, t]() { parse_loc_part(p + cut[t], p + cut[t + 1], parts[t]); });
-        parse_loc_part(p + cut[0], p + cut[1], parts[0]);
+        for (unsigned t = 1; t < T; t++) pool.emplace_back(work, t);
+        work(0);
         for (auto &th : pool) th.join();
     }
+    for (char o : okv)
+        if (!o) return -1;
     const double tp1 = tnow();
-    munmap(m, n);
-    const double tp2 = tnow();
+    const double tp2 = tp1;
     uint64_t lines_before = 0;
     for (unsigned t = 0; t < T; t++) {
         if (parts[t].err) {
