@@ -352,6 +352,56 @@ static void parse_loc_part(const char *b, const char *e, LocPart &o) {
     uint32_t &last_cid = o.last_cid, &last_pid = o.last_pid;
     int64_t &last_group = o.last_group;
     while (b < e) {
+        // The common row in one pass over its bytes: the contig of the row before, a tab, digits, a tab, the k-mer, a tab, digits,
+        // a line feed.  Anything else (another contig, a sign, CR LF, a fifth field, a malformed row ...) takes the general code
+        // below, which decides what it is.
+        if (have_last) {
+            const size_t nlen0 = name.size();
+            const char *q = b;
+            if ((size_t)(e - q) > nlen0 + 1 && q[nlen0] == '\t' && !memcmp(q, name.data(), nlen0)) {
+                q += nlen0 + 1;
+                int64_t st = 0;
+                const char *d0 = q;
+                while (q < e && (unsigned)(*q - '0') <= 9u) st = st * 10 + (*q++ - '0');
+                if (q > d0 && q - d0 <= 18 && q < e && *q == '\t') {
+                    q++;
+                    uint64_t c = 0;
+                    while (q < e && *q != '\t' && *q != '\n') c = (c << 2) | kEncode.v[(uint8_t)*q++];
+                    if (q < e && *q == '\t') {
+                        q++;
+                        int64_t g = 0;
+                        const char *g0 = q;
+                        while (q < e && (unsigned)(*q - '0') <= 9u) g = g * 10 + (*q++ - '0');
+                        if (q > g0 && q - g0 <= 18 && q < e && *q == '\n') {
+                            o.lines++;
+                            uint32_t pid;
+                            if (g == last_group) {
+                                pid = last_pid;
+                            } else {
+                                auto key = std::make_pair(last_cid, g);
+                                auto lt = pairmap.find(key);
+                                if (lt == pairmap.end()) {
+                                    pid = (uint32_t)o.pairs.size();
+                                    pairmap.emplace(key, pid);
+                                    o.pairs.push_back(key);
+                                } else {
+                                    pid = lt->second;
+                                }
+                                last_group = g;
+                                last_pid = pid;
+                            }
+                            o.cid.push_back(last_cid);
+                            o.pid.push_back(pid);
+                            o.start.push_back(st);
+                            o.group.push_back(g);
+                            o.code.push_back(c);
+                            b = q + 1;
+                            continue;
+                        }
+                    }
+                }
+            }
+        }
         const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
         const char *le = nl ? nl : e;
         const char *next = nl ? nl + 1 : e;
@@ -495,12 +545,12 @@ static bool parse_db_parallel(const char *path, HugeVec<uint64_t> &codes, int &k
         parts[t].reserve((size_t)(cut[t + 1] - cut[t]) / 16 + 16);
         okv[t] = for_line_stretches(fd, cut[t], cut[t + 1], [&](const char *b, const char *e) {
             while (b < e) {  // every line is a k-mer, the empty ones too (the reference encodes whatever `lines` yields)
-                const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
-                const char *le = nl ? nl : e;
-                const char *next = nl ? nl + 1 : e;
-                if (le > b && le[-1] == '\r') le--;
-                parts[t].push_back(encode_kmer(b, (size_t)(le - b)));
-                b = next;
+                uint64_t c = 0;
+                const char *q = b;
+                while (q < e && *q != '\n') c = (c << 2) | kEncode.v[(uint8_t)*q++];  // (encoded while the line end is looked for)
+                if (q > b && q[-1] == '\r') c = encode_kmer(b, (size_t)(q - 1 - b));  // CR LF: without the CR
+                parts[t].push_back(c);
+                b = q < e ? q + 1 : e;
             }
         }) ? 1 : 0;
     };
