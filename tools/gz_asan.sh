@@ -63,4 +63,28 @@ for f in bad_flip bad_trunc bad_crc; do  # damaged files: an error, never a sani
     if grep -q "ERROR: AddressSanitizer\|runtime error" "$D/$f.err"; then cat "$D/$f.err"; exit 1; fi
     echo "refused $f: $(tail -1 "$D/$f.err")"
 done
+# ---- the table parsers (gs_sunkdb_load: threads / single reader, mapping / pread) on files of tools/fuzz_tables.py's generator
+python3 - "$D" <<'PY'
+import os, sys
+sys.path.insert(0, "tools")
+import numpy as np
+import fuzz_tables
+d = sys.argv[1]
+for seed in range(1, 13):
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([11, 20, 20, 25, 32]))
+    big = seed % 2 == 0
+    dbt, loct, bad = fuzz_tables.make(rng, k, big)
+    open(os.path.join(d, f"t{seed}.db"), "wb").write(dbt)
+    open(os.path.join(d, f"t{seed}.loc"), "wb").write(loct)
+PY
+for seed in 1 2 3 4 5 6 7 8 9 10 11 12; do
+    for th in "" 1 3; do
+        if [ -n "$th" ]; then export GAVISUNK_LOC_THREADS=$th; else unset GAVISUNK_LOC_THREADS; fi
+        "$D/gz_asan_main" --tables "$D/t$seed.db" "$D/t$seed.loc" > "$D/t.out" 2> "$D/t.err" || { cat "$D/t.err"; exit 1; }
+        if grep -q "ERROR: AddressSanitizer\|runtime error" "$D/t.err"; then cat "$D/t.err"; exit 1; fi
+    done
+    tail -1 "$D/t.out"
+done
+unset GAVISUNK_LOC_THREADS
 echo "gz_asan: all clean"

@@ -10,7 +10,26 @@
 
 #include "gavisunk.h"
 
+// `--tables db loc`: the two table parsers and the host join (gs_sunkdb_load, gs_sunkdb_keys ...) under the sanitizers
+static int tables(const char *db, const char *loc) {
+    gs_sunkdb *d = nullptr;
+    const int rc = gs_sunkdb_load(db, loc, &d);
+    if (rc != GS_OK) {
+        printf("refused (%d): %s\n", rc, gs_last_error());
+        return 0;
+    }
+    uint64_t sum = 0;
+    const uint64_t nk = gs_sunkdb_n_keys(d), nr = gs_sunkdb_n_rows(d);
+    for (uint64_t i = 0; i < nk; i++) sum += gs_sunkdb_keys(d)[i] + gs_sunkdb_key_row(d)[i] + gs_sunkdb_key_loc(d)[i];
+    for (uint64_t i = 0; i < nr; i++) sum += gs_sunkdb_row_contig(d)[i] + (uint64_t)gs_sunkdb_row_start(d)[i] + (uint64_t)gs_sunkdb_row_group(d)[i] + gs_sunkdb_row_loc(d)[i];
+    printf("ok tables: k %d, %llu keys, %llu rows, %u contigs, checksum %llx\n", gs_sunkdb_k(d), (unsigned long long)nk, (unsigned long long)nr,
+           gs_sunkdb_n_contigs(d), (unsigned long long)sum);
+    gs_sunkdb_free(d);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc == 4 && !strcmp(argv[1], "--tables")) return tables(argv[2], argv[3]);
     if (argc < 4) {
         fprintf(stderr, "usage: gz_asan_main file.gz threads want_bytes\n");
         return 2;
