@@ -306,12 +306,14 @@ static bool parse_i64(const char *b, const char *e, int64_t &v) {
         b++;
     }
     if (b == e) return false;
-    int64_t x = 0;
+    uint64_t x = 0;
     for (; b < e; b++) {
         if (*b < '0' || *b > '9') return false;
-        x = x * 10 + (*b - '0');
+        if (x > (UINT64_MAX - 9) / 10) return false;  // (Nim's parseInt raises on overflow: a malformed row)
+        x = x * 10 + (uint64_t)(*b - '0');
     }
-    v = neg ? -x : x;
+    if (x > (uint64_t)INT64_MAX + (neg ? 1u : 0u)) return false;
+    v = neg ? (int64_t)(0 - x) : (int64_t)x;
     return true;
 }
 
