@@ -30,19 +30,44 @@ def stale(lib: str = LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _deps_mtime() -> float:
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "gavisunk.h")]
+    return max(os.path.getmtime(d) for d in deps)
+
+
 def build(force: bool = False, verbose: bool = False, tuning: bool = False, variant: str = "", defines=()) -> str:
     """tuning=True builds libgavisunk_tuning.so with -DGS_TUNING: the phase-off / pipeline-depth switches the timing
     experiments under tools/ use (GAVISUNK_LIB=.../libgavisunk_tuning.so selects it).  The product library has none.
-    variant="x" + defines: libgavisunk_x.so compiled with those -D switches (kernel A/B experiments, tools/kbench.sh)."""
+    variant="x" + defines: libgavisunk_x.so compiled with those -D switches (kernel A/B experiments, tools/kbench.sh).
+    Every source is compiled to an object of its own (in parallel, only when it or a header changed), then linked."""
     lib = LIB_TUNING if tuning else LIB
+    tag = "tuning" if tuning else "product"
     if variant:
         lib = os.path.join(HERE, f"libgavisunk_{variant}.so")
+        tag = "variant_" + variant
         force = True
     if not force and not stale(lib):
         return lib
-    cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC] + (["-DGS_TUNING"] if tuning else []) + list(defines) + [
-           "-o", lib] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread", "-ldl"]
+    objdir = os.path.join(HERE, "build", tag)
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + (
+        ["-DGS_TUNING"] if tuning else []) + list(defines)
+    hdr_t = _deps_mtime()
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((s, subprocess.Popen(cmd)))
+    failed = [s for s, p in jobs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for " + ", ".join(failed))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs + ["-lz", "-pthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
