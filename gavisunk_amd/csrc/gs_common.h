@@ -52,10 +52,10 @@ int select_flagged_u32(const uint32_t *in, const uint8_t *flag, uint32_t *out, u
 int db_join_device(int device, const gs_sunkdb *db, uint64_t **d_keys, uint32_t **d_loc, uint32_t **d_payload, uint64_t *n_keys);
 
 // the pair test / clean-up / largest component kernels over device arrays (gs_pair.hip); rows of a read = [d_off[r], d_off[r+1])
-int pair_component_device(uint32_t n_reads, uint64_t n_rows, const uint64_t *d_off, const int64_t *d_pos, const int64_t *d_start,
+int pair_component_device(int device, uint32_t n_reads, uint64_t n_rows, const uint64_t *d_off, const int64_t *d_pos, const int64_t *d_start,
                           const int64_t *d_id, uint32_t *d_outn, int64_t *d_out);
 // contig-wide union-find over device arrays (gs_pair.hip)
-int union_regions_device(uint64_t n_rows, const uint32_t *d_row_read, const uint32_t *d_row_vertex, uint32_t n_vertices,
+int union_regions_device(int device, uint64_t n_rows, const uint32_t *d_row_read, const uint32_t *d_row_vertex, uint32_t n_vertices,
                          const int64_t *d_vertex_id, uint32_t *d_size, int64_t *d_min, int64_t *d_max);
 
 // (gs_device.hip, for the on-device record parser of gs_ingest.hip) gs_reads_from_device_ascii for bases that kernels on the

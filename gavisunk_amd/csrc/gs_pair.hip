@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "gs_common.h"
+#include "gs_devpool.h"
 
 using namespace gs;
 
@@ -42,12 +43,15 @@ __device__ __forceinline__ bool pair_kept(int64_t pi, int64_t pj, int64_t si, in
     return !((ratio >= 1.1) || (ratio <= 0.9));
 }
 
-constexpr int kPairThreads = 256;
+// The three kernels take one workgroup per read.  A read has tens of rows on a haploid genome and hundreds to thousands on a
+// diploid one: the reads of a chunk are split by size (`list`), 64 threads for those of up to kSmallRead rows, 256 for the others.
+constexpr int kSmallRead = 96;
 
-__global__ __launch_bounds__(kPairThreads) void k_pair_count(const uint64_t *read_off, const int64_t *pos, const int64_t *start,
+template <int kPairThreads>
+__global__ __launch_bounds__(kPairThreads) void k_pair_count(const uint32_t *list, const uint64_t *read_off, const int64_t *pos, const int64_t *start,
                                                              uint32_t *row_edges, uint8_t *orient, uint8_t *any_kept) {
     __shared__ unsigned long long s_ones, s_zeros;
-    const uint32_t r = blockIdx.x;
+    const uint32_t r = list[blockIdx.x];
     const uint64_t lo = read_off[r];
     const int n = (int)(read_off[r + 1] - lo);
     if (threadIdx.x == 0) s_ones = s_zeros = 0;
@@ -75,10 +79,11 @@ __global__ __launch_bounds__(kPairThreads) void k_pair_count(const uint64_t *rea
     }
 }
 
-__global__ __launch_bounds__(kPairThreads) void k_pair_edges(const uint64_t *read_off, const int64_t *pos, const int64_t *start,
+template <int kPairThreads>
+__global__ __launch_bounds__(kPairThreads) void k_pair_edges(const uint32_t *list, const uint64_t *read_off, const int64_t *pos, const int64_t *start,
                                                              const uint8_t *orient, const uint64_t *row_edge_off,
                                                              uint32_t *edge_i, uint32_t *edge_j) {
-    const uint32_t r = blockIdx.x;
+    const uint32_t r = list[blockIdx.x];
     const uint64_t lo = read_off[r];
     const int n = (int)(read_off[r + 1] - lo);
     const bool o = orient[r] != 0;
@@ -116,16 +121,16 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
 //   rank[i]  where it first occurs there
 //   multi-position clean-up (:167-181), then the graph over ID values with vertices numbered by first appearance
 //   (source, then target, edge by edge), its largest component (lowest label on ties), its IDs in vertex order (:189-198)
-constexpr int kGraphThreads = 256;
-__global__ __launch_bounds__(kGraphThreads) void k_pair_graph(uint32_t n_reads, const uint64_t *read_off, const int64_t *pos,
+template <int kGraphThreads>
+__global__ __launch_bounds__(kGraphThreads) void k_pair_graph(const uint32_t *list, const uint64_t *read_off, const int64_t *pos,
                                                               const int64_t *id, const uint8_t *any_kept,
                                                               const uint64_t *row_edge_off, const uint32_t *edge_i,
                                                               const uint32_t *edge_j, uint8_t *edge_bad, uint32_t *deg,
                                                               uint32_t *rank, uint32_t *vert, uint32_t *parent, uint32_t *csize,
                                                               uint32_t *app, int64_t *goodpos_of, int64_t *out_ids,
                                                               uint32_t *out_n) {
-    __shared__ uint32_t s_nv, s_best_root, s_m;
-    const uint32_t r = blockIdx.x;
+    __shared__ uint32_t s_nv;
+    const uint32_t r = list[blockIdx.x];
     const int tid = threadIdx.x;
     const uint64_t lo = read_off[r];
     const int n = (int)(read_off[r + 1] - lo);
@@ -306,27 +311,26 @@ __global__ void k_widen_u32(const uint32_t *in, uint64_t *out, uint64_t n) {
 // engine; gs_pair_component below: the host-array form).  d_out_n[n_reads], d_out_ids[n_rows]; synchronous.  The reads are
 // taken in chunks whose pair lists (at most n (n - 1) / 2 surviving pairs per read of n rows) stay below kMaxChunkPairs: a
 // genome-scale hit list has ~1e10 pairs in all, a chunk's edge arrays a few GB.
-int gs::pair_component_device(uint32_t n_reads, uint64_t n_rows, const uint64_t *d_off, const int64_t *d_pos, const int64_t *d_start,
+int gs::pair_component_device(int device, uint32_t n_reads, uint64_t n_rows, const uint64_t *d_off, const int64_t *d_pos, const int64_t *d_start,
                               const int64_t *d_id, uint32_t *d_outn, int64_t *d_out) {
     if (!n_reads) return GS_OK;
     uint64_t kMaxChunkPairs = 400000000ULL;
     if (const char *e = getenv("GAVISUNK_PAIR_CHUNK")) kMaxChunkPairs = (uint64_t)std::max(1, atoi(e));  // (test knob: many small chunks)
+    hipStream_t st = chain_stream(device);
     std::vector<uint64_t> off((size_t)n_reads + 1);
-    HIP_TRY(hipMemcpy(off.data(), d_off, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    DevBuf db;
+    HIP_TRY(hipMemcpyAsync(off.data(), d_off, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    PoolScope db(device);
     int rc;
     uint64_t *d_reoff, *d_rowe64, *d_scan;
     uint32_t *d_rowe, *d_deg, *d_rank, *d_vert, *d_parent, *d_size, *d_app;
     int64_t *d_gp;
     uint8_t *d_orient, *d_any;
-    if ((rc = db.put(&d_rowe, (const uint32_t *)nullptr, n_rows + 1)) || (rc = db.put(&d_reoff, (const uint64_t *)nullptr, n_rows + 1)) ||
-        (rc = db.put(&d_orient, (const uint8_t *)nullptr, n_reads)) || (rc = db.put(&d_any, (const uint8_t *)nullptr, n_reads)) ||
-        (rc = db.put(&d_deg, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_rank, (const uint32_t *)nullptr, n_rows)) ||
-        (rc = db.put(&d_vert, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_parent, (const uint32_t *)nullptr, n_rows)) ||
-        (rc = db.put(&d_size, (const uint32_t *)nullptr, n_rows)) || (rc = db.put(&d_app, (const uint32_t *)nullptr, n_rows)) ||
-        (rc = db.put(&d_gp, (const int64_t *)nullptr, n_rows)))
+    if ((rc = db.get(&d_rowe, n_rows + 1)) || (rc = db.get(&d_reoff, n_rows + 1)) || (rc = db.get(&d_orient, n_reads)) ||
+        (rc = db.get(&d_any, n_reads)) || (rc = db.get(&d_deg, n_rows)) || (rc = db.get(&d_rank, n_rows)) || (rc = db.get(&d_vert, n_rows)) ||
+        (rc = db.get(&d_parent, n_rows)) || (rc = db.get(&d_size, n_rows)) || (rc = db.get(&d_app, n_rows)) || (rc = db.get(&d_gp, n_rows)))
         return rc;
-    HIP_TRY(hipMemset(d_rowe, 0, (n_rows + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(d_rowe, 0, (n_rows + 1) * sizeof(uint32_t), st));
     // chunk boundaries and the largest chunk (rows, for the scan buffers)
     std::vector<uint32_t> cuts(1, 0);
     uint64_t acc = 0, max_rows = 0;
@@ -340,33 +344,52 @@ int gs::pair_component_device(uint32_t n_reads, uint64_t n_rows, const uint64_t 
     }
     cuts.push_back(n_reads);
     for (size_t c = 0; c + 1 < cuts.size(); c++) max_rows = std::max(max_rows, off[cuts[c + 1]] - off[cuts[c]]);
-    if ((rc = db.put(&d_rowe64, (const uint64_t *)nullptr, max_rows + 1)) || (rc = db.put(&d_scan, (const uint64_t *)nullptr, max_rows + 1))) return rc;
+    if ((rc = db.get(&d_rowe64, max_rows + 1)) || (rc = db.get(&d_scan, max_rows + 1))) return rc;
     size_t tb = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_rowe64, d_scan, (uint64_t)0, (size_t)max_rows + 1, rocprim::plus<uint64_t>()));
-    void *d_tmp;
-    if ((rc = db.put((uint8_t **)&d_tmp, (const uint8_t *)nullptr, tb))) return rc;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_rowe64, d_scan, (uint64_t)0, (size_t)max_rows + 1, rocprim::plus<uint64_t>(), st));
+    uint8_t *d_tmp;
+    uint32_t *d_list;
+    if ((rc = db.get(&d_tmp, tb)) || (rc = db.get(&d_list, n_reads))) return rc;
+    std::vector<uint32_t> lists(n_reads);
     uint32_t *d_ei = nullptr, *d_ej = nullptr;
     uint8_t *d_bad = nullptr;
     uint64_t edge_cap = 0;
     auto free_edges = [&]() {
-        if (d_ei) (void)hipFree(d_ei);
-        if (d_ej) (void)hipFree(d_ej);
-        if (d_bad) (void)hipFree(d_bad);
+        pool_free(device, d_ei);
+        pool_free(device, d_ej);
+        pool_free(device, d_bad);
         d_ei = d_ej = nullptr;
         d_bad = nullptr;
     };
     for (size_t c = 0; c + 1 < cuts.size(); c++) {
         const uint32_t r0 = cuts[c], nr = cuts[c + 1] - r0;
         const uint64_t lo = off[r0], rows = off[cuts[c + 1]] - lo;
-        hipLaunchKernelGGL(k_pair_count, dim3(nr), dim3(kPairThreads), 0, 0, d_off + r0, d_pos, d_start, d_rowe, d_orient + r0, d_any + r0);
+        // the chunk's reads by size: [small ... | big ...] (absolute read indices)
+        uint32_t n_small = 0;
+        for (uint32_t r = r0; r < r0 + nr; r++) n_small += (off[r + 1] - off[r] <= (uint64_t)kSmallRead) ? 1u : 0u;
+        {
+            uint32_t a = 0, b = n_small;
+            for (uint32_t r = r0; r < r0 + nr; r++) lists[(off[r + 1] - off[r] <= (uint64_t)kSmallRead) ? a++ : b++] = r;
+        }
+        const uint32_t n_big = nr - n_small;
+        hipError_t e = hipMemcpyAsync(d_list, lists.data(), (size_t)nr * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // (`lists` is refilled by the next chunk)
+        if (e != hipSuccess) {
+            free_edges();
+            set_error("gs_pair_component: %s", hipGetErrorString(e));
+            return GS_E_NODEVICE;
+        }
+        if (n_small) hipLaunchKernelGGL(k_pair_count<64>, dim3(n_small), dim3(64), 0, st, d_list, d_off, d_pos, d_start, d_rowe, d_orient, d_any);
+        if (n_big) hipLaunchKernelGGL(k_pair_count<256>, dim3(n_big), dim3(256), 0, st, d_list + n_small, d_off, d_pos, d_start, d_rowe, d_orient, d_any);
         // surviving pairs per row -> their offsets in the chunk's edge list (exclusive scan, on the device)
-        hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, 0, d_rowe + lo, d_rowe64, rows);
-        hipError_t e = hipMemsetAsync(d_rowe64 + rows, 0, sizeof(uint64_t), 0);
+        hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, st, d_rowe + lo, d_rowe64, rows);
+        e = hipMemsetAsync(d_rowe64 + rows, 0, sizeof(uint64_t), st);
         size_t tb2 = tb;
-        if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp, tb2, d_rowe64, d_scan, (uint64_t)0, (size_t)rows + 1, rocprim::plus<uint64_t>());
-        if (e == hipSuccess) e = hipMemcpyAsync(d_reoff + lo, d_scan, (rows + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, 0);
+        if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp, tb2, d_rowe64, d_scan, (uint64_t)0, (size_t)rows + 1, rocprim::plus<uint64_t>(), st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_reoff + lo, d_scan, (rows + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, st);
         uint64_t n_edges = 0;
-        if (e == hipSuccess) e = hipMemcpy(&n_edges, d_scan + rows, sizeof(uint64_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpyAsync(&n_edges, d_scan + rows, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
             free_edges();
             set_error("gs_pair_component: %s", hipGetErrorString(e));
@@ -375,18 +398,27 @@ int gs::pair_component_device(uint32_t n_reads, uint64_t n_rows, const uint64_t 
         if (n_edges > edge_cap) {
             free_edges();
             edge_cap = std::max<uint64_t>(n_edges, 1024);
-            if (hipMalloc((void **)&d_ei, edge_cap * 4) != hipSuccess || hipMalloc((void **)&d_ej, edge_cap * 4) != hipSuccess ||
-                hipMalloc((void **)&d_bad, edge_cap) != hipSuccess) {
+            d_ei = static_cast<uint32_t *>(pool_alloc(device, edge_cap * 4));
+            d_ej = static_cast<uint32_t *>(pool_alloc(device, edge_cap * 4));
+            d_bad = static_cast<uint8_t *>(pool_alloc(device, edge_cap));
+            if (!d_ei || !d_ej || !d_bad) {
                 free_edges();
                 set_error("gs_pair_component: device allocation of %llu pairs failed", (unsigned long long)edge_cap);
                 return GS_E_NOMEM;
             }
         }
-        hipLaunchKernelGGL(k_pair_edges, dim3(nr), dim3(kPairThreads), 0, 0, d_off + r0, d_pos, d_start, d_orient + r0, d_reoff, d_ei, d_ej);
-        hipLaunchKernelGGL(k_pair_graph, dim3(nr), dim3(kGraphThreads), 0, 0, nr, d_off + r0, d_pos, d_id, d_any + r0, d_reoff,
-                           d_ei, d_ej, d_bad, d_deg, d_rank, d_vert, d_parent, d_size, d_app, d_gp, d_out, d_outn + r0);
+        if (n_small) {
+            hipLaunchKernelGGL(k_pair_edges<64>, dim3(n_small), dim3(64), 0, st, d_list, d_off, d_pos, d_start, d_orient, d_reoff, d_ei, d_ej);
+            hipLaunchKernelGGL(k_pair_graph<64>, dim3(n_small), dim3(64), 0, st, d_list, d_off, d_pos, d_id, d_any, d_reoff, d_ei, d_ej, d_bad, d_deg,
+                               d_rank, d_vert, d_parent, d_size, d_app, d_gp, d_out, d_outn);
+        }
+        if (n_big) {
+            hipLaunchKernelGGL(k_pair_edges<256>, dim3(n_big), dim3(256), 0, st, d_list + n_small, d_off, d_pos, d_start, d_orient, d_reoff, d_ei, d_ej);
+            hipLaunchKernelGGL(k_pair_graph<256>, dim3(n_big), dim3(256), 0, st, d_list + n_small, d_off, d_pos, d_id, d_any, d_reoff, d_ei, d_ej, d_bad,
+                               d_deg, d_rank, d_vert, d_parent, d_size, d_app, d_gp, d_out, d_outn);
+        }
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess && c + 2 < cuts.size()) e = hipStreamSynchronize(st);  // (the next chunk may replace the edge arrays)
         if (e != hipSuccess) {
             free_edges();
             set_error("gs_pair_component: %s", hipGetErrorString(e));
@@ -394,6 +426,7 @@ int gs::pair_component_device(uint32_t n_reads, uint64_t n_rows, const uint64_t 
         }
     }
     free_edges();
+    HIP_TRY(hipStreamSynchronize(st));
     return GS_OK;
 }
 
@@ -419,7 +452,7 @@ extern "C" int gs_pair_component(int device, uint32_t n_reads, const uint64_t *r
         (rc = db.put(&d_start, start, n_rows)) || (rc = db.put(&d_id, id, n_rows)) ||
         (rc = db.put(&d_out, (const int64_t *)nullptr, n_rows)) || (rc = db.put(&d_outn, (const uint32_t *)nullptr, n_reads)))
         return rc;
-    if ((rc = gs::pair_component_device(n_reads, n_rows, d_off, d_pos, d_start, d_id, d_outn, d_out))) return rc;
+    if ((rc = gs::pair_component_device(device, n_reads, n_rows, d_off, d_pos, d_start, d_id, d_outn, d_out))) return rc;
     HIP_TRY(hipMemcpy(out_n, d_outn, n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (n_rows) HIP_TRY(hipMemcpy(out_ids, d_out, n_rows * sizeof(int64_t), hipMemcpyDeviceToHost));
     return GS_OK;
@@ -520,23 +553,24 @@ __global__ void k_uf_stats(uint32_t *parent, const long long *vertex_id, uint32_
 }  // namespace
 
 // device arrays in, device arrays out (comp_* of n_vertices entries each); synchronous
-int gs::union_regions_device(uint64_t n_rows, const uint32_t *d_rr, const uint32_t *d_rv, uint32_t n_vertices, const int64_t *d_vid,
+int gs::union_regions_device(int device, uint64_t n_rows, const uint32_t *d_rr, const uint32_t *d_rv, uint32_t n_vertices, const int64_t *d_vid,
                              uint32_t *d_size, int64_t *d_min, int64_t *d_max) {
     if (!n_vertices) return GS_OK;
-    DevBuf db;
+    hipStream_t st = chain_stream(device);
+    PoolScope db(device);
     int rc;
     uint32_t *d_parent;
-    if ((rc = db.put(&d_parent, (const uint32_t *)nullptr, n_vertices))) return rc;
-    HIP_TRY(hipMemset(d_size, 0, n_vertices * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(d_min, 0x7F, n_vertices * sizeof(long long)));  // 0x7F7F...: above every ID
-    HIP_TRY(hipMemset(d_max, 0x80, n_vertices * sizeof(long long)));  // 0x8080...: below every ID
-    hipLaunchKernelGGL(k_uf_init, dim3((n_vertices + 255) / 256), dim3(256), 0, 0, d_parent, n_vertices);
+    if ((rc = db.get(&d_parent, n_vertices))) return rc;
+    HIP_TRY(hipMemsetAsync(d_size, 0, n_vertices * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(d_min, 0x7F, n_vertices * sizeof(long long), st));  // 0x7F7F...: above every ID
+    HIP_TRY(hipMemsetAsync(d_max, 0x80, n_vertices * sizeof(long long), st));  // 0x8080...: below every ID
+    hipLaunchKernelGGL(k_uf_init, dim3((n_vertices + 255) / 256), dim3(256), 0, st, d_parent, n_vertices);
     if (n_rows > 1)
-        hipLaunchKernelGGL(k_uf_union, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, 0, d_parent, d_rv, d_rr, n_rows);
-    hipLaunchKernelGGL(k_uf_stats, dim3((n_vertices + 255) / 256), dim3(256), 0, 0, d_parent, (const long long *)d_vid, n_vertices, d_size,
+        hipLaunchKernelGGL(k_uf_union, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, d_parent, d_rv, d_rr, n_rows);
+    hipLaunchKernelGGL(k_uf_stats, dim3((n_vertices + 255) / 256), dim3(256), 0, st, d_parent, (const long long *)d_vid, n_vertices, d_size,
                        (long long *)d_min, (long long *)d_max);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(st));
     return GS_OK;
 }
 
@@ -562,7 +596,7 @@ extern "C" int gs_union_regions(int device, uint64_t n_rows, const uint32_t *row
         (rc = db.put(&d_vid, vertex_id, n_vertices)) || (rc = db.put(&d_min, (const int64_t *)nullptr, n_vertices)) ||
         (rc = db.put(&d_max, (const int64_t *)nullptr, n_vertices)))
         return rc;
-    if ((rc = gs::union_regions_device(n_rows, d_rr, d_rv, n_vertices, d_vid, d_size, d_min, d_max))) return rc;
+    if ((rc = gs::union_regions_device(device, n_rows, d_rr, d_rv, n_vertices, d_vid, d_size, d_min, d_max))) return rc;
     HIP_TRY(hipMemcpy(comp_size, d_size, n_vertices * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(comp_min, d_min, n_vertices * sizeof(int64_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(comp_max, d_max, n_vertices * sizeof(int64_t), hipMemcpyDeviceToHost));

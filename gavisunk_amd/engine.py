@@ -675,7 +675,7 @@ class LocRows:
     def from_sunkset(cls, sunks: "DeviceSunkSet") -> "LocRows":
         h = C.c_void_p()
         check(lib().gs_locrows_from_sunkset_dev(sunks.device, sunks._h, C.byref(h)))
-        return cls(h, sunks.device, keepalive=sunks)  # (borrows the set's device arrays)
+        return cls(h, sunks.device)  # (a packed copy: the handle does not refer to the set afterwards)
 
     def key_contig(self) -> np.ndarray:
         out = np.zeros(max(self.n_locs, 1), np.uint32)
@@ -830,6 +830,14 @@ def pairstage_from_rows(row_contig, row_name, row_id, contigs_in, device: int = 
     check(lib().gs_pairstage_from_rows(device, len(rc), rc.ctypes.data if len(rc) else None, rn.ctypes.data if len(rc) else None,
                                        ri.ctypes.data if len(rc) else None, len(ci), ci.ctypes.data if len(ci) else None, C.byref(h)))
     return _pairstage_result(h)
+
+
+def hits_on_device(table: "DeviceTable", reads: "DeviceReads") -> int:
+    """Rows of the last pass over `reads` (its hit list stays in device memory until the batch's next pass): what a RowSet that
+    takes them should be sized for."""
+    p, n = C.c_void_p(), C.c_uint64(0)
+    check(lib().gs_tag_hits_device(table._h, reads._h, C.byref(p), C.byref(n)))
+    return n.value
 
 
 def free_device(ptr, device: int = 0) -> None:

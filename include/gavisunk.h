@@ -521,7 +521,8 @@ int gs_tag_hits_device(gs_table *t, gs_reads *r, const void **d_hits, uint64_t *
 
 /* kmer.loc rows in device memory: what turns a hit's payload (the loc row) into `chrom, start, ID` and the dense id of
  * `chrom:ID` (kmerpos_annot3.nim:44-69 keeps them in `coords`).  From the host arrays of a gs_sunkdb (row_contig / row_start /
- * row_group / row_loc), or straight from a device-resident SUNK set (borrows its arrays: the set must outlive the handle). */
+ * row_group / row_loc), or straight from a device-resident SUNK set.  Either way the handle owns ONE packed 16-byte record per row
+ * {start, contig, ID, key} (a row of a hit list is one random 16-byte load); it does not refer to the set afterwards. */
 typedef struct gs_locrows gs_locrows;
 int gs_locrows_create(int device, uint64_t n_rows, const uint32_t *row_contig, const int64_t *row_start, const int64_t *row_group,
                       const uint32_t *row_loc, gs_locrows **out);
@@ -578,6 +579,8 @@ typedef int (*gs_reduce_u32_fn)(void *ctx, void *d_counts, uint64_t n);
 int gs_rowset_bad_keys_reduced(const gs_rowset *hap1, const gs_rowset *hap2, uint32_t n_keys, const uint8_t *key_hap, gs_reduce_u32_fn reduce,
                                void *reduce_ctx, uint8_t *bad_host, uint32_t meancov[2], void **d_bad);
 int gs_device_free(int device, void *p);
+/* The second half keeps its device temporaries in a pool between calls (csrc/gs_devpool.h): hand the idle ones back to the driver. */
+int gs_device_pool_trim(int device);
 int gs_device_copy_to_host(int device, void *host, const void *d_src, uint64_t nbytes);
 int gs_device_copy_from_host(int device, void *d_dst, const void *host, uint64_t nbytes);
 /* process-by-contig_lowmem_AR.py:50-260 over a row set (rows of several contigs are handled contig by contig, like the

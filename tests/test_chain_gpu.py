@@ -154,7 +154,7 @@ def _rows_with_many_contigs(rng, n_contigs_big):
     return rows, contigs
 
 
-@pytest.mark.parametrize("big", [44, 200])
+@pytest.mark.parametrize("big", [44, 200, 300])  # (300 contigs in one read: more than a workgroup's run arrays hold -> global scratch)
 def test_table_growth_is_replayed_exactly(tmp_path, big):
     rng = np.random.default_rng(big)
     rows, contigs = _rows_with_many_contigs(rng, big)
@@ -224,4 +224,76 @@ def test_ids_out_of_range_fail_loudly():
     assert e.value.status == _lib.GS_E_ARG
     seg_name, bc, bg, bd, kept = rs.diag_filter(["a", "b", "c"], [1, 1, 1])  # the right count works
     assert len(seg_name) == 3
+    rs.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_reads_of_every_kernel_class(tmp_path, seed):
+    """gs_diag.hip takes a read by its row count: up to 128 rows four waves to a workgroup, up to 1024 one wave with 32 KiB of LDS,
+    longer ones in global scratch.  Reads on both sides of every boundary, one to six contigs each, both orientations, IDs that
+    repeat inside the band, exact ties between contigs -- against the oracle and against the host-array implementation."""
+    rng = np.random.default_rng(seed)
+    contigs = [f"c{j}_{int(rng.integers(0, 999))}" for j in range(9)]
+    sizes = [1, 2, 3, 5, 63, 64, 65, 127, 128, 129, 130, 300, 1000, 1023, 1024, 1025, 1500, 2049, 4100] + [int(x) for x in rng.integers(2, 200, 25)]
+    rows = []
+    for r, n in enumerate(sizes):
+        picks = rng.choice(len(contigs), size=int(rng.integers(1, 7)), replace=False)
+        weights = rng.dirichlet(np.ones(len(picks)) * 0.6)
+        bases = {int(c): int(rng.integers(10**5, 10**7)) for c in picks}
+        sign = 1 if rng.random() < 0.5 else -1
+        pos = 0
+        per = []
+        for _ in range(n):
+            pos += int(rng.integers(1, 400))
+            c = int(rng.choice(picks, p=weights))
+            jitter = int(rng.integers(-6000, 6000)) if rng.random() < 0.25 else int(rng.integers(-40, 40))
+            start = bases[c] + sign * pos + jitter + (5 * 10**6 if sign < 0 else 0)
+            per.append((pos, contigs[c], start, (start // 2000) * 2000))  # coarse IDs: they repeat inside the band
+        if r % 5 == 0 and len(picks) >= 2:  # an exact tie: the first contig's rows again on the second (same hit count, same groups' count)
+            a, b = contigs[int(picks[0])], contigs[int(picks[1])]
+            per = [x for x in per if x[1] != b]
+            per += [(p, b, s, g) for p, c_, s, g in per if c_ == a]
+            per.sort(key=lambda x: x[0])
+        rows += [(f"q{r:03d}", *x) for x in per]
+    text = "".join(f"{a}\t{b}\t{c}\t{d}\t{e}\n" for a, b, c, d, e in rows)
+    (tmp_path / "x.sunkpos").write_text(text)
+    fai = contigs[:8]
+    exp = oracle.diag_filter_v3(oracle.parse_sunkpos(text), fai)
+    sp = engine.SunkPos(str(tmp_path / "x.sunkpos"))
+    rs = engine.RowSet.from_sunkpos(sp)
+    fs = set(fai)
+    seg_name, bc2, bg2, bd2, kept = rs.diag_filter(sp.contigs, [1 if c in fs else 0 for c in sp.contigs])
+    got = "".join(f"{sp.seg_name(s)}\t{sp.contigs[c]}\t{g}\t{chr(d)}\t{g}\n" for s, (c, g, d) in enumerate(zip(bc2.tolist(), bg2.tolist(), bd2.tolist())) if c != _lib.GS_NONE)
+    assert got == exp and exp.count("\n") > 25
+    bc, bg, bd, keep = engine.diag_filter(sp, fai)
+    assert np.array_equal(bc, bc2) and np.array_equal(bg, bg2) and np.array_equal(bd[bc != _lib.GS_NONE], bd2[bc2 != _lib.GS_NONE])
+    assert np.array_equal(keep, rs.keep_flags()) and kept == int(keep.sum())
+    rs.close()
+    sp.close()
+
+
+def test_more_ties_than_the_first_tie_list_holds():
+    """Every read an exact tie between two contigs (two rows, two groups each): the slot order of Nim's Table decides all of them; the
+    kernel's list of such reads starts with room for 65 536 and is re-made at the size the first go asked for."""
+    n_reads = 70_000
+    rng = np.random.default_rng(3)
+    contigs = [f"t{j}" for j in range(40)]
+    a = rng.integers(0, 40, n_reads)
+    b = (a + rng.integers(1, 40, n_reads)) % 40
+    base = rng.integers(10**4, 10**6, n_reads)
+    name = np.repeat(np.arange(n_reads, dtype=np.uint32), 4)
+    pos = np.tile(np.array([100, 200, 1300, 1400], np.uint32), n_reads)
+    contig = np.stack([a, b, a, b], 1).reshape(-1).astype(np.uint32)
+    start = (np.repeat(base, 4) + pos).astype(np.uint32)
+    ident = (start // 1000 * 1000).astype(np.uint32)
+    rs = engine.RowSet()
+    rs.append_host(name, pos, contig, start, ident, np.zeros(len(name), np.uint32))
+    seg_name, bc, bg, bd, kept = rs.diag_filter(contigs, np.ones(40, np.uint8))
+    assert np.array_equal(seg_name, np.arange(n_reads)) and (bg == 2).all() and (bd == ord("-")).all()  # ("-" is tried first and "+" is no better)
+    # the Table (64 slots, no growth): the contig whose hash lands in the lower slot, the first inserted keeping its slot on a clash
+    h = np.array([oracle.murmur3_32(c.encode()) or 314159265 for c in contigs], dtype=np.uint64) & 63
+    sa, sb = h[a], h[b]
+    sb = np.where(sb == sa, (sb + 1) & 63, sb)
+    want = np.where(sa < sb, a, b)
+    assert np.array_equal(bc, want) and kept == 2 * n_reads
     rs.close()
