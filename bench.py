@@ -644,6 +644,63 @@ def both_halves_leg(table, batches, locrows, contig_names, device, steps, warmup
                     "the last pass's second half is inside the timed region"}
 
 
+def rows_text_leg(table, batches, locrows, sunks, contig_names, device, sample_rows):
+    """`cli_config3_rows` key: ONE pass's hit list (every resident batch) written as the tagger's output file -- formatted on the
+    device (csrc/gs_format.hip), 32 MiB pieces through pinned buffers, pwrite on host threads.  Names are the synthetic reads'
+    (`r0000042`).  The head of the file against the oracle's rows of the parity sample, the tail against the last hits of the last
+    batch looked up row by row."""
+    from gavisunk_amd import engine
+    import tempfile
+
+    d = tempfile.mkdtemp(prefix="gsrows_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    path = os.path.join(d, "pass.sunkpos")
+    names = []
+    for dr, r0, rl in batches:
+        blob = "".join(f"r{r0 + i:07d}" for i in range(len(rl))).encode()
+        ln = np.array([len(f"r{r0 + i:07d}") for i in (0, len(rl) - 1)])
+        assert ln[0] == ln[1]  # (fixed width within a batch)
+        w = int(ln[0])
+        names.append((np.frombuffer(blob, np.uint8), np.arange(len(rl), dtype=np.uint64) * w, np.full(len(rl), w, np.uint32)))
+    try:
+        t0 = time.perf_counter()
+        with engine.RowWriter(path) as out:
+            for (dr, r0, rl), nm in zip(batches, names):
+                out.write_device(table, dr, locrows, contig_names, names=nm)
+            n_rows = out.close()
+        dt = time.perf_counter() - t0
+        size = os.path.getsize(path)
+        with open(path, "rb") as f:
+            head = f.read(1 << 22)
+            f.seek(max(size - (1 << 16), 0))
+            tail = f.read()
+        # head: the oracle's rows of the parity sample (read, pos, loc row) as text
+        ok_head = None
+        if sample_rows is not None and len(sample_rows["read"]):
+            k_ = min(len(sample_rows["read"]), 2000)
+            exp = []
+            for rd, ps, p in zip(sample_rows["read"][:k_].tolist(), sample_rows["pos"][:k_].tolist(), sample_rows["row"][:k_].astype(np.int64).tolist()):
+                pp = int(sunks.pos(p, p + 1)[0])
+                exp.append(f"r{rd:07d}\t{ps}\t{contig_names[pp >> 32]}\t{pp & 0xFFFFFFFF}\t{int(sunks.group(p, p + 1)[0])}\n")
+            exp = "".join(exp).encode()
+            ok_head = head[: len(exp)] == exp
+        # tail: the last hits of the last batch (its host mirror), looked up row by row
+        dr, r0, rl = batches[-1]
+        hv = engine.hits_view(table, dr)
+        last = hv[-200:]
+        exp = []
+        for rd, ps, p in zip(last["read"].tolist(), last["pos"].tolist(), last["payload"].tolist()):
+            pp = int(sunks.pos(p, p + 1)[0])
+            exp.append(f"r{r0 + rd:07d}\t{ps}\t{contig_names[pp >> 32]}\t{pp & 0xFFFFFFFF}\t{int(sunks.group(p, p + 1)[0])}\n")
+        exp = "".join(exp).encode()
+        ok_tail = tail.endswith(exp) and len(exp) > 0
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    return {"rows": int(n_rows), "bytes": int(size), "seconds": round(dt, 3), "rows_per_s": n_rows / dt, "GB_per_s": size / dt / 1e9,
+            "head_equals_oracle_rows": ok_head, "tail_equals_hit_list": bool(ok_tail), "file": "tmpfs (/dev/shm)" if d.startswith("/dev/shm") else "tmp dir",
+            "path": "hit list in HBM -> k_row_len -> exclusive scan -> k_row_write (a wave stages 64 lines in LDS) -> 32 MiB pinned pieces -> pwrite (csrc/gs_format.hip)"}
+
+
 def _lib_handle():
     from gavisunk_amd import _lib
     return _lib.lib()
@@ -1101,6 +1158,7 @@ def main():
             out["no_exchange"] = d["no_exchange"]
         # ---- parity on the head of the stream + CPU baseline (outside the timed region) --------------------------
         sample = res["sample"]
+        oracle_rows = None
         if sample is not None:
             from oracle import oracle
 
@@ -1110,6 +1168,7 @@ def main():
             otable = oracle.Table(K, sub["code"], sub["code"], (sub["pos"] >> np.uint64(32)).astype(np.uint32), sub["group"].astype(np.int64))
             buf, off = oracle.concat_reads(seqs)
             orc, oh, _, octr = otable.tag(buf, off, cap=1 << 24)
+            oracle_rows = {"read": oh["read"], "pos": oh["pos"], "row": sub["rows"][oh["row"]]}
             # (1) the same reads through the engine on their own (all counters comparable) ...
             chk = engine.DeviceReads.from_ascii(seqs, K, device)
             st, gh, _, gctr = engine.tag(table, chk)
@@ -1147,6 +1206,12 @@ def main():
                                                               ("rows_in", "reads_with_a_best_contig", "rows_after_diag_filter", "tsv_rows", "validated_intervals")))
                 both["tagger_alone"] = out["value"]
                 out["engine_both_halves"] = both
+                try:
+                    out["cli_config3_rows"] = rows_text_leg(res["table"], res["batches"], lr, res["kept_sunks"][0], res["kept_sunks"][1], device,
+                                                            oracle_rows)
+                    log(f"rows as text: {out['cli_config3_rows']['rows']} rows, {out['cli_config3_rows']['bytes'] / 2**30:.2f} GiB in {out['cli_config3_rows']['seconds']:.2f} s")
+                except Exception as e:  # (a measurement leg must not cost the headline)
+                    out["cli_config3_rows"] = {"failed": repr(e)}
                 log(f"both halves: {both['value'] / 1e9:.1f} Gbase/s ({both['ms_per_step']:.1f} ms per step; the tagger alone {out['value'] / 1e9:.1f})")
                 lr.close()
             except Exception as e:  # (a measurement leg must not cost the headline)

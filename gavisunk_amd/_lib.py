@@ -69,6 +69,7 @@ SIGNATURES = {
     "gs_rowwriter_open": (I, [C.c_char_p, C.POINTER(P)]),
     "gs_rowwriter_rows": (I, [P, P, U64, P, P, P, P, P]),
     "gs_rowwriter_close": (I, [P, C.POINTER(U64)]),
+    "gs_rowwriter_rows_device": (I, [P, P, P, P, U32, P, P, P, P, U32, P]),
     "gs_gz_open": (I, [C.c_char_p, I, C.POINTER(P)]),
     "gs_gz_read": (I, [P, U64, P, U64, C.POINTER(P), C.POINTER(U64)]),
     "gs_gz_free_buffer": (None, [P]),

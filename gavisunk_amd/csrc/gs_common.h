@@ -138,6 +138,21 @@ struct gs_batch {
     uint64_t bases = 0;
 };
 
+// the tagger's output file (gs_host.cpp: rows formatted on the host; gs_format.hip: rows formatted on the device)
+struct gs_rowwriter {
+    FILE *f = nullptr;
+    std::vector<char> buf;
+    uint64_t rows = 0;
+    void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};  // staging of device-formatted text (allocated on first use, gs_format.hip)
+    bool flush() {
+        if (buf.empty()) return true;
+        const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        buf.clear();
+        return ok;
+    }
+};
+void rowwriter_release_pinned(gs_rowwriter *w);  // gs_format.hip
+
 struct gs_sunkpos {
     std::vector<uint32_t> row_seg, row_contig;
     std::vector<int64_t> row_pos, row_start, row_group;

@@ -1244,17 +1244,6 @@ int gs_diag_filter_step2_files(const char *sunkpos_path, const char *diag_path, 
 // ------------------------------------------------------------------------------------- output rows
 // `name \t i \t chrom \t start \t group \n` (kmerpos_annot3.nim:93), formatted and written natively: a genome-scale pass emits
 // 1e7 .. 1e8 rows, far beyond what a per-row Python format survives.
-struct gs_rowwriter {
-    FILE *f = nullptr;
-    std::vector<char> buf;
-    uint64_t rows = 0;
-    bool flush() {
-        if (buf.empty()) return true;
-        const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
-        buf.clear();
-        return ok;
-    }
-};
 static inline char *put_u64(char *p, uint64_t v) {
     char tmp[24];
     int n = 0;
@@ -1350,6 +1339,7 @@ int gs_rowwriter_close(gs_rowwriter *w, uint64_t *rows_out) {
     bool ok = w->flush();
     ok = fclose(w->f) == 0 && ok;
     if (rows_out) *rows_out = w->rows;
+    rowwriter_release_pinned(w);
     delete w;
     if (!ok) {
         set_error("gs_rowwriter_close: write failed");

@@ -592,6 +592,20 @@ class RowWriter:
         else:
             check(lib().gs_rowwriter_rows(self._h, hits.ctypes.data, len(hits), db._h, None, None, None, reads._h))
 
+    def write_device(self, table: "DeviceTable", reads, locrows: "LocRows", contig_names: Sequence[str], names_of=None, names=None) -> None:
+        """The rows of the LAST pass over `reads` (DeviceReads), formatted on the device from its hit list where it lies
+        (gs_rowwriter_rows_device).  Read names: from the text block a device-parsed batch came from; names_of: the ReadBatch the
+        reads came from when they were parsed on the host; names: (bytes as uint8 array, offsets uint64, lengths uint32) otherwise."""
+        arr = (C.c_char_p * max(len(contig_names), 1))(*[c.encode() for c in contig_names])
+        if names is None and getattr(reads, "_name_off", None) is not None:
+            names = (np.frombuffer(reads._text, dtype=np.uint8), reads._name_off, reads._name_len)
+        if names is not None:
+            base, off, ln = (np.ascontiguousarray(names[0], np.uint8), np.ascontiguousarray(names[1], np.uint64), np.ascontiguousarray(names[2], np.uint32))
+            check(lib().gs_rowwriter_rows_device(self._h, table._h, reads._h, locrows._h, len(contig_names), arr, base.ctypes.data,
+                                                 off.ctypes.data, ln.ctypes.data, len(ln), None))
+        else:
+            check(lib().gs_rowwriter_rows_device(self._h, table._h, reads._h, locrows._h, len(contig_names), arr, None, None, None, 0, names_of._h))
+
     def close(self) -> int:
         n = C.c_uint64(0)
         if getattr(self, "_h", None):
@@ -666,8 +680,9 @@ class LocRows:
     @classmethod
     def from_db(cls, db: "SunkDB", device: int = 0) -> "LocRows":
         h = C.c_void_p()
-        rc_, rs_, rg_, rl_ = (np.ascontiguousarray(db.row_contig, np.uint32), np.ascontiguousarray(db.row_start, np.int64),
-                              np.ascontiguousarray(db.row_group, np.int64), np.ascontiguousarray(db.row_loc, np.uint32))
+        rc_, rs_, rg_ = (np.ascontiguousarray(db.row_contig, np.uint32), np.ascontiguousarray(db.row_start, np.int64), np.ascontiguousarray(db.row_group, np.int64))
+        # (a SunkDB from a sidecar carries no dense (chrom, ID) ids: the rows then serve the output writer, which does not use them)
+        rl_ = np.ascontiguousarray(db.row_loc, np.uint32) if len(db.row_loc) == len(rc_) else np.full(len(rc_), _lib.GS_MISSING, np.uint32)
         check(lib().gs_locrows_create(device, len(rc_), rc_.ctypes.data, rs_.ctypes.data, rg_.ctypes.data, rl_.ctypes.data, C.byref(h)))
         return cls(h, device)
 
@@ -830,6 +845,14 @@ def pairstage_from_rows(row_contig, row_name, row_id, contigs_in, device: int = 
     check(lib().gs_pairstage_from_rows(device, len(rc), rc.ctypes.data if len(rc) else None, rn.ctypes.data if len(rc) else None,
                                        ri.ctypes.data if len(rc) else None, len(ci), ci.ctypes.data if len(ci) else None, C.byref(h)))
     return _pairstage_result(h)
+
+
+def hits_view(table: "DeviceTable", reads: "DeviceReads") -> np.ndarray:
+    """The rows of the last pass over `reads` as a view of the batch's pinned host mirror (gs_tag_hits_view; the next pass over the
+    batch overwrites it)."""
+    p, n = C.c_void_p(), C.c_uint64(0)
+    check(lib().gs_tag_hits_view(table._h, reads._h, C.byref(p), C.byref(n)))
+    return _view(p.value, n.value, HIT_DTYPE)
 
 
 def hits_on_device(table: "DeviceTable", reads: "DeviceReads") -> int:

@@ -137,6 +137,34 @@ class _Prefetch:
         self._t.join(timeout=5)
 
 
+class _Rows:
+    """Where a batch's rows become text: on the device, from the pass's hit list where it lies (gs_rowwriter_rows_device; the
+    location rows go to the device once, when the first batch has rows), or -- GAVISUNK_ROWS=host -- on the host from the hits
+    the pass copied back (gs_rowwriter_rows, one thread, three lookups per row into the host arrays of the location table)."""
+
+    def __init__(self, out: "engine.RowWriter", db, table, device: int):
+        self.out, self.db, self.table, self.device = out, db, table, device
+        self.on_device = os.environ.get("GAVISUNK_ROWS", "device") != "host"
+        self.lr = None
+
+    def write(self, hits, dev, names_of=None) -> None:
+        if not len(hits):
+            return
+        if not self.on_device:
+            self.out.write(hits, names_of if names_of is not None else dev, self.db)
+            return
+        if self.lr is None:
+            t0 = time.perf_counter()
+            self.lr = engine.LocRows.from_db(self.db, self.device)
+            _tick("loc_rows_to_device", t0)
+        self.out.write_device(self.table, dev, self.lr, self.db.contigs, names_of)
+
+    def close(self) -> None:
+        if self.lr is not None:
+            self.lr.close()
+            self.lr = None
+
+
 def _tag_text_blocks(blocks, db, table, ofile: str, device: int):
     """The reads file as text blocks parsed on the GPU (gs_reads_from_text).  -> exit code, or None
     when the text is outside the regular FASTA / FASTQ subset the device parser takes (nothing useful is written then)."""
@@ -148,6 +176,7 @@ def _tag_text_blocks(blocks, db, table, ofile: str, device: int):
         todo: "queue.Queue" = queue.Queue(maxsize=2)
         done: "queue.Queue" = queue.Queue()
         failed = []
+        rows = _Rows(out, db, table, device)
 
         def writer():
             while True:
@@ -158,7 +187,7 @@ def _tag_text_blocks(blocks, db, table, ofile: str, device: int):
                 try:
                     if not failed:
                         t1 = time.perf_counter()
-                        out.write(hits, dev, db)
+                        rows.write(hits, dev)
                         _tick("write_rows", t1)
                 except BaseException as e:  # noqa: BLE001 (handed to the main thread)
                     failed.append(e)
@@ -210,6 +239,7 @@ def _tag_text_blocks(blocks, db, table, ofile: str, device: int):
             wt.join()
             _tick("wait_for_writer", t0)
             close_done()
+            rows.close()
         if failed:
             raise failed[0]
     return rc
@@ -225,10 +255,12 @@ def _tag_host_batches(batches, db, table, ofile: str, batch_bases: int) -> int:
     with engine.RowWriter(ofile) as out:
         if first is None:
             return 0
+        rows = _Rows(out, db, table, table.device)
         if second is None:
             dev = engine.DeviceReads(first, db.k, table.device)
             st, hits, _, _ = engine.tag(table, dev)
-            out.write(hits, first, db)
+            rows.write(hits, dev, names_of=first)
+            rows.close()
             dev.close()
             first.close()
             if st == _lib.GS_E_KEYERROR:
@@ -245,7 +277,7 @@ def _tag_host_batches(batches, db, table, ofile: str, batch_bases: int) -> int:
             while len(pending) > upto:
                 st, hits, _, _ = stream.next(copy=False)
                 b, dev = pending.pop(0)
-                out.write(hits, b, db)
+                out.write(hits, b, db)  # (a stream slot's hit list is not a handle of ours: these rows are formatted on the host)
                 if dev is not None:
                     dev.close()
                 b.close()
@@ -278,6 +310,7 @@ def _tag_host_batches(batches, db, table, ofile: str, batch_bases: int) -> int:
                     dev.close()
                 b.close()
             stream.close()
+            rows.close()
         return rc
 
 

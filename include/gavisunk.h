@@ -309,6 +309,14 @@ int gs_rowwriter_open(const char *path, gs_rowwriter **out);
 int gs_rowwriter_rows(gs_rowwriter *w, const gs_hit *hits, uint64_t n, const gs_sunkdb *db, const uint8_t *names_base,
                       const uint64_t *name_off, const uint32_t *name_len, const gs_batch *batch);
 int gs_rowwriter_close(gs_rowwriter *w, uint64_t *rows_out);
+/* The same bytes for the rows of the LAST PASS over `r`, whose hit list is still in device memory: measured, placed and written
+ * as text by kernels (csrc/gs_format.hip; the loc record of a row is one 16-byte gather from `lr`), the finished text handed to the
+ * file in 32 MiB pieces.  Names: (names_base + name_off[read], name_len[read]) for the n_names reads of the batch, or `batch` when
+ * name_off is NULL.  contig_names[n_contigs] = the names behind the loc rows' contig ids (gs_sunkdb_contig_name). */
+struct gs_locrows;
+int gs_rowwriter_rows_device(gs_rowwriter *w, gs_table *t, gs_reads *r, const struct gs_locrows *lr, uint32_t n_contigs,
+                             const char *const *contig_names, const uint8_t *names_base, const uint64_t *name_off, const uint32_t *name_len,
+                             uint32_t n_names, const gs_batch *batch);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU: read-sharded tagging, the SUNK table replicated.  One process per GPU; the data plane is
