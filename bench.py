@@ -79,7 +79,7 @@ def source_hash() -> str:
 def traffic_for(workload_key: str):
     """HBM bytes per launch from a separate rocprofv3 --pmc run (never collected inside the bench); quoted only for the
     exact workload and kernel sources they were measured on (profiles/r04/traffic.json: one entry per GPU workload)."""
-    for rnd in ("r04", "r03"):
+    for rnd in ("r05", "r04", "r03"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
             e = tj[workload_key]
@@ -827,6 +827,9 @@ def main():
     ap.add_argument("--no-config2", action="store_true", help="skip the config-2 extra key")
     ap.add_argument("--no-engine", action="store_true", help="skip the streaming-engine leg")
     ap.add_argument("--no-chain", action="store_true", help="skip the device-resident stage-2/3 leg (`pair_stage` key)")
+    ap.add_argument("--no-sharded-chain", action="store_true", help="N > 1: skip the read-sharded second half (`pair_stage` key)")
+    ap.add_argument("--sharded-chain-timeout", type=float, default=240.0,
+                    help="N > 1: seconds after which the read-sharded second half is given up: the line goes out without it and every rank exits 0")
     ap.add_argument("--sharded-chain", action="store_true",
                     help="N > 1: also run the read-sharded second half (dist.sharded_second_half: every rank filters and pair-tests its own hit list, "
                          "counters by all-reduce, TSV rows merged on the root) -> `pair_stage` key; every rank then defines the SUNK set itself")
@@ -954,16 +957,26 @@ def main():
             # the probe kernels of every batch are queued first; while they run, the rows of the PREVIOUS pass (still in device
             # memory: phase 2 of this pass has not started) go to the root over xGMI -- the gather of pass i overlaps the probing
             # of pass i + 1, and the last pass's gather is flushed inside the timed region (flush_gathers below)
-            for dr, _, _ in batches:
-                _lib.check(L.gs_tag_phase1_launch(table._h, dr._h))
+            # (a rank that fails here still walks the same collectives as the others -- the gather of the previous pass, the exchange --
+            # and says so IN the exchange: every rank then raises, and the launcher sees N non-zero exits, not N - 1 hung ranks)
+            failure = None
+            try:
+                for dr, _, _ in batches:
+                    _lib.check(L.gs_tag_phase1_launch(table._h, dr._h))
+            except Exception as e:  # noqa: BLE001
+                failure = e
             flush_gathers()
             summ_local = []
-            for dr, _, _ in batches:
-                has, lastloc = C.c_uint32(0), C.c_uint32(0)
-                _lib.check(L.gs_tag_phase1_wait(table._h, dr._h, C.byref(has), C.byref(lastloc)))
-                summ_local.append((has.value, lastloc.value))
+            try:
+                if failure is None:
+                    for dr, _, _ in batches:
+                        has, lastloc = C.c_uint32(0), C.c_uint32(0)
+                        _lib.check(L.gs_tag_phase1_wait(table._h, dr._h, C.byref(has), C.byref(lastloc)))
+                        summ_local.append((has.value, lastloc.value))
+            except Exception as e:  # noqa: BLE001
+                failure = e
             mine = next(((1, l) for h, l in reversed(summ_local) if h), (0, _lib.GS_NONE))
-            summ = comm.exchange_summaries(*mine)
+            summ = gdist.checked_summaries(comm, *mine, error=failure)
             carry = gdist.resolve_carry(summ, rank)
             for (dr, _, _), (h, l) in zip(batches, summ_local):
                 _lib.check(L.gs_tag_phase2(table._h, dr._h, carry))
@@ -1080,8 +1093,9 @@ def main():
         pass_step_s = c["total_ms"] / launches / 1e3 * len(res["batches"])
         bpb = alg_bytes_per_base(h_raw, h_emit)
         achieved = n_bases * bpb / probe_step_s / 1e9
-        default_size = a.genome_mb is None and a.reads is None and not a.group_len
-        wkey = f"{res['wname']}:k{K}:{'full' if default_size else 'reduced'}"
+        full_genome = a.genome_mb is None and a.reads is None
+        default_size = full_genome and not a.group_len
+        wkey = f"{res['wname']}:k{K}:{'full' if default_size else f'group_len_{a.group_len}' if full_genome else 'reduced'}"
         traffic, tnote = traffic_for(wkey) if world == 1 else (None, None)
         n50 = synth_gpu.n50(res["rlen"]) if len(res["rlen"]) else 0
         out = {
@@ -1093,7 +1107,7 @@ def main():
                                 "note": "the same ranks over the same resident reads WITHOUT the carry exchange and the hit gather (every rank's batches "
                                         "through the one-GPU streaming engine, max over ranks): value / this = what the exchange + gather cost; "
                                         "this / n_gpus = the one-GPU rate of this workload"}} if res.get("solo") else {}),
-            "config": {"workload": (w["title"] if default_size else "REDUCED rehearsal (not the headline workload) of " + w["title"]) +
+            "config": {"workload": (w["title"] if full_genome else "REDUCED rehearsal (not the headline workload) of " + w["title"]) +
                                    f": {(a.genome_mb if a.genome_mb is not None else w['genome_mb']):g} Mb{' per haplotype' if w['kind'] == 'diploid' else ''} in 24 contigs, exact SUNK set, "
                                    f"{len(res['rlen'])} synthetic ONT reads per GPU, N50 {n50}, k={K}",
                        "reads_per_gpu": int(len(res["rlen"])), "bases_per_gpu": n_bases, "device_batches_per_gpu": len(res["batches"]),
@@ -1137,12 +1151,7 @@ def main():
         shards = [rank]
         bps = a.batches or 8
     res = run_workload(wname, shards, bps, a.steps, a.warmup, want_sample=True,
-                       want_chain=((world == 1 and not a.no_chain) or (world > 1 and a.sharded_chain)))
-    sharded = None
-    if world > 1 and a.sharded_chain and res.get("kept_sunks"):
-        lr = engine.LocRows.from_sunkset(res["kept_sunks"][0])
-        sharded = sharded_chain_leg(comm, res["table"], res["batches"], lr, res["kept_sunks"][1], device, rank * len(res["rlen"]))
-        lr.close()
+                       want_chain=((world == 1 and not a.no_chain) or (world > 1 and not a.no_sharded_chain)))
 
     out = None
     if rank == 0:
@@ -1216,15 +1225,41 @@ def main():
                 lr.close()
             except Exception as e:  # (a measurement leg must not cost the headline)
                 out["pair_stage"] = {"failed": repr(e)}
-        if sharded is not None:
-            out["pair_stage"] = sharded
-            out["pair_stage"]["workload"] = "every rank's own hit list of the headline workload (read-sharded second half)"
-            log(f"sharded pair stage: {sharded['rows_in']} rows on {world} ranks in {sharded['seconds_total']:.2f} s = {sharded['rows_per_s'] / 1e6:.1f} Mrow/s")
         if not a.no_engine and world == 1:
             try:
                 out.update(engine_leg(a, res["table"], res["batches"], device))
             except Exception as e:  # (a measurement leg must not cost the headline)
                 out["engine_note"] = f"engine leg failed: {e}"
+    # ---- N > 1: the read-sharded second half, AFTER everything the headline line needs has been measured.  Its collectives
+    # (all-reduce of the reads-per-SUNK counters, variable-size gather of the TSV rows) have never run on more than one GPU before
+    # the driver's scaling run: whatever happens here -- an exception on some rank, a collective that never returns -- the line
+    # still goes out, once, with what was measured before it, and every rank exits 0 (a watchdog THREAD: a main thread stuck in a
+    # C call never runs a signal handler) ----
+    line_written = threading.Lock()
+
+    def emit_line_and_exit(why):
+        if rank == 0 and line_written.acquire(blocking=False):
+            out["pair_stage"] = {"failed": why, "workload": "every rank's own hit list of the headline workload (read-sharded second half)"}
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os._exit(0)
+
+    if world > 1 and not a.no_sharded_chain and res.get("kept_sunks"):
+        watchdog = threading.Timer(a.sharded_chain_timeout, emit_line_and_exit, args=(f"gave up after {a.sharded_chain_timeout:g} s",))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            lr = engine.LocRows.from_sunkset(res["kept_sunks"][0])
+            sharded = sharded_chain_leg(comm, res["table"], res["batches"], lr, res["kept_sunks"][1], device, rank * len(res["rlen"]))
+            lr.close()
+        except BaseException as e:  # noqa: BLE001 (this rank leaves the run here: the others' watchdogs let them follow)
+            watchdog.cancel()
+            log(f"sharded pair stage failed on rank {rank}: {e!r}")
+            emit_line_and_exit(repr(e))
+        watchdog.cancel()
+        if rank == 0 and sharded is not None:
+            out["pair_stage"] = sharded
+            out["pair_stage"]["workload"] = "every rank's own hit list of the headline workload (read-sharded second half)"
+            log(f"sharded pair stage: {sharded['rows_in']} rows on {world} ranks in {sharded['seconds_total']:.2f} s = {sharded['rows_per_s'] / 1e6:.1f} Mrow/s")
     release(res)
     # ---- the other genome-scale workload as an extra key --------------------------------------------------------------
     if not a.no_extra and a.workload == "auto" and K == 20 and ((a.genome_mb is None and a.reads is None) or a.rehearse_extra) and not a.group_len:
@@ -1245,6 +1280,26 @@ def main():
                 out["diploid_strong"]["note"] = ("BASELINE.json configs[3]: the two-haplotype table replicated, the FIXED 40x read set (8 shards of ~15 Gbase, "
                                                  "~1.2e11 bases) cut over the ranks -- total work fixed, so this key scales strongly; divide by the N = 1 line's diploid_shard.value x 8 shards")
             release(ex)
+    # ---- every other BASELINE.json config, and the realistic group length, driver-timed (a few steps each) -------------
+    if not a.no_extra and a.workload == "auto" and K == 20 and a.genome_mb is None and a.reads is None and not a.group_len and world == 1:
+        for key, wname, k_, gl, note in (
+                ("config5_k21", "config5", 21, 0, "BASELINE.json configs[4] at k = 21 (config/config.yaml:2 sets the SUNK length)"),
+                ("config5_k25", "config5", 25, 0, "BASELINE.json configs[4] at k = 25"),
+                ("config3_group_len_200", "config3", 20, 200,
+                 "the headline genome with a 44-base interspersed element every 200 bases of unique sequence: location groups of ~157 SUNKs (7.75e6 groups) instead of "
+                 "~12 000 -- workflow/rules/defineSUNKs.smk:124-126 makes a group per merged interval, a real T2T haplotype sits between this and the headline")):
+            try:
+                K, a.group_len = k_, gl
+                ex = run_workload(wname, [0], 8, 3, 1, want_sample=False)
+                d = describe(ex, False)
+                out[key] = {k2: d[k2] for k2 in ("value", "unit", "ms_per_step", "config", "roofline")}
+                out[key]["steps"] = 3
+                out[key]["note"] = note
+                release(ex)
+            except Exception as e:  # (a measurement leg must not cost the headline)
+                out[key] = {"failed": repr(e)}
+            finally:
+                K, a.group_len = 20, 0
     if rank == 0:
         if not a.no_config2 and world == 1 and K == 20:
             out["config2"] = config2_leg(a, device)

@@ -185,6 +185,7 @@ SIGNATURES = {
     "gs_rowset_bad_keys_reduced": (I, [P, P, U32, P, P, P, P, P, C.POINTER(P)]),
     "gs_device_free": (I, [I, P]),
     "gs_device_pool_trim": (I, [I]),
+    "gs_selftest_inject_launch_error": (I, [I]),
     "gs_device_copy_to_host": (I, [I, P, P, U64]),
     "gs_device_copy_from_host": (I, [I, P, P, U64]),
     "gs_pairstage_from_rows": (I, [I, U64, P, P, P, U32, P, C.POINTER(P)]),

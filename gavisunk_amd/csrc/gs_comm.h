@@ -173,6 +173,27 @@ int table_receive_init(gs_table *t, int device, const TableMeta &hm) {
     return GS_OK;
 }
 
+// RCCL probes the pointers it is handed with hipPointerGetAttributes, which leaves hipErrorInvalidValue in this thread's last-error
+// slot although nothing failed; the next rocprim call (or a HIP_TRY(hipGetLastError()) after one of our launches) would report
+// it as its own.  It is dropped AFTER a collective -- that code and only that code.  A sticky error of our own earlier launches
+// must still fail the call: the slot is looked at BEFORE the collective, where nothing of RCCL's can be in it.
+int comm_enter(const char *who) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: an earlier HIP call on this thread failed: %s", who, hipGetErrorString(e));
+        return GS_E_NODEVICE;
+    }
+    return GS_OK;
+}
+int comm_leave(const char *who) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && e != hipErrorInvalidValue) {
+        set_error("%s: %s", who, hipGetErrorString(e));
+        return GS_E_NODEVICE;
+    }
+    return GS_OK;
+}
+
 // every rank contributes a status; all of them get the first non-zero one in rank order (0 = all fine)
 int comm_agree(Rccl *R, gs_comm *c, int mine, int *agreed) {
     *agreed = mine;
@@ -183,7 +204,7 @@ int comm_agree(Rccl *R, gs_comm *c, int mine, int *agreed) {
     std::vector<unsigned long long> all((size_t)c->nranks);
     HIP_TRY(hipMemcpyAsync(all.data(), c->d_meta, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipGetLastError();  // (see gs_gather_hits)
+    if (int rc = comm_leave("comm_agree")) return rc;
     *agreed = 0;
     for (int i = 0; i < c->nranks; i++)
         if ((long long)all[i] != 0) {
@@ -237,6 +258,7 @@ int gs_comm_init(int device, int nranks, int rank, const void *unique_id, gs_com
     Rccl *R = rccl();
     if (!R) return GS_E_NODEVICE;
     HIP_TRY(hipSetDevice(device));
+    if (int rc0 = comm_enter("gs_comm_init")) return rc0;
     auto *c = new gs_comm();
     std::unique_ptr<gs_comm, void (*)(gs_comm *)> guard(c, gs_comm_destroy);
     c->device = device;
@@ -248,7 +270,7 @@ int gs_comm_init(int device, int nranks, int rank, const void *unique_id, gs_com
     NCCL_TRY(R->CommInitRank(&c->comm, nranks, id, rank));
     int rc;
     if ((rc = dev_alloc(&c->d_meta, (uint64_t)4 * nranks))) return rc;
-    (void)hipGetLastError();  // (see gs_gather_hits)
+    if ((rc = comm_leave("gs_comm_init"))) return rc;
     *out = guard.release();
     return GS_OK;
 }
@@ -271,6 +293,7 @@ int gs_table_broadcast(gs_comm *c, int root, gs_table *mine, gs_table **out) {
         *out = mine;
         return GS_OK;
     }
+    if (int rce = comm_enter("gs_table_broadcast")) return rce;
     // the scalars first (through a device buffer: one collective, no second transport)
     TableMeta hm{};
     int rc = GS_OK;
@@ -310,7 +333,7 @@ int gs_table_broadcast(gs_comm *c, int root, gs_table *mine, gs_table **out) {
             NCCL_TRY(R->Broadcast(b + o, b + o, std::min<size_t>(piece, a.bytes - o), ncclUint8, root, c->comm, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipGetLastError();  // (see gs_gather_hits)
+    if (int rcl = comm_leave("gs_table_broadcast")) return rcl;
     if (!is_root) guard.release();
     *out = t;
     return GS_OK;
@@ -358,13 +381,13 @@ int gs_comm_allgather_u64(gs_comm *c, const uint64_t *mine, uint32_t n, uint64_t
     Rccl *R = rccl();
     if (!R) return GS_E_NODEVICE;
     HIP_TRY(hipSetDevice(c->device));
+    if (int rce = comm_enter("gs_comm_allgather_u64")) return rce;
     unsigned long long *seg = c->d_meta + (size_t)n * c->rank;
     HIP_TRY(hipMemcpyAsync(seg, mine, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     if (c->nranks > 1) NCCL_TRY(R->AllGather(seg, c->d_meta, n, ncclUint64, c->comm, c->stream));
     HIP_TRY(hipMemcpyAsync(out, c->d_meta, (size_t)n * c->nranks * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipGetLastError();  // (see gs_gather_hits)
-    return GS_OK;
+    return comm_leave("gs_comm_allgather_u64");
 }
 
 int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read_offset, gs_hit *out, uint64_t cap, uint64_t *n_out) {
@@ -379,7 +402,9 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
     // A rank whose pass failed -- a KeyError is data-dependent: one shard meets the db k-mer without loc row, the others do not
     // (kmerpos_annot3.nim:90) -- must not leave the others inside a collective: its status travels WITH the counts, every rank
     // takes part in the exchange of the meta, and all of them return the same code before any row is sent.
-    int st = check_pair(t, r, "gs_gather_hits");
+    // (a sticky error of an earlier launch of ours counts as this rank's failure and travels with the counts as well)
+    int st = comm_enter("gs_gather_hits");
+    if (!st) st = check_pair(t, r, "gs_gather_hits");
     if (!st) st = settle(t, r);
     if (!st && r->ps.res_keyerr) {
         set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
@@ -440,9 +465,10 @@ int gs_gather_hits(gs_comm *c, int root, gs_table *t, gs_reads *r, uint32_t read
         NCCL_TRY(R->Send(r->hits, (size_t)r->ps.res_n * sizeof(gs_hit), ncclUint8, root, c->comm, c->stream));
     }
     if (n > 1) NCCL_TRY(R->GroupEnd());
-    // (RCCL probes pointers with hipPointerGetAttributes and leaves "invalid argument" in this thread's last-error slot: dropped
-    // here, so that the check after OUR kernels below, and rocprim's own checks in later calls, see only our errors)
-    (void)hipGetLastError();
+    // (RCCL probes pointers with hipPointerGetAttributes and leaves "invalid argument" in this thread's last-error slot: that code
+    // is dropped here -- comm_leave -- so that the check after OUR kernels below, and rocprim's own checks in later calls, see only
+    // our errors)
+    if ((rc = comm_leave("gs_gather_hits"))) return rc;
     if (is_root) {
         uint64_t at = 0;
         for (int i = 0; i < n; i++) {  // shard-local read indices -> indices in the whole input
@@ -518,14 +544,15 @@ int gs_comm_allreduce_u32(gs_comm *c, void *d_buf, uint64_t n) {
     Rccl *R = rccl();
     if (!R) return GS_E_NODEVICE;
     HIP_TRY(hipSetDevice(c->device));
+    // (a failure here leaves the other ranks in the collective: callers agree on a status BEFORE they come here -- dist.py)
+    if (int rce = comm_enter("gs_comm_allreduce_u32")) return rce;
     const uint64_t piece = (uint64_t)1 << 28;  // 1 GiB of counters per collective
     for (uint64_t o = 0; o < n; o += piece) {
         uint32_t *b = static_cast<uint32_t *>(d_buf) + o;
         NCCL_TRY(R->AllReduce(b, b, (size_t)std::min(piece, n - o), ncclUint32, ncclSum, c->comm, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipGetLastError();  // (RCCL's own pointer probes leave "invalid argument" behind: not ours, and rocprim would report it)
-    return GS_OK;
+    return comm_leave("gs_comm_allreduce_u32");
 }
 // the same as a gs_reduce_u32_fn (gs_rowset_bad_keys_reduced): ctx = the communicator
 int gs_comm_reduce_u32(void *ctx, void *d_buf, uint64_t n) { return gs_comm_allreduce_u32(static_cast<gs_comm *>(ctx), d_buf, n); }
@@ -545,6 +572,8 @@ int gs_comm_gatherv_host(gs_comm *c, int root, const void *mine, uint64_t nbytes
     HIP_TRY(hipSetDevice(c->device));
     const int n = c->nranks;
     const bool is_root = c->rank == root;
+    if (!status) status = comm_enter("gs_comm_gatherv_host");  // (a sticky error of ours travels as this rank's status: nobody is left waiting)
+    else (void)hipGetLastError();
     const unsigned long long meta_mine[2] = {status ? 0ull : (unsigned long long)nbytes, (unsigned long long)(long long)status};
     HIP_TRY(hipMemcpyAsync(c->d_meta + 2 * c->rank, meta_mine, sizeof meta_mine, hipMemcpyHostToDevice, c->stream));
     if (n > 1) NCCL_TRY(R->AllGather(c->d_meta + 2 * c->rank, c->d_meta, 2, ncclUint64, c->comm, c->stream));
@@ -611,8 +640,7 @@ int gs_comm_gatherv_host(gs_comm *c, int root, const void *mine, uint64_t nbytes
         return GS_E_NODEVICE;
     }
     if (is_root) *out = host;
-    (void)hipGetLastError();
-    return GS_OK;
+    return comm_leave("gs_comm_gatherv_host");
 }
 
 // plain copies between host memory and device pointers this library handed out (the counters of gs_rowset_bad_keys_reduced when

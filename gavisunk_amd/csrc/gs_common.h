@@ -1,10 +1,13 @@
 // Internal declarations shared by the host (gs_host.cpp) and device (gs_device.hip) halves of
 // libgavisunk.so.  The public contract is include/gavisunk.h.
 #pragma once
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -70,6 +73,25 @@ constexpr int kTileWords = 64;
 
 void gs_advise_huge(void *p, size_t bytes);  // madvise(MADV_HUGEPAGE) (gs_host.cpp)
 
+// fn(t) for t = 0 .. T - 1, one thread per t beside the calling one (which takes t = 0).  A thread that cannot be started --
+// std::system_error under a pids / ulimit cap -- has its t run by the caller instead; the ones that were started are always joined
+// (an exception out of std::thread's constructor with joinable threads in the vector would end in std::terminate, or cross the C
+// boundary into ctypes).
+template <typename F>
+void gs_parallel_for(unsigned T, F fn) {
+    std::vector<std::thread> pool;
+    std::vector<unsigned> mine(1, 0u);
+    for (unsigned t = 1; t < T; t++) {
+        try {
+            pool.emplace_back(fn, t);
+        } catch (const std::system_error &) {
+            mine.push_back(t);
+        }
+    }
+    for (unsigned t : mine) fn(t);
+    for (auto &th : pool) th.join();
+}
+
 // std::vector for the row arrays of a parsed table (1e8 .. 1e9 entries each): resize() leaves the new elements uninitialised
 // (they are written right after, by several threads: no single-threaded zero fill, first touch in parallel), and allocations of
 // 4 MiB and more are 2 MiB-aligned and marked for transparent huge pages (a quarter of the page faults of 1e9 rows x 32 bytes)
@@ -117,7 +139,7 @@ struct gs_sunkdb {
     // arrays below (gs_sunkdb_keys / _key_row / _key_loc: the first call pays for it)
     HugeVec<uint64_t> db_codes;
     HugeVec<uint64_t> row_code;
-    bool joined = false;
+    std::atomic<bool> joined{false};  // (set under join_mu when the host join is complete; read without it by the accessors)
     std::mutex join_mu;
     std::vector<uint64_t> keys;     // distinct db codes, first-seen order
     std::vector<uint32_t> key_row;  // winning loc row or GS_MISSING

@@ -746,6 +746,8 @@ __global__ __launch_bounds__(256) void k_emit(TableView tab, CompactView ct, MzV
     }
 }
 
+__global__ void k_selftest_nop() {}
+
 // ------------------------------------------------------------------------------------------
 // table build
 // ------------------------------------------------------------------------------------------
@@ -2522,6 +2524,18 @@ int gs_tag_hits_device(gs_table *t, gs_reads *r, const void **d_hits, uint64_t *
         set_error("key not found: a read window is in the SUNK db but has no row in the loc table [KeyError]");
         return GS_E_KEYERROR;
     }
+    return GS_OK;
+}
+
+// (tests) a launch that fails -- a block of 4096 threads -- and leaves its error in this thread's last-error slot, as a failed launch
+// of ours would: the next entry point that checks the slot must report it (gs_comm_*: checked BEFORE a collective, csrc/gs_comm.h)
+int gs_selftest_inject_launch_error(int device) {
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_selftest_inject_launch_error: HIP device %d not available", device);
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_selftest_nop, dim3(1), dim3(4096), 0, 0);
     return GS_OK;
 }
 

@@ -581,10 +581,7 @@ static bool parse_db_parallel(const char *path, HugeVec<uint64_t> &codes, int &k
         }) ? 1 : 0;
     };
     {
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < T; t++) pool.emplace_back(work, t);
-        work(0);
-        for (auto &th : pool) th.join();
+        gs_parallel_for(T, work);
     }
     for (char o : okv)
         if (!o) return false;
@@ -605,10 +602,7 @@ static bool parse_db_parallel(const char *path, HugeVec<uint64_t> &codes, int &k
             if (!parts[t].empty()) memcpy(codes.data() + at[t], parts[t].data(), parts[t].size() * sizeof(uint64_t));
             HugeVec<uint64_t>().swap(parts[t]);
         };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < T; t++) pool.emplace_back(place, t);
-        place(0);
-        for (auto &th : pool) th.join();
+        gs_parallel_for(T, place);
     }
     return true;
 }
@@ -648,10 +642,7 @@ static int parse_loc_parallel(const char *path, gs_sunkdb *d, HugeVec<uint64_t> 
                 if (!o.err) parse_loc_part(b, e, o);
             }) ? 1 : 0;
         };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < T; t++) pool.emplace_back(work, t);
-        work(0);
-        for (auto &th : pool) th.join();
+        gs_parallel_for(T, work);
     }
     for (char o : okv)
         if (!o) return -1;
@@ -711,10 +702,7 @@ static int parse_loc_parallel(const char *path, gs_sunkdb *d, HugeVec<uint64_t> 
             }
             parts[t] = LocPart();  // (640 MB per 2e7 rows go back to the system here, on this thread)
         };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < T; t++) pool.emplace_back(place, t);
-        place(0);
-        for (auto &th : pool) th.join();
+        gs_parallel_for(T, place);
     }
     if (getenv("GAVISUNK_TIMING"))
         fprintf(stderr, "[sunkdb] loc: %u threads, parse %.3f s, munmap %.3f s, merge + place %.3f s\n", T, tp1 - tp0, tp2 - tp1, tnow() - tp2);
@@ -743,10 +731,7 @@ static void join_host(gs_sunkdb *d) {
         if (n < (1u << 16)) {
             for (unsigned p2 = 0; p2 < kMapParts; p2++) fn(p2);
         } else {
-            std::vector<std::thread> pool;
-            for (unsigned p2 = 1; p2 < kMapParts; p2++) pool.emplace_back(fn, p2);
-            fn(0);
-            for (auto &t : pool) t.join();
+            gs_parallel_for(kMapParts, fn);
         }
     };
     // distinct db codes, first occurrences, file order
@@ -796,10 +781,7 @@ static void join_host(gs_sunkdb *d) {
         }
     };
     const unsigned nthr = nk < (1u << 16) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nthr; t++) pool.emplace_back(join_range, nk * t / nthr, nk * (t + 1) / nthr);
-    join_range(0, nk / nthr);
-    for (auto &t : pool) t.join();
+    gs_parallel_for(nthr, [&](unsigned t) { join_range(nk * t / nthr, nk * (t + 1) / nthr); });
     HugeVec<uint64_t>().swap(d->row_code);
     d->joined = true;
 }
@@ -1244,6 +1226,10 @@ int gs_diag_filter_step2_files(const char *sunkpos_path, const char *diag_path, 
 // ------------------------------------------------------------------------------------- output rows
 // `name \t i \t chrom \t start \t group \n` (kmerpos_annot3.nim:93), formatted and written natively: a genome-scale pass emits
 // 1e7 .. 1e8 rows, far beyond what a per-row Python format survives.
+// (the pinned staging of the device formatter is gs_format.hip's: this default stands in where the host parsers are built alone --
+// tools/gz_asan.sh)
+__attribute__((weak)) void rowwriter_release_pinned(gs_rowwriter *) {}
+
 static inline char *put_u64(char *p, uint64_t v) {
     char tmp[24];
     int n = 0;

@@ -13,11 +13,13 @@
 //   resolve the last 32 KiB of every used piece, in order (each needs only the window before it), then all markers in parallel
 //           while the symbols are narrowed to bytes; CRC-32 and ISIZE of every gzip member are checked (pieces in parallel,
 //           combined), so a corrupt file fails like it does under zlib.
-// Anything unusual (no block found, a decode error on the proven path, a bad trailer) ends the parallel mode: the reader reports
-// it, and the caller falls back to zlib from the start of the file -- the result is byte-identical or the same error.
+// Anything unusual (a decode error on the proven path, a bad trailer, a failed check) fails the read: gs_gz_read returns GS_E_IO
+// (GS_E_NOMEM when memory runs out) where zlib would report a damaged file; the command line maps it to the reference's "cannot
+// open the file" exit (kmerpos_annot3.py).  There is no second reader behind this one.
 #include <zlib.h>
 
 #include <algorithm>
+#include <system_error>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -532,6 +534,7 @@ struct Piece {
 size_t skip_gzip_header(const uint8_t *p, size_t n, size_t pos) {
     if (pos + 10 > n || p[pos] != 0x1f || p[pos + 1] != 0x8b || p[pos + 2] != 8) return 0;
     const uint8_t flg = p[pos + 3];
+    if (flg & 0xE0) return 0;  // (reserved bits: zero in every gzip file, RFC 1952 2.3.1 -- and one more test of a member start found by search)
     size_t q = pos + 10;
     if (flg & 4) {  // FEXTRA
         if (q + 2 > n) return 0;
@@ -560,6 +563,7 @@ bool decode_blocks(const uint8_t *data, size_t n, Bits &b, Piece &pc, const std:
     RawVec<uint16_t> &out = pc.sym;
     size_t si = first_stop;
     BlockCodes dyn;
+    bool member_start = false;  // the position is the first block of a member whose header this loop has just read
     for (;;) {
         const uint64_t here = b.bitpos();
         if (stops) {
@@ -570,6 +574,14 @@ bool decode_blocks(const uint8_t *data, size_t n, Bits &b, Piece &pc, const std:
                 return true;
             }
         }
+        if (member_start && !one_block && out.size() - kWindow > max_symbols) {
+            // a member has ended and the next one's header has been read: as proven a boundary as a block start on the path --
+            // and in a file of many small members (bgzip: one final block per 64 KiB member) the only kind there is
+            pc.end_bit = here;
+            pc.budget_stop = true;
+            return true;
+        }
+        member_start = false;
         b.refill();
         const uint32_t bfinal = b.take(1), btype = b.take(2);
         if (btype == 3) {
@@ -709,21 +721,43 @@ bool decode_blocks(const uint8_t *data, size_t n, Bits &b, Piece &pc, const std:
                 return false;
             }
             b.seek((uint64_t)d0 * 8);
+            member_start = true;
         }
     }
 }
 
-// the first bit position in [from, to) where a non-final dynamic block starts that decodes as a whole
+// the first bit position in [from, to) where a piece can start: a non-final dynamic block that decodes as a whole, or the first
+// block of a gzip MEMBER (magic, a well-formed header, a block of any kind that decodes: files of many members -- bgzip writes one
+// final block per 64 KiB member -- have no non-final blocks to find).  Either is a candidate only: a start counts when the piece
+// before it lands on it.
 bool find_block(const uint8_t *data, size_t n, uint64_t from, uint64_t to, uint64_t *found) {
     Bits b;
     b.p = data;
     b.n = n;
     BlockCodes bc;
     Piece trial;
+    auto decodes = [&](uint64_t pos) {  // the whole block at `pos` (into a scratch piece: markers and all)
+        trial.sym.reserve(kWindow + (1u << 20));
+        trial.sym.resize(kWindow);
+        memset(trial.sym.data(), 0, kWindow * sizeof(uint16_t));
+        trial.members.clear();
+        trial.start_bit = pos;
+        trial.err.clear();
+        b.seek(pos);
+        if (!decode_blocks(data, n, b, trial, nullptr, 0, true, (size_t)1 << 24)) return false;
+        return trial.n_out() >= 64;  // (a real block of a big file is not this small; a false positive usually is)
+    };
     for (uint64_t pos = from; pos < to; pos++) {
-        // quick reject on the first 13 bits: BFINAL = 0, BTYPE = 2 (bits: 0, then 0 1), HLIT <= 29, HDIST <= 29
         const size_t by = (size_t)(pos >> 3);
         if (by + 4 > n) return false;
+        if (!(pos & 7) && data[by] == 0x1f && data[by + 1] == 0x8b && data[by + 2] == 8) {  // a member?
+            const size_t d0 = skip_gzip_header(data, n, by);
+            if (d0 && (uint64_t)d0 * 8 < to && decodes((uint64_t)d0 * 8)) {
+                *found = (uint64_t)d0 * 8;
+                return true;
+            }
+        }
+        // quick reject on the first 13 bits: BFINAL = 0, BTYPE = 2 (bits: 0, then 0 1), HLIT <= 29, HDIST <= 29
         uint32_t w;
         memcpy(&w, data + by, 4);
         w >>= (pos & 7);
@@ -732,16 +766,7 @@ bool find_block(const uint8_t *data, size_t n, uint64_t from, uint64_t to, uint6
         if (((w >> 8) & 31u) > 29u) continue;    // HDIST
         b.seek(pos + 3);
         if (!read_dynamic_header(b, bc)) continue;
-        // the whole block must decode (into a scratch piece: markers and all)
-        trial.sym.reserve(kWindow + (1u << 20));
-        trial.sym.resize(kWindow);
-        memset(trial.sym.data(), 0, kWindow * sizeof(uint16_t));
-        trial.members.clear();
-        trial.start_bit = pos;
-        trial.err.clear();
-        b.seek(pos);
-        if (!decode_blocks(data, n, b, trial, nullptr, 0, true, (size_t)1 << 24)) continue;
-        if (trial.n_out() < 64) continue;  // (a real block of a big file is not this small; a false positive usually is)
+        if (!decodes(pos)) continue;
         *found = pos;
         return true;
     }
@@ -867,6 +892,22 @@ struct gs_gzfile {
 };
 
 namespace {
+// `fn` on up to `want` threads beside the calling one (fn pulls its work from a shared counter, so any number of threads, the
+// calling thread alone included, finishes it).  A thread that cannot be created -- std::system_error under a pids / ulimit cap --
+// is simply not there; the ones that were are always joined.
+template <typename F>
+void run_on_threads(int want, F &fn) {
+    std::vector<std::thread> th;
+    try {
+        for (int t = 0; t < want; t++) th.emplace_back(fn);
+    } catch (const std::system_error &) {
+    }
+    fn();
+    for (auto &t : th) t.join();
+}
+}  // namespace
+
+namespace {
 
 // one group: up to `want` pieces of `piece_bytes` compressed bytes each, decoded in parallel, appended to z->out
 bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
@@ -907,7 +948,6 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
     pcs[0].found = true;
     pcs[0].start_bit = start;
     {
-        std::vector<std::thread> th;
         std::atomic<size_t> nexti{1};
         auto work = [&]() {
             for (;;) {
@@ -921,8 +961,8 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                 }
             }
         };
-        for (int t = 0; t < z->threads && (size_t)t + 1 < np; t++) th.emplace_back(guarded(work));
-        for (auto &t : th) t.join();
+        auto gw = guarded(work);
+        run_on_threads((int)std::min<size_t>((size_t)std::max(z->threads - 1, 0), np > 1 ? np - 2 : 0), gw);
     }
     if (oom.load()) throw std::bad_alloc();
     if (dbg) fprintf(stderr, "[gz] find %.3f s\n", now() - t0), t0 = now();
@@ -935,7 +975,6 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
         }
     // ---- decode
     {
-        std::vector<std::thread> th;
         std::atomic<size_t> nexti{0};
         auto work = [&]() {
             for (;;) {
@@ -956,8 +995,8 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                 pc.ok = decode_blocks(data, n, b, pc, &stops, fs, false, std::max<size_t>(piece_bytes * 32, (size_t)1 << 26));
             }
         };
-        for (int t = 0; t < z->threads && (size_t)t < np; t++) th.emplace_back(guarded(work));
-        for (auto &t : th) t.join();
+        auto gw = guarded(work);
+        run_on_threads((int)std::min<size_t>((size_t)std::max(z->threads - 1, 0), np ? np - 1 : 0), gw);
     }
     if (oom.load()) throw std::bad_alloc();
     if (dbg) fprintf(stderr, "[gz] decode %.3f s\n", now() - t0), t0 = now();
@@ -1020,7 +1059,6 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
     };
     std::vector<std::vector<SegCrc>> segs(chain.size());
     {
-        std::vector<std::thread> th;
         std::atomic<size_t> nextc{0};
         auto work = [&]() {
             for (;;) {
@@ -1076,8 +1114,8 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                 newlines.fetch_add(nl, std::memory_order_relaxed);
             }
         };
-        for (int t = 0; t < z->threads && (size_t)t < chain.size(); t++) th.emplace_back(guarded(work));
-        for (auto &t : th) t.join();
+        auto gw = guarded(work);
+        run_on_threads((int)std::min<size_t>((size_t)std::max(z->threads - 1, 0), chain.size() ? chain.size() - 1 : 0), gw);
     }
     if (oom.load()) throw std::bad_alloc();
     z->newlines += newlines.load();
@@ -1219,6 +1257,11 @@ int gs_gz_read(gs_gzfile *z, uint64_t want, const uint8_t *prefix, uint64_t pref
         z->err = "out of memory";
         set_error("gs_gz_read: out of memory");
         return GS_E_NOMEM;
+    } catch (const std::exception &e) {  // (nothing may cross the C boundary)
+        z->failed = true;
+        z->err = e.what();
+        set_error("gs_gz_read: %s", e.what());
+        return GS_E_IO;
     }
     *data = z->out.p;
     *n = z->out.n;

@@ -72,10 +72,7 @@ bool read_parallel(int fd, void *dst, size_t bytes, uint64_t off) {
             lo += (size_t)r;
         }
     };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < T; t++) pool.emplace_back(work, t);
-    work(0);
-    for (auto &th : pool) th.join();
+    gs_parallel_for(T, work);
     for (char o : okv)
         if (!o) return false;
     return true;

@@ -319,6 +319,9 @@ int gs_table_create_from_db(int device, const gs_sunkdb *db, gs_table **out) {
         return GS_E_ARG;
     }
     *out = nullptr;
+    // the lazy host join (gs_sunkdb_keys / _key_row / _key_loc from another thread) MOVES db_codes out and frees row_code under this
+    // mutex: the table is built from one consistent state of the handle, whichever it is
+    std::lock_guard<std::mutex> lock(const_cast<gs_sunkdb *>(db)->join_mu);
     if (db->joined)
         return gs_table_create(device, db->k, db->keys.size(), db->keys.data(), db->key_loc.data(), db->key_row.data(), out);
     if (gs_device_count() <= device || device < 0) {

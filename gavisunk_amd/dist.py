@@ -54,6 +54,24 @@ def resolve_carry(summaries: Sequence[Tuple[int, int]], rank: int, carry0: int =
     return int(carry0)
 
 
+PASS_FAILED = 2  # in the "has a raw hit" word of a phase-1 summary: this rank's pass failed before the exchange
+
+
+class RankFailed(RuntimeError):
+    """A rank of a read-sharded run failed before an exchange; raised on EVERY rank after it."""
+
+
+def checked_summaries(comm, has_raw: int, last_loc: int, error: BaseException | None = None):
+    """The one exchange of a read-sharded pass with a status in it: a rank whose phase 1 failed (`error`) still takes part -- its
+    `has a raw hit` word says PASS_FAILED -- and every rank raises RankFailed after the exchange, so that all of them leave the run
+    (exit code != 0) instead of waiting in the next collective for a rank that is gone.  -> the summaries of all ranks."""
+    summ = comm.exchange_summaries(PASS_FAILED if error is not None else has_raw, last_loc)
+    failed = [r for r, (h, _) in enumerate(summ) if h == PASS_FAILED]
+    if failed:
+        raise RankFailed(f"the tagging pass of rank(s) {failed} failed before the carry exchange" + (f": {error}" if error is not None else "")) from error
+    return summ
+
+
 class Comm:
     """One rank of a read-sharded run.  Control plane = torch.distributed over gloo (rendezvous, barrier, the 8-byte phase-1
     summaries, scalars); data plane = RCCL behind the C-ABI (gs_comm_*: table broadcast, hit gather) when `rccl`.
@@ -234,18 +252,34 @@ def sharded_second_half(comm: Comm, rows, contig_names, in_fai, key_hap, name_gr
         if code:
             raise err if err is not None else GsError(int(code) - (1 << 32), f"the diagonal filter of rank {r} failed")
     cap_in = carried_capacity([m[0] for m in meta], comm.rank)
-    if cap_in > 64:  # (a read with more than 43 distinct contigs somewhere before this shard: rare, and exact either way)
-        *diag, kept, _ = rows.diag_filter(contig_names, in_fai, cap_in=cap_in, want_cap=True)
-    rows.keep_filtered()
-    bad, meancov, d_bad = engine.RowSet.bad_keys(rows, other_hap if other_hap is not None else rows, key_hap, keep_on_device=True,
-                                                 reduce=comm.reducer())
+    # every step between two exchanges runs under the same rule: a rank that fails keeps walking the SAME sequence of collectives as
+    # the others, carrying its status, and all ranks raise together at the next agreement -- nobody waits inside a collective for a
+    # rank that has left
+    try:
+        if cap_in > 64:  # (a read with more than 43 distinct contigs somewhere before this shard: rare, and exact either way)
+            *diag, kept, _ = rows.diag_filter(contig_names, in_fai, cap_in=cap_in, want_cap=True)
+        rows.keep_filtered()
+    except GsError as e:
+        status, err = e.status, e
+    meta = comm.exchange_summaries(0, status & 0xFFFFFFFF)  # agreed BEFORE the counters' all-reduce
+    for r, (_, code) in enumerate(meta):
+        if code:
+            raise err if err is not None else GsError(int(code) - (1 << 32), f"step 2 of rank {r} failed")
+    bad = meancov = d_bad = None
+    try:  # (gs_rowset_bad_keys_reduced enters the reduce once per haplotype whatever happens locally)
+        bad, meancov, d_bad = engine.RowSet.bad_keys(rows, other_hap if other_hap is not None else rows, key_hap, keep_on_device=True,
+                                                     reduce=comm.reducer())
+    except GsError as e:
+        status, err = e.status, e
     res = None
     try:
-        res = rows.pair_stage(name_grank, name_long, d_key_bad=d_bad)
+        if not status:
+            res = rows.pair_stage(name_grank, name_long, d_key_bad=d_bad)
     except GsError as e:
         status, err = e.status, e
     finally:
-        engine.free_device(d_bad, rows.device)
+        if d_bad:
+            engine.free_device(d_bad, rows.device)
     # this rank's TSV rows (read index in the whole input, global name rank) and its input contigs, in one message
     t = len(res["row_id"]) if res is not None else 0
     rec = np.zeros(t, ROW_DTYPE)

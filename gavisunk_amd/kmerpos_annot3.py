@@ -350,6 +350,14 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
         except OSError as e:
             sys.stderr.write(f"cannot open the file {reads}: {e}\n")
             rc = 1
+        except _lib.GsError as e:
+            # the native gzip reader refuses a damaged / truncated .gz (GS_E_IO) or runs out of memory on it (GS_E_NOMEM) where
+            # gzip.open raised BadGzipFile, an OSError: the same message and exit code (what was written so far stays, as it
+            # does when the reference dies in the middle of a file)
+            if e.status not in (_lib.GS_E_IO, _lib.GS_E_NOMEM):
+                raise
+            sys.stderr.write(f"cannot open the file {reads}: {e.msg}\n")
+            rc = 1
         blocks.close()
         if rc is None:
             batches = _Prefetch(reads, batch_bases)

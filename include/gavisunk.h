@@ -589,6 +589,9 @@ int gs_rowset_bad_keys_reduced(const gs_rowset *hap1, const gs_rowset *hap2, uin
 int gs_device_free(int device, void *p);
 /* The second half keeps its device temporaries in a pool between calls (csrc/gs_devpool.h): hand the idle ones back to the driver. */
 int gs_device_pool_trim(int device);
+/* (tests) makes a kernel launch fail on this thread: the error stays in HIP's last-error slot, as a failed launch of the library's
+ * own would; the gs_comm_* entry points look at the slot BEFORE their collectives and fail on it. */
+int gs_selftest_inject_launch_error(int device);
 int gs_device_copy_to_host(int device, void *host, const void *d_src, uint64_t nbytes);
 int gs_device_copy_from_host(int device, void *d_dst, const void *host, uint64_t nbytes);
 /* process-by-contig_lowmem_AR.py:50-260 over a row set (rows of several contigs are handled contig by contig, like the

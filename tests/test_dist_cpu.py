@@ -131,3 +131,48 @@ def test_comm_control_plane(world, tmp_path):
     out = str(tmp_path / "ok.npy")
     mp.spawn(_ctrl_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert np.load(out).all()
+
+
+def _failing_worker(rank, world, port, out_dir):
+    """Two passes: the first is fine; in the second, rank 1's phase 1 fails (as a GsError of a kernel launch or an allocation would).
+    It still takes part in the exchange, with the status word; EVERY rank raises after it and exits non-zero."""
+    import sys
+    import time
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = gdist.Comm(device=0, rccl=False)
+    t0 = time.time()
+    summ = gdist.checked_summaries(comm, rank % 2, 7 + rank)
+    assert summ == [(r % 2, 7 + r) for r in range(world)]
+    try:
+        gdist.checked_summaries(comm, 1, 3, error=RuntimeError("injected: phase 1 failed") if rank == 1 else None)
+    except gdist.RankFailed as e:
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write(f"{time.time() - t0:.3f}\n{e}\n")
+        dist.destroy_process_group()
+        sys.exit(3)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write("no error raised\n")
+
+
+def test_a_failing_rank_takes_every_rank_down_in_bounded_time(tmp_path):
+    """bench.py --gpus N / dist.py: the ONE exchange of a pass carries a status word; a rank whose pass failed before it poisons its
+    summary instead of leaving, so no rank is left waiting inside a collective (gloo's default timeout is 30 minutes)."""
+    import time
+
+    world = 3
+    t0 = time.time()
+    ctx = mp.spawn(_failing_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
+    deadline = t0 + 120
+    while any(p.is_alive() for p in ctx.processes) and time.time() < deadline:
+        time.sleep(0.2)
+    alive = [p.is_alive() for p in ctx.processes]
+    for p in ctx.processes:
+        if p.is_alive():
+            p.kill()
+    assert not any(alive), "a rank was still waiting two minutes after another one had failed"
+    assert [p.exitcode for p in ctx.processes] == [3, 3, 3]
+    for r in range(world):
+        secs, msg = (tmp_path / f"rank{r}.txt").read_text().split("\n", 1)
+        assert float(secs) < 60 and "rank(s) [1]" in msg

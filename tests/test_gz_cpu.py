@@ -134,3 +134,37 @@ def test_fuzz_slice(tmp_path):
             os.environ.pop("GAVISUNK_GZ_PIECE_KB", None)
         else:
             os.environ["GAVISUNK_GZ_PIECE_KB"] = old
+
+
+def test_bgzf_shaped_files_are_read_in_parallel_and_in_bounded_calls(tmp_path):
+    """bgzip / BGZF -- the usual packaging of ONT .fq.gz -- is a file of thousands of gzip members, each ONE final block of at most
+    64 KiB: there is no non-final dynamic block for the finder to find.  Member starts are piece starts too, and a member's end
+    is a place to stop a read call: several pieces per call, calls of bounded size (the whole file used to come back from one)."""
+    rnd = random.Random(9)
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, rnd.randbytes(n := rnd.randint(200, 4000)).translate(ACGT), b"#" * n) for i in range(6000))
+    blob = b"".join(_gz(text[i:i + 65280], 6, mtime=0) for i in range(0, len(text), 65280)) + _gz(b"", 6, mtime=0)
+    p = tmp_path / "bgzf.fq.gz"
+    p.write_bytes(blob)
+    L = _lib.lib()
+    os.environ["GAVISUNK_GZ_PIECE_KB"] = "256"
+    try:
+        z = C.c_void_p()
+        _lib.check(L.gs_gz_open(str(p).encode(), 4, C.byref(z)))
+        want, sizes, out = 2 << 20, [], []
+        while True:
+            q, n = C.c_void_p(), C.c_uint64(0)
+            _lib.check(L.gs_gz_read(z, want, None, 0, C.byref(q), C.byref(n)))
+            if n.value:
+                out.append(C.string_at(q.value, n.value))
+                sizes.append(n.value)
+            L.gs_gz_free_buffer(q)
+            if not n.value or L.gs_gz_at_end(z):
+                break
+        d = C.c_uint64(0)
+        used = L.gs_gz_pieces(z, C.byref(d))
+        L.gs_gz_close(z)
+    finally:
+        del os.environ["GAVISUNK_GZ_PIECE_KB"]
+    assert b"".join(out) == text and len(text) > 20_000_000
+    assert len(sizes) >= 4 and max(sizes) < 16 << 20, sizes  # (calls of about `want`, not one call of everything)
+    assert used >= 2 * len(sizes)                             # (several pieces per call: the members were found)

@@ -39,6 +39,8 @@ files = {
     "members.gz": b"".join(gzip.compress(seq[a:a + 1_500_000], 1) for a in range(0, len(seq), 1_500_000)),
     "mixed.gz": gzip.compress(text[:3_000_000], 6) + gzip.compress(rand[:500_000], 0) + gzip.compress(seq[:5_000_000], 1) + gzip.compress(b"", 6),
     "tiny.gz": gzip.compress(b"@r\nACGT\n+\n####\n", 6), "empty.gz": gzip.compress(b"", 6),
+    # bgzip's shape: thousands of members of one final block each (member starts are the only piece starts there are)
+    "bgzf.gz": b"".join(gzip.compress(seq[a:a + 65280], 6) for a in range(0, 12_000_000, 65280)) + gzip.compress(b"", 6),
 }
 for k, v in files.items():
     open(os.path.join(d, k), "wb").write(v)
@@ -50,7 +52,7 @@ open(os.path.join(d, "bad_crc.gz"), "wb").write(bytes(crc))
 print("files:", " ".join(sorted(os.listdir(d))))
 PY
 export GAVISUNK_GZ_PIECE_KB=256 ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1
-for f in seq1 seq6 seq9 text6 fixed huff stored rand6 sync members mixed tiny empty; do
+for f in seq1 seq6 seq9 text6 fixed huff stored rand6 sync members mixed tiny empty bgzf; do
     for t in 1 3 8; do
         "$D/gz_asan_main" "$D/$f.gz" $t 1000000
     done
