@@ -39,6 +39,7 @@ SIGNATURES = {
     "gs_version": (C.c_char_p, []),
     "gs_device_count": (I, []),
     "gs_device_synchronize": (I, [I]),
+    "gs_device_blocking_sync": (I, [I, I]),
     "gs_selftest_minimizer_rule": (I, [I, I, I, U64, U32, C.POINTER(U64), C.POINTER(U32), C.POINTER(U32)]),
     "gs_sunkdb_load": (I, [C.c_char_p, C.c_char_p, C.POINTER(P)]),
     "gs_sunkdb_free": (None, [P]),

@@ -1697,6 +1697,20 @@ int gs_device_synchronize(int device) {
     return GS_OK;
 }
 
+// How this process waits for the device: HIP's default is to SPIN (lowest latency: what the engine and bench.py want).  A command line
+// whose host side is the bottleneck -- kmerpos_annot3 on a .fq.gz: every CPU of the box's quota inflates, while the main, staging
+// and writer threads each burn one waiting for a copy or a kernel -- asks for blocking waits instead.  Call before anything else
+// touches the device.
+int gs_device_blocking_sync(int device, int on) {
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_device_blocking_sync: HIP device %d not available", device);
+        return GS_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleSpin));
+    return GS_OK;
+}
+
 #ifdef GS_TUNING
 // (libgavisunk_tuning.so only; not in include/gavisunk.h) the census counters of k_probe_mz (gs_mz.h: g_mz_census) of `device`
 int gs_tuning_census(int device, uint64_t out[16], int reset) {

@@ -318,6 +318,12 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
     host_parse = os.environ.get("GAVISUNK_PARSE", "device") == "host"
     last_timing.clear()
     t_run = time.perf_counter()
+    if reads.endswith(".gz") and os.environ.get("GAVISUNK_SPIN") != "1":
+        # a compressed read file is inflated by every CPU the box gives us (the critical path at genome scale): the main, staging and
+        # writer threads wait for the device by blocking, not by spinning on a core each
+        blocking = _lib.lib().gs_device_blocking_sync(device, 1) == 0
+    else:
+        blocking = False
     batches = _Prefetch(reads, batch_bases) if host_parse else None
     blocks = None if host_parse else _Prefetch(reads, min(batch_bases, 1 << 30), text=True, device=device)  # (read and copied meanwhile)
     try:
@@ -367,6 +373,8 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
         batches.close()
     table.close()
     db.close()
+    if blocking:  # (a caller that goes on in this process -- bench.py -- gets its spinning waits back)
+        _lib.lib().gs_device_blocking_sync(device, 0)
     return rc
 
 

@@ -46,6 +46,9 @@ const char *gs_version(void);
 int gs_device_count(void);
 /* hipDeviceSynchronize on `device`: everything the library (or RCCL through gs_comm_*) enqueued there has finished */
 int gs_device_synchronize(int device);
+/* on != 0: this process waits for the device by blocking instead of spinning (hipDeviceScheduleBlockingSync): for command lines whose
+ * host threads need every CPU (the .fq.gz reader); call before anything else touches the device.  The engine's default is to spin. */
+int gs_device_blocking_sync(int device, int on);
 /* Self-test of the minimiser-addressed table's window -> region rule (gs_mz.h): on `n_tiles` tiles of 2048 windows of
  * pseudo-random and low-complexity sequence (from `seed`), the wave-parallel sliding form the tagging kernel uses is compared
  * with the rule applied window by window (the form the table build uses).  *mismatches = windows that differ (0 = pass);

@@ -201,6 +201,16 @@ def test_rccl_exchanges_with_one_rank():
         rs.close()
         got = comm.gatherv(np.arange(10, dtype=np.uint32))
         assert len(got) == 1 and np.array_equal(got[0].view(np.uint32), np.arange(10, dtype=np.uint32))
+        # a failed launch of OURS before a collective must fail the call (the slot is looked at before RCCL can write its probe's
+        # "invalid argument" into it; only that code is dropped afterwards), and the call after it is clean again
+        from gavisunk_amd import _lib
+        L = _lib.lib()
+        for call in (lambda: comm.gatherv(np.arange(4, dtype=np.uint32)), lambda: comm.exchange_summaries(1, 2)):
+            _lib.check(L.gs_selftest_inject_launch_error(0))
+            with pytest.raises(_lib.GsError) as e:
+                call()
+            assert e.value.status == _lib.GS_E_NODEVICE
+            call()
         comm.rccl.close()
         comm.rccl = None
     finally:
