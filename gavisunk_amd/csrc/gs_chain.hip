@@ -69,6 +69,19 @@ hipStream_t gs::chain_stream(int device) {
         // the highest priority the device offers: the chain is a string of short kernels that wait for each other (and for the host
         // between them); beside a tagging pass whose probe kernels fill every CU (all 160 KiB of LDS included) they would otherwise
         // queue behind workgroups of a kernel that is bound by the memory system's request rate, not by the CUs it holds
+        // (experiment knob: the chain confined to N of the CUs, every (CUs / N)-th one -- see profiles/r05)
+        if (const char *e = getenv("GAVISUNK_CHAIN_CUS")) {
+            hipDeviceProp_t prop;
+            const int want = atoi(e);
+            if (want > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && want < prop.multiProcessorCount) {
+                const int ncu = prop.multiProcessorCount, step = std::max(ncu / want, 1);
+                std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+                for (int i = 0; i < ncu; i += step) mask[(size_t)i / 32] |= 1u << (i % 32);
+                if (hipExtStreamCreateWithCUMask(&p.stream, (uint32_t)mask.size(), mask.data()) == hipSuccess) return p.stream;
+                (void)hipGetLastError();
+                p.stream = nullptr;
+            }
+        }
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
         if (getenv("GAVISUNK_CHAIN_PRIORITY") && !atoi(getenv("GAVISUNK_CHAIN_PRIORITY"))) greatest = least;  // (A/B knob of the timing experiments)

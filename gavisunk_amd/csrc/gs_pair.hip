@@ -45,7 +45,62 @@ __device__ __forceinline__ bool pair_kept(int64_t pi, int64_t pj, int64_t si, in
 
 // The three kernels take one workgroup per read.  A read has tens of rows on a haploid genome and hundreds to thousands on a
 // diploid one: the reads of a chunk are split by size (`list`), 64 threads for those of up to kSmallRead rows, 256 for the others.
-constexpr int kSmallRead = 96;
+constexpr int kSmallRead = 64;
+
+// reads of at most 64 rows, one wave each: lane i holds row i; the pair test (an fp64 division per pair: the cost of this stage) is
+// made ONCE -- lane i walks all j by cross-lane reads and keeps two 64-bit masks, "pair (i, j) kept" and "pos[i] > pos[j]" -- and
+// orientation, edge counts and (k_pair_edges_small) the ordered edge list all come from the masks.  (The general form below tests
+// every pair three times.)
+__global__ __launch_bounds__(64) void k_pair_count_small(const uint32_t *list, const uint64_t *read_off, const int64_t *pos, const int64_t *start,
+                                                         uint32_t *row_edges, uint8_t *orient, uint8_t *any_kept, uint64_t *edge_mask) {
+    const uint32_t r = list[blockIdx.x];
+    const uint64_t lo = read_off[r];
+    const int n = (int)(read_off[r + 1] - lo);
+    const int i = threadIdx.x;
+    int64_t pi = 0, si = 0;
+    if (i < n) {
+        pi = pos[lo + i];
+        si = start[lo + i];
+    }
+    uint64_t kept = 0, dir = 0;
+    for (int j = 1; j < n; j++) {  // wave-uniform trip count
+        const int64_t pj = __shfl(pi, j, 64), sj = __shfl(si, j, 64);
+        if (i < j) {
+            if (pair_kept(pi, pj, si, sj)) kept |= 1ULL << j;
+            if (pi > pj) dir |= 1ULL << j;
+        }
+    }
+    uint32_t ones = (uint32_t)__popcll(kept & dir), zeros = (uint32_t)__popcll(kept & ~dir);
+    for (int o = 32; o > 0; o >>= 1) {
+        ones += __shfl_xor((int)ones, o, 64);
+        zeros += __shfl_xor((int)zeros, o, 64);
+    }
+    const bool o = ones > zeros;  // np.unique sorts [0, 1]; argmax takes the first maximum -> tie gives 0
+    if (i == 0) {
+        orient[r] = o ? 1 : 0;
+        any_kept[r] = (ones + zeros) > 0 ? 1 : 0;
+    }
+    if (i < n) {
+        const uint64_t m = kept & (o ? dir : ~dir);
+        row_edges[lo + i] = (uint32_t)__popcll(m);
+        edge_mask[lo + i] = m;
+    }
+}
+__global__ __launch_bounds__(64) void k_pair_edges_small(const uint32_t *list, const uint64_t *read_off, const uint64_t *edge_mask,
+                                                         const uint64_t *row_edge_off, uint32_t *edge_i, uint32_t *edge_j) {
+    const uint32_t r = list[blockIdx.x];
+    const uint64_t lo = read_off[r];
+    const int n = (int)(read_off[r + 1] - lo);
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    uint64_t w = row_edge_off[lo + i], m = edge_mask[lo + i];
+    while (m) {  // the surviving pairs of row i in j order = the order of `sub2`'s rows (:157-158)
+        edge_i[w] = (uint32_t)i;
+        edge_j[w] = (uint32_t)(__ffsll((long long)m) - 1);
+        w++;
+        m &= m - 1;
+    }
+}
 
 template <int kPairThreads>
 __global__ __launch_bounds__(kPairThreads) void k_pair_count(const uint32_t *list, const uint64_t *read_off, const int64_t *pos, const int64_t *start,
@@ -138,9 +193,30 @@ __global__ __launch_bounds__(kGraphThreads) void k_pair_graph(const uint32_t *li
     if (n < 2 || !any_kept[r]) return;  // `if sum(mask) < 1: continue` (:148)
     const uint64_t e0 = row_edge_off[lo], e1 = row_edge_off[lo + n];
     const uint64_t E = e1 - e0;
+    // The per-row arrays: global scratch for the 256-thread form (reads of any length); LDS for the 64-thread form, whose reads have at
+    // most kSmallRead rows -- its phases are O(n^2) loops of DEPENDENT loads over these arrays, bound by their latency (3.3 ms for
+    // 3.6e5 reads of ~18 rows with them in global memory).  (Surviving pairs stay in global memory: up to n (n - 1) / 2 per read.)
+    __shared__ int64_t s_i64[kGraphThreads == 64 ? 3 : 1][kGraphThreads == 64 ? kSmallRead : 1];
+    __shared__ uint32_t s_u32[kGraphThreads == 64 ? 6 : 1][kGraphThreads == 64 ? kSmallRead : 1];
     const int64_t *P = pos + lo, *ID = id + lo;
     uint32_t *dg = deg + lo, *rk = rank + lo, *vt = vert + lo, *pa = parent + lo, *cs = csize + lo, *ap = app + lo;
     int64_t *gp = goodpos_of + lo;
+    if constexpr (kGraphThreads == 64) {
+        for (int i = tid; i < n; i += kGraphThreads) {
+            s_i64[0][i] = P[i];
+            s_i64[1][i] = ID[i];
+        }
+        P = s_i64[0];
+        ID = s_i64[1];
+        gp = s_i64[2];
+        dg = s_u32[0];
+        rk = s_u32[1];
+        vt = s_u32[2];
+        pa = s_u32[3];
+        cs = s_u32[4];
+        ap = s_u32[5];
+        __syncthreads();
+    }
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     for (int i = tid; i < n; i += kGraphThreads) {
         dg[i] = 0;
@@ -349,7 +425,8 @@ int gs::pair_component_device(int device, uint32_t n_reads, uint64_t n_rows, con
     HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_rowe64, d_scan, (uint64_t)0, (size_t)max_rows + 1, rocprim::plus<uint64_t>(), st));
     uint8_t *d_tmp;
     uint32_t *d_list;
-    if ((rc = db.get(&d_tmp, tb)) || (rc = db.get(&d_list, n_reads))) return rc;
+    uint64_t *d_emask;
+    if ((rc = db.get(&d_tmp, tb)) || (rc = db.get(&d_list, n_reads)) || (rc = db.get(&d_emask, n_rows))) return rc;
     std::vector<uint32_t> lists(n_reads);
     uint32_t *d_ei = nullptr, *d_ej = nullptr;
     uint8_t *d_bad = nullptr;
@@ -379,7 +456,7 @@ int gs::pair_component_device(int device, uint32_t n_reads, uint64_t n_rows, con
             set_error("gs_pair_component: %s", hipGetErrorString(e));
             return GS_E_NODEVICE;
         }
-        if (n_small) hipLaunchKernelGGL(k_pair_count<64>, dim3(n_small), dim3(64), 0, st, d_list, d_off, d_pos, d_start, d_rowe, d_orient, d_any);
+        if (n_small) hipLaunchKernelGGL(k_pair_count_small, dim3(n_small), dim3(64), 0, st, d_list, d_off, d_pos, d_start, d_rowe, d_orient, d_any, d_emask);
         if (n_big) hipLaunchKernelGGL(k_pair_count<256>, dim3(n_big), dim3(256), 0, st, d_list + n_small, d_off, d_pos, d_start, d_rowe, d_orient, d_any);
         // surviving pairs per row -> their offsets in the chunk's edge list (exclusive scan, on the device)
         hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, st, d_rowe + lo, d_rowe64, rows);
@@ -408,7 +485,7 @@ int gs::pair_component_device(int device, uint32_t n_reads, uint64_t n_rows, con
             }
         }
         if (n_small) {
-            hipLaunchKernelGGL(k_pair_edges<64>, dim3(n_small), dim3(64), 0, st, d_list, d_off, d_pos, d_start, d_orient, d_reoff, d_ei, d_ej);
+            hipLaunchKernelGGL(k_pair_edges_small, dim3(n_small), dim3(64), 0, st, d_list, d_off, d_emask, d_reoff, d_ei, d_ej);
             hipLaunchKernelGGL(k_pair_graph<64>, dim3(n_small), dim3(64), 0, st, d_list, d_off, d_pos, d_id, d_any, d_reoff, d_ei, d_ej, d_bad, d_deg,
                                d_rank, d_vert, d_parent, d_size, d_app, d_gp, d_out, d_outn);
         }

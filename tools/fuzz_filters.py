@@ -24,7 +24,8 @@ def fuzz_diag(seed, tmp):
     in_fai = contigs[:ncontig]
     rows = []
     for r in range(int(rng.integers(1, 400))):
-        n = int(rng.integers(1, int(rng.choice([3, 12, 60, 200]))))
+        # (gs_diag.hip takes a read by its row count: <= 128 / 256 / 512 / 1024 rows in LDS, longer ones in global scratch)
+        n = int(rng.integers(1, int(rng.choice([3, 12, 60, 200, 3, 12, 60, 200, 3, 12, 60, 200, 130, 300, 700, 1500, 3000]))))
         picks = rng.choice(len(contigs), size=int(rng.integers(1, min(len(contigs), 48) + 1)), replace=False)
         base = int(rng.integers(0, 10**6))
         pos = 0

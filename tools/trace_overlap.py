@@ -42,7 +42,12 @@ for n in sorted(set(alone) | set(beside), key=lambda n: -(alone[n][1] + beside[n
     if a[1] + b[1] < 2e5:
         continue
     print(f"{n:42s} {a[0]:5d} {a[1] / max(a[0], 1) / 1e3:10.1f} | {b[0]:5d} {b[1] / max(b[0], 1) / 1e3:10.1f}")
-print("\nprobe launches: start ms, duration ms, chain-kernel ms inside")
+print("\nprobe launches: start ms, duration ms, chain-kernel ms inside | the chain kernels that ran inside it (ms of overlap)")
 for ps, pe in probes[-40:]:
-    inside = sum(min(e, pe) - max(s, ps) for s, e, n in chain if e > ps and s < pe)
-    print(f"{(ps - t0) / 1e6:10.1f} {(pe - ps) / 1e6:8.2f} {inside / 1e6:8.2f}")
+    ov = defaultdict(float)
+    for s, e, n in chain:
+        if e > ps and s < pe:
+            ov[n] += (min(e, pe) - max(s, ps)) / 1e6
+    inside = sum(ov.values())
+    top = ", ".join(f"{n} {v:.1f}" for n, v in sorted(ov.items(), key=lambda kv: -kv[1])[:7] if v >= 0.2)
+    print(f"{(ps - t0) / 1e6:10.1f} {(pe - ps) / 1e6:8.2f} {inside / 1e6 * 1e6:8.2f} | {top}")
