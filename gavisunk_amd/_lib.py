@@ -78,6 +78,13 @@ SIGNATURES = {
     "gs_gz_mode": (C.c_char_p, [P]),
     "gs_gz_pieces": (U64, [P, C.POINTER(U64)]),
     "gs_gz_close": (None, [P]),
+    "gs_bgzf_open": (I, [C.c_char_p, I, C.POINTER(P)]),
+    "gs_bgzf_next": (I, [P, U64, C.POINTER(P)]),
+    "gs_bgzf_at_end": (I, [P]),
+    "gs_bgzf_bytes_in": (U64, [P]),
+    "gs_bgzf_close": (None, [P]),
+    "gs_textstage_names": (I, [P, P, P, U32, P, P]),
+    "gs_textstage_copy": (I, [P, P, U64, C.POINTER(U64)]),
     "gs_text_record_cut": (U64, [P, U64]),
     "gs_gz_newlines": (U64, [P]),
     "gs_text_record_cut_counted": (U64, [P, U64, U64]),

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgavisunk.so")
 LIB_TUNING = os.path.join(HERE, "libgavisunk_tuning.so")  # -DGS_TUNING: experiment switches for tools/ (never shipped, never loaded by default)
-SOURCES = ["gs_device.hip", "gs_filter.hip", "gs_pair.hip", "gs_chain.hip", "gs_diag.hip", "gs_format.hip", "gs_sunkdef.hip", "gs_ingest.hip", "gs_host.cpp", "gs_inflate.cpp"]
+SOURCES = ["gs_device.hip", "gs_filter.hip", "gs_pair.hip", "gs_chain.hip", "gs_diag.hip", "gs_format.hip", "gs_sunkdef.hip", "gs_ingest.hip", "gs_bgzf.hip", "gs_host.cpp", "gs_inflate.cpp"]
 LIB_SYNTH = os.path.join(HERE, "libgssynth.so")  # bench / test support: synthetic inputs generated on the GPU (gs_synth.hip)
 
 

@@ -1,0 +1,962 @@
+// DEFLATE on the GPU for BGZF-shaped `.fq.gz`: the read files rule SUNK_annot is given (workflow/rules/tagONT.smk:17,36) come out of
+// `seqtk seq -F '#' | rustybam fastq-split`, whose `.gz` writer is bgzip's format -- a gzip file of thousands of MEMBERS, each at
+// most 64 KiB of text in (usually) one final block, its compressed size in the header's `BC` extra field and its inflated size in
+// the trailer.  Everything a parallel decoder wants is therefore known before a single Huffman code is read: where every member's
+// deflate data starts, and where its text goes.  So
+//   * the host only walks the headers of a chunk of the file (pread into pinned memory, 18 bytes looked at per member) and hands the
+//     compressed bytes to the device: 3 GB cross PCIe instead of the 20 GB of text they hold;
+//   * k_bgzf_inflate: ONE LANE PER MEMBER.  A lane builds its block's Huffman tables in its own columns of the wave's LDS (lit/len:
+//     8-bit direct table, distances: 7-bit; longer codes by canonical search in a per-lane scratch row) and decodes straight to the
+//     member's place in the text: literals gathered 8 to a store, matches copied 8 bytes at a time from the lane's own output;
+//   * k_bgzf_crc checks every member's CRC-32 (and the decoder its ISIZE and that the block ends where the member does): a damaged
+//     file fails as it does under zlib;
+//   * the text block -- cut where a record ends, the rest carried to the front of the next one -- goes to the record parser of
+//     gs_ingest.hip where it lies: it never exists on the host.
+// Files that are not BGZF (no `BC` field in the first member) are refused with GS_E_IRREGULAR: the caller reads them with the
+// host reader (csrc/gs_inflate.cpp).
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gs_common.h"
+
+using gs::set_error;
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GS_E_NODEVICE;                                                             \
+        }                                                                                     \
+    } while (0)
+
+namespace {
+
+typedef uint64_t u64u __attribute__((aligned(1)));
+typedef uint32_t u32u __attribute__((aligned(1)));
+
+struct Member {
+    uint32_t coff;   // deflate data: offset in the chunk
+    uint32_t clen;
+    uint32_t ooff;   // text: offset in the block
+    uint32_t isize;
+    uint32_t crc;
+};
+enum : uint32_t { kOk = 0, kBadCode = 1, kBadDist = 2, kOverrun = 3, kBadStored = 4, kBadLens = 5, kBadSize = 6, kBadCrc = 7, kBadType = 8 };
+
+#ifndef GS_BGZF_LL_BITS
+#define GS_BGZF_LL_BITS 8
+#endif
+#ifndef GS_BGZF_D_BITS
+#define GS_BGZF_D_BITS 7
+#endif
+constexpr int kLLBits = GS_BGZF_LL_BITS, kDBits = GS_BGZF_D_BITS;
+constexpr uint16_t kLong = 0xFFFFu, kInvalid = 0xFFFEu;
+constexpr int kScratchBytes = 1408;  // per lane: code lengths (320) + two canonical sets (count / first code / first index / running: 4 x 16 x 2 B each) + sorted symbols (288 + 32) x 2 B
+
+struct Canon {  // a lane's row of global scratch, for codes longer than the direct tables' index
+    uint16_t *count, *first_code, *first_idx, *next, *sorted;
+};
+
+struct BitIn {
+    const uint8_t *ip;
+    uint64_t bb;
+    uint32_t bc;
+    __device__ __forceinline__ void refill() {
+        if (bc <= 32u) {
+            bb |= (uint64_t)(*reinterpret_cast<const u32u *>(ip)) << bc;
+            ip += 4;
+            bc += 32u;
+        }
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t n) {
+        const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
+        bb >>= n;
+        bc -= n;
+        return v;
+    }
+};
+
+// table entry: symbol | length << 9
+__device__ __forceinline__ uint32_t build_tables(const uint8_t *lens, int nsym, uint16_t *tab /* [1 << tbits][64], this lane's column */, int tbits,
+                                                 const Canon &cn) {
+    for (int l = 0; l < 16; l++) cn.count[l] = 0;
+    for (int s = 0; s < nsym; s++) cn.count[lens[s]]++;
+    cn.count[0] = 0;
+    uint32_t code = 0, idx = 0;
+    int left = 1;  // Kraft: over-subscribed sets are refused (an incomplete one is legal: a single distance code)
+    for (int l = 1; l < 16; l++) {
+        left <<= 1;
+        left -= (int)cn.count[l];
+        if (left < 0) return kBadLens;
+        code = (code + cn.count[l - 1]) << 1;
+        cn.first_code[l] = (uint16_t)code;
+        cn.next[l] = (uint16_t)code;
+        cn.first_idx[l] = (uint16_t)idx;
+        idx += cn.count[l];
+    }
+    for (int j = 0; j < (1 << tbits); j++) tab[j * 64] = kInvalid;
+    uint16_t offs[16];
+    for (int l = 0; l < 16; l++) offs[l] = cn.first_idx[l];
+    for (int s = 0; s < nsym; s++) {
+        const int l = lens[s];
+        if (!l) continue;
+        const uint32_t c = cn.next[l]++;
+        cn.sorted[offs[l]++] = (uint16_t)s;
+        const uint32_t r = __brev(c) >> (32 - l);
+        if (l <= tbits) {
+            for (uint32_t j = r; j < (1u << tbits); j += (1u << l)) tab[j * 64] = (uint16_t)(s | (l << 9));
+        } else {
+            tab[(r & ((1u << tbits) - 1u)) * 64] = kLong;
+        }
+    }
+    return kOk;
+}
+// a code longer than the direct table's index: bit by bit, most significant first (the codes of one length are consecutive)
+__device__ __forceinline__ int canon_decode(BitIn &b, const Canon &cn) {
+    uint32_t code = 0;
+    for (int l = 1; l < 16; l++) {
+        code = (code << 1) | (uint32_t)((b.bb >> (l - 1)) & 1u);
+        const uint32_t d = code - cn.first_code[l];
+        if (code >= cn.first_code[l] && d < cn.count[l]) {
+            b.bb >>= l;
+            b.bc -= l;
+            return cn.sorted[cn.first_idx[l] + d];
+        }
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const Member *mem, uint32_t n_members, uint8_t *text, uint8_t *scratch,
+                                                     uint32_t *status) {
+    __shared__ uint16_t s_ll[1 << kLLBits][64];
+    __shared__ uint16_t s_dt[1 << kDBits][64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t mi = blockIdx.x * 64u + lane;
+    if (mi >= n_members) return;
+    const Member m = mem[mi];
+    uint16_t *ll = &s_ll[0][lane], *dt = &s_dt[0][lane];
+    uint8_t *row = scratch + (size_t)mi * kScratchBytes;
+    uint8_t *lens = row;
+    uint16_t *w = reinterpret_cast<uint16_t *>(row + 320);
+    const Canon cl{w, w + 16, w + 32, w + 48, w + 128}, cd{w + 64, w + 80, w + 96, w + 112, w + 128 + 288};
+    BitIn b{comp + m.coff, 0, 0};
+    const uint8_t *const iend = comp + m.coff + m.clen;
+    uint8_t *op = text + m.ooff;
+    uint8_t *const obase = op, *const oend = op + m.isize;
+    uint64_t wbuf = 0;
+    uint32_t wn = 0, err = kOk;
+    auto flush = [&]() {  // the gathered literals out (the bytes behind them in the store are overwritten by what follows)
+        if (!wn) return;
+        if (op + 8 <= oend) {
+            *reinterpret_cast<u64u *>(op) = wbuf;
+        } else {
+            for (uint32_t i = 0; i < wn && op + i < oend; i++) op[i] = (uint8_t)(wbuf >> (8 * i));
+        }
+        op += wn;
+        wbuf = 0;
+        wn = 0;
+    };
+    bool last = false;
+    while (!last && err == kOk) {
+        b.refill();
+        if (b.ip > iend + 8) {  // (every block takes bits: a damaged member cannot keep a lane busy beyond its own data)
+            err = kOverrun;
+            break;
+        }
+        last = b.take(1) != 0;
+        const uint32_t btype = b.take(2);
+        if (btype == 0) {  // stored: to the next byte, LEN / NLEN, the bytes
+            flush();
+            b.take(b.bc & 7u);
+            b.refill();
+            const uint32_t len = b.take(16), nlen = b.take(16);
+            if ((len ^ nlen) != 0xFFFFu) {
+                err = kBadStored;
+                break;
+            }
+            const uint8_t *src = b.ip - (b.bc >> 3);  // (bytes the bit buffer holds go back to the input)
+            b.bb = 0;
+            b.bc = 0;
+            if (src + len > iend || op + len > oend) {
+                err = kOverrun;
+                break;
+            }
+            for (uint32_t i = 0; i < len; i++) op[i] = src[i];
+            op += len;
+            b.ip = src + len;
+            continue;
+        }
+        if (btype == 3) {
+            err = kBadType;
+            break;
+        }
+        int nll = 288, nd = 30;
+        if (btype == 1) {
+            for (int s = 0; s < 144; s++) lens[s] = 8;
+            for (int s = 144; s < 256; s++) lens[s] = 9;
+            for (int s = 256; s < 280; s++) lens[s] = 7;
+            for (int s = 280; s < 288; s++) lens[s] = 8;
+            for (int s = 0; s < 30; s++) lens[288 + s] = 5;
+        } else {
+            b.refill();
+            nll = (int)b.take(5) + 257;
+            nd = (int)b.take(5) + 1;
+            const int ncl = (int)b.take(4) + 4;
+            if (nll > 286 || nd > 30) {
+                err = kBadLens;
+                break;
+            }
+            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t *cll = lens + 288;  // (the 19 code-length code lengths: in the distance lengths' place for a moment)
+            for (int i = 0; i < 19; i++) cll[i] = 0;
+            for (int i = 0; i < ncl; i++) {
+                b.refill();
+                cll[order[i]] = (uint8_t)b.take(3);
+            }
+            if ((err = build_tables(cll, 19, dt, kDBits, cd)) != kOk) break;
+            int i = 0;
+            uint8_t tmp[320];
+            while (i < nll + nd) {
+                b.refill();
+                if (b.ip > iend + 8) {
+                    err = kOverrun;
+                    break;
+                }
+                const uint16_t e = dt[((uint32_t)b.bb & ((1u << kDBits) - 1u)) * 64];
+                int sym;
+                if (e < kInvalid) {
+                    b.take(e >> 9);
+                    sym = e & 0x1FF;
+                } else {
+                    sym = e == kLong ? canon_decode(b, cd) : -1;
+                }
+                if (sym < 0) {
+                    err = kBadCode;
+                    break;
+                }
+                if (sym < 16) {
+                    tmp[i++] = (uint8_t)sym;
+                } else {
+                    int rep, val = 0;
+                    if (sym == 16) {
+                        if (!i) {
+                            err = kBadLens;
+                            break;
+                        }
+                        val = tmp[i - 1];
+                        rep = 3 + (int)b.take(2);
+                    } else if (sym == 17) {
+                        rep = 3 + (int)b.take(3);
+                    } else {
+                        rep = 11 + (int)b.take(7);
+                    }
+                    if (i + rep > nll + nd) {
+                        err = kBadLens;
+                        break;
+                    }
+                    while (rep--) tmp[i++] = (uint8_t)val;
+                }
+            }
+            if (err != kOk) break;
+            if (!tmp[256]) {  // (no end-of-block code)
+                err = kBadLens;
+                break;
+            }
+            for (int s = 0; s < nll; s++) lens[s] = tmp[s];
+            for (int s = nll; s < 288; s++) lens[s] = 0;
+            for (int s = 0; s < nd; s++) lens[288 + s] = tmp[nll + s];
+            for (int s = nd; s < 30; s++) lens[288 + s] = 0;
+            nll = 288;
+            nd = 30;
+        }
+        if ((err = build_tables(lens, nll, ll, kLLBits, cl)) != kOk) break;
+        if ((err = build_tables(lens + 288, nd, dt, kDBits, cd)) != kOk) break;
+        // ---- the block's symbols ----
+        for (;;) {
+            b.refill();
+            if (b.ip > iend + 8) {
+                err = kOverrun;
+                break;
+            }
+            int sym;
+            {
+                const uint16_t e = ll[((uint32_t)b.bb & ((1u << kLLBits) - 1u)) * 64];
+                if (e < kInvalid) {
+                    b.take(e >> 9);
+                    sym = e & 0x1FF;
+                } else if (e == kLong) {
+                    sym = canon_decode(b, cl);
+                } else {
+                    sym = -1;
+                }
+            }
+            if (sym < 0) {
+                err = kBadCode;
+                break;
+            }
+            if (sym < 256) {
+                wbuf |= (uint64_t)sym << (8 * wn);
+                if (++wn == 8) {
+                    if (op + 8 > oend) {
+                        err = kOverrun;
+                        break;
+                    }
+                    *reinterpret_cast<u64u *>(op) = wbuf;
+                    op += 8;
+                    wbuf = 0;
+                    wn = 0;
+                }
+                continue;
+            }
+            if (sym == 256) break;
+            const uint32_t c = (uint32_t)sym - 257u;
+            if (c > 28u) {
+                err = kBadCode;
+                break;
+            }
+            uint32_t len;
+            if (c < 8u) len = 3u + c;
+            else if (c == 28u) len = 258u;
+            else {
+                const uint32_t eb = (c >> 2) - 1u;
+                len = ((4u + (c & 3u)) << eb) + 3u + b.take(eb);
+            }
+            b.refill();
+            int ds;
+            {
+                const uint16_t e = dt[((uint32_t)b.bb & ((1u << kDBits) - 1u)) * 64];
+                if (e < kInvalid) {
+                    b.take(e >> 9);
+                    ds = e & 0x1FF;
+                } else if (e == kLong) {
+                    ds = canon_decode(b, cd);
+                } else {
+                    ds = -1;
+                }
+            }
+            if (ds < 0 || ds > 29) {
+                err = kBadCode;
+                break;
+            }
+            uint32_t dist;
+            if (ds < 4) dist = (uint32_t)ds + 1u;
+            else {
+                const uint32_t eb = ((uint32_t)ds >> 1) - 1u;
+                dist = ((2u + ((uint32_t)ds & 1u)) << eb) + 1u + b.take(eb);
+            }
+            flush();
+            if (dist > (uint32_t)(op - obase)) {
+                err = kBadDist;
+                break;
+            }
+            if (op + len > oend) {
+                err = kOverrun;
+                break;
+            }
+            const uint8_t *src = op - dist;
+            uint8_t *const mend = op + len;
+            if (dist >= 8u) {
+                while (op + 8 <= mend) {
+                    *reinterpret_cast<u64u *>(op) = *reinterpret_cast<const u64u *>(src);
+                    op += 8;
+                    src += 8;
+                }
+                if (op < mend) {
+                    if (op + 8 <= oend) {
+                        *reinterpret_cast<u64u *>(op) = *reinterpret_cast<const u64u *>(src);  // (what lies behind the match is written next)
+                    } else {
+                        for (; op < mend; op++, src++) *op = *src;
+                    }
+                    op = mend;
+                }
+            } else if (dist == 1u) {  // a run of one byte (the quality line of `seqtk seq -F '#'`, homopolymers)
+                const uint64_t v = 0x0101010101010101ULL * (uint64_t)*src;
+                while (op + 8 <= mend) {
+                    *reinterpret_cast<u64u *>(op) = v;
+                    op += 8;
+                }
+                if (op < mend) {
+                    if (op + 8 <= oend) *reinterpret_cast<u64u *>(op) = v;
+                    else
+                        for (uint8_t *q = op; q < mend; q++) *q = (uint8_t)v;
+                    op = mend;
+                }
+            } else {  // overlapping copies of a short period: byte by byte
+                for (; op < mend; op++, src++) *op = *src;
+            }
+        }
+    }
+    if (err == kOk) {
+        flush();
+        if (op != oend) err = kBadSize;                                     // ISIZE
+        else if (b.ip - (b.bc >> 3) > iend) err = kOverrun;                 // the last block ended behind the member's data
+    }
+    if (err != kOk) atomicCAS(status, 0u, (mi << 4) | err);
+}
+
+// CRC-32 of every member's text against its trailer (a lane per member; eight bytes per load, the table in LDS)
+__global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *text, const Member *mem, uint32_t n_members, uint32_t *status) {
+    __shared__ uint32_t tab[256];
+    for (uint32_t i = threadIdx.x; i < 256u; i += 64u) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        tab[i] = c;
+    }
+    __syncthreads();
+    const uint32_t mi = blockIdx.x * 64u + threadIdx.x;
+    if (mi >= n_members) return;
+    const Member m = mem[mi];
+    const uint8_t *p = text + m.ooff, *e = p + m.isize;
+    uint32_t c = 0xFFFFFFFFu;
+    for (; p + 8 <= e; p += 8) {
+        uint64_t v = *reinterpret_cast<const u64u *>(p);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            c = tab[(c ^ (uint32_t)v) & 0xFFu] ^ (c >> 8);
+            v >>= 8;
+        }
+    }
+    for (; p < e; p++) c = tab[(c ^ *p) & 0xFFu] ^ (c >> 8);
+    if ((c ^ 0xFFFFFFFFu) != m.crc) atomicCAS(status, 0u, (mi << 4) | kBadCrc);
+}
+
+__global__ void k_count_newlines(const uint8_t *t, uint64_t n, unsigned long long *out) {
+    uint32_t mine = 0;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (uint64_t)gridDim.x * blockDim.x * 8) {
+        if (i + 8 <= n) {
+            uint64_t v = *reinterpret_cast<const u64u *>(t + i) ^ 0x0A0A0A0A0A0A0A0AULL;
+            // bytes that are zero: (v - 0x01..) & ~v & 0x80..   (exact per byte only without borrows: count them one by one instead)
+#pragma unroll
+            for (int k = 0; k < 8; k++) mine += ((v >> (8 * k)) & 0xFFu) == 0u ? 1u : 0u;
+        } else {
+            for (uint64_t j = i; j < n; j++) mine += t[j] == '\n' ? 1u : 0u;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor((int)mine, o, 64);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(out, (unsigned long long)mine);
+}
+
+__global__ void k_gather_names(const uint8_t *text, const uint64_t *name_off, const uint32_t *name_len, const uint64_t *blob_off, uint32_t n, uint8_t *blob) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint8_t *s = text + name_off[r];
+    uint8_t *d = blob + blob_off[r];
+    for (uint32_t i = 0; i < name_len[r]; i++) d[i] = s[i];
+}
+
+const char *err_text(uint32_t e) {
+    switch (e) {
+        case kBadCode: return "invalid Huffman code";
+        case kBadDist: return "a match reaches before the member's start";
+        case kOverrun: return "the data runs past the member's end";
+        case kBadStored: return "a stored block's length check fails";
+        case kBadLens: return "invalid code lengths";
+        case kBadSize: return "a member's text is not as long as its trailer says";
+        case kBadCrc: return "a member fails its CRC-32 check";
+        default: return "invalid block type";
+    }
+}
+
+constexpr size_t kChunk = (size_t)64 << 20;  // compressed bytes read, indexed and handed over at a time (at most)
+
+// members that lie completely in buf[0, n) and whose text fits below text_end: their descriptors (offsets into buf / into the text
+// from `text_at`), bytes of buf used
+int walk_members(const uint8_t *buf, size_t n, bool at_eof, uint64_t text_at, uint64_t text_end, std::vector<Member> &out, size_t *used,
+                 uint64_t *text_bytes) {
+    size_t p = 0;
+    uint64_t t = text_at;
+    while (p < n) {
+        if (p + 18 > n) {
+            if (at_eof) {
+                set_error("truncated gzip member header");
+                return GS_E_IO;
+            }
+            break;
+        }
+        if (buf[p] != 0x1f || buf[p + 1] != 0x8b || buf[p + 2] != 8 || !(buf[p + 3] & 4)) {
+            set_error("not a BGZF member (no gzip magic / no extra field) at byte %zu of a chunk", p);
+            return GS_E_IRREGULAR;
+        }
+        if (buf[p + 3] & ~4u) {  // (name, comment, header CRC: bgzip writes none of them)
+            set_error("a BGZF member with header fields bgzip does not write");
+            return GS_E_IRREGULAR;
+        }
+        const size_t xlen = (size_t)buf[p + 10] | ((size_t)buf[p + 11] << 8);
+        if (p + 12 + xlen > n) {
+            if (at_eof) {
+                set_error("truncated gzip member header");
+                return GS_E_IO;
+            }
+            break;
+        }
+        size_t bsize = 0;
+        for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+            const size_t slen = (size_t)buf[q + 2] | ((size_t)buf[q + 3] << 8);
+            if (buf[q] == 'B' && buf[q + 1] == 'C' && slen == 2 && q + 6 <= p + 12 + xlen) bsize = ((size_t)buf[q + 4] | ((size_t)buf[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (!bsize || bsize < 12 + xlen + 8) {
+            set_error("a gzip member without a BGZF block size");
+            return GS_E_IRREGULAR;
+        }
+        if (p + bsize > n) {
+            if (at_eof) {
+                set_error("truncated BGZF member");
+                return GS_E_IO;
+            }
+            break;
+        }
+        Member m;
+        m.coff = (uint32_t)(p + 12 + xlen);
+        m.clen = (uint32_t)(bsize - 12 - xlen - 8);
+        const uint8_t *tr = buf + p + bsize - 8;
+        m.crc = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        m.isize = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (m.isize > (1u << 16)) {
+            set_error("a BGZF member of more than 64 KiB");
+            return GS_E_IRREGULAR;
+        }
+        if (t + m.isize > text_end) break;  // (the block is full: this member opens the next one)
+        m.ooff = (uint32_t)t;
+        t += m.isize;
+        if (m.isize) out.push_back(m);  // (the empty end-of-file member carries nothing)
+        p += bsize;
+    }
+    *used = p;
+    *text_bytes = t - text_at;
+    return GS_OK;
+}
+
+}  // namespace
+
+struct gs_bgzf {
+    size_t chunk = kChunk;  // (GAVISUNK_BGZF_CHUNK_KB: a test knob -- small chunks, many blocks)
+    int device = 0;
+    int fd = -1;
+    uint64_t file_size = 0, file_at = 0;       // file_at: behind the last member handed to a slot
+    uint8_t *h_chunk[2] = {nullptr, nullptr};  // pinned: one is read into while the other's copy to the device is in flight
+    hipEvent_t h_free[2] = {nullptr, nullptr};
+    int hk = 0;
+    // the compressed bytes of one text block as they lie in the file, its members, how much text they make: two of them, so that the
+    // NEXT block's bytes are read (page cache -> pinned -> device, on the copy stream) while this block's members are being inflated
+    struct Slot {
+        uint8_t *d_comp = nullptr;
+        size_t comp_cap = 0, comp_at = 0;
+        std::vector<Member> members;
+        uint64_t text = 0;       // bytes of text of the members (their ooff counts from 0: the carried bytes go in front at launch)
+        bool filled = false, last = false;
+        hipEvent_t copied = nullptr;
+    } slot[2];
+    int cur = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Member *d_mem = nullptr;
+    uint8_t *d_scratch = nullptr;
+    size_t mem_cap = 0;
+    uint32_t *d_status = nullptr;
+    unsigned long long *d_count = nullptr;
+    hipStream_t st = nullptr, st_copy = nullptr;
+    uint8_t *d_rem = nullptr;     // the bytes behind the last block's last whole record
+    size_t rem_n = 0, rem_cap = 0;
+    std::vector<uint8_t> tail;
+    uint64_t bytes_in = 0, bytes_out = 0;
+    bool read_done = false;       // every member of the file is in a slot (or has been inflated)
+    bool at_end = false;          // ... and inflated
+};
+
+namespace {
+// members worth about `want` bytes of text (at most `room`) from the file's current position into slot `sl`: chunk by chunk into pinned
+// memory (headers walked there) and on to the device on the copy stream
+int fill_slot(gs_bgzf *z, gs_bgzf::Slot &sl, uint64_t want, uint64_t room, bool trace) {
+    sl.members.clear();
+    sl.comp_at = 0;
+    sl.text = 0;
+    sl.filled = false;
+    sl.last = false;
+    if (z->read_done) return GS_OK;
+    const uint64_t left0 = z->file_size - z->file_at;
+    const size_t need = (size_t)std::min<uint64_t>(left0, std::max<uint64_t>(want / 2, (uint64_t)128 << 20)) + z->chunk + 64;
+    if (need > sl.comp_cap) {
+        HIP_TRY(hipStreamSynchronize(z->st_copy));
+        HIP_TRY(hipStreamSynchronize(z->st));
+        (void)hipFree(sl.d_comp);
+        sl.d_comp = nullptr;
+        sl.comp_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sl.d_comp), need));
+        sl.comp_cap = need;
+    }
+    std::vector<Member> part;
+    while (!z->read_done && sl.text < want && sl.comp_at + z->chunk + 64 <= sl.comp_cap) {
+        const int k = z->hk;
+        const uint64_t left = z->file_size - z->file_at;
+        const size_t take = (size_t)std::min<uint64_t>(z->chunk, left);
+        HIP_TRY(hipEventSynchronize(z->h_free[k]));  // (this pinned buffer's last copy has left it)
+        if (trace) fprintf(stderr, "[bgzf] chunk at %llu: reading %zu bytes\n", (unsigned long long)z->file_at, take);
+        {  // four threads read a quarter each (one thread copies out of the page cache at 5-6 GB/s: it would be the whole run)
+            constexpr unsigned kReaders = 4;
+            bool ok[kReaders] = {true, true, true, true};
+            uint8_t *dst = z->h_chunk[k];
+            const int fd = z->fd;
+            const uint64_t at = z->file_at;
+            const unsigned T = take >= ((size_t)4 << 20) ? kReaders : 1u;
+            gs_parallel_for(T, [&](unsigned t) {
+                size_t lo = take * t / T;
+                const size_t hi = take * (t + 1) / T;
+                while (lo < hi) {
+                    const ssize_t r = pread(fd, dst + lo, hi - lo, (off_t)(at + lo));
+                    if (r <= 0) {
+                        ok[t] = false;
+                        return;
+                    }
+                    lo += (size_t)r;
+                }
+            });
+            if (!(ok[0] && ok[1] && ok[2] && ok[3])) {
+                set_error("gs_bgzf_next: read failed");
+                return GS_E_IO;
+            }
+        }
+        memset(z->h_chunk[k] + take, 0, 64);
+        const bool eof = take == left;
+        part.clear();
+        size_t used = 0;
+        uint64_t text_bytes = 0;
+        int rc = walk_members(z->h_chunk[k], take, eof, sl.text, room, part, &used, &text_bytes);
+        if (rc != GS_OK) return rc;
+        if (!used) {
+            if (sl.text) break;  // (the block is full)
+            set_error("gs_bgzf_next: a member larger than a chunk");
+            return GS_E_IRREGULAR;
+        }
+        HIP_TRY(hipMemcpyAsync(sl.d_comp + sl.comp_at, z->h_chunk[k], used + 64, hipMemcpyHostToDevice, z->st_copy));
+        HIP_TRY(hipEventRecord(z->h_free[k], z->st_copy));
+        for (Member &m : part) {
+            m.coff += (uint32_t)sl.comp_at;
+            sl.members.push_back(m);
+        }
+        sl.comp_at += used;
+        sl.text += text_bytes;
+        z->file_at += used;
+        z->bytes_in += used;
+        if (z->file_at >= z->file_size) z->read_done = true;
+        z->hk ^= 1;
+    }
+    HIP_TRY(hipEventRecord(sl.copied, z->st_copy));
+    sl.filled = true;
+    sl.last = z->read_done;
+    return GS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+void gs_bgzf_close(gs_bgzf *z) {
+    if (!z) return;
+    (void)hipSetDevice(z->device);
+    if (z->st) (void)hipStreamSynchronize(z->st);
+    if (z->st_copy) (void)hipStreamSynchronize(z->st_copy);
+    if (z->fd >= 0) close(z->fd);
+    for (int k = 0; k < 2; k++) {
+        if (z->h_chunk[k]) (void)hipHostFree(z->h_chunk[k]);
+        if (z->h_free[k]) (void)hipEventDestroy(z->h_free[k]);
+        (void)hipFree(z->slot[k].d_comp);
+        if (z->slot[k].copied) (void)hipEventDestroy(z->slot[k].copied);
+    }
+    if (z->ev0) (void)hipEventDestroy(z->ev0);
+    if (z->ev1) (void)hipEventDestroy(z->ev1);
+    (void)hipFree(z->d_mem);
+    (void)hipFree(z->d_scratch);
+    (void)hipFree(z->d_status);
+    (void)hipFree(z->d_count);
+    (void)hipFree(z->d_rem);
+    if (z->st) (void)hipStreamDestroy(z->st);
+    if (z->st_copy) (void)hipStreamDestroy(z->st_copy);
+    delete z;
+}
+
+// GS_E_IRREGULAR: the file is not BGZF (read it with gs_gz_*); GS_E_IO: it cannot be opened
+int gs_bgzf_open(const char *path, int device, gs_bgzf **out) {
+    if (!path || !out) {
+        set_error("gs_bgzf_open: null argument");
+        return GS_E_ARG;
+    }
+    *out = nullptr;
+    if (gs_device_count() <= device || device < 0) {
+        set_error("gs_bgzf_open: HIP device %d not available -- there is no CPU fallback", device);
+        return GS_E_NODEVICE;
+    }
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        set_error("cannot open the file %s", path);
+        return GS_E_IO;
+    }
+    struct stat sb;
+    uint8_t head[18];
+    if (fstat(fd, &sb) != 0 || pread(fd, head, sizeof head, 0) != (ssize_t)sizeof head || head[0] != 0x1f || head[1] != 0x8b || head[2] != 8 || head[3] != 4 ||
+        head[12] != 'B' || head[13] != 'C') {  // (bgzip writes the BC field first)
+        close(fd);
+        set_error("%s is not a BGZF file", path);
+        return GS_E_IRREGULAR;
+    }
+    HIP_TRY(hipSetDevice(device));
+    auto *z = new gs_bgzf();
+    z->device = device;
+    z->fd = fd;
+    z->file_size = (uint64_t)sb.st_size;
+    if (const char *ck = getenv("GAVISUNK_BGZF_CHUNK_KB")) z->chunk = std::min(kChunk, (size_t)std::max(128, atoi(ck)) << 10);
+    hipError_t e = hipStreamCreateWithFlags(&z->st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&z->st_copy, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; k++) {
+        e = hipHostMalloc(reinterpret_cast<void **>(&z->h_chunk[k]), z->chunk + 64, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&z->h_free[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&z->slot[k].copied, hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreate(&z->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&z->ev1);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&z->d_status), sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&z->d_count), sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        gs_bgzf_close(z);
+        set_error("gs_bgzf_open: %s", hipGetErrorString(e));
+        return GS_E_NOMEM;
+    }
+    *out = z;
+    return GS_OK;
+}
+
+int gs_bgzf_at_end(const gs_bgzf *z) { return z ? ((z->at_end && !z->rem_n) ? 1 : 0) : 1; }
+
+// The next text block: members worth about `want` bytes of text inflated on the device behind what the last block left over, cut
+// where the last whole record ends (FASTQ: four lines per record; FASTA: before the last '>' line).  *stage = NULL at the end of
+// the file, or when not one whole record fit (ask again, with a larger `want`).  GS_E_IO: a damaged file (what zlib reports as such).
+int gs_bgzf_next(gs_bgzf *z, uint64_t want, gs_textstage **stage) {
+    if (!z || !stage) {
+        set_error("gs_bgzf_next: null argument");
+        return GS_E_ARG;
+    }
+    *stage = nullptr;
+    if (z->at_end && !z->rem_n) return GS_OK;
+    HIP_TRY(hipSetDevice(z->device));
+    want = std::min<uint64_t>(std::max<uint64_t>(want, 1u << 20), 0xC0000000ull);
+    const bool trace = getenv("GAVISUNK_BGZF_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[bgzf] next: want %llu, carried %zu, file at %llu of %llu\n", (unsigned long long)want, z->rem_n, (unsigned long long)z->file_at, (unsigned long long)z->file_size);
+    // the members of a block make at most `room` bytes of text: what is wanted and one chunk's worth beyond it (a chunk is taken whole)
+    const uint64_t room = std::min<uint64_t>(want + (uint64_t)z->chunk * 8, 0xF0000000ull);
+    gs_bgzf::Slot &sl = z->slot[z->cur];
+    if (!sl.filled && !z->at_end) {
+        int rc = fill_slot(z, sl, want, room, trace);
+        if (rc != GS_OK) return rc;
+    }
+    const uint64_t block_text = z->at_end ? 0 : sl.text;
+    if ((uint64_t)z->rem_n + block_text > 0xFFFFFF00ull) {
+        set_error("gs_bgzf_next: a record of more than %llu bytes of text", (unsigned long long)z->rem_n);
+        return GS_E_IRREGULAR;
+    }
+    size_t cap = 0;
+    uint8_t *d_text = gs::stage_buffer(z->device, (size_t)(z->rem_n + block_text) + 64, &cap);
+    if (!d_text) return GS_E_NOMEM;
+    struct Release {
+        int dev;
+        uint8_t *p;
+        size_t cap;
+        ~Release() {
+            if (p) gs::stage_buffer_release(dev, p, cap);
+        }
+    } rel{z->device, d_text, cap};
+    uint64_t n = 0;
+    if (z->rem_n) {
+        HIP_TRY(hipMemcpyAsync(d_text, z->d_rem, z->rem_n, hipMemcpyDeviceToDevice, z->st));
+        n = z->rem_n;
+        z->rem_n = 0;
+    }
+    const uint32_t nm = z->at_end ? 0u : (uint32_t)sl.members.size();
+    if (trace) fprintf(stderr, "[bgzf] %u members, %zu compressed bytes, %llu bytes of text behind %llu carried\n", nm, sl.comp_at, (unsigned long long)block_text, (unsigned long long)n);
+    bool launched = false;
+    if (nm) {
+        if (nm > z->mem_cap) {
+            HIP_TRY(hipStreamSynchronize(z->st));
+            (void)hipFree(z->d_mem);
+            (void)hipFree(z->d_scratch);
+            z->d_mem = nullptr;
+            z->d_scratch = nullptr;
+            z->mem_cap = std::max<size_t>((size_t)nm + nm / 4 + 1024, 60000);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&z->d_mem), z->mem_cap * sizeof(Member)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&z->d_scratch), z->mem_cap * (size_t)kScratchBytes));
+        }
+        HIP_TRY(hipStreamWaitEvent(z->st, sl.copied, 0));  // (the slot's compressed bytes have arrived)
+        HIP_TRY(hipMemcpyAsync(z->d_mem, sl.members.data(), (size_t)nm * sizeof(Member), hipMemcpyHostToDevice, z->st));
+        HIP_TRY(hipMemsetAsync(z->d_status, 0, sizeof(uint32_t), z->st));
+        HIP_TRY(hipEventRecord(z->ev0, z->st));
+        hipLaunchKernelGGL(k_bgzf_inflate, dim3((nm + 63) / 64), dim3(64), 0, z->st, sl.d_comp, z->d_mem, nm, d_text + n, z->d_scratch, z->d_status);
+        hipLaunchKernelGGL(k_bgzf_crc, dim3((nm + 63) / 64), dim3(64), 0, z->st, d_text + n, z->d_mem, nm, z->d_status);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(z->ev1, z->st));
+        launched = true;
+    }
+    if (!z->at_end) {
+        n += block_text;
+        if (sl.last) z->at_end = true;
+    }
+    // while this block's members are being inflated: the next block's compressed bytes
+    gs_bgzf::Slot &nx = z->slot[z->cur ^ 1];
+    if (!z->read_done) {
+        int rc = fill_slot(z, nx, want, room, trace);
+        if (rc != GS_OK) {
+            (void)hipStreamSynchronize(z->st);
+            return rc;
+        }
+    }
+    if (launched) {
+        uint32_t status = 0;
+        HIP_TRY(hipMemcpyAsync(&status, z->d_status, sizeof status, hipMemcpyDeviceToHost, z->st));
+        HIP_TRY(hipStreamSynchronize(z->st));
+        if (getenv("GAVISUNK_TIMING")) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, z->ev0, z->ev1);
+            fprintf(stderr, "[gs_bgzf_next] %u members, %.1f MB -> %.1f MB: inflate + crc kernels %.2f ms\n", nm, sl.comp_at / 1e6, block_text / 1e6, ms);
+        }
+        if (status) {
+            set_error("gs_bgzf_next: %s (member %u of the block that ends at byte %llu)", err_text(status & 15u), status >> 4, (unsigned long long)z->file_at);
+            return GS_E_IO;
+        }
+    }
+    sl.filled = false;
+    z->cur ^= 1;
+    if (!n) return GS_OK;
+    // ---- the cut: where the last whole record ends ----
+    uint8_t first = 0;
+    HIP_TRY(hipMemcpyAsync(&first, d_text, 1, hipMemcpyDeviceToHost, z->st));
+    unsigned long long nl = 0;
+    HIP_TRY(hipMemsetAsync(z->d_count, 0, sizeof(unsigned long long), z->st));
+    hipLaunchKernelGGL(k_count_newlines, dim3(2048), dim3(256), 0, z->st, d_text, n, z->d_count);
+    HIP_TRY(hipMemcpyAsync(&nl, z->d_count, sizeof nl, hipMemcpyDeviceToHost, z->st));
+    HIP_TRY(hipStreamSynchronize(z->st));
+    uint64_t cut = n;
+    if (!z->at_end) {
+        size_t tail_n = (size_t)std::min<uint64_t>(n, (uint64_t)32 << 20);
+        for (;;) {
+            z->tail.resize(tail_n);
+            HIP_TRY(hipMemcpyAsync(z->tail.data(), d_text + (n - tail_n), tail_n, hipMemcpyDeviceToHost, z->st));
+            HIP_TRY(hipStreamSynchronize(z->st));
+            const uint8_t *t = z->tail.data();
+            int64_t at = -1;  // index in the tail of the byte BEHIND the last whole record
+            if (first == '>') {  // FASTA: the last record may be incomplete, whatever it ends with: cut in front of its '>' line
+                for (size_t i = tail_n; i-- > 1;)
+                    if (t[i] == '>' && t[i - 1] == '\n') {
+                        at = (int64_t)i;
+                        break;
+                    }
+            } else {  // four lines per record: behind the newline whose number is the largest multiple of four
+                uint64_t skip = nl & 3u;
+                for (size_t i = tail_n; i-- > 0;)
+                    if (t[i] == '\n') {
+                        if (!skip) {
+                            at = (int64_t)i + 1;
+                            break;
+                        }
+                        skip--;
+                    }
+                if (nl < 4) at = -2;  // (not one whole record yet)
+            }
+            if (at >= 0) {
+                cut = (n - tail_n) + (uint64_t)at;
+                break;
+            }
+            if (tail_n == n || at == -2) {
+                cut = 0;
+                break;
+            }
+            tail_n = (size_t)std::min<uint64_t>(n, (uint64_t)tail_n * 4);
+        }
+    }
+    if (cut < n) {
+        const size_t r = (size_t)(n - cut);
+        if (r > z->rem_cap) {
+            (void)hipFree(z->d_rem);
+            z->d_rem = nullptr;
+            z->rem_cap = r + r / 2 + (1u << 20);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&z->d_rem), z->rem_cap));
+        }
+        HIP_TRY(hipMemcpyAsync(z->d_rem, d_text + cut, r, hipMemcpyDeviceToDevice, z->st));
+        HIP_TRY(hipStreamSynchronize(z->st));
+        z->rem_n = r;
+    }
+    z->bytes_out += cut;
+    if (!cut) {
+        if (z->at_end) z->rem_n = 0;
+        // (a record longer than a block: the caller asks again, with more room)
+        return GS_OK;
+    }
+    *stage = gs::stage_adopt(z->device, d_text, (uint32_t)cut, cap, first);
+    rel.p = nullptr;
+    return GS_OK;
+}
+
+// the names of a parsed block whose text exists only on the device: gathered there, copied as one blob (blob_off[n + 1] on the host)
+int gs_textstage_names(const gs_textstage *stage, const uint64_t *name_off, const uint32_t *name_len, uint32_t n, uint8_t *blob, uint64_t *blob_off) {
+    if (!stage || (n && (!name_off || !name_len || !blob_off))) {
+        set_error("gs_textstage_names: null argument");
+        return GS_E_ARG;
+    }
+    blob_off[0] = 0;
+    for (uint32_t i = 0; i < n; i++) blob_off[i + 1] = blob_off[i] + name_len[i];
+    if (!n || !blob_off[n]) return GS_OK;
+    if (!blob) {
+        set_error("gs_textstage_names: null argument");
+        return GS_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(stage->device));
+    uint64_t *d_no = nullptr, *d_bo = nullptr;
+    uint32_t *d_nl = nullptr;
+    uint8_t *d_blob = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_no), (size_t)n * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_bo), ((size_t)n + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_nl), (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_blob), blob_off[n]);
+    if (e == hipSuccess) e = hipMemcpy(d_no, name_off, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_bo, blob_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_nl, name_len, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gather_names, dim3((n + 255) / 256), dim3(256), 0, 0, stage->d_text, d_no, d_nl, d_bo, n, d_blob);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(blob, d_blob, blob_off[n], hipMemcpyDeviceToHost);
+    (void)hipFree(d_no);
+    (void)hipFree(d_bo);
+    (void)hipFree(d_nl);
+    (void)hipFree(d_blob);
+    if (e != hipSuccess) {
+        set_error("gs_textstage_names: %s", hipGetErrorString(e));
+        return GS_E_NODEVICE;
+    }
+    return GS_OK;
+}
+
+// (tests, tools) the staged text on the host
+int gs_textstage_copy(const gs_textstage *stage, uint8_t *out, uint64_t cap, uint64_t *n) {
+    if (!stage || !n) {
+        set_error("gs_textstage_copy: null argument");
+        return GS_E_ARG;
+    }
+    *n = stage->n;
+    if (!out) return GS_OK;
+    if (cap < stage->n) {
+        set_error("gs_textstage_copy: %u bytes do not fit in %llu", stage->n, (unsigned long long)cap);
+        return GS_E_CAPACITY;
+    }
+    HIP_TRY(hipSetDevice(stage->device));
+    if (stage->n) HIP_TRY(hipMemcpy(out, stage->d_text, stage->n, hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
+uint64_t gs_bgzf_bytes_in(const gs_bgzf *z) { return z ? z->bytes_in : 0; }
+
+}  // extern "C"

@@ -66,6 +66,20 @@ int union_regions_device(int device, uint64_t n_rows, const uint32_t *d_row_read
 int reads_from_parsed_text(int device, const void *d_seq, const uint64_t *off, uint32_t n_reads, int k, uint64_t *d_boff_scratch,
                            gs_reads **out);
 
+// a FASTA / FASTQ text block in device memory (gs_ingest.hip: copied there by gs_text_stage; gs_bgzf.hip: inflated there)
+}  // namespace gs
+struct gs_textstage {
+    int device = 0;
+    uint8_t *d_text = nullptr;
+    uint32_t n = 0;
+    uint8_t first = 0;
+    size_t cap = 0;
+};
+namespace gs {
+uint8_t *stage_buffer(int device, size_t want, size_t *cap);          // from the cache of staged-text buffers, or fresh
+void stage_buffer_release(int device, uint8_t *p, size_t cap);
+gs_textstage *stage_adopt(int device, uint8_t *d_text, uint32_t n, size_t cap, uint8_t first);
+
 constexpr int kTileWindows = 2048;  // windows per tile = 64 lanes x 32 windows (one 64-bit word per lane)
 constexpr int kTileWords = 64;
 

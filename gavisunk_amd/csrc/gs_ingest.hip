@@ -199,14 +199,6 @@ __global__ __launch_bounds__(256) void k_gather_lines(const uint8_t *__restrict_
 
 extern "C" {
 
-struct gs_textstage {
-    int device = 0;
-    uint8_t *d_text = nullptr;
-    uint32_t n = 0;
-    uint8_t first = 0;
-    size_t cap = 0;
-};
-
 namespace {
 // Device buffers of staged text blocks are kept for the next block instead of being freed: hipFree / hipMalloc synchronise the
 // whole device, and in the command-line pipeline one thread stages block i + 1 while another parses and tags block i -- each
@@ -248,6 +240,31 @@ StageCache &stage_cache() {
     return *c;
 }
 }  // namespace
+
+}  // extern "C"
+// (for gs_bgzf.hip, whose text blocks are MADE on the device: a buffer from the same cache, and a stage handle around it)
+uint8_t *gs::stage_buffer(int device, size_t want, size_t *cap) {
+    uint8_t *p = stage_cache().get(device, want, cap);
+    if (p) return p;
+    *cap = std::max<size_t>(want + want / 8, 1);
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&p), *cap) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("out of device memory (%zu bytes of text)", want);
+        return nullptr;
+    }
+    return p;
+}
+void gs::stage_buffer_release(int device, uint8_t *p, size_t cap) { stage_cache().put(device, p, cap); }
+gs_textstage *gs::stage_adopt(int device, uint8_t *d_text, uint32_t n, size_t cap, uint8_t first) {
+    auto *st = new gs_textstage();
+    st->device = device;
+    st->d_text = d_text;
+    st->n = n;
+    st->cap = cap;
+    st->first = first;
+    return st;
+}
+extern "C" {
 
 int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstage **out) {
     if (!out || (!text && n_bytes)) {

@@ -309,6 +309,66 @@ class StagedText:
     __del__ = close
 
 
+class DeviceText:
+    """A FASTA / FASTQ text block that exists only in device memory (inflated there: BgzfReader); DeviceReads.from_staged parses it."""
+
+    text = None  # (no host copy: DeviceReads.from_staged fetches the read names from the device)
+
+    def __init__(self, h, device: int):
+        self._h, self.device = h, device
+
+    def host_copy(self) -> bytes:
+        n = C.c_uint64(0)
+        check(lib().gs_textstage_copy(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint8)
+        check(lib().gs_textstage_copy(self._h, out.ctypes.data, len(out), C.byref(n)))
+        return out[: n.value].tobytes()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_text_stage_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class BgzfReader:
+    """DEFLATE on the GPU for BGZF-shaped `.fq.gz` (gs_bgzf_*, csrc/gs_bgzf.hip): blocks of whole records, inflated on the device
+    from the compressed bytes.  Raises GsError(GS_E_IRREGULAR) for a file that is not BGZF (gz_text_blocks reads those)."""
+
+    def __init__(self, path: str, device: int = 0):
+        h = C.c_void_p()
+        check(lib().gs_bgzf_open(path.encode(), device, C.byref(h)))
+        self._h, self.device = h, device
+
+    def blocks(self, max_bytes: int = 1 << 30) -> Iterator[DeviceText]:
+        L = lib()
+        # (a launch inflates 64 MiB of compressed bytes -- ~0.4 GB of text -- or more in ~35-45 ms whatever their number: blocks of
+        # less make no sense; later ones double up to max_bytes)
+        want = min(max_bytes, 256 << 20)
+        grow = want
+        while True:
+            st = C.c_void_p()
+            check(L.gs_bgzf_next(self._h, grow, C.byref(st)))
+            if st.value:
+                yield DeviceText(st, self.device)
+                want = min(2 * want, max_bytes)
+                grow = want
+            elif L.gs_bgzf_at_end(self._h):
+                return
+            else:  # (not one whole record fit: a read longer than the block)
+                if grow >= (3 << 30):
+                    raise _lib.GsError(_lib.GS_E_IRREGULAR, "a record of more than 3 GiB of text")
+                grow *= 4
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gs_bgzf_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+
 class DeviceTable:
     """SUNK hash table resident on one GPU (gs_table)."""
 
@@ -404,7 +464,15 @@ class DeviceReads:
         L = lib()
         h, ix = C.c_void_p(), C.c_void_p()
         check(L.gs_reads_from_staged_text(staged._h, k, C.byref(h), C.byref(ix)))
-        return cls._with_index(h, ix, staged.text, k, staged.device)
+        self = cls._with_index(h, ix, staged.text, k, staged.device)
+        if staged.text is None and self.n_reads:
+            # the text exists only on the device (BgzfReader): the read names are gathered there and come over as one blob
+            off = np.zeros(self.n_reads + 1, np.uint64)
+            off[1:] = np.cumsum(self._name_len, dtype=np.uint64)
+            blob = np.zeros(max(int(off[-1]), 1), np.uint8)
+            check(L.gs_textstage_names(staged._h, self._name_off.ctypes.data, self._name_len.ctypes.data, self.n_reads, blob.ctypes.data, off.ctypes.data))
+            self._text, self._name_off = blob, off[:-1].copy()
+        return self
 
     @classmethod
     def _with_index(cls, h, ix, text, k: int, device: int) -> "DeviceReads":

@@ -69,7 +69,29 @@ class _Prefetch:
 
     def _work(self, path, max_bases):
         try:
-            if self._text:
+            bgzf = None
+            if self._text and path.endswith(".gz") and os.environ.get("GAVISUNK_GZ", "device") == "device":
+                try:  # BGZF (what rustybam fastq-split / bgzip write): the compressed bytes go to the device and are inflated THERE
+                    bgzf = engine.BgzfReader(path, self._device)
+                except _lib.GsError as e:
+                    if e.status != _lib.GS_E_IRREGULAR:
+                        raise
+            if bgzf is not None:
+                def inflated():
+                    # (blocks of up to 3 GiB of text: ~5e4 members, a lane each, fill the device's wave slots in one launch)
+                    it = bgzf.blocks(max_bases if max_bases < (1 << 30) else 3 << 30)
+                    try:
+                        while True:
+                            t0 = time.perf_counter()
+                            st = next(it, None)
+                            _tick("read_and_inflate_on_device", t0)
+                            if st is None:
+                                return
+                            yield st
+                    finally:
+                        bgzf.close()
+                src = inflated()
+            elif self._text:
                 # two stages of their own: the text of block i + 1 is read / inflated (native threads, no GIL) while block i is
                 # copied to the device
                 tq: queue.Queue = queue.Queue(maxsize=1)
@@ -318,12 +340,9 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
     host_parse = os.environ.get("GAVISUNK_PARSE", "device") == "host"
     last_timing.clear()
     t_run = time.perf_counter()
-    if reads.endswith(".gz") and os.environ.get("GAVISUNK_SPIN") != "1":
-        # a compressed read file is inflated by every CPU the box gives us (the critical path at genome scale): the main, staging and
-        # writer threads wait for the device by blocking, not by spinning on a core each
-        blocking = _lib.lib().gs_device_blocking_sync(device, 1) == 0
-    else:
-        blocking = False
+    # (round 5 tried blocking device waits for .gz inputs -- hipDeviceScheduleBlockingSync, to leave the CPUs to the inflate threads: 3 %
+    # on the host reader, and an intermittent deadlock inside the HIP runtime with three threads on the device: profiles/r05/NOTES.md)
+    blocking = False
     batches = _Prefetch(reads, batch_bases) if host_parse else None
     blocks = None if host_parse else _Prefetch(reads, min(batch_bases, 1 << 30), text=True, device=device)  # (read and copied meanwhile)
     try:

@@ -204,6 +204,25 @@ typedef struct gs_textstage gs_textstage;
 int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstage **out);
 void gs_text_stage_free(gs_textstage *st);
 int gs_reads_from_staged_text(const gs_textstage *stage, int k, gs_reads **out, gs_textindex **index);
+
+/* DEFLATE on the GPU for BGZF-shaped `.fq.gz` (csrc/gs_bgzf.hip): what `rustybam fastq-split` and bgzip write, and what rule
+ * SUNK_annot is given (tagONT.smk:17,36) -- a gzip file of members of at most 64 KiB of text, each with its compressed size in the
+ * header and its inflated size in the trailer.  The host walks the headers and hands the COMPRESSED bytes to the device; a lane per
+ * member inflates straight to the member's place in a text block (CRC-32 and size of every member checked: a damaged file fails
+ * with GS_E_IO where zlib fails); the block -- whole records, the rest carried to the next -- goes to gs_reads_from_staged_text
+ * where it lies.  gs_bgzf_open: GS_E_IRREGULAR = not a BGZF file (read it with gs_gz_*).  gs_bgzf_next: *stage = NULL at the end
+ * of the file, or when not one whole record fit (ask again with a larger `want`). */
+typedef struct gs_bgzf gs_bgzf;
+int gs_bgzf_open(const char *path, int device, gs_bgzf **out);
+int gs_bgzf_next(gs_bgzf *z, uint64_t want_text_bytes, gs_textstage **stage);
+int gs_bgzf_at_end(const gs_bgzf *z);
+uint64_t gs_bgzf_bytes_in(const gs_bgzf *z);
+void gs_bgzf_close(gs_bgzf *z);
+/* the names of a parsed block whose text exists only on the device: blob_off[n + 1] (host) <- running sums of name_len, blob <- the
+ * names back to back (gathered on the device, one copy); blob may be NULL to learn the size (blob_off[n]) */
+int gs_textstage_names(const gs_textstage *stage, const uint64_t *name_off, const uint32_t *name_len, uint32_t n, uint8_t *blob, uint64_t *blob_off);
+/* (tests, tools) a staged text on the host: *n <- its size; out may be NULL */
+int gs_textstage_copy(const gs_textstage *stage, uint8_t *out, uint64_t cap, uint64_t *n);
 void gs_textindex_free(gs_textindex *ix);
 uint32_t gs_textindex_n_reads(const gs_textindex *ix);
 const uint64_t *gs_textindex_name_off(const gs_textindex *ix);
