@@ -58,7 +58,18 @@ enum : uint32_t { kOk = 0, kBadCode = 1, kBadDist = 2, kOverrun = 3, kBadStored 
 #ifndef GS_BGZF_D_BITS
 #define GS_BGZF_D_BITS 7
 #endif
+#ifndef GS_BGZF_LANES
+#define GS_BGZF_LANES 16
+#endif
+#ifndef GS_BGZF_WAVES_EU
+#define GS_BGZF_WAVES_EU 3
+#endif
+#define GS_BGZF_OCC __attribute__((amdgpu_waves_per_eu(GS_BGZF_WAVES_EU)))
 constexpr int kLLBits = GS_BGZF_LL_BITS, kDBits = GS_BGZF_D_BITS;
+// Members per wavefront.  A lane's tables are 834 bytes of LDS, so a CU holds 192 members whatever this is; with 16 to a wave they
+// are 12 waves (three to a SIMD) instead of 3: a wave that waits for memory -- and every turn of the loop does, once -- leaves its
+// SIMD to the others, fewer lanes share a turn's rare paths, and a CU takes new members 16 at a time (3.5 GB block: 52 -> 43 ms).
+constexpr int kLanes = GS_BGZF_LANES;
 constexpr uint16_t kLong = 0xFFFFu, kInvalid = 0xFFFEu;
 constexpr int kScratchBytes = 1408;  // per lane: code lengths (320) + two canonical sets (count / first code / first index / running: 4 x 16 x 2 B each) + sorted symbols (288 + 32) x 2 B
 
@@ -66,16 +77,19 @@ struct Canon {  // a lane's row of global scratch, for codes longer than the dir
     uint16_t *count, *first_code, *first_idx, *next, *sorted;
 };
 
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+
+// The member's bits: `bc` valid bits in `bb` (what lies above them in `bb` is the stream's next bits too, or zero), `ip` = the next
+// byte that is not counted in `bc`.
 struct BitIn {
     const uint8_t *ip;
     uint64_t bb;
     uint32_t bc;
-    __device__ __forceinline__ void refill() {
-        if (bc <= 32u) {
-            bb |= (uint64_t)(*reinterpret_cast<const u32u *>(ip)) << bc;
-            ip += 4;
-            bc += 32u;
-        }
+    __device__ __forceinline__ void refill() {  // to at least 56 bits
+        bb |= *reinterpret_cast<const u64u *>(ip) << bc;
+        const uint32_t nb = (63u - bc) >> 3;
+        ip += nb;
+        bc += nb * 8u;
     }
     __device__ __forceinline__ uint32_t take(uint32_t n) {
         const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
@@ -85,9 +99,16 @@ struct BitIn {
     }
 };
 
+// What the decoder of codes LONGER than a direct table's index needs, in the lane's LDS columns: the first code of length
+// tbits + 1 and the number of codes of every length from there to 15 (`cn_lds`, 16 - tbits entries); the symbols of those codes in
+// canonical order either in LDS too (`sym_lds`: distances and code-length codes, at most 32) or in the lane's scratch row from
+// `*long_base` on (literals / lengths).  (With these in global memory a long code cost a dozen dependent loads, and with 64 members
+// to a wavefront three loop turns in four had a lane on that path: 6 us per symbol.)
+constexpr int kSymLds = 32;
+
 // table entry: symbol | length << 9
 __device__ __forceinline__ uint32_t build_tables(const uint8_t *lens, int nsym, uint16_t *tab /* [1 << tbits][64], this lane's column */, int tbits,
-                                                 const Canon &cn) {
+                                                 const Canon &cn, uint16_t *cn_lds, uint8_t *sym_lds, uint32_t *long_base) {
     for (int l = 0; l < 16; l++) cn.count[l] = 0;
     for (int s = 0; s < nsym; s++) cn.count[lens[s]]++;
     cn.count[0] = 0;
@@ -102,60 +123,121 @@ __device__ __forceinline__ uint32_t build_tables(const uint8_t *lens, int nsym, 
         cn.next[l] = (uint16_t)code;
         cn.first_idx[l] = (uint16_t)idx;
         idx += cn.count[l];
+        if (l == tbits + 1) {
+            cn_lds[0] = (uint16_t)code;
+            *long_base = cn.first_idx[l];
+        }
+        if (l > tbits) cn_lds[(l - tbits) * kLanes] = cn.count[l];
     }
-    for (int j = 0; j < (1 << tbits); j++) tab[j * 64] = kInvalid;
+    for (int j = 0; j < (1 << tbits); j++) tab[j * kLanes] = kInvalid;
     uint16_t offs[16];
     for (int l = 0; l < 16; l++) offs[l] = cn.first_idx[l];
     for (int s = 0; s < nsym; s++) {
         const int l = lens[s];
         if (!l) continue;
         const uint32_t c = cn.next[l]++;
-        cn.sorted[offs[l]++] = (uint16_t)s;
+        const uint32_t at = offs[l]++;
+        cn.sorted[at] = (uint16_t)s;
         const uint32_t r = __brev(c) >> (32 - l);
         if (l <= tbits) {
-            for (uint32_t j = r; j < (1u << tbits); j += (1u << l)) tab[j * 64] = (uint16_t)(s | (l << 9));
+            for (uint32_t j = r; j < (1u << tbits); j += (1u << l)) tab[j * kLanes] = (uint16_t)(s | (l << 9));
         } else {
-            tab[(r & ((1u << tbits) - 1u)) * 64] = kLong;
+            tab[(r & ((1u << tbits) - 1u)) * kLanes] = kLong;
+            if (sym_lds) sym_lds[(at - *long_base) * kLanes] = (uint8_t)s;  // (nsym <= kSymLds for these tables)
         }
     }
     return kOk;
 }
-// a code longer than the direct table's index: bit by bit, most significant first (the codes of one length are consecutive)
-__device__ __forceinline__ int canon_decode(BitIn &b, const Canon &cn) {
-    uint32_t code = 0;
-    for (int l = 1; l < 16; l++) {
-        code = (code << 1) | (uint32_t)((b.bb >> (l - 1)) & 1u);
-        const uint32_t d = code - cn.first_code[l];
-        if (code >= cn.first_code[l] && d < cn.count[l]) {
-            b.bb >>= l;
-            b.bc -= l;
-            return cn.sorted[cn.first_idx[l] + d];
+// a code longer than the direct table's index: the canonical search from length TBITS + 1 on (the codes of one length are
+// consecutive, and no shorter code is a prefix: the direct table said so), every length looked at without a branch
+template <int TBITS, bool SYM_LDS>
+__device__ __forceinline__ int canon_decode(BitIn &b, const uint16_t *cn_lds, const uint8_t *sym_lds, const uint16_t *sorted_long) {
+    constexpr int L0 = TBITS + 1;
+    uint32_t cnt[16 - L0];
+    uint32_t first = cn_lds[0];
+#pragma unroll
+    for (int i = 0; i < 16 - L0; i++) cnt[i] = cn_lds[(1 + i) * kLanes];
+    const uint32_t bits = (uint32_t)b.bb;
+    uint32_t code = __brev(bits) >> (32 - L0), idx = 0, hit_len = 0, hit_at = 0;
+#pragma unroll
+    for (int l = L0; l < 16; l++) {
+        const uint32_t d = code - first, c = cnt[l - L0];
+        if (d < c && !hit_len) {
+            hit_len = (uint32_t)l;
+            hit_at = idx + d;
         }
+        idx += c;
+        first = (first + c) << 1;
+        code = (code << 1) | ((bits >> l) & 1u);
     }
-    return -1;
+    if (!hit_len) return -1;
+    b.bb >>= hit_len;
+    b.bc -= hit_len;
+    return SYM_LDS ? (int)sym_lds[hit_at * kLanes] : (int)sorted_long[hit_at];
 }
 
-__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const Member *mem, uint32_t n_members, uint8_t *text, uint8_t *scratch,
+#ifdef GS_BGZF_PROF  // (experiments: what a lane's time goes to; never in the product library)
+__device__ unsigned long long g_prof[8];
+#define PROF_ADD(i, v) prof[i] += (v)
+#define PROF_T() wall_clock64()
+#else
+#define PROF_ADD(i, v) ((void)0)
+#define PROF_T() 0ull
+#endif
+
+#ifndef GS_BGZF_FAST_TURNS
+#define GS_BGZF_FAST_TURNS 8
+#endif
+
+// How the loop is laid out, and why.  The 64 members of a wavefront are decoded in lock step, so a loop turn costs the wave every
+// instruction ANY of its lanes needs: with one loop that handles whatever symbol comes (long codes, runs, overlapping copies, block
+// headers), three turns in four had some lane on a rare path and every turn cost ~1000 instructions (3.8 us) -- for lanes that
+// mostly wanted 100.  So the loop has two parts:
+//   * FAST turns (GS_BGZF_FAST_TURNS in a row): a symbol is taken only if all of it is common -- a literal or a match whose codes
+//     are in the direct tables, at most 32 bytes long, not overlapping its own output, not at the very end of the text.  Anything
+//     else leaves the lane's state untouched and the lane sits out the remaining fast turns;
+//   * one GENERAL step: the next thing of the lane's stream whatever it is (block header and tables, stored block, any symbol).
+// A fast turn does not wait for memory: the eight input bytes it refills from were asked for a turn earlier (`pre`), and a match's
+// source bytes are asked for when it is decoded and stored when the lane's next store is due (`settle`).
+__global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *comp, const Member *mem, uint32_t n_members, uint8_t *text, uint8_t *scratch,
                                                      uint32_t *status) {
-    __shared__ uint16_t s_ll[1 << kLLBits][64];
-    __shared__ uint16_t s_dt[1 << kDBits][64];
+    __shared__ uint16_t s_ll[1 << kLLBits][kLanes];
+    __shared__ uint16_t s_dt[1 << kDBits][kLanes];
+    __shared__ uint16_t s_cnl[16 - kLLBits][kLanes], s_cnd[16 - kDBits][kLanes];
+    __shared__ uint8_t s_dsym[kSymLds][kLanes];
     const uint32_t lane = threadIdx.x;
-    const uint32_t mi = blockIdx.x * 64u + lane;
-    if (mi >= n_members) return;
+    const uint32_t mi = blockIdx.x * kLanes + lane;
+    if (lane >= (uint32_t)kLanes || mi >= n_members) return;
     const Member m = mem[mi];
-    uint16_t *ll = &s_ll[0][lane], *dt = &s_dt[0][lane];
+    uint16_t *ll = &s_ll[0][lane], *dt = &s_dt[0][lane], *cnl = &s_cnl[0][lane], *cnd = &s_cnd[0][lane];
+    uint8_t *dsym = &s_dsym[0][lane];
+    uint32_t long_ll = 0, long_d = 0;
     uint8_t *row = scratch + (size_t)mi * kScratchBytes;
     uint8_t *lens = row;
     uint16_t *w = reinterpret_cast<uint16_t *>(row + 320);
     const Canon cl{w, w + 16, w + 32, w + 48, w + 128}, cd{w + 64, w + 80, w + 96, w + 112, w + 128 + 288};
+    const uint16_t *ll_long = cl.sorted;
     BitIn b{comp + m.coff, 0, 0};
     const uint8_t *const iend = comp + m.coff + m.clen;
     uint8_t *op = text + m.ooff;
     uint8_t *const obase = op, *const oend = op + m.isize;
     uint64_t wbuf = 0;
     uint32_t wn = 0, err = kOk;
+    // a match copied late: its source bytes (up to 32) are asked for when it is decoded, and stored when the lane's next store is
+    // due -- every store of the lane comes after it, so what it writes behind the match's end is overwritten
+    u32x4u pend_a = {0u, 0u, 0u, 0u}, pend_b = {0u, 0u, 0u, 0u};
+    uint8_t *pend_dst = nullptr;
+    uint32_t pend_len = 0;
+    auto settle = [&]() {
+        if (pend_dst) {
+            *reinterpret_cast<u32x4u *>(pend_dst) = pend_a;
+            if (pend_len > 16u) *reinterpret_cast<u32x4u *>(pend_dst + 16) = pend_b;
+            pend_dst = nullptr;
+        }
+    };
     auto flush = [&]() {  // the gathered literals out (the bytes behind them in the store are overwritten by what follows)
         if (!wn) return;
+        settle();
         if (op + 8 <= oend) {
             *reinterpret_cast<u64u *>(op) = wbuf;
         } else {
@@ -165,159 +247,261 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
         wbuf = 0;
         wn = 0;
     };
-    bool last = false;
-    while (!last && err == kOk) {
-        b.refill();
-        if (b.ip > iend + 8) {  // (every block takes bits: a damaged member cannot keep a lane busy beyond its own data)
-            err = kOverrun;
-            break;
-        }
-        last = b.take(1) != 0;
-        const uint32_t btype = b.take(2);
-        if (btype == 0) {  // stored: to the next byte, LEN / NLEN, the bytes
-            flush();
-            b.take(b.bc & 7u);
-            b.refill();
-            const uint32_t len = b.take(16), nlen = b.take(16);
-            if ((len ^ nlen) != 0xFFFFu) {
-                err = kBadStored;
-                break;
-            }
-            const uint8_t *src = b.ip - (b.bc >> 3);  // (bytes the bit buffer holds go back to the input)
-            b.bb = 0;
-            b.bc = 0;
-            if (src + len > iend || op + len > oend) {
-                err = kOverrun;
-                break;
-            }
-            for (uint32_t i = 0; i < len; i++) op[i] = src[i];
-            op += len;
-            b.ip = src + len;
-            continue;
-        }
-        if (btype == 3) {
-            err = kBadType;
-            break;
-        }
-        int nll = 288, nd = 30;
-        if (btype == 1) {
-            for (int s = 0; s < 144; s++) lens[s] = 8;
-            for (int s = 144; s < 256; s++) lens[s] = 9;
-            for (int s = 256; s < 280; s++) lens[s] = 7;
-            for (int s = 280; s < 288; s++) lens[s] = 8;
-            for (int s = 0; s < 30; s++) lens[288 + s] = 5;
-        } else {
-            b.refill();
-            nll = (int)b.take(5) + 257;
-            nd = (int)b.take(5) + 1;
-            const int ncl = (int)b.take(4) + 4;
-            if (nll > 286 || nd > 30) {
-                err = kBadLens;
-                break;
-            }
-            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-            uint8_t *cll = lens + 288;  // (the 19 code-length code lengths: in the distance lengths' place for a moment)
-            for (int i = 0; i < 19; i++) cll[i] = 0;
-            for (int i = 0; i < ncl; i++) {
-                b.refill();
-                cll[order[i]] = (uint8_t)b.take(3);
-            }
-            if ((err = build_tables(cll, 19, dt, kDBits, cd)) != kOk) break;
-            int i = 0;
-            uint8_t tmp[320];
-            while (i < nll + nd) {
-                b.refill();
-                if (b.ip > iend + 8) {
-                    err = kOverrun;
-                    break;
+#ifdef GS_BGZF_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = PROF_T();
+#endif
+    bool done = false, in_block = false, last = false;
+    uint64_t pre = *reinterpret_cast<const u64u *>(b.ip);  // the eight bytes at b.ip
+    while (!done) {
+        // ---- fast turns ----
+        if (in_block) {
+            bool go = true;
+            for (int turn = 0; turn < GS_BGZF_FAST_TURNS && go; turn++) {
+                go = false;
+                {  // at least 56 bits (a symbol takes at most 48), from bytes asked for a turn ago
+                    b.bb |= pre << b.bc;
+                    const uint32_t nb = (63u - b.bc) >> 3;
+                    b.ip += nb;
+                    b.bc += nb * 8u;
+                    pre = *reinterpret_cast<const u64u *>(b.ip);
                 }
-                const uint16_t e = dt[((uint32_t)b.bb & ((1u << kDBits) - 1u)) * 64];
-                int sym;
-                if (e < kInvalid) {
-                    b.take(e >> 9);
-                    sym = e & 0x1FF;
-                } else {
-                    sym = e == kLong ? canon_decode(b, cd) : -1;
-                }
-                if (sym < 0) {
-                    err = kBadCode;
-                    break;
-                }
-                if (sym < 16) {
-                    tmp[i++] = (uint8_t)sym;
-                } else {
-                    int rep, val = 0;
-                    if (sym == 16) {
-                        if (!i) {
-                            err = kBadLens;
-                            break;
-                        }
-                        val = tmp[i - 1];
-                        rep = 3 + (int)b.take(2);
-                    } else if (sym == 17) {
-                        rep = 3 + (int)b.take(3);
+                if (b.ip > iend + 8) break;  // (the general step reports it)
+                const uint32_t e = ll[((uint32_t)b.bb & ((1u << kLLBits) - 1u)) * kLanes];
+                if (e >= kInvalid) break;
+                const uint32_t l1 = e >> 9, sym = e & 0x1FFu;
+                if (sym < 256u) {
+                    if (wn == 7u) {
+                        if (op + 8 > oend) break;
+                        settle();
+                        *reinterpret_cast<u64u *>(op) = wbuf | ((uint64_t)sym << 56);
+                        op += 8;
+                        wbuf = 0;
+                        wn = 0;
                     } else {
-                        rep = 11 + (int)b.take(7);
+                        wbuf |= (uint64_t)sym << (8u * wn);
+                        wn++;
                     }
-                    if (i + rep > nll + nd) {
-                        err = kBadLens;
-                        break;
-                    }
-                    while (rep--) tmp[i++] = (uint8_t)val;
+                    b.bb >>= l1;
+                    b.bc -= l1;
+                    PROF_ADD(3, 1);
+                    go = true;
+                    continue;
                 }
-            }
-            if (err != kOk) break;
-            if (!tmp[256]) {  // (no end-of-block code)
-                err = kBadLens;
-                break;
-            }
-            for (int s = 0; s < nll; s++) lens[s] = tmp[s];
-            for (int s = nll; s < 288; s++) lens[s] = 0;
-            for (int s = 0; s < nd; s++) lens[288 + s] = tmp[nll + s];
-            for (int s = nd; s < 30; s++) lens[288 + s] = 0;
-            nll = 288;
-            nd = 30;
-        }
-        if ((err = build_tables(lens, nll, ll, kLLBits, cl)) != kOk) break;
-        if ((err = build_tables(lens + 288, nd, dt, kDBits, cd)) != kOk) break;
-        // ---- the block's symbols ----
-        for (;;) {
-            b.refill();
-            if (b.ip > iend + 8) {
-                err = kOverrun;
-                break;
-            }
-            int sym;
-            {
-                const uint16_t e = ll[((uint32_t)b.bb & ((1u << kLLBits) - 1u)) * 64];
-                if (e < kInvalid) {
-                    b.take(e >> 9);
-                    sym = e & 0x1FF;
-                } else if (e == kLong) {
-                    sym = canon_decode(b, cl);
+                const uint32_t c = sym - 257u;
+                if (c > 28u) break;  // (the end of the block, or a code that is not one)
+                uint64_t t = b.bb >> l1;
+                uint32_t used = l1, len;
+                if (c < 8u) {
+                    len = 3u + c;
+                } else if (c == 28u) {
+                    len = 258u;
                 } else {
-                    sym = -1;
+                    const uint32_t eb = (c >> 2) - 1u;
+                    len = ((4u + (c & 3u)) << eb) + 3u + ((uint32_t)t & ((1u << eb) - 1u));
+                    t >>= eb;
+                    used += eb;
                 }
-            }
-            if (sym < 0) {
-                err = kBadCode;
-                break;
-            }
-            if (sym < 256) {
-                wbuf |= (uint64_t)sym << (8 * wn);
-                if (++wn == 8) {
-                    if (op + 8 > oend) {
-                        err = kOverrun;
-                        break;
-                    }
+                const uint32_t e2 = dt[((uint32_t)t & ((1u << kDBits) - 1u)) * kLanes];
+                if (e2 >= kInvalid) break;
+                const uint32_t l2 = e2 >> 9, ds = e2 & 0x1FFu;
+                if (ds > 29u) break;
+                t >>= l2;
+                used += l2;
+                uint32_t dist;
+                if (ds < 4u) {
+                    dist = ds + 1u;
+                } else {
+                    const uint32_t eb = (ds >> 1) - 1u;
+                    dist = ((2u + (ds & 1u)) << eb) + 1u + ((uint32_t)t & ((1u << eb) - 1u));
+                    t >>= eb;
+                    used += eb;
+                }
+                uint8_t *const at = op + wn;  // (where the match goes once the gathered literals are out)
+                if (len > 32u || len > dist || dist > (uint32_t)(at - obase) || at + 32 > oend) break;
+                b.bb = t;
+                b.bc -= used;
+                settle();
+                if (wn) {
                     *reinterpret_cast<u64u *>(op) = wbuf;
-                    op += 8;
                     wbuf = 0;
                     wn = 0;
                 }
+                const uint8_t *src = at - dist;
+                pend_a = *reinterpret_cast<const u32x4u *>(src);
+                if (len > 16u) pend_b = *reinterpret_cast<const u32x4u *>(src + 16);
+                pend_dst = at;
+                pend_len = len;
+                op = at + len;
+                PROF_ADD(4, 1);
+                go = true;
+            }
+        }
+        // ---- the general step ----
+        PROF_ADD(2, 1);
+        b.refill();
+        if (b.ip > iend + 8) {  // (a damaged member cannot keep a lane busy beyond its own data)
+            err = kOverrun;
+            break;
+        }
+        if (!in_block) {
+            if (last) {
+                done = true;
+                break;
+            }
+            const unsigned long long t_hdr = PROF_T();
+            (void)t_hdr;
+            last = b.take(1) != 0;
+            const uint32_t btype = b.take(2);
+            if (btype == 0) {  // stored: to the next byte, LEN / NLEN, the bytes
+                flush();
+                settle();
+                b.take(b.bc & 7u);
+                b.refill();
+                const uint32_t len = b.take(16), nlen = b.take(16);
+                if ((len ^ nlen) != 0xFFFFu) {
+                    err = kBadStored;
+                    break;
+                }
+                const uint8_t *src = b.ip - (b.bc >> 3);  // (bytes the bit buffer holds go back to the input)
+                b.bb = 0;
+                b.bc = 0;
+                if (src + len > iend || op + len > oend) {
+                    err = kOverrun;
+                    break;
+                }
+                for (uint32_t i = 0; i < len; i++) op[i] = src[i];
+                op += len;
+                b.ip = src + len;
+                pre = *reinterpret_cast<const u64u *>(b.ip);
                 continue;
             }
-            if (sym == 256) break;
+            if (btype == 3) {
+                err = kBadType;
+                break;
+            }
+            int nll = 288, nd = 30;
+            if (btype == 1) {
+                for (int s = 0; s < 144; s++) lens[s] = 8;
+                for (int s = 144; s < 256; s++) lens[s] = 9;
+                for (int s = 256; s < 280; s++) lens[s] = 7;
+                for (int s = 280; s < 288; s++) lens[s] = 8;
+                for (int s = 0; s < 30; s++) lens[288 + s] = 5;
+            } else {
+                b.refill();
+                nll = (int)b.take(5) + 257;
+                nd = (int)b.take(5) + 1;
+                const int ncl = (int)b.take(4) + 4;
+                if (nll > 286 || nd > 30) {
+                    err = kBadLens;
+                    break;
+                }
+                const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                uint8_t *cll = lens + 288;  // (the 19 code-length code lengths: in the distance lengths' place for a moment)
+                for (int i = 0; i < 19; i++) cll[i] = 0;
+                for (int i = 0; i < ncl; i++) {
+                    b.refill();
+                    cll[order[i]] = (uint8_t)b.take(3);
+                }
+                if ((err = build_tables(cll, 19, dt, kDBits, cd, cnd, dsym, &long_d)) != kOk) break;
+                int i = 0;
+                uint8_t tmp[320];
+                while (i < nll + nd) {
+                    b.refill();
+                    if (b.ip > iend + 8) {
+                        err = kOverrun;
+                        break;
+                    }
+                    const uint16_t e = dt[((uint32_t)b.bb & ((1u << kDBits) - 1u)) * kLanes];
+                    int sym;
+                    if (e < kInvalid) {
+                        b.take(e >> 9);
+                        sym = e & 0x1FF;
+                    } else {
+                        sym = e == kLong ? canon_decode<kDBits, true>(b, cnd, dsym, nullptr) : -1;
+                    }
+                    if (sym < 0) {
+                        err = kBadCode;
+                        break;
+                    }
+                    if (sym < 16) {
+                        tmp[i++] = (uint8_t)sym;
+                    } else {
+                        int rep, val = 0;
+                        if (sym == 16) {
+                            if (!i) {
+                                err = kBadLens;
+                                break;
+                            }
+                            val = tmp[i - 1];
+                            rep = 3 + (int)b.take(2);
+                        } else if (sym == 17) {
+                            rep = 3 + (int)b.take(3);
+                        } else {
+                            rep = 11 + (int)b.take(7);
+                        }
+                        if (i + rep > nll + nd) {
+                            err = kBadLens;
+                            break;
+                        }
+                        while (rep--) tmp[i++] = (uint8_t)val;
+                    }
+                }
+                if (err != kOk) break;
+                if (!tmp[256]) {  // (no end-of-block code)
+                    err = kBadLens;
+                    break;
+                }
+                for (int s = 0; s < nll; s++) lens[s] = tmp[s];
+                for (int s = nll; s < 288; s++) lens[s] = 0;
+                for (int s = 0; s < nd; s++) lens[288 + s] = tmp[nll + s];
+                for (int s = nd; s < 30; s++) lens[288 + s] = 0;
+                nll = 288;
+                nd = 30;
+            }
+            if ((err = build_tables(lens, nll, ll, kLLBits, cl, cnl, nullptr, &long_ll)) != kOk) break;
+            if ((err = build_tables(lens + 288, nd, dt, kDBits, cd, cnd, dsym, &long_d)) != kOk) break;
+            ll_long = cl.sorted + long_ll;
+            in_block = true;
+            PROF_ADD(1, PROF_T() - t_hdr);
+            pre = *reinterpret_cast<const u64u *>(b.ip);
+            continue;
+        }
+        // one symbol, whatever it is
+        int sym;
+        {
+            const uint16_t e = ll[((uint32_t)b.bb & ((1u << kLLBits) - 1u)) * kLanes];
+            if (e < kInvalid) {
+                b.take(e >> 9);
+                sym = e & 0x1FF;
+            } else if (e == kLong) {
+                sym = canon_decode<kLLBits, false>(b, cnl, nullptr, ll_long);
+                PROF_ADD(5, 1);
+            } else {
+                sym = -1;
+            }
+        }
+        if (sym < 0) {
+            err = kBadCode;
+            break;
+        }
+        if (sym < 256) {
+            PROF_ADD(3, 1);
+            wbuf |= (uint64_t)sym << (8 * wn);
+            if (++wn == 8) {
+                if (op + 8 > oend) {
+                    err = kOverrun;
+                    break;
+                }
+                settle();
+                *reinterpret_cast<u64u *>(op) = wbuf;
+                op += 8;
+                wbuf = 0;
+                wn = 0;
+            }
+        } else if (sym == 256) {
+            in_block = false;
+        } else {
             const uint32_t c = (uint32_t)sym - 257u;
             if (c > 28u) {
                 err = kBadCode;
@@ -333,12 +517,13 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
             b.refill();
             int ds;
             {
-                const uint16_t e = dt[((uint32_t)b.bb & ((1u << kDBits) - 1u)) * 64];
+                const uint16_t e = dt[((uint32_t)b.bb & ((1u << kDBits) - 1u)) * kLanes];
                 if (e < kInvalid) {
                     b.take(e >> 9);
                     ds = e & 0x1FF;
                 } else if (e == kLong) {
-                    ds = canon_decode(b, cd);
+                    ds = canon_decode<kDBits, true>(b, cnd, dsym, nullptr);
+                    PROF_ADD(7, 1);
                 } else {
                     ds = -1;
                 }
@@ -354,6 +539,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
                 dist = ((2u + ((uint32_t)ds & 1u)) << eb) + 1u + b.take(eb);
             }
             flush();
+            settle();
             if (dist > (uint32_t)(op - obase)) {
                 err = kBadDist;
                 break;
@@ -364,7 +550,23 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
             }
             const uint8_t *src = op - dist;
             uint8_t *const mend = op + len;
-            if (dist >= 8u) {
+            PROF_ADD(4, 1);
+            if (dist < 8u && len > dist) PROF_ADD(6, 1);
+            if (dist >= 16u) {
+                while (op + 16 <= mend) {
+                    *reinterpret_cast<u32x4u *>(op) = *reinterpret_cast<const u32x4u *>(src);
+                    op += 16;
+                    src += 16;
+                }
+                if (op < mend) {
+                    if (op + 16 <= oend) {
+                        *reinterpret_cast<u32x4u *>(op) = *reinterpret_cast<const u32x4u *>(src);  // (what lies behind the match is written next)
+                    } else {
+                        for (; op < mend; op++, src++) *op = *src;
+                    }
+                    op = mend;
+                }
+            } else if (dist >= 8u) {
                 while (op + 8 <= mend) {
                     *reinterpret_cast<u64u *>(op) = *reinterpret_cast<const u64u *>(src);
                     op += 8;
@@ -372,35 +574,41 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
                 }
                 if (op < mend) {
                     if (op + 8 <= oend) {
-                        *reinterpret_cast<u64u *>(op) = *reinterpret_cast<const u64u *>(src);  // (what lies behind the match is written next)
+                        *reinterpret_cast<u64u *>(op) = *reinterpret_cast<const u64u *>(src);
                     } else {
                         for (; op < mend; op++, src++) *op = *src;
                     }
                     op = mend;
                 }
-            } else if (dist == 1u) {  // a run of one byte (the quality line of `seqtk seq -F '#'`, homopolymers)
-                const uint64_t v = 0x0101010101010101ULL * (uint64_t)*src;
-                while (op + 8 <= mend) {
+            } else {
+                // a period of 1 .. 7 bytes (the quality line of `seqtk seq -F '#'`, homopolymers, short tandem repeats): the period
+                // from its own bytes, repeated to fill a register, stored in steps of the largest multiple of the period that fits
+                // -- no load waits for a store of this match
+                uint64_t v = 0;
+                for (uint32_t i = 0; i < dist; i++) v |= (uint64_t)src[i] << (8u * i);
+                for (uint32_t sft = dist; sft < 8u; sft <<= 1) v |= v << (8u * sft);
+                const uint32_t step = (8u / dist) * dist;
+                while (op + 8 <= oend && op < mend) {
                     *reinterpret_cast<u64u *>(op) = v;
-                    op += 8;
+                    op += step;
                 }
-                if (op < mend) {
-                    if (op + 8 <= oend) *reinterpret_cast<u64u *>(op) = v;
-                    else
-                        for (uint8_t *q = op; q < mend; q++) *q = (uint8_t)v;
-                    op = mend;
-                }
-            } else {  // overlapping copies of a short period: byte by byte
-                for (; op < mend; op++, src++) *op = *src;
+                for (uint32_t i = 0; op < mend; op++, i++) *op = (uint8_t)(v >> (8u * (i % dist)));  // (the last bytes of the text)
+                op = mend;
             }
         }
+        pre = *reinterpret_cast<const u64u *>(b.ip);
     }
+    settle();
     if (err == kOk) {
         flush();
         if (op != oend) err = kBadSize;                                     // ISIZE
         else if (b.ip - (b.bc >> 3) > iend) err = kOverrun;                 // the last block ended behind the member's data
     }
     if (err != kOk) atomicCAS(status, 0u, (mi << 4) | err);
+#ifdef GS_BGZF_PROF
+    prof[0] = PROF_T() - t_begin;
+    for (int i = 0; i < 8; i++) atomicAdd(&g_prof[i], prof[i]);
+#endif
 }
 
 // CRC-32 of every member's text against its trailer (a lane per member; eight bytes per load, the table in LDS)
@@ -795,7 +1003,7 @@ int gs_bgzf_next(gs_bgzf *z, uint64_t want, gs_textstage **stage) {
         HIP_TRY(hipMemcpyAsync(z->d_mem, sl.members.data(), (size_t)nm * sizeof(Member), hipMemcpyHostToDevice, z->st));
         HIP_TRY(hipMemsetAsync(z->d_status, 0, sizeof(uint32_t), z->st));
         HIP_TRY(hipEventRecord(z->ev0, z->st));
-        hipLaunchKernelGGL(k_bgzf_inflate, dim3((nm + 63) / 64), dim3(64), 0, z->st, sl.d_comp, z->d_mem, nm, d_text + n, z->d_scratch, z->d_status);
+        hipLaunchKernelGGL(k_bgzf_inflate, dim3((nm + kLanes - 1) / kLanes), dim3(64), 0, z->st, sl.d_comp, z->d_mem, nm, d_text + n, z->d_scratch, z->d_status);
         hipLaunchKernelGGL(k_bgzf_crc, dim3((nm + 63) / 64), dim3(64), 0, z->st, d_text + n, z->d_mem, nm, z->d_status);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(z->ev1, z->st));
@@ -822,6 +1030,13 @@ int gs_bgzf_next(gs_bgzf *z, uint64_t want, gs_textstage **stage) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, z->ev0, z->ev1);
             fprintf(stderr, "[gs_bgzf_next] %u members, %.1f MB -> %.1f MB: inflate + crc kernels %.2f ms\n", nm, sl.comp_at / 1e6, block_text / 1e6, ms);
+#ifdef GS_BGZF_PROF
+            unsigned long long pr[8], zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_prof), sizeof pr);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof zero);
+            fprintf(stderr, "[prof] per member: %.0f ticks in all, %.0f in headers + tables; %.0f loop turns = %.0f literals + %.0f matches (long codes: %.1f literal / length, %.1f distance; %.0f bytes of short-period copies)\n",
+                    (double)pr[0] / nm, (double)pr[1] / nm, (double)pr[2] / nm, (double)pr[3] / nm, (double)pr[4] / nm, (double)pr[5] / nm, (double)pr[7] / nm, (double)pr[6] / nm);
+#endif
         }
         if (status) {
             set_error("gs_bgzf_next: %s (member %u of the block that ends at byte %llu)", err_text(status & 15u), status >> 4, (unsigned long long)z->file_at);

@@ -100,12 +100,78 @@ struct DevMem {  // bump allocation from the arena; side allocations are freed w
     }
 };
 
-__global__ void k_line_start_flags(const uint8_t *__restrict__ text, uint32_t n, uint8_t *__restrict__ flag, unsigned long long *n_lines) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool f = i < n && (i == 0u || text[i - 1] == '\n');
-    if (i < n) flag[i] = f ? 1 : 0;
-    const unsigned long long b = __ballot(f);
-    if ((threadIdx.x & 63u) == 0u && b) atomicAdd(n_lines, (unsigned long long)__popcll(b));
+// Line starts = position 0 and every position after a '\n' (if inside the text), in order.  Two passes over the text, 16 bytes per
+// lane and load: the newlines of each 16 KB tile are counted, the counts are scanned, and the second pass writes the positions to
+// their places (a wave-level prefix over the lanes' counts, the waves' totals through LDS).  The text is addressed from the 16-byte
+// boundary at or below its first byte ("virtual" offsets, `head` = the bytes before the text), so that every load is aligned.
+constexpr uint32_t kLsTile = 16384, kLsSub = 4096;  // bytes per workgroup, bytes per round of its 256 lanes
+
+// bit 7 of every byte of `x` that is '\n'
+__device__ inline uint32_t nl_bytes(uint32_t x) {
+    const uint32_t y = x ^ 0x0A0A0A0Au;
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+}
+
+// the newline bytes of the 16 bytes at virtual offset `v`, as four words of bit-7 flags; only those at [lo, hi) count
+__device__ inline uint4 nl_of_chunk(const uint8_t *__restrict__ vbase, uint64_t v, uint64_t lo, uint64_t hi) {
+    uint4 m = make_uint4(0u, 0u, 0u, 0u);
+    if (v + 16u <= lo || v >= hi) return m;
+    const uint4 w = *reinterpret_cast<const uint4 *>(vbase + v);
+    m = make_uint4(nl_bytes(w.x), nl_bytes(w.y), nl_bytes(w.z), nl_bytes(w.w));
+    if (v < lo || v + 16u > hi) {  // a chunk at either end of the text: drop the flags of the bytes outside
+        uint32_t *mm = reinterpret_cast<uint32_t *>(&m);
+        for (uint32_t b = 0; b < 16u; b++)
+            if (v + b < lo || v + b >= hi) mm[b >> 2] &= ~(0x80u << ((b & 3u) * 8u));
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_nl_count(const uint8_t *__restrict__ vbase, uint64_t lo, uint64_t hi, uint32_t *__restrict__ tile_count) {
+    __shared__ uint32_t s_w[4];
+    uint32_t c = 0;
+    const uint64_t t0 = (uint64_t)blockIdx.x * kLsTile;
+    for (uint32_t j = 0; j < kLsTile / kLsSub; j++) {
+        const uint4 m = nl_of_chunk(vbase, t0 + j * kLsSub + threadIdx.x * 16u, lo, hi);
+        c += __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
+    }
+    for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void k_nl_write(const uint8_t *__restrict__ vbase, uint64_t lo, uint64_t hi, uint32_t head,
+                                                  const uint32_t *__restrict__ tile_base, uint32_t *__restrict__ ls) {
+    __shared__ uint32_t s_w[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ls[0] = 0u;
+    uint32_t base = 1u + tile_base[blockIdx.x];
+    const uint64_t t0 = (uint64_t)blockIdx.x * kLsTile;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t j = 0; j < kLsTile / kLsSub; j++) {
+        const uint64_t v = t0 + j * kLsSub + threadIdx.x * 16u;
+        const uint4 m = nl_of_chunk(vbase, v, lo, hi);
+        const uint32_t c = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
+        uint32_t inc = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o);
+            if ((int)lane >= o) inc += up;
+        }
+        __syncthreads();  // (the totals of the round before have been read)
+        if (lane == 63u) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 4u; w++) {
+            if (w < wave) before += s_w[w];
+            all += s_w[w];
+        }
+        if (c) {
+            uint32_t at = base + before + inc - c;
+            const uint32_t mm[4] = {m.x, m.y, m.z, m.w};
+            for (uint32_t q = 0; q < 4u; q++)
+                for (uint32_t f = mm[q]; f; f &= f - 1u) ls[at++] = (uint32_t)(v - head) + q * 4u + ((uint32_t)__ffs(f) >> 3);  // the byte AFTER the newline
+        }
+        base += all;
+    }
 }
 
 // per line: its length without '\n' / '\r', its first byte (0 for an empty line); the index of the last non-empty line
@@ -369,30 +435,34 @@ int gs_reads_from_staged_text(const gs_textstage *stage, int k, gs_reads **out, 
     const bool fastq = stage->first == '@';
     DevMem mem(device);
     const uint8_t *d_text = stage->d_text;
-    uint8_t *d_flag, *d_c0, *d_hdr, *d_seq;
-    uint32_t *d_ls, *d_llen, *d_seqbytes, *d_base, *d_scalars, *d_hdr_line, *d_name_off, *d_name_len, *d_rec_off;
+    uint8_t *d_c0, *d_hdr, *d_seq;
+    uint32_t *d_ls, *d_llen, *d_seqbytes, *d_base, *d_scalars, *d_hdr_line, *d_name_off, *d_name_len, *d_rec_off, *d_tile;
     unsigned long long *d_count;
-    HIP_TRY(mem.get(&d_flag, n));
+    // line starts (see k_nl_count): a newline at the text's last byte starts no line
+    const uint32_t head = (uint32_t)(reinterpret_cast<uintptr_t>(stage->d_text) & 15u);
+    const uint8_t *vbase = stage->d_text - head;
+    const uint64_t lo = head, hi = (uint64_t)head + n - 1u;
+    const uint32_t n_tiles = (uint32_t)(((uint64_t)head + n + kLsTile - 1u) / kLsTile);
+    HIP_TRY(mem.get(&d_tile, (size_t)n_tiles + 1));
     HIP_TRY(mem.get(&d_count, 2));
     HIP_TRY(mem.get(&d_scalars, 4));
     lap("mallocs");
     HIP_TRY(hipMemset(d_scalars, 0, 16));
     HIP_TRY(hipMemset(d_count, 0, 16));
-    hipLaunchKernelGGL(k_line_start_flags, dim3((n + 255) / 256), dim3(256), 0, 0, d_text, n, d_flag, d_count + 1);
-    unsigned long long n_lines_counted = 0;
-    HIP_TRY(hipMemcpy(&n_lines_counted, d_count + 1, 8, hipMemcpyDeviceToHost));
-    // line starts = the positions whose flag is set, in order
-    HIP_TRY(mem.get(&d_ls, (size_t)n_lines_counted + 1));
+    HIP_TRY(hipMemset(d_tile + n_tiles, 0, 4));
+    hipLaunchKernelGGL(k_nl_count, dim3(n_tiles), dim3(256), 0, 0, vbase, lo, hi, d_tile);
     size_t tb = 0;
     void *d_tmp = nullptr;
     rocprim::counting_iterator<uint32_t> iota(0u);
-    HIP_TRY(rocprim::select(nullptr, tb, iota, d_flag, d_ls, d_count, (size_t)n));
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_tile, d_tile, 0u, (size_t)n_tiles + 1, rocprim::plus<uint32_t>()));
     HIP_TRY(mem.get(reinterpret_cast<uint8_t **>(&d_tmp), tb));
-    HIP_TRY(rocprim::select(d_tmp, tb, iota, d_flag, d_ls, d_count, (size_t)n));
+    HIP_TRY(rocprim::exclusive_scan(d_tmp, tb, d_tile, d_tile, 0u, (size_t)n_tiles + 1, rocprim::plus<uint32_t>()));
+    uint32_t n_newlines = 0;
+    HIP_TRY(hipMemcpy(&n_newlines, d_tile + n_tiles, 4, hipMemcpyDeviceToHost));
+    const uint32_t n_lines = n_newlines + 1u;
+    HIP_TRY(mem.get(&d_ls, (size_t)n_lines + 1));
+    hipLaunchKernelGGL(k_nl_write, dim3(n_tiles), dim3(256), 0, 0, vbase, lo, hi, head, d_tile, d_ls);
     lap("line starts");
-    unsigned long long n_lines64 = 0;
-    HIP_TRY(hipMemcpy(&n_lines64, d_count, 8, hipMemcpyDeviceToHost));
-    const uint32_t n_lines = (uint32_t)n_lines64;
     HIP_TRY(mem.get(&d_llen, n_lines));
     HIP_TRY(mem.get(&d_c0, n_lines));
     HIP_TRY(mem.get(&d_hdr, n_lines));
