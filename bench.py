@@ -363,13 +363,27 @@ def cli_large_leg(a, device):
             t1 = time.perf_counter()
             big_bases, nb = big.n_bases, big.n_reads
 
+            import struct
+            import zlib
+
+            def bgzf_member(chunk):  # bgzip's container: <= 64 KiB of text per member, its compressed size in the `BC` extra field
+                c = zlib.compressobj(1, zlib.DEFLATED, -15)
+                raw = c.compress(chunk) + c.flush()
+                return (b"\x1f\x8b\x08\x04" + b"\0" * 6 + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(raw) + 8 - 1) + raw +
+                        struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
             def member(lo):
                 hi = min(lo + 500, nb)
-                return gzip.compress(b"".join(b"@g%d\n" % (lo + j) + sq + b"\n+\n" + b"#" * len(sq) + b"\n" for j, sq in enumerate(big.host_reads(lo, hi))), 1)
+                text = b"".join(b"@g%d\n" % (lo + j) + sq + b"\n+\n" + b"#" * len(sq) + b"\n" for j, sq in enumerate(big.host_reads(lo, hi)))
+                return gzip.compress(text, 1), b"".join(bgzf_member(text[at:at + 65280]) for at in range(0, len(text), 65280))
 
-            with open(f"{d}/big.fq.gz", "wb") as f, ThreadPoolExecutor(16) as pool:
-                for blob in pool.map(member, range(0, nb, 500)):
+            # the same text twice: as plain multi-member gzip, and in bgzip's container -- what `rustybam fastq-split` (tagONT.smk:17)
+            # writes its `.gz` outputs in, and what the GPU inflate path (csrc/gs_bgzf.hip) takes
+            with open(f"{d}/big.fq.gz", "wb") as f, open(f"{d}/big.bgzf.fq.gz", "wb") as fz, ThreadPoolExecutor(16) as pool:
+                for blob, zblob in pool.map(member, range(0, nb, 500)):
                     f.write(blob)
+                    fz.write(zblob)
+                fz.write(bgzf_member(b""))
             big.close()
             log(f"genome-scale reads: {nb} reads, {big_bases} bases -> big.fq.gz {os.path.getsize(f'{d}/big.fq.gz') / 2**30:.2f} GiB ({time.perf_counter() - t1:.1f} s)")
         log(f"CLI at {n_keys} keys: files written ({time.perf_counter() - t0:.1f} s; db {os.path.getsize(f'{d}/db') / 2**30:.1f} GiB, loc {os.path.getsize(f'{d}/loc') / 2**30:.1f} GiB)")
@@ -414,6 +428,34 @@ def cli_large_leg(a, device):
                      "note": "`python -m gavisunk_amd.kmerpos_annot3 big.fq.gz db loc out` with the sidecar: multi-member .fq.gz (quals '#') inflated by the native parallel reader "
                              "(gs_gz_*), text blocks copied to the device and parsed there, rows written natively (gs_rowwriter_*).  read_or_inflate_text and "
                              "copy_text_to_device run on the reader thread beside the others; wait_for_reader is what the main thread waits for them"}
+
+            # the same reads in bgzip's container: read, inflated (on the GPU), parsed, tagged, written -- the bytes of the run above
+            bgzf_runs = []
+            for rep in range(2):
+                t1 = time.perf_counter()
+                rc6 = kmerpos_annot3.main([f"{d}/big.bgzf.fq.gz", f"{d}/db", f"{d}/loc", f"{d}/out.bgzf"])
+                bgzf_runs.append(time.perf_counter() - t1)
+            tmz = dict(kmerpos_annot3.last_timing)
+            tmz.pop("rows", None)
+
+            def same_file(x, y):
+                if os.path.getsize(x) != os.path.getsize(y):
+                    return False
+                with open(x, "rb") as fx, open(y, "rb") as fy:
+                    while True:
+                        bx, by = fx.read(1 << 24), fy.read(1 << 24)
+                        if bx != by:
+                            return False
+                        if not bx:
+                            return True
+
+            t_z = min(bgzf_runs)
+            scale["bgzf"] = {"fq_gz_GiB": round(os.path.getsize(f"{d}/big.bgzf.fq.gz") / 2**30, 2), "seconds": round(t_z, 2), "seconds_of_each_run": [round(x, 2) for x in bgzf_runs],
+                             "cli_bases_per_s": big_bases / t_z, "seconds_by_phase": {k_: round(v, 2) for k_, v in tmz.items()},
+                             "same_bytes_as_the_gzip_run": bool(rc6 == 0 and "read_and_inflate_on_device" in tmz and same_file(f"{d}/out.big", f"{d}/out.bgzf")),
+                             "note": "the same reads in bgzip's container (members of <= 64 KiB of text with their compressed size in the header: what `rustybam fastq-split` "
+                                     "writes, tagONT.smk:17): the compressed bytes go to the device, k_bgzf_inflate decodes a member per lane, CRC-32 and ISIZE checked there, "
+                                     "the text block is parsed where it lies (csrc/gs_bgzf.hip); seconds = the faster of two runs"}
 
         res = {"keys": int(n_keys), "read_bases": int(n_bases), "rows_out": open(f"{d}/out.plain", "rb").read().count(b"\n"),
                "parse_and_build_every_run": {"seconds": round(t_plain, 2), "cli_bases_per_s": n_bases / t_plain, "seconds_by_phase": phases.get("plain")},
