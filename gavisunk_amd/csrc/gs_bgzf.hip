@@ -772,6 +772,7 @@ struct gs_bgzf {
     Member *d_mem = nullptr;
     uint8_t *d_scratch = nullptr;
     size_t mem_cap = 0;
+    unsigned readers = 4;  // threads that read a chunk of the file (GAVISUNK_BGZF_READERS)
     size_t members_in_flight = 49152;  // what one launch of k_bgzf_inflate keeps resident: CUs x (LDS of a CU / LDS of a lane)
     uint32_t *d_status = nullptr;
     unsigned long long *d_count = nullptr;
@@ -816,12 +817,13 @@ int fill_slot(gs_bgzf *z, gs_bgzf::Slot &sl, uint64_t want, uint64_t room, bool 
         HIP_TRY(hipEventSynchronize(z->h_free[k]));  // (this pinned buffer's last copy has left it)
         if (trace) fprintf(stderr, "[bgzf] chunk at %llu: reading %zu bytes\n", (unsigned long long)z->file_at, take);
         {  // four threads read a quarter each (one thread copies out of the page cache at 5-6 GB/s: it would be the whole run)
-            constexpr unsigned kReaders = 4;
-            bool ok[kReaders] = {true, true, true, true};
+            constexpr unsigned kMaxReaders = 16;
+            bool ok[kMaxReaders];
+            for (unsigned t = 0; t < kMaxReaders; t++) ok[t] = true;
             uint8_t *dst = z->h_chunk[k];
             const int fd = z->fd;
             const uint64_t at = z->file_at;
-            const unsigned T = take >= ((size_t)4 << 20) ? kReaders : 1u;
+            const unsigned T = take >= ((size_t)4 << 20) ? z->readers : 1u;
             gs_parallel_for(T, [&](unsigned t) {
                 size_t lo = take * t / T;
                 const size_t hi = take * (t + 1) / T;
@@ -834,7 +836,9 @@ int fill_slot(gs_bgzf *z, gs_bgzf::Slot &sl, uint64_t want, uint64_t room, bool 
                     lo += (size_t)r;
                 }
             });
-            if (!(ok[0] && ok[1] && ok[2] && ok[3])) {
+            bool all_ok = true;
+            for (unsigned t = 0; t < T; t++) all_ok = all_ok && ok[t];
+            if (!all_ok) {
                 set_error("gs_bgzf_next: read failed");
                 return GS_E_IO;
             }
@@ -932,6 +936,7 @@ int gs_bgzf_open(const char *path, int device, gs_bgzf **out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             z->members_in_flight = (size_t)prop.multiProcessorCount * (size_t)(prop.maxSharedMemoryPerMultiProcessor / kInflateLdsBytes) * (size_t)kLanes;
     }
+    if (const char *rk = getenv("GAVISUNK_BGZF_READERS")) z->readers = (unsigned)std::min(16, std::max(1, atoi(rk)));
     if (const char *ck = getenv("GAVISUNK_BGZF_CHUNK_KB")) z->chunk = std::min(kChunk, (size_t)std::max(128, atoi(ck)) << 10);
     hipError_t e = hipStreamCreateWithFlags(&z->st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&z->st_copy, hipStreamNonBlocking);

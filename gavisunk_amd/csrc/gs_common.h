@@ -74,6 +74,7 @@ struct gs_textstage {
     uint32_t n = 0;
     uint8_t first = 0;
     size_t cap = 0;
+    uint32_t skew = 0;  // bytes of the buffer in front of the text (GAVISUNK_TEST_STAGE_SKEW: the parser takes text at any alignment)
 };
 namespace gs {
 uint8_t *stage_buffer(int device, size_t want, size_t *cap);          // from the cache of staged-text buffers, or fresh

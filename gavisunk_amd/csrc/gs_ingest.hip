@@ -352,15 +352,17 @@ int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstag
     st->n = (uint32_t)n_bytes;
     st->first = n_bytes ? text[0] : 0;
     const size_t n = st->n;
-    st->d_text = stage_cache().get(device, n, &st->cap);
+    if (const char *sk = getenv("GAVISUNK_TEST_STAGE_SKEW")) st->skew = (uint32_t)atoi(sk) & 15u;
+    st->d_text = stage_cache().get(device, n + st->skew, &st->cap);
     if (!st->d_text) {
-        st->cap = std::max<size_t>(n + n / 8, 1);  // (a little room: the next block of a file is about this long)
+        st->cap = std::max<size_t>(n + n / 8 + st->skew, 1);  // (a little room: the next block of a file is about this long)
         if (hipMalloc(reinterpret_cast<void **>(&st->d_text), st->cap) != hipSuccess) {
             delete st;
             set_error("gs_text_stage: out of device memory (%zu bytes)", n);
             return GS_E_NOMEM;
         }
     }
+    st->d_text += st->skew;
     // the text through two small pinned buffers on a stream of its own (a pageable copy of a few hundred MB makes the runtime
     // pin the whole range first); callable from a second thread while the first one loads the SUNK table
     constexpr size_t kStage = 8u << 20;
@@ -374,7 +376,7 @@ int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstag
     static thread_local Stage sg;
     auto fail = [&](hipError_t e) {
         set_error("gs_text_stage: %s", hipGetErrorString(e));
-        (void)hipFree(st->d_text);
+        (void)hipFree(st->d_text - st->skew);
         delete st;
         return GS_E_NODEVICE;
     };
@@ -405,7 +407,7 @@ int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstag
 
 void gs_text_stage_free(gs_textstage *st) {
     if (!st) return;
-    if (st->d_text) stage_cache().put(st->device, st->d_text, st->cap);
+    if (st->d_text) stage_cache().put(st->device, st->d_text - st->skew, st->cap);
     delete st;
 }
 

@@ -176,6 +176,22 @@ def test_blocks_of_whole_records(tmp_path):
             assert names == [f"r{i}" for i in range(len(seqs))] and lens == [len(s) for s in seqs]
 
 
+@pytest.mark.parametrize("skew", [1, 7, 15])
+def test_text_at_any_alignment(skew, tmp_path, monkeypatch):
+    """The line-start kernels read 16 aligned bytes per lane: a text that starts anywhere in such a chunk (and ends anywhere in
+    one) gives the same reads -- several 16 KiB tiles, lines that end on tile and chunk boundaries, CRLF, no final newline."""
+    monkeypatch.setenv("GAVISUNK_TEST_STAGE_SKEW", str(skew))
+    rng = np.random.default_rng(skew)
+    seqs = [bytes(synth.codes_to_ascii(rng.integers(0, 4, int(n), dtype=np.uint8))) for n in (16384 - 4 - skew, 1, 15, 16, 17, 4096, 30000, 16384 * 2, 63)]
+    fq = b"".join(b"@q%d some words\n" % i + s + b"\n+\n" + b"#" * len(s) + b"\n" for i, s in enumerate(seqs))
+    _same_reads(fq, tmp_path, seqs)
+    _same_reads(fq[:-1], tmp_path)
+    _same_reads(fq.replace(b"\n", b"\r\n"), tmp_path)
+    fa = b"".join(b">a%d\n" % i + b"".join(s[j:j + 61] + b"\n" for j in range(0, len(s), 61)) for i, s in enumerate(seqs))
+    _same_reads(fa, tmp_path, seqs)
+    _same_reads(b">x\n" + b"\n" * 40000 + b"ACGTACGTACGTACGTACGTACGT\n", tmp_path)  # (a newline in every byte of two tiles)
+
+
 def test_random_texts_never_differ_from_the_host_parser(tmp_path):
     """Random mixtures of the building blocks of both formats, regular or not: refused, or equal."""
     rng = np.random.default_rng(11)
