@@ -101,10 +101,10 @@ struct BitIn {
 
 // What the decoder of codes LONGER than a direct table's index needs, in the lane's LDS columns: the first code of length
 // tbits + 1 and the number of codes of every length from there to 15 (`cn_lds`, 16 - tbits entries); the symbols of those codes in
-// canonical order either in LDS too (`sym_lds`: distances and code-length codes, at most 32) or in the lane's scratch row from
+// canonical order either in LDS too (`sym_lds`: distances and code-length codes, at most 30) or in the lane's scratch row from
 // `*long_base` on (literals / lengths).  (With these in global memory a long code cost a dozen dependent loads, and with 64 members
 // to a wavefront three loop turns in four had a lane on that path: 6 us per symbol.)
-constexpr int kSymLds = 32;
+constexpr int kSymLds = 30;  // (a distance alphabet has 30 symbols, the code-length alphabet 19; with 30 a workgroup's LDS is 26 x 512 bytes)
 
 // table entry: symbol | length << 9
 __device__ __forceinline__ uint32_t build_tables(const uint8_t *lens, int nsym, uint16_t *tab /* [1 << tbits][64], this lane's column */, int tbits,

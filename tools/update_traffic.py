@@ -71,6 +71,26 @@ with open(os.path.join(dst, "README.md"), "w") as f:
             "|---|---|---|---|---|---|---|---|---|\n" + "\n".join(rows) + "\n\n"
             "Second half: `chain_config3_kernel_stats.csv` (a run with the `pair_stage` / `engine_both_halves` / `cli_config3_rows` legs), `chain_pmc.txt` "
             "(counters of its largest kernels), `trace_overlap*.txt` (which chain kernels ran beside probe kernels, and what each cost the other).\n")
+    # ---- the reader side: BGZF inflate and the record parser (tools/bgzf_profile.sh) ----
+    lines = []
+    for lv in (1, 6):
+        ks = os.path.join(dst, f"bgzf_level{lv}_kernel_stats.csv")
+        if os.path.exists(ks):
+            for x in csv.DictReader(open(ks)):
+                if "k_bgzf" in x["Name"] or "k_count_newlines" in x["Name"]:
+                    nm = x["Name"].split("(anonymous namespace)::")[-1].split("(")[0] if x["Name"].startswith("(anonymous") else x["Name"].split("(")[0]
+                    lines.append(f"| level {lv} | `{nm}` | {x['Calls']} | {float(x['TotalDurationNs']) / 1e6:.1f} | {float(x['AverageNs']) / 1e6:.2f} | {float(x['MaxNs']) / 1e6:.2f} |")
+    ks = os.path.join(dst, "ingest_kernel_stats.csv")
+    if os.path.exists(ks):
+        for x in csv.DictReader(open(ks)):
+            nm = (x["Name"][len("(anonymous namespace)::"):] if x["Name"].startswith("(anonymous namespace)::") else x["Name"]).split("(")[0]
+            if nm.startswith(("k_nl_", "k_line", "k_fastq", "k_records", "k_gather_lines", "k_pack_reads")):
+                lines.append(f"| parser, 1.2 GB block | `{nm}` | {x['Calls']} | {float(x['TotalDurationNs']) / 1e6:.2f} | {float(x['AverageNs']) / 1e6:.3f} | {float(x['MaxNs']) / 1e6:.3f} |")
+    if lines:
+        f.write("\nReader side (`tools/bgzf_profile.sh`): `bgzf_level{1,6}_kernel_stats.csv` = `rocprofv3 --kernel-trace --stats` of `tools/bgzf_time.py 10 <level>` "
+                "(3 passes over a 10 GB text file in bgzip's container, blocks of 0.4 ... 3.5 GB of text, one launch each; `bgzf_level*_time.txt` = the same run's "
+                "per-block times without the profiler), `ingest_kernel_stats.csv` = the record parser on one 1.2 GB FASTQ block, three times.\n\n"
+                "| run | kernel | calls | total ms | average ms | max ms |\n|---|---|---|---|---|---|\n" + "\n".join(lines) + "\n")
     extra = os.path.join(dst, "NOTES.md")
     if os.path.exists(extra):
         f.write("\n" + open(extra).read())
