@@ -78,7 +78,7 @@ with open(os.path.join(dst, "README.md"), "w") as f:
         if os.path.exists(ks):
             for x in csv.DictReader(open(ks)):
                 if "k_bgzf" in x["Name"] or "k_count_newlines" in x["Name"]:
-                    nm = x["Name"].split("(anonymous namespace)::")[-1].split("(")[0] if x["Name"].startswith("(anonymous") else x["Name"].split("(")[0]
+                    nm = (x["Name"][len("(anonymous namespace)::"):] if x["Name"].startswith("(anonymous namespace)::") else x["Name"]).split("(")[0]
                     lines.append(f"| level {lv} | `{nm}` | {x['Calls']} | {float(x['TotalDurationNs']) / 1e6:.1f} | {float(x['AverageNs']) / 1e6:.2f} | {float(x['MaxNs']) / 1e6:.2f} |")
     ks = os.path.join(dst, "ingest_kernel_stats.csv")
     if os.path.exists(ks):
