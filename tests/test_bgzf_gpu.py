@@ -15,12 +15,12 @@ pytestmark = pytest.mark.gpu
 ACGT = bytes(b"ACGT"[i & 3] for i in range(256))
 
 
-def bgzf(data: bytes, level: int = 6, block: int = 65280, strategy=zlib.Z_DEFAULT_STRATEGY, eof: bool = True) -> bytes:
+def bgzf(data: bytes, level: int = 6, block: int = 65280, strategy=zlib.Z_DEFAULT_STRATEGY, eof: bool = True, mem_level: int = 8) -> bytes:
     """bgzip's container: gzip members of at most 64 KiB of text, each with its compressed size in a `BC` extra field."""
     out = []
     for a in list(range(0, len(data), block)) + ([len(data)] if eof else []):
         chunk = data[a:a + block] if a < len(data) else b""
-        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, mem_level, strategy)
         raw = c.compress(chunk) + c.flush()
         bsize = 12 + 6 + len(raw) + 8
         assert bsize <= 65536
@@ -67,6 +67,53 @@ def test_inflates_to_zlibs_bytes(tmp_path, fastq, kind):
     assert len(blocks) >= 2 and all(b[:1] == b"@" and b[-1:] == b"\n" for b in blocks)  # whole records, every block
     # every block is made of whole four-line records
     assert all(b.count(b"\n") % 4 == 0 for b in blocks)
+
+
+def _fuzz_record(rnd: random.Random, i: int) -> bytes:
+    """a four-line record whose lines are built to reach every path of the decoder: random bases, tandem repeats of every short
+    period (overlapping copies of distance 1 .. 20), long exact repeats (matches of 33 .. 258 bytes), qualities from one repeated
+    byte to all 94 printable characters (literal codes longer than the direct table's 8 bits)"""
+    n = rnd.choice([1, 2, 7, 40, 300, 2000, 9000, 30000])
+    kind = rnd.randrange(5)
+    if kind == 0:
+        seq = rnd.randbytes(n).translate(ACGT)
+    elif kind == 1:
+        unit = rnd.randbytes(rnd.randint(1, 20)).translate(ACGT)
+        seq = (unit * (n // len(unit) + 1))[:n]
+    elif kind == 2:
+        piece = rnd.randbytes(rnd.randint(33, 400)).translate(ACGT)
+        seq = b"".join(piece if rnd.random() < 0.7 else rnd.randbytes(rnd.randint(1, 50)).translate(ACGT) for _ in range(n // len(piece) + 1))[:n]
+    elif kind == 3:
+        seq = bytes(rnd.choice(b"ACGTNacgtn") for _ in range(min(n, 3000)))
+    else:
+        seq = (rnd.randbytes(max(n // 3, 1)).translate(ACGT) * 4)[:n]
+    qk = rnd.randrange(4)
+    if qk == 0:
+        qual = b"#" * len(seq)
+    elif qk == 1:
+        qual = bytes(33 + (b % 94) for b in rnd.randbytes(len(seq)))
+    elif qk == 2:
+        qual = bytes(rnd.choice(b"#+5?I") for _ in range(min(len(seq), 4000))).ljust(len(seq), b"I")
+    else:
+        qual = (bytes(33 + (b % 40) for b in rnd.randbytes(rnd.randint(2, 18))) * (len(seq) // 2 + 1))[:len(seq)]
+    name = b"@r%d" % i + (b" " + bytes(33 + (b % 94) for b in rnd.randbytes(rnd.randint(0, 60))) if rnd.random() < 0.5 else b"")
+    return name + b"\n" + seq + b"\n+\n" + qual + b"\n"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_records_levels_strategies_block_sizes(tmp_path, seed):
+    """what the encoder can do to the stream -- level, strategy, memory level (1: a new deflate block every 128 symbols, dozens of
+    blocks per member), member size -- times what the text can look like: the same bytes as zlib's"""
+    rnd = random.Random(1000 + seed)
+    data = b"".join(_fuzz_record(rnd, i) for i in range(rnd.randint(150, 500)))
+    level = rnd.choice([1, 2, 4, 6, 9])
+    strategy = rnd.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_FIXED])
+    mem_level = rnd.choice([1, 2, 5, 8, 9])
+    block = rnd.choice([65280, 65280, 30000, 4096, 300]) if strategy != zlib.Z_HUFFMAN_ONLY else rnd.choice([30000, 4096, 300])
+    p = tmp_path / "f.fq.gz"
+    p.write_bytes(bgzf(data, level, block, strategy, mem_level=mem_level))
+    got = b"".join(inflate(p, rnd.choice([1 << 20, 1 << 22, 1 << 26]), chunk_kb=rnd.choice([128, 512, 4096])))
+    assert got == data, (level, strategy, mem_level, block)
 
 
 def test_fasta_empty_and_tiny(tmp_path):
