@@ -6,8 +6,9 @@
 //   * the host only walks the headers of a chunk of the file (pread into pinned memory, 18 bytes looked at per member) and hands the
 //     compressed bytes to the device: 3 GB cross PCIe instead of the 20 GB of text they hold;
 //   * k_bgzf_inflate: ONE LANE PER MEMBER.  A lane builds its block's Huffman tables in its own columns of the wave's LDS (lit/len:
-//     8-bit direct table, distances: 7-bit; longer codes by canonical search in a per-lane scratch row) and decodes straight to the
-//     member's place in the text: literals gathered 8 to a store, matches copied 8 bytes at a time from the lane's own output;
+//     8-bit direct table, distances: 7-bit; longer codes by canonical search with its counts in LDS too) and decodes straight to the
+//     member's place in the text: literals gathered 8 to a store, short matches loaded when decoded and stored a turn later, runs
+//     and short periods from a register pattern (see the kernel for the loop's two parts);
 //   * k_bgzf_crc checks every member's CRC-32 (and the decoder its ISIZE and that the block ends where the member does): a damaged
 //     file fails as it does under zlib;
 //   * the text block -- cut where a record ends, the rest carried to the front of the next one -- goes to the record parser of
@@ -59,16 +60,18 @@ enum : uint32_t { kOk = 0, kBadCode = 1, kBadDist = 2, kOverrun = 3, kBadStored 
 #define GS_BGZF_D_BITS 7
 #endif
 #ifndef GS_BGZF_LANES
-#define GS_BGZF_LANES 16
+#define GS_BGZF_LANES 32
 #endif
 #ifndef GS_BGZF_WAVES_EU
-#define GS_BGZF_WAVES_EU 3
+#define GS_BGZF_WAVES_EU 2
 #endif
 #define GS_BGZF_OCC __attribute__((amdgpu_waves_per_eu(GS_BGZF_WAVES_EU)))
 constexpr int kLLBits = GS_BGZF_LL_BITS, kDBits = GS_BGZF_D_BITS;
-// Members per wavefront.  A lane's tables are 834 bytes of LDS, so a CU holds 192 members whatever this is; with 16 to a wave they
-// are 12 waves (three to a SIMD) instead of 3: a wave that waits for memory -- and every turn of the loop does, once -- leaves its
-// SIMD to the others, fewer lanes share a turn's rare paths, and a CU takes new members 16 at a time (3.5 GB block: 52 -> 43 ms).
+// Members per wavefront.  A lane's tables are 832 bytes of LDS, so a CU holds 192 members whatever this is.  Measured on blocks of
+// 2.3 - 3.1 GB (level 1): 64 and 32 members to a wave take 28 ms whatever the block's size -- one wave's own chain of instructions
+// and waits (rocprofv3 --pmc: ~500 instructions and 3.4 L2 requests per symbol, 56 % of the wave-cycles waiting); 16 to a wave take
+// the same for blocks of up to 36 000 members and 45 - 50 ms for 48 000: three waves to a SIMD with a quarter of the lanes live are
+// bound by VALU issue.  32: the smaller workgroup (26 KiB of LDS) finds room beside other kernels sooner than one of 52 KiB.
 constexpr int kLanes = GS_BGZF_LANES;
 constexpr uint16_t kLong = 0xFFFFu, kInvalid = 0xFFFEu;
 constexpr int kScratchBytes = 1408;  // per lane: code lengths (320) + two canonical sets (count / first code / first index / running: 4 x 16 x 2 B each) + sorted symbols (288 + 32) x 2 B
@@ -188,20 +191,27 @@ __device__ unsigned long long g_prof[8];
 // LDS of one workgroup of k_bgzf_inflate (its five arrays)
 constexpr size_t kInflateLdsBytes = (size_t)kLanes * (((size_t)(1 << kLLBits) + (1 << kDBits) + (16 - kLLBits) + (16 - kDBits)) * 2 + kSymLds);
 
+#ifndef GS_BGZF_GROUP
+#define GS_BGZF_GROUP 2
+#endif
+constexpr int kGroup = GS_BGZF_GROUP;  // symbols per fast turn (2, 3 and 4 measure the same: 28 - 31 ms per 3.1 GB block; 2 is the least code)
+
 #ifndef GS_BGZF_FAST_TURNS
 #define GS_BGZF_FAST_TURNS 8
 #endif
 
-// How the loop is laid out, and why.  The 64 members of a wavefront are decoded in lock step, so a loop turn costs the wave every
+// How the loop is laid out, and why.  The members of a wavefront are decoded in lock step, so a loop turn costs the wave every
 // instruction ANY of its lanes needs: with one loop that handles whatever symbol comes (long codes, runs, overlapping copies, block
 // headers), three turns in four had some lane on a rare path and every turn cost ~1000 instructions (3.8 us) -- for lanes that
 // mostly wanted 100.  So the loop has two parts:
-//   * FAST turns (GS_BGZF_FAST_TURNS in a row): a symbol is taken only if all of it is common -- a literal or a match whose codes
-//     are in the direct tables, at most 32 bytes long, not overlapping its own output, not at the very end of the text.  Anything
-//     else leaves the lane's state untouched and the lane sits out the remaining fast turns;
+//   * FAST turns (GS_BGZF_FAST_TURNS in a row), up to GS_BGZF_GROUP symbols each: a symbol is taken only if all of it is common -- a
+//     literal, or a match whose codes are in the direct tables, at most 32 bytes long (16 behind the turn's first symbol), not
+//     overlapping its own output, not reading what this turn has yet to store, not at the very end of the text.  Anything else
+//     leaves the lane's state untouched and the lane sits out the remaining fast turns (or, for the last three, the turn);
 //   * one GENERAL step: the next thing of the lane's stream whatever it is (block header and tables, stored block, any symbol).
-// A fast turn does not wait for memory: the eight input bytes it refills from were asked for a turn earlier (`pre`), and a match's
-// source bytes are asked for when it is decoded and stored when the lane's next store is due (`settle`).
+// A fast turn waits for memory ONCE, at its top: the 32 input bytes it refills from (`P`) and the source bytes of the matches of the
+// turn before were asked for a turn earlier; what they produce is stored then, in stream order (`settle`), and no instruction of the
+// turn's symbol steps needs memory.
 __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *comp, const Member *mem, uint32_t n_members, uint8_t *text, uint8_t *scratch,
                                                      uint32_t *status) {
     __shared__ uint16_t s_ll[1 << kLLBits][kLanes];
@@ -226,16 +236,34 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
     uint8_t *const obase = op, *const oend = op + m.isize;
     uint64_t wbuf = 0;
     uint32_t wn = 0, err = kOk;
-    // a match copied late: its source bytes (up to 32) are asked for when it is decoded, and stored when the lane's next store is
-    // due -- every store of the lane comes after it, so what it writes behind the match's end is overwritten
-    u32x4u pend_a = {0u, 0u, 0u, 0u}, pend_b = {0u, 0u, 0u, 0u};
-    uint8_t *pend_dst = nullptr;
-    uint32_t pend_len = 0;
+    // Stores of a fast turn are made LATE, in stream order, at the top of the next turn (or before any other store of the lane):
+    // slot j = what the turn's j-th symbol left behind -- eight bytes of gathered literals at `lit_at` and / or a match's source
+    // bytes (16; slot 0: 32 if `wide0`), asked for when the match was decoded, for `mat_at`.  Every store of the lane comes after
+    // them, so what a store writes behind its own bytes is overwritten by the next one.
+    constexpr uint32_t kNoAt = 0xFFFFFFFFu;
+    uint32_t lit_at[kGroup], mat_at[kGroup];
+    uint64_t lit_buf[kGroup];
+    u32x4u mat_a[kGroup], mat_b0 = {0u, 0u, 0u, 0u};
+    bool wide0 = false;
+#pragma unroll
+    for (int j = 0; j < kGroup; j++) {
+        lit_at[j] = kNoAt;
+        mat_at[j] = kNoAt;
+        lit_buf[j] = 0;
+        mat_a[j] = mat_b0;
+    }
     auto settle = [&]() {
-        if (pend_dst) {
-            *reinterpret_cast<u32x4u *>(pend_dst) = pend_a;
-            if (pend_len > 16u) *reinterpret_cast<u32x4u *>(pend_dst + 16) = pend_b;
-            pend_dst = nullptr;
+#pragma unroll
+        for (int j = 0; j < kGroup; j++) {
+            if (lit_at[j] != kNoAt) {
+                *reinterpret_cast<u64u *>(obase + lit_at[j]) = lit_buf[j];
+                lit_at[j] = kNoAt;
+            }
+            if (mat_at[j] != kNoAt) {
+                *reinterpret_cast<u32x4u *>(obase + mat_at[j]) = mat_a[j];
+                if (j == 0 && wide0) *reinterpret_cast<u32x4u *>(obase + mat_at[j] + 16) = mat_b0;
+                mat_at[j] = kNoAt;
+            }
         }
     };
     auto flush = [&]() {  // the gathered literals out (the bytes behind them in the store are overwritten by what follows)
@@ -255,92 +283,156 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
     const unsigned long long t_begin = PROF_T();
 #endif
     bool done = false, in_block = false, last = false;
-    uint64_t pre = *reinterpret_cast<const u64u *>(b.ip);  // the eight bytes at b.ip
+    uint64_t P[4];  // the 32 bytes at b.ip, asked for at the end of the turn (or general step) before
+    auto load_pre = [&]() {
+        const u32x4u lo = *reinterpret_cast<const u32x4u *>(b.ip), hi = *reinterpret_cast<const u32x4u *>(b.ip + 16);
+        P[0] = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+        P[1] = (uint64_t)lo.z | ((uint64_t)lo.w << 32);
+        P[2] = (uint64_t)hi.x | ((uint64_t)hi.y << 32);
+        P[3] = (uint64_t)hi.z | ((uint64_t)hi.w << 32);
+    };
+    load_pre();
     while (!done) {
-        // ---- fast turns ----
+        // ---- fast turns: up to kGroup symbols each, one wait for memory at the top ----
+        const unsigned long long t_fast = PROF_T();
+        (void)t_fast;
         if (in_block) {
-            bool go = true;
-            for (int turn = 0; turn < GS_BGZF_FAST_TURNS && go; turn++) {
-                go = false;
-                {  // at least 56 bits (a symbol takes at most 48), from bytes asked for a turn ago
-                    b.bb |= pre << b.bc;
-                    const uint32_t nb = (63u - b.bc) >> 3;
-                    b.ip += nb;
-                    b.bc += nb * 8u;
-                    pre = *reinterpret_cast<const u64u *>(b.ip);
-                }
-                if (b.ip > iend + 8) break;  // (the general step reports it)
-                const uint32_t e = ll[((uint32_t)b.bb & ((1u << kLLBits) - 1u)) * kLanes];
-                if (e >= kInvalid) break;
-                const uint32_t l1 = e >> 9, sym = e & 0x1FFu;
-                if (sym < 256u) {
-                    if (wn == 7u) {
-                        if (op + 8 > oend) break;
-                        settle();
-                        *reinterpret_cast<u64u *>(op) = wbuf | ((uint64_t)sym << 56);
-                        op += 8;
+            bool stay = true;
+            for (int turn = 0; turn < GS_BGZF_FAST_TURNS && stay; turn++) {
+                PROF_ADD(5, 1);
+                settle();
+                const uint32_t turn_lo = (uint32_t)(op - obase);  // what lies behind it is not in memory before the next turn
+                uint32_t poff = 0;                                // bytes of P this turn has taken
+                bool more = true;
+#pragma unroll
+                for (int j = 0; j < kGroup; j++) {
+                    if (!more) continue;
+                    more = false;
+                    {  // at least 56 bits (a symbol takes at most 48)
+                        uint64_t w8;
+                        if (j == 0) {
+                            w8 = P[0];
+                        } else {
+                            const uint32_t kk = poff >> 3, sh = (poff & 7u) * 8u;
+                            const uint64_t lo = kk == 0u ? P[0] : kk == 1u ? P[1] : P[2], hi = kk == 0u ? P[1] : kk == 1u ? P[2] : P[3];
+                            w8 = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+                        }
+                        b.bb |= w8 << b.bc;
+                        const uint32_t nb = (63u - b.bc) >> 3;
+                        poff += nb;
+                        b.ip += nb;
+                        b.bc += nb * 8u;
+                    }
+                    // (leave: the general step takes this symbol -- or reports what is wrong with it)
+                    if (b.ip > iend + 8) {
+                        stay = false;
+                        continue;
+                    }
+                    const uint32_t e = ll[((uint32_t)b.bb & ((1u << kLLBits) - 1u)) * kLanes];
+                    if (e >= kInvalid) {
+                        stay = false;
+                        continue;
+                    }
+                    const uint32_t l1 = e >> 9, sym = e & 0x1FFu;
+                    if (sym < 256u) {
+                        if (wn == 7u) {
+                            if (op + 8 > oend) {
+                                stay = false;
+                                continue;
+                            }
+                            const uint64_t full = wbuf | ((uint64_t)sym << 56);
+                            if (j == 0) {
+                                *reinterpret_cast<u64u *>(op) = full;  // (nothing of this turn is pending yet)
+                            } else {
+                                lit_at[j] = (uint32_t)(op - obase);
+                                lit_buf[j] = full;
+                            }
+                            op += 8;
+                            wbuf = 0;
+                            wn = 0;
+                        } else {
+                            wbuf |= (uint64_t)sym << (8u * wn);
+                            wn++;
+                        }
+                        b.bb >>= l1;
+                        b.bc -= l1;
+                        PROF_ADD(3, 1);
+                        more = true;
+                        continue;
+                    }
+                    const uint32_t c = sym - 257u;
+                    if (c > 28u) {  // (the end of the block, or a code that is not one)
+                        stay = false;
+                        continue;
+                    }
+                    uint64_t t = b.bb >> l1;
+                    uint32_t used = l1, len;
+                    if (c < 8u) {
+                        len = 3u + c;
+                    } else if (c == 28u) {
+                        len = 258u;
+                    } else {
+                        const uint32_t eb = (c >> 2) - 1u;
+                        len = ((4u + (c & 3u)) << eb) + 3u + ((uint32_t)t & ((1u << eb) - 1u));
+                        t >>= eb;
+                        used += eb;
+                    }
+                    const uint32_t e2 = dt[((uint32_t)t & ((1u << kDBits) - 1u)) * kLanes];
+                    if (e2 >= kInvalid) {
+                        stay = false;
+                        continue;
+                    }
+                    const uint32_t l2 = e2 >> 9, ds = e2 & 0x1FFu;
+                    if (ds > 29u) {
+                        stay = false;
+                        continue;
+                    }
+                    t >>= l2;
+                    used += l2;
+                    uint32_t dist;
+                    if (ds < 4u) {
+                        dist = ds + 1u;
+                    } else {
+                        const uint32_t eb = (ds >> 1) - 1u;
+                        dist = ((2u + (ds & 1u)) << eb) + 1u + ((uint32_t)t & ((1u << eb) - 1u));
+                        t >>= eb;
+                        used += eb;
+                    }
+                    uint8_t *const at = op + wn;  // (where the match goes once the gathered literals are out)
+                    const uint32_t at_off = (uint32_t)(at - obase);
+                    if (len > 32u || len > dist || dist > at_off || at + 32 > oend) {
+                        stay = false;
+                        continue;
+                    }
+                    if (j > 0 && (len > 16u || at_off - dist + len > turn_lo)) continue;  // (first symbol of the next turn: more room, nothing pending)
+                    b.bb = t;
+                    b.bc -= used;
+                    if (wn) {
+                        if (j == 0) {
+                            *reinterpret_cast<u64u *>(op) = wbuf;
+                        } else {
+                            lit_at[j] = (uint32_t)(op - obase);
+                            lit_buf[j] = wbuf;
+                        }
                         wbuf = 0;
                         wn = 0;
-                    } else {
-                        wbuf |= (uint64_t)sym << (8u * wn);
-                        wn++;
                     }
-                    b.bb >>= l1;
-                    b.bc -= l1;
-                    PROF_ADD(3, 1);
-                    go = true;
-                    continue;
+                    const uint8_t *src = at - dist;
+                    mat_a[j] = *reinterpret_cast<const u32x4u *>(src);
+                    if (j == 0) {
+                        wide0 = len > 16u;
+                        if (wide0) mat_b0 = *reinterpret_cast<const u32x4u *>(src + 16);
+                    }
+                    mat_at[j] = at_off;
+                    op = at + len;
+                    PROF_ADD(4, 1);
+                    more = true;
                 }
-                const uint32_t c = sym - 257u;
-                if (c > 28u) break;  // (the end of the block, or a code that is not one)
-                uint64_t t = b.bb >> l1;
-                uint32_t used = l1, len;
-                if (c < 8u) {
-                    len = 3u + c;
-                } else if (c == 28u) {
-                    len = 258u;
-                } else {
-                    const uint32_t eb = (c >> 2) - 1u;
-                    len = ((4u + (c & 3u)) << eb) + 3u + ((uint32_t)t & ((1u << eb) - 1u));
-                    t >>= eb;
-                    used += eb;
-                }
-                const uint32_t e2 = dt[((uint32_t)t & ((1u << kDBits) - 1u)) * kLanes];
-                if (e2 >= kInvalid) break;
-                const uint32_t l2 = e2 >> 9, ds = e2 & 0x1FFu;
-                if (ds > 29u) break;
-                t >>= l2;
-                used += l2;
-                uint32_t dist;
-                if (ds < 4u) {
-                    dist = ds + 1u;
-                } else {
-                    const uint32_t eb = (ds >> 1) - 1u;
-                    dist = ((2u + (ds & 1u)) << eb) + 1u + ((uint32_t)t & ((1u << eb) - 1u));
-                    t >>= eb;
-                    used += eb;
-                }
-                uint8_t *const at = op + wn;  // (where the match goes once the gathered literals are out)
-                if (len > 32u || len > dist || dist > (uint32_t)(at - obase) || at + 32 > oend) break;
-                b.bb = t;
-                b.bc -= used;
-                settle();
-                if (wn) {
-                    *reinterpret_cast<u64u *>(op) = wbuf;
-                    wbuf = 0;
-                    wn = 0;
-                }
-                const uint8_t *src = at - dist;
-                pend_a = *reinterpret_cast<const u32x4u *>(src);
-                if (len > 16u) pend_b = *reinterpret_cast<const u32x4u *>(src + 16);
-                pend_dst = at;
-                pend_len = len;
-                op = at + len;
-                PROF_ADD(4, 1);
-                go = true;
+                load_pre();
             }
         }
         // ---- the general step ----
+        PROF_ADD(6, PROF_T() - t_fast);
         PROF_ADD(2, 1);
         b.refill();
         if (b.ip > iend + 8) {  // (a damaged member cannot keep a lane busy beyond its own data)
@@ -376,7 +468,7 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
                 for (uint32_t i = 0; i < len; i++) op[i] = src[i];
                 op += len;
                 b.ip = src + len;
-                pre = *reinterpret_cast<const u64u *>(b.ip);
+                load_pre();
                 continue;
             }
             if (btype == 3) {
@@ -467,7 +559,7 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
             ll_long = cl.sorted + long_ll;
             in_block = true;
             PROF_ADD(1, PROF_T() - t_hdr);
-            pre = *reinterpret_cast<const u64u *>(b.ip);
+            load_pre();
             continue;
         }
         // one symbol, whatever it is
@@ -479,7 +571,6 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
                 sym = e & 0x1FF;
             } else if (e == kLong) {
                 sym = canon_decode<kLLBits, false>(b, cnl, nullptr, ll_long);
-                PROF_ADD(5, 1);
             } else {
                 sym = -1;
             }
@@ -526,7 +617,6 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
                     ds = e & 0x1FF;
                 } else if (e == kLong) {
                     ds = canon_decode<kDBits, true>(b, cnd, dsym, nullptr);
-                    PROF_ADD(7, 1);
                 } else {
                     ds = -1;
                 }
@@ -554,7 +644,6 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
             const uint8_t *src = op - dist;
             uint8_t *const mend = op + len;
             PROF_ADD(4, 1);
-            if (dist < 8u && len > dist) PROF_ADD(6, 1);
             if (dist >= 16u) {
                 while (op + 16 <= mend) {
                     *reinterpret_cast<u32x4u *>(op) = *reinterpret_cast<const u32x4u *>(src);
@@ -599,7 +688,7 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
                 op = mend;
             }
         }
-        pre = *reinterpret_cast<const u64u *>(b.ip);
+        load_pre();
     }
     settle();
     if (err == kOk) {
@@ -1052,8 +1141,8 @@ int gs_bgzf_next(gs_bgzf *z, uint64_t want, gs_textstage **stage) {
             unsigned long long pr[8], zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_prof), sizeof pr);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof zero);
-            fprintf(stderr, "[prof] per member: %.0f ticks in all, %.0f in headers + tables; %.0f loop turns = %.0f literals + %.0f matches (long codes: %.1f literal / length, %.1f distance; %.0f bytes of short-period copies)\n",
-                    (double)pr[0] / nm, (double)pr[1] / nm, (double)pr[2] / nm, (double)pr[3] / nm, (double)pr[4] / nm, (double)pr[5] / nm, (double)pr[7] / nm, (double)pr[6] / nm);
+            fprintf(stderr, "[prof] per member: %.0f ticks (10 ns) in all, %.0f in headers + tables, %.0f in fast turns; %.0f general steps, %.0f fast turns, %.0f literals + %.0f matches\n",
+                    (double)pr[0] / nm, (double)pr[1] / nm, (double)pr[6] / nm, (double)pr[2] / nm, (double)pr[5] / nm, (double)pr[3] / nm, (double)pr[4] / nm);
 #endif
         }
         if (status) {
