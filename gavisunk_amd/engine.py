@@ -343,8 +343,10 @@ class BgzfReader:
 
     def blocks(self, max_bytes: int = 1 << 30) -> Iterator[DeviceText]:
         L = lib()
-        # (a launch inflates 64 MiB of compressed bytes -- ~0.4 GB of text -- or more in ~35-45 ms whatever their number: blocks of
-        # less make no sense; later ones double up to max_bytes)
+        # (a launch inflates 64 MiB of compressed bytes -- ~0.4 GB of text -- or fifty times as much in ~30 ms: blocks of less make no
+        # sense.  The first block is small so that the parser and the tagger start early; the next ones grow eightfold up to
+        # max_bytes -- every block costs the consumer a few synchronisations: 0.73-0.80 s against 0.84-0.93 s with doubling, on the
+        # command line's 20 GB of text; GAVISUNK_BGZF_GROW for experiments)
         want = min(max_bytes, 256 << 20)
         grow = want
         while True:
@@ -352,7 +354,7 @@ class BgzfReader:
             check(L.gs_bgzf_next(self._h, grow, C.byref(st)))
             if st.value:
                 yield DeviceText(st, self.device)
-                want = min(2 * want, max_bytes)
+                want = min(int(os.environ.get("GAVISUNK_BGZF_GROW", "8")) * want, max_bytes)
                 grow = want
             elif L.gs_bgzf_at_end(self._h):
                 return
