@@ -22,6 +22,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -766,6 +767,7 @@ const char *err_text(uint32_t e) {
     }
 }
 
+constexpr size_t kTailPinned = (size_t)1 << 20;
 constexpr size_t kChunk = (size_t)64 << 20;  // compressed bytes read, indexed and handed over at a time (at most)
 
 // members that lie completely in buf[0, n) and whose text fits below text_end: their descriptors (offsets into buf / into the text
@@ -869,6 +871,7 @@ struct gs_bgzf {
     uint8_t *d_rem = nullptr;     // the bytes behind the last block's last whole record
     size_t rem_n = 0, rem_cap = 0;
     std::vector<uint8_t> tail;
+    uint8_t *h_tail = nullptr;  // pinned, kTailPinned bytes
     uint64_t bytes_in = 0, bytes_out = 0;
     bool read_done = false;       // every member of the file is in a slot (or has been inflated)
     bool at_end = false;          // ... and inflated
@@ -897,13 +900,21 @@ int fill_slot(gs_bgzf *z, gs_bgzf::Slot &sl, uint64_t want, uint64_t room, bool 
     }
     std::vector<Member> part;
     size_t per_chunk = 0;  // members of the last chunk: about what the next one holds
+    const bool timing = getenv("GAVISUNK_TIMING") != nullptr;
+    double ms_wait = 0, ms_read = 0, ms_walk = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    const auto t_fill = now();
     while (!z->read_done && sl.text < want && sl.comp_at + z->chunk + 64 <= sl.comp_cap) {
         // (a launch with a few members more than the device keeps resident runs twice as long as one without: 46 ms against 28)
         if (!sl.members.empty() && sl.members.size() + per_chunk > z->members_in_flight && sl.members.size() * 4 >= z->members_in_flight * 3) break;
         const int k = z->hk;
         const uint64_t left = z->file_size - z->file_at;
         const size_t take = (size_t)std::min<uint64_t>(z->chunk, left);
+        auto t0 = now();
         HIP_TRY(hipEventSynchronize(z->h_free[k]));  // (this pinned buffer's last copy has left it)
+        ms_wait += since(t0);
+        t0 = now();
         if (trace) fprintf(stderr, "[bgzf] chunk at %llu: reading %zu bytes\n", (unsigned long long)z->file_at, take);
         {  // four threads read a quarter each (one thread copies out of the page cache at 5-6 GB/s: it would be the whole run)
             constexpr unsigned kMaxReaders = 16;
@@ -937,7 +948,10 @@ int fill_slot(gs_bgzf *z, gs_bgzf::Slot &sl, uint64_t want, uint64_t room, bool 
         part.clear();
         size_t used = 0;
         uint64_t text_bytes = 0;
+        ms_read += since(t0);
+        t0 = now();
         int rc = walk_members(z->h_chunk[k], take, eof, sl.text, room, part, &used, &text_bytes);
+        ms_walk += since(t0);
         if (rc != GS_OK) return rc;
         if (!used) {
             if (sl.text) break;  // (the block is full)
@@ -961,6 +975,9 @@ int fill_slot(gs_bgzf *z, gs_bgzf::Slot &sl, uint64_t want, uint64_t room, bool 
     HIP_TRY(hipEventRecord(sl.copied, z->st_copy));
     sl.filled = true;
     sl.last = z->read_done;
+    if (timing && sl.comp_at)
+        fprintf(stderr, "[gs_bgzf fill] %.1f MB of the file in %.1f ms: %.1f reading (%u threads), %.1f walking member headers, %.1f waiting for a pinned buffer's copy\n",
+                sl.comp_at / 1e6, since(t_fill), ms_read, z->readers, ms_walk, ms_wait);
     return GS_OK;
 }
 }  // namespace
@@ -973,6 +990,7 @@ void gs_bgzf_close(gs_bgzf *z) {
     if (z->st) (void)hipStreamSynchronize(z->st);
     if (z->st_copy) (void)hipStreamSynchronize(z->st_copy);
     if (z->fd >= 0) close(z->fd);
+    if (z->h_tail) (void)hipHostFree(z->h_tail);
     for (int k = 0; k < 2; k++) {
         if (z->h_chunk[k]) (void)hipHostFree(z->h_chunk[k]);
         if (z->h_free[k]) (void)hipEventDestroy(z->h_free[k]);
@@ -1034,6 +1052,7 @@ int gs_bgzf_open(const char *path, int device, gs_bgzf **out) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&z->h_free[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&z->slot[k].copied, hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&z->h_tail), kTailPinned, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreate(&z->ev0);
     if (e == hipSuccess) e = hipEventCreate(&z->ev1);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&z->d_status), sizeof(uint32_t));
@@ -1163,12 +1182,17 @@ int gs_bgzf_next(gs_bgzf *z, uint64_t want, gs_textstage **stage) {
     HIP_TRY(hipStreamSynchronize(z->st));
     uint64_t cut = n;
     if (!z->at_end) {
-        size_t tail_n = (size_t)std::min<uint64_t>(n, (uint64_t)32 << 20);
+        // (the end of the text: 1 MiB through a pinned buffer holds a dozen records of long reads; more only if it does not)
+        size_t tail_n = (size_t)std::min<uint64_t>(n, (uint64_t)kTailPinned);
         for (;;) {
-            z->tail.resize(tail_n);
-            HIP_TRY(hipMemcpyAsync(z->tail.data(), d_text + (n - tail_n), tail_n, hipMemcpyDeviceToHost, z->st));
+            uint8_t *dst = z->h_tail;
+            if (tail_n > kTailPinned || !dst) {
+                z->tail.resize(tail_n);
+                dst = z->tail.data();
+            }
+            HIP_TRY(hipMemcpyAsync(dst, d_text + (n - tail_n), tail_n, hipMemcpyDeviceToHost, z->st));
             HIP_TRY(hipStreamSynchronize(z->st));
-            const uint8_t *t = z->tail.data();
+            const uint8_t *t = dst;
             int64_t at = -1;  // index in the tail of the byte BEHIND the last whole record
             if (first == '>') {  // FASTA: the last record may be incomplete, whatever it ends with: cut in front of its '>' line
                 for (size_t i = tail_n; i-- > 1;)
@@ -1196,7 +1220,7 @@ int gs_bgzf_next(gs_bgzf *z, uint64_t want, gs_textstage **stage) {
                 cut = 0;
                 break;
             }
-            tail_n = (size_t)std::min<uint64_t>(n, (uint64_t)tail_n * 4);
+            tail_n = (size_t)std::min<uint64_t>(n, (uint64_t)tail_n * 16);
         }
     }
     if (cut < n) {
@@ -1236,13 +1260,35 @@ int gs_textstage_names(const gs_textstage *stage, const uint64_t *name_off, cons
         return GS_E_ARG;
     }
     HIP_TRY(hipSetDevice(stage->device));
-    uint64_t *d_no = nullptr, *d_bo = nullptr;
-    uint32_t *d_nl = nullptr;
-    uint8_t *d_blob = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_no), (size_t)n * 8);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_bo), ((size_t)n + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_nl), (size_t)n * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_blob), blob_off[n]);
+    // one device buffer per calling thread, kept between calls (a hipMalloc / hipFree pair per block would synchronise the device
+    // four times -- each time behind the reader thread's inflate kernel)
+    struct Scratch {
+        uint8_t *p = nullptr;
+        size_t cap = 0;
+        int device = -1;
+    };
+    static thread_local Scratch sc;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_bo = up((size_t)n * 8), o_nl = o_bo + up(((size_t)n + 1) * 8), o_blob = o_nl + up((size_t)n * 4), need = o_blob + up(blob_off[n]);
+    hipError_t e = hipSuccess;
+    if (sc.device != stage->device || sc.cap < need) {
+        if (sc.p) {
+            (void)hipSetDevice(sc.device);
+            (void)hipFree(sc.p);
+            (void)hipSetDevice(stage->device);
+        }
+        sc = Scratch();
+        e = hipMalloc(reinterpret_cast<void **>(&sc.p), need + need / 2);
+        if (e == hipSuccess) {
+            sc.cap = need + need / 2;
+            sc.device = stage->device;
+        } else {
+            sc.p = nullptr;
+        }
+    }
+    uint64_t *d_no = reinterpret_cast<uint64_t *>(sc.p), *d_bo = reinterpret_cast<uint64_t *>(sc.p + o_bo);
+    uint32_t *d_nl = reinterpret_cast<uint32_t *>(sc.p + o_nl);
+    uint8_t *d_blob = sc.p + o_blob;
     if (e == hipSuccess) e = hipMemcpy(d_no, name_off, (size_t)n * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_bo, blob_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_nl, name_len, (size_t)n * 4, hipMemcpyHostToDevice);
@@ -1251,10 +1297,6 @@ int gs_textstage_names(const gs_textstage *stage, const uint64_t *name_off, cons
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(blob, d_blob, blob_off[n], hipMemcpyDeviceToHost);
-    (void)hipFree(d_no);
-    (void)hipFree(d_bo);
-    (void)hipFree(d_nl);
-    (void)hipFree(d_blob);
     if (e != hipSuccess) {
         set_error("gs_textstage_names: %s", hipGetErrorString(e));
         return GS_E_NODEVICE;
