@@ -49,12 +49,14 @@ class _Prefetch:
     the first batch is ready when the k-mer list and the location table are, later ones while the GPU tags their
     predecessors.  Errors of the reads file surface where the reference meets them: when the batch is asked for."""
 
-    def __init__(self, path: str, max_bases: int, text: bool = False, device: int = 0):
+    def __init__(self, path: str, max_bases: int, text: bool = False, device: int = 0, bgzf_ok: bool = True):
         """text=True: blocks of the file's text, already copied to the device (engine.text_blocks -> engine.StagedText, for the
-        on-device record parser) instead of parsed batches"""
+        on-device record parser) instead of parsed batches; bgzf_ok=False: a `.gz` is read by the host reader whatever its shape"""
         self._q: queue.Queue = queue.Queue(maxsize=1)
         self._stop = threading.Event()
         self._text, self._device = text, device
+        self._bgzf_ok = bgzf_ok
+        self.used_bgzf = False
         self._t = threading.Thread(target=self._work, args=(path, max_bases), daemon=True)
         self._t.start()
 
@@ -70,13 +72,15 @@ class _Prefetch:
     def _work(self, path, max_bases):
         try:
             bgzf = None
-            if self._text and path.endswith(".gz") and os.environ.get("GAVISUNK_GZ", "device") == "device":
+            if self._text and self._bgzf_ok and path.endswith(".gz") and os.environ.get("GAVISUNK_GZ", "device") == "device":
                 try:  # BGZF (what rustybam fastq-split / bgzip write): the compressed bytes go to the device and are inflated THERE
                     bgzf = engine.BgzfReader(path, self._device)
                 except _lib.GsError as e:
                     if e.status != _lib.GS_E_IRREGULAR:
                         raise
             if bgzf is not None:
+                self.used_bgzf = True
+
                 def inflated():
                     # (blocks of up to 3 GiB of text: ~5e4 members, a lane each, fill the device's wave slots in one launch)
                     it = bgzf.blocks(max_bases if max_bases < (1 << 30) else 3 << 30)
@@ -379,10 +383,27 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
             # the native gzip reader refuses a damaged / truncated .gz (GS_E_IO) or runs out of memory on it (GS_E_NOMEM) where
             # gzip.open raised BadGzipFile, an OSError: the same message and exit code (what was written so far stays, as it
             # does when the reference dies in the middle of a file)
-            if e.status not in (_lib.GS_E_IO, _lib.GS_E_NOMEM):
+            if e.status == _lib.GS_E_IRREGULAR and blocks.used_bgzf:
+                # a file that starts in bgzip's container and goes on as plain gzip members (still a valid gzip file): once more from
+                # the start with the host reader (the output file is opened anew: nothing of the first attempt stays)
+                blocks.close()
+                last_timing.clear()
+                blocks = _Prefetch(reads, min(batch_bases, 1 << 30), text=True, device=device, bgzf_ok=False)
+                try:
+                    rc = _tag_text_blocks(blocks, db, table, ofile, device)
+                except OSError as e2:
+                    sys.stderr.write(f"cannot open the file {reads}: {e2}\n")
+                    rc = 1
+                except _lib.GsError as e2:
+                    if e2.status not in (_lib.GS_E_IO, _lib.GS_E_NOMEM):
+                        raise
+                    sys.stderr.write(f"cannot open the file {reads}: {e2.msg}\n")
+                    rc = 1
+            elif e.status not in (_lib.GS_E_IO, _lib.GS_E_NOMEM):
                 raise
-            sys.stderr.write(f"cannot open the file {reads}: {e.msg}\n")
-            rc = 1
+            else:
+                sys.stderr.write(f"cannot open the file {reads}: {e.msg}\n")
+                rc = 1
         blocks.close()
         if rc is None:
             batches = _Prefetch(reads, batch_bases)

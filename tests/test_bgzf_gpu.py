@@ -189,3 +189,40 @@ def test_command_line_on_a_bgzf_file(tmp_path):
     finally:
         del os.environ["GAVISUNK_BATCH_BASES"], os.environ["GAVISUNK_BGZF_CHUNK_KB"]
     assert (tmp_path / "gz2.sunkpos").read_bytes() == want
+
+
+def test_a_file_that_goes_on_as_plain_gzip(tmp_path):
+    """bgzip members followed by plain gzip members are one valid gzip file: the reader refuses it where the container ends (it
+    never misreads), and the command line starts over with the host reader -- the rows of the plain text."""
+    import gzip
+
+    rng = np.random.default_rng(5)
+    fam = rng.integers(0, 4, 400, dtype=np.uint8)
+    contigs = []
+    for j in range(3):
+        c = rng.integers(0, 4, 50_000, dtype=np.uint8)
+        for at in range(1500, len(c) - 500, 2100):
+            c[at:at + 400] = fam
+        contigs.append(c)
+    (tmp_path / "a.fa").write_bytes(b"".join(b">c%d\n%s\n" % (j, synth.codes_to_ascii(c)) for j, c in enumerate(contigs)))
+    assert define_sunks.main(["-k", "20", str(tmp_path / "a.fa"), "--db", str(tmp_path / "db"), "--loc", str(tmp_path / "loc")]) == 0
+    reads = synth.simulate_reads(rng, contigs, synth.lognormal_lengths(rng, 300, median=7000, sigma=0.6, lo=30, hi=40000))
+    synth.write_fasta(str(tmp_path / "r.fq"), [f"q{i}" for i in range(len(reads))], reads, fastq=True)
+    text = (tmp_path / "r.fq").read_bytes()
+    cut = text.rfind(b"\n@q", 0, len(text) // 2) + 1
+    mixed = bgzf(text[:cut], 6, eof=False) + gzip.compress(text[cut:], 6)
+    assert gzip.decompress(mixed) == text
+    (tmp_path / "m.fq.gz").write_bytes(mixed)
+    with pytest.raises(_lib.GsError) as e:
+        inflate(tmp_path / "m.fq.gz", 1 << 18, chunk_kb=128)
+    assert e.value.status == _lib.GS_E_IRREGULAR
+    os.environ["GAVISUNK_BATCH_BASES"] = "100000"  # (several blocks: rows are written before the container ends)
+    os.environ["GAVISUNK_BGZF_CHUNK_KB"] = "128"
+    try:
+        assert kmerpos_annot3.main([str(tmp_path / "m.fq.gz"), str(tmp_path / "db"), str(tmp_path / "loc"), str(tmp_path / "m.sunkpos")]) == 0
+    finally:
+        del os.environ["GAVISUNK_BATCH_BASES"], os.environ["GAVISUNK_BGZF_CHUNK_KB"]
+    assert kmerpos_annot3.main([str(tmp_path / "r.fq"), str(tmp_path / "db"), str(tmp_path / "loc"), str(tmp_path / "p.sunkpos")]) == 0
+    want = (tmp_path / "p.sunkpos").read_bytes()
+    assert want.count(b"\n") > 100 and (tmp_path / "m.sunkpos").read_bytes() == want
+    assert "read_or_inflate_text" in kmerpos_annot3.last_timing
