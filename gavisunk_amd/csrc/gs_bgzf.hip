@@ -13,8 +13,9 @@
 //     file fails as it does under zlib;
 //   * the text block -- cut where a record ends, the rest carried to the front of the next one -- goes to the record parser of
 //     gs_ingest.hip where it lies: it never exists on the host.
-// Files that are not BGZF (no `BC` field in the first member) are refused with GS_E_IRREGULAR: the caller reads them with the
-// host reader (csrc/gs_inflate.cpp).
+// Files that are not BGZF (no `BC` field in the first member) are refused with GS_E_IRREGULAR at gs_bgzf_open, a member outside
+// the container later in the file with the same status by gs_bgzf_next: the caller reads such files with the host reader
+// (csrc/gs_inflate.cpp), from the start.
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
@@ -206,9 +207,10 @@ constexpr int kGroup = GS_BGZF_GROUP;  // symbols per fast turn (2, 3 and 4 meas
 // headers), three turns in four had some lane on a rare path and every turn cost ~1000 instructions (3.8 us) -- for lanes that
 // mostly wanted 100.  So the loop has two parts:
 //   * FAST turns (GS_BGZF_FAST_TURNS in a row), up to GS_BGZF_GROUP symbols each: a symbol is taken only if all of it is common -- a
-//     literal, or a match whose codes are in the direct tables, at most 32 bytes long (16 behind the turn's first symbol), not
-//     overlapping its own output, not reading what this turn has yet to store, not at the very end of the text.  Anything else
-//     leaves the lane's state untouched and the lane sits out the remaining fast turns (or, for the last three, the turn);
+//     literal, or a match whose codes are in the direct tables, at most 32 bytes long, not overlapping its own output, not at the
+//     very end of the text.  Anything else leaves the lane's state untouched and the lane sits out the remaining fast turns; a
+//     match behind the turn's first symbol that is longer than 16 bytes, or reads what this turn has yet to store, only ends the
+//     turn for the lane (it is the next turn's first symbol);
 //   * one GENERAL step: the next thing of the lane's stream whatever it is (block header and tables, stored block, any symbol).
 // A fast turn waits for memory ONCE, at its top: the 32 input bytes it refills from (`P`) and the source bytes of the matches of the
 // turn before were asked for a turn earlier; what they produce is stored then, in stream order (`settle`), and no instruction of the

@@ -211,7 +211,8 @@ int gs_reads_from_staged_text(const gs_textstage *stage, int k, gs_reads **out, 
  * member inflates straight to the member's place in a text block (CRC-32 and size of every member checked: a damaged file fails
  * with GS_E_IO where zlib fails); the block -- whole records, the rest carried to the next -- goes to gs_reads_from_staged_text
  * where it lies.  gs_bgzf_open: GS_E_IRREGULAR = not a BGZF file (read it with gs_gz_*).  gs_bgzf_next: *stage = NULL at the end
- * of the file, or when not one whole record fit (ask again with a larger `want`). */
+ * of the file, or when not one whole record fit (ask again with a larger `want`); GS_E_IRREGULAR = a member that is not in the
+ * container (a bgzip file with plain gzip members appended: read the file with gs_gz_*, from the start). */
 typedef struct gs_bgzf gs_bgzf;
 int gs_bgzf_open(const char *path, int device, gs_bgzf **out);
 int gs_bgzf_next(gs_bgzf *z, uint64_t want_text_bytes, gs_textstage **stage);
