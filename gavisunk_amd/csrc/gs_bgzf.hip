@@ -648,6 +648,18 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
             uint8_t *const mend = op + len;
             PROF_ADD(4, 1);
             if (dist >= 16u) {
+                if (dist >= 64u) {  // (four loads before their stores: one wait for 64 bytes)
+                    while (op + 64 <= mend) {
+                        const u32x4u c0 = *reinterpret_cast<const u32x4u *>(src), c1 = *reinterpret_cast<const u32x4u *>(src + 16);
+                        const u32x4u c2 = *reinterpret_cast<const u32x4u *>(src + 32), c3 = *reinterpret_cast<const u32x4u *>(src + 48);
+                        *reinterpret_cast<u32x4u *>(op) = c0;
+                        *reinterpret_cast<u32x4u *>(op + 16) = c1;
+                        *reinterpret_cast<u32x4u *>(op + 32) = c2;
+                        *reinterpret_cast<u32x4u *>(op + 48) = c3;
+                        op += 64;
+                        src += 64;
+                    }
+                }
                 while (op + 16 <= mend) {
                     *reinterpret_cast<u32x4u *>(op) = *reinterpret_cast<const u32x4u *>(src);
                     op += 16;
@@ -679,9 +691,22 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
                 // a period of 1 .. 7 bytes (the quality line of `seqtk seq -F '#'`, homopolymers, short tandem repeats): the period
                 // from its own bytes, repeated to fill a register, stored in steps of the largest multiple of the period that fits
                 // -- no load waits for a store of this match
-                uint64_t v = 0;
-                for (uint32_t i = 0; i < dist; i++) v |= (uint64_t)src[i] << (8u * i);
+                uint64_t v;
+                if (src + 8 <= oend) {  // the period's bytes by one load (what it brings behind them is masked away)
+                    v = *reinterpret_cast<const u64u *>(src) & (~0ULL >> (64u - 8u * dist));
+                } else {
+                    v = 0;
+                    for (uint32_t i = 0; i < dist; i++) v |= (uint64_t)src[i] << (8u * i);
+                }
                 for (uint32_t sft = dist; sft < 8u; sft <<= 1) v |= v << (8u * sft);
+                if ((8u % dist) == 0u) {  // periods 1, 2, 4: sixteen bytes to a store (a quality line's 258-byte run: 17 stores)
+                    const uint32_t lo32 = (uint32_t)v, hi32 = (uint32_t)(v >> 32);
+                    const u32x4u v16 = {lo32, hi32, lo32, hi32};
+                    while (op + 16 <= oend && op < mend) {
+                        *reinterpret_cast<u32x4u *>(op) = v16;
+                        op += 16;
+                    }
+                }
                 const uint32_t step = (8u / dist) * dist;
                 while (op + 8 <= oend && op < mend) {
                     *reinterpret_cast<u64u *>(op) = v;
