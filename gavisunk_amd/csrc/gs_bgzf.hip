@@ -295,6 +295,17 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
         P[3] = (uint64_t)hi.z | ((uint64_t)hi.w << 32);
     };
     load_pre();
+    // to at least 56 bits from the bytes of P at offset `poff` (<= 21)
+    auto refill_from_pre = [&](uint32_t &poff) {
+        const uint32_t kk = poff >> 3, sh = (poff & 7u) * 8u;
+        const uint64_t lo = kk == 0u ? P[0] : kk == 1u ? P[1] : P[2], hi = kk == 0u ? P[1] : kk == 1u ? P[2] : P[3];
+        const uint64_t w8 = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+        b.bb |= w8 << b.bc;
+        const uint32_t nb = (63u - b.bc) >> 3;
+        poff += nb;
+        b.ip += nb;
+        b.bc += nb * 8u;
+    };
     while (!done) {
         // ---- fast turns: up to kGroup symbols each, one wait for memory at the top ----
         const unsigned long long t_fast = PROF_T();
@@ -437,7 +448,8 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
         // ---- the general step ----
         PROF_ADD(6, PROF_T() - t_fast);
         PROF_ADD(2, 1);
-        b.refill();
+        uint32_t gpoff = 0;  // bytes of P this step has taken (P: asked for at the end of the last turn or step)
+        refill_from_pre(gpoff);
         if (b.ip > iend + 8) {  // (a damaged member cannot keep a lane busy beyond its own data)
             err = kOverrun;
             break;
@@ -611,7 +623,7 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
                 const uint32_t eb = (c >> 2) - 1u;
                 len = ((4u + (c & 3u)) << eb) + 3u + b.take(eb);
             }
-            b.refill();
+            refill_from_pre(gpoff);
             int ds;
             {
                 const uint16_t e = dt[((uint32_t)b.bb & ((1u << kDBits) - 1u)) * kLanes];
@@ -633,6 +645,25 @@ __global__ __launch_bounds__(64) GS_BGZF_OCC void k_bgzf_inflate(const uint8_t *
             else {
                 const uint32_t eb = ((uint32_t)ds >> 1) - 1u;
                 dist = ((2u + ((uint32_t)ds & 1u)) << eb) + 1u + b.take(eb);
+            }
+            if (len <= 32u && len <= dist && dist <= (uint32_t)(op + wn - obase) && op + wn + 32 <= oend) {
+                // (here because of a long code, not because of the copy: copied late like a fast turn's first match)
+                settle();
+                if (wn) {
+                    *reinterpret_cast<u64u *>(op) = wbuf;
+                    op += wn;
+                    wbuf = 0;
+                    wn = 0;
+                }
+                const uint8_t *src = op - dist;
+                mat_a[0] = *reinterpret_cast<const u32x4u *>(src);
+                wide0 = len > 16u;
+                if (wide0) mat_b0 = *reinterpret_cast<const u32x4u *>(src + 16);
+                mat_at[0] = (uint32_t)(op - obase);
+                op += len;
+                PROF_ADD(4, 1);
+                load_pre();
+                continue;
             }
             flush();
             settle();
