@@ -71,7 +71,7 @@ enum : uint32_t { kOk = 0, kBadCode = 1, kBadDist = 2, kOverrun = 3, kBadStored 
 constexpr int kLLBits = GS_BGZF_LL_BITS, kDBits = GS_BGZF_D_BITS;
 // Members per wavefront.  A lane's tables are 832 bytes of LDS, so a CU holds 192 members whatever this is.  Measured on blocks of
 // 2.3 - 3.1 GB (level 1): 64 and 32 members to a wave take 28 ms whatever the block's size -- one wave's own chain of instructions
-// and waits (rocprofv3 --pmc: ~440 instructions and 3.2 L2 requests per symbol, 62 % of the wave-cycles waiting); 16 to a wave take
+// and waits (rocprofv3 --pmc: ~440 instructions and 3.4 L2 requests per symbol, 57 % of the wave-cycles waiting); 16 to a wave take
 // the same for blocks of up to 36 000 members and 45 - 50 ms for 48 000: three waves to a SIMD with a quarter of the lanes live are
 // bound by VALU issue.  32: the smaller workgroup (26 KiB of LDS) finds room beside other kernels sooner than one of 52 KiB.
 constexpr int kLanes = GS_BGZF_LANES;
