@@ -10,6 +10,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <chrono>
 #include <future>
 #include <string>
@@ -197,16 +198,17 @@ int format_rows(Ctx &c, gs_table *t, gs_reads *r, const gs_locrows *lr, uint32_t
 
 constexpr size_t kPiece = (size_t)32 << 20;
 
+// at < 0: the output has no positions (a pipe, /dev/stdout into one): the bytes go behind what was written before
 bool pwrite_all(int fd, const uint8_t *p, size_t n, off_t at) {
     while (n) {
-        const ssize_t w = pwrite(fd, p, n, at);
+        const ssize_t w = at < 0 ? write(fd, p, n) : pwrite(fd, p, n, at);
         if (w <= 0) {
             if (w < 0 && errno == EINTR) continue;
             return false;
         }
         p += w;
         n -= (size_t)w;
-        at += w;
+        if (at >= 0) at += w;
     }
     return true;
 }
@@ -251,10 +253,13 @@ int gs_rowwriter_rows_device(gs_rowwriter *w, gs_table *t, gs_reads *r, const gs
         set_error("gs_rowwriter_rows_device: write failed");
         return GS_E_IO;
     }
+    // (the reference opens <out> with open(ofile, fmWrite), kmerpos_annot3.nim:80: a pipe or /dev/stdout is as good as a file.  Such an
+    // output has no positions: its pieces are written one after the other, each behind the one before)
     const off_t at0 = ftello(w->f);
     const int fd = fileno(w->f);
-    if (at0 < 0 || fd < 0) {
-        set_error("gs_rowwriter_rows_device: the output is not a seekable file");
+    const bool seekable = at0 >= 0;
+    if (fd < 0 || (!seekable && errno != ESPIPE)) {
+        set_error("gs_rowwriter_rows_device: the output file cannot be written");
         return GS_E_IO;
     }
     // device -> pinned piece -> pwrite on another thread, four pieces in flight
@@ -264,6 +269,7 @@ int gs_rowwriter_rows_device(gs_rowwriter *w, gs_table *t, gs_reads *r, const gs
     uint64_t done = 0;
     for (int k = 0; done < total && rc == GS_OK; k = (k + 1) & 3) {
         if (busy[k].valid()) ok = busy[k].get() && ok;
+        if (!ok) break;  // (a reader that went away, a full disk: no point in formatting on)
         if (!w->pinned[k] && hipHostMalloc(&w->pinned[k], kPiece, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             w->pinned[k] = nullptr;
@@ -280,7 +286,8 @@ int gs_rowwriter_rows_device(gs_rowwriter *w, gs_table *t, gs_reads *r, const gs
             break;
         }
         const uint8_t *src = static_cast<const uint8_t *>(w->pinned[k]);
-        const off_t at = at0 + (off_t)done;
+        const off_t at = seekable ? at0 + (off_t)done : (off_t)-1;
+        if (!seekable && busy[(k + 3) & 3].valid()) ok = busy[(k + 3) & 3].get() && ok;  // (in order: the piece before is out)
         try {
             busy[k] = std::async(std::launch::async, pwrite_all, fd, src, m, at);
         } catch (const std::exception &) {  // (no thread to be had: on this one)
@@ -291,7 +298,7 @@ int gs_rowwriter_rows_device(gs_rowwriter *w, gs_table *t, gs_reads *r, const gs
     for (auto &b : busy)
         if (b.valid()) ok = b.get() && ok;
     if (rc != GS_OK) return rc;
-    if (!ok || fseeko(w->f, at0 + (off_t)total, SEEK_SET) != 0) {
+    if (!ok || (seekable && fseeko(w->f, at0 + (off_t)total, SEEK_SET) != 0)) {
         set_error("gs_rowwriter_rows_device: write failed");
         return GS_E_IO;
     }

@@ -73,3 +73,35 @@ def test_device_text_equals_host_text(tmp_path, kind):
                   for r, p, k in zip(oh["read"].tolist(), oh["pos"].tolist(), oh["row"].tolist()))
     assert exp.encode() == want
     db.close()
+
+
+def test_device_text_into_a_pipe(tmp_path):
+    """<out> may be anything `open(ofile, fmWrite)` takes (kmerpos_annot3.nim:80) -- a FIFO, /dev/stdout into a pipe: an output
+    without positions gets the device-formatted pieces one behind the other; same bytes as into a file, several batches."""
+    import threading
+
+    rng = np.random.default_rng(4)
+    _case(tmp_path, rng, [f"q{i}" for i in range(180)])
+    want = _run(tmp_path, "file.sunkpos")
+    assert want.count(b"\n") > 300
+    fifo = tmp_path / "out.fifo"
+    os.mkfifo(fifo)
+    got = []
+
+    def reader():
+        with open(fifo, "rb") as f:
+            got.append(f.read())
+
+    t = threading.Thread(target=reader, daemon=True)
+    t.start()
+    old = os.environ.get("GAVISUNK_BATCH_BASES")
+    os.environ["GAVISUNK_BATCH_BASES"] = "200000"
+    try:
+        assert kmerpos_annot3.main([str(tmp_path / "r.fq"), str(tmp_path / "db"), str(tmp_path / "loc"), str(fifo)]) == 0
+    finally:
+        if old is None:
+            os.environ.pop("GAVISUNK_BATCH_BASES", None)
+        else:
+            os.environ["GAVISUNK_BATCH_BASES"] = old
+    t.join(timeout=30)
+    assert not t.is_alive() and got and got[0] == want
