@@ -87,6 +87,10 @@ struct RawBuf {  // uninitialised storage (a 230 MB std::vector would be zeroed 
 static bool inflate_whole_file(const char *path, RawBuf &out) {
     const Deflate &lib = deflate_lib();
     if (!lib.ok() || getenv("GAVISUNK_NO_LIBDEFLATE")) return false;
+    // (only a regular file can be opened, measured and opened again: a FIFO or /dev/stdin is read once, by gzopen below, as the
+    // reference's gzopen does)
+    struct stat sb;
+    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode)) return false;
     FILE *fp = fopen(path, "rb");
     if (!fp) return false;
     std::vector<unsigned char> in;
@@ -545,6 +549,10 @@ static uint64_t next_line_start(int fd, uint64_t q, uint64_t n) {
 // the k-mer list (one k-mer per line) parsed by several threads: -> false when not applicable (gzip, small, cannot map)
 static bool parse_db_parallel(const char *path, HugeVec<uint64_t> &codes, int &k) {
     if (getenv("GAVISUNK_LOC_THREADS") && atoi(getenv("GAVISUNK_LOC_THREADS")) <= 1) return false;
+    {  // (a FIFO is read once, by the serial reader: it must not be opened and closed here first)
+        struct stat st0;
+        if (stat(path, &st0) != 0 || !S_ISREG(st0.st_mode)) return false;
+    }
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return false;
     struct stat st;
@@ -609,6 +617,10 @@ static bool parse_db_parallel(const char *path, HugeVec<uint64_t> &codes, int &k
 
 static int parse_loc_parallel(const char *path, gs_sunkdb *d, HugeVec<uint64_t> &row_code, uint64_t *err_line) {
     if (getenv("GAVISUNK_LOC_THREADS") && atoi(getenv("GAVISUNK_LOC_THREADS")) <= 1) return -1;
+    {  // (a FIFO is read once, by the serial reader: it must not be opened and closed here first)
+        struct stat st0;
+        if (stat(path, &st0) != 0 || !S_ISREG(st0.st_mode)) return -1;
+    }
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return -1;
     struct stat st;

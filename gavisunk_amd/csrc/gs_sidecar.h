@@ -22,7 +22,7 @@ struct FileStamp {
 
 bool file_stamp(const char *path, FileStamp *out) {
     struct stat st;
-    if (stat(path, &st) != 0) return false;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return false;  // (what can be read only once has no stamp: no sidecar for it)
     out->size = (uint64_t)st.st_size;
     out->mtime_ns = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
     FILE *f = fopen(path, "rb");

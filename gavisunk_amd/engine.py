@@ -245,6 +245,17 @@ def gz_text_blocks(path: str, max_bytes: int = 1 << 30, threads: int = 0):
         L.gs_gz_close(z)
 
 
+def is_regular_file(path: str) -> bool:
+    """False for what can be read only once (a FIFO, a character device, /dev/stdin into a pipe); True when the path does not
+    exist either: opening it then fails where it always did."""
+    import stat
+
+    try:
+        return stat.S_ISREG(os.stat(path).st_mode)
+    except OSError:
+        return True
+
+
 def text_blocks(path: str, max_bytes: int = 1 << 30) -> Iterator[bytes]:
     """The (decompressed) text of a FASTA / FASTQ file in blocks of whole records, for DeviceReads.from_text: FASTA blocks end
     before a line that starts with '>', FASTQ blocks after a multiple of four lines (the regular four-line form; anything
@@ -254,16 +265,24 @@ def text_blocks(path: str, max_bytes: int = 1 << 30) -> Iterator[bytes]:
 
     import mmap
 
-    with open(path, "rb") as probe:
-        gz = probe.read(2) == b"\x1f\x8b"
-        size = os.fstat(probe.fileno()).st_size
-        if not gz and 0 < size <= max_bytes:  # one block: the file's pages as they are (no copy on the host at all)
-            yield mmap.mmap(probe.fileno(), 0, access=mmap.ACCESS_READ)  # (unmapped when its last user lets go of it)
+    if not is_regular_file(path):
+        # a FIFO, /dev/stdin, a process substitution: opened ONCE and read to its end, as the reference's gzopen does (a second
+        # open would wait for a writer that has gone); gzip through Python's zlib on the one stream
+        f = open(path, "rb", buffering=1 << 20)
+        if f.peek(2)[:2] == b"\x1f\x8b":
+            f = gzip.GzipFile(fileobj=f)
+            f.myfileobj = f.fileobj  # (closed with it)
+    else:
+        with open(path, "rb") as probe:
+            gz = probe.read(2) == b"\x1f\x8b"
+            size = os.fstat(probe.fileno()).st_size
+            if not gz and 0 < size <= max_bytes:  # one block: the file's pages as they are (no copy on the host at all)
+                yield mmap.mmap(probe.fileno(), 0, access=mmap.ACCESS_READ)  # (unmapped when its last user lets go of it)
+                return
+        if gz and os.environ.get("GAVISUNK_GZ", "native") != "python":
+            yield from gz_text_blocks(path, max_bytes)
             return
-    if gz and os.environ.get("GAVISUNK_GZ", "native") != "python":
-        yield from gz_text_blocks(path, max_bytes)
-        return
-    f = gzip.open(path, "rb") if gz else open(path, "rb")
+        f = gzip.open(path, "rb") if gz else open(path, "rb")
     try:
         rem = b""
         while True:

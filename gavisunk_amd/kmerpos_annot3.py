@@ -341,7 +341,9 @@ def _tag_host_batches(batches, db, table, ofile: str, batch_bases: int) -> int:
 
 
 def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_bases: int = 1 << 31) -> int:
-    host_parse = os.environ.get("GAVISUNK_PARSE", "device") == "host"
+    # (a reads "file" that can be read only once -- a FIFO, /dev/stdin -- goes through the host reader: one gzopen, any text shape;
+    # the device parser's route hands texts it does not take back to be read AGAIN)
+    host_parse = os.environ.get("GAVISUNK_PARSE", "device") == "host" or not engine.is_regular_file(reads)
     last_timing.clear()
     t_run = time.perf_counter()
     # (round 5 tried blocking device waits for .gz inputs -- hipDeviceScheduleBlockingSync, to leave the CPUs to the inflate threads: 3 %

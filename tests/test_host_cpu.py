@@ -308,3 +308,66 @@ def test_fuzz_tables_slice(tmp_path, monkeypatch):
             assert err is None, err
     finally:
         os.environ.pop("GAVISUNK_LOC_THREADS", None)
+
+
+def _feed_fifo(path, data):
+    """a writer of `data` on the far side of a new FIFO (a thread: the reader under test opens the near side)"""
+    import threading
+
+    os.mkfifo(path)
+
+    def work():
+        try:
+            with open(path, "wb") as f:
+                f.write(data)
+        except BrokenPipeError:  # (the reader closed early: the test's assertion says so)
+            pass
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    return t
+
+
+@pytest.mark.timeout(120)
+def test_inputs_that_can_be_read_only_once(tmp_path, monkeypatch):
+    """The reference opens each of its inputs once (gzopen / open, kmerpos_annot3.nim:20,44,85): a FIFO or a process substitution
+    is as good as a file.  Reads (plain and gzip, whatever the name ends with) through the host reader and the text-block reader,
+    the k-mer list and the location table above the size where the parallel parsers would open them a second time."""
+    import gzip
+
+    rng = np.random.default_rng(5)
+    seqs = [synth.codes_to_ascii(rng.integers(0, 4, int(n), dtype=np.uint8)) for n in rng.integers(30, 3000, 400)]
+    txt = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, s, b"#" * len(s)) for i, s in enumerate(seqs))
+    for i, (data, name) in enumerate([(txt, "a.fq"), (txt, "b.fq.gz"), (gzip.compress(txt, 1), "c.fq"), (gzip.compress(txt, 1), "d.fq.gz")]):
+        p = str(tmp_path / f"{i}_{name}")
+        t = _feed_fifo(p, data)
+        got = b"".join(bytes(b) for b in engine.text_blocks(p, 100_000))
+        t.join(10)
+        assert got == txt, name
+        p = str(tmp_path / f"{i}_host_{name}")
+        t = _feed_fifo(p, data)
+        n, bases = 0, 0
+        for b in engine.read_batches(p, max_bases=300_000):
+            n += b.n_reads
+            bases += int(b.len.sum())
+            b.close()
+        t.join(10)
+        assert (n, bases) == (len(seqs), sum(len(s) for s in seqs)), name
+    # the two tables: > 4 MiB each (the parallel parsers' threshold)
+    codes = np.unique(rng.integers(0, 1 << 40, 250_000, dtype=np.uint64))
+    kmers = [synth.decode_kmer(int(c), 20) for c in codes.tolist()]
+    db_txt = "".join(k + "\n" for k in kmers).encode()
+    loc_txt = "".join("contig_%d\t%d\t%s\t%d\n" % (i % 3, 7 * i, k, i // 12) for i, k in enumerate(kmers)).encode()
+    assert len(db_txt) > (4 << 20) and len(loc_txt) > (4 << 20)
+    (tmp_path / "db").write_bytes(db_txt)
+    (tmp_path / "loc").write_bytes(loc_txt)
+    want = engine.SunkDB(str(tmp_path / "db"), str(tmp_path / "loc"))
+    t1, t2 = _feed_fifo(str(tmp_path / "db.fifo"), db_txt), _feed_fifo(str(tmp_path / "loc.fifo"), loc_txt)
+    got = engine.SunkDB(str(tmp_path / "db.fifo"), str(tmp_path / "loc.fifo"))
+    t1.join(10)
+    t2.join(10)
+    assert got.k == want.k == 20 and got.contigs == want.contigs
+    assert np.array_equal(got.keys, want.keys) and np.array_equal(got.key_row, want.key_row)
+    assert np.array_equal(got.row_start, want.row_start) and np.array_equal(got.row_group, want.row_group)
+    got.close()
+    want.close()

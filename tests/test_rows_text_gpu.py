@@ -105,3 +105,41 @@ def test_device_text_into_a_pipe(tmp_path):
             os.environ["GAVISUNK_BATCH_BASES"] = old
     t.join(timeout=30)
     assert not t.is_alive() and got and got[0] == want
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_reads_from_a_pipe(tmp_path, gz):
+    """<reads> that can be read only once (a FIFO; the reference's gzopen takes one): the command line reads it through the host
+    reader's single open -- the same rows as from the file, plain and gzip, in several batches."""
+    import gzip
+    import threading
+
+    rng = np.random.default_rng(6)
+    _case(tmp_path, rng, [f"p{i}" for i in range(180)])
+    want = _run(tmp_path, "file.sunkpos")
+    assert want.count(b"\n") > 300
+    data = (tmp_path / "r.fq").read_bytes()
+    fifo = tmp_path / ("in.fq.gz" if gz else "in.fq")
+    os.mkfifo(fifo)
+
+    def feeder():
+        try:
+            with open(fifo, "wb") as f:
+                f.write(gzip.compress(data, 1) if gz else data)
+        except BrokenPipeError:
+            pass
+
+    t = threading.Thread(target=feeder, daemon=True)
+    t.start()
+    old = os.environ.get("GAVISUNK_BATCH_BASES")
+    os.environ["GAVISUNK_BATCH_BASES"] = "200000"
+    try:
+        assert kmerpos_annot3.main([str(fifo), str(tmp_path / "db"), str(tmp_path / "loc"), str(tmp_path / "pipe.sunkpos")]) == 0
+    finally:
+        if old is None:
+            os.environ.pop("GAVISUNK_BATCH_BASES", None)
+        else:
+            os.environ["GAVISUNK_BATCH_BASES"] = old
+    t.join(timeout=30)
+    assert not t.is_alive()
+    assert (tmp_path / "pipe.sunkpos").read_bytes() == want
