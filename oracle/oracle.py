@@ -627,8 +627,9 @@ def process_by_contig(sunkpos_text: str, rlen_text: str, bad_text: str) -> Tuple
 
 
 def badsunks(fai1_text: str, fai2_text: str, sunkpos1_text: str, sunkpos2_text: str) -> set:
-    """badsunks_AR.py:20-103 (PARITY UNPINNED: the script does not run under pandas 2.x, SURVEY.md 8c);
-    restated from the source text.  Returns the set the script writes (in arbitrary order) to <outpath>."""
+    """badsunks_AR.py:20-103, restated from the source text.  Returns the set the script writes (in arbitrary order) to <outpath>.
+    Pinned by tests/golden/badsunks/*: the script's own outputs, run in place under pandas 2.x through a two-function adapter that
+    restores the pandas-1.3 naming it was written for (tests/golden/_shim/pandas13_names.py; tests/test_oracle_golden.py)."""
     from collections import Counter
 
     def one(fai_text, sp_text):

@@ -54,3 +54,29 @@ def test_contig_names_with_colons(tmp_path):
         assert badsunks.main([str(p["f1"]), str(p["f2"]), str(p["s1"]), str(p["s2"]), str(p["out"])]) == 0
         exp = oracle.badsunks(fai1, fai2, sp1, sp2)
         assert p["out"].read_text() == "".join(e + "\n" for e in sorted(exp)) and len(exp) > 5
+
+
+@pytest.mark.parametrize("name", ["synth", "coverage", "amy", "colon_first_part_in_fai", "colon_whole_name_in_fai"])
+def test_matches_the_reference_script(name, tmp_path, capsys):
+    """tests/golden/badsunks/*: what the reference's own badsunks_AR.py wrote for these inputs (make_golden_badsunks.py runs it in
+    place through the pandas-1.3 naming adapter): the same set, the same two "mean coverage" values, the same failure when no
+    SUNK counts as the haplotype's own."""
+    import json
+    import os
+
+    from conftest import ROOT
+
+    d = os.path.join(ROOT, "tests", "golden", "badsunks", name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    argv = [os.path.join(d, n) for n in ("f1", "f2", "s1", "s2")] + [str(tmp_path / "out")]
+    if meta["rc"] != 0:
+        with pytest.raises(SystemExit):
+            badsunks.main(argv)
+        return
+    capsys.readouterr()
+    assert badsunks.main(argv) == 0
+    out = capsys.readouterr().out
+    assert (tmp_path / "out").read_text() == open(os.path.join(d, "expected")).read()
+    ref = open(os.path.join(d, "stdout")).read().splitlines()
+    assert [ln for ln in out.splitlines() if ln.startswith("mean coverage")] == [ln for ln in ref if ln.startswith("mean coverage")]
+    assert out.splitlines()[-1] == ref[-1] == str(meta["n_bad"])

@@ -86,3 +86,27 @@ def test_oracle_config2_full_size_against_reference_binary():
     st, gr = sunks.start[row], sunks.group[row]
     got = [b"r%d\t%d\tctg5M\t%d\t%d" % (a, b, c, e) for a, b, c, e in zip(rd.tolist(), pos.tolist(), st.tolist(), gr.tolist())]
     assert got == want
+
+
+BADSUNKS_CASES = ["synth", "coverage", "amy", "colon_first_part_in_fai", "colon_whole_name_in_fai"]
+
+
+@pytest.mark.parametrize("name", BADSUNKS_CASES)
+def test_badsunks_matches_reference_script(name):
+    """tests/golden/badsunks/*: the output sets of the reference's own badsunks_AR.py (run in place by make_golden_badsunks.py
+    through the pandas-1.3 naming adapter of _shim/pandas13_names.py).  `colon_whole_name_in_fai`: no SUNK counts as this
+    haplotype's (`str.split(":", 1)` looks up the text before the first colon), the script dies on `mode().values[0]`."""
+    import json
+    import os
+
+    from conftest import ROOT
+
+    d = os.path.join(ROOT, "tests", "golden", "badsunks", name)
+    rd = lambda n: open(os.path.join(d, n)).read()  # noqa: E731
+    meta = json.load(open(os.path.join(d, "case.json")))
+    if meta["rc"] != 0:
+        with pytest.raises(ValueError):
+            oracle.badsunks(rd("f1"), rd("f2"), rd("s1"), rd("s2"))
+        return
+    got = sorted(oracle.badsunks(rd("f1"), rd("f2"), rd("s1"), rd("s2")))
+    assert got == rd("expected").splitlines() and len(got) == meta["n_bad"] > 20
