@@ -66,11 +66,13 @@ SIGNATURES = {
     "gs_batch_word_off": (P, [P]),
     "gs_batch_len": (P, [P]),
     "gs_batch_name": (C.c_char_p, [P, U32]),
+    "gs_batch_names": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(U64)]),
     "gs_batch_from_ascii": (I, [P, P, U32, C.POINTER(P)]),
     "gs_rowwriter_open": (I, [C.c_char_p, C.POINTER(P)]),
     "gs_rowwriter_rows": (I, [P, P, U64, P, P, P, P, P]),
     "gs_rowwriter_close": (I, [P, C.POINTER(U64)]),
     "gs_rowwriter_rows_device": (I, [P, P, P, P, U32, P, P, P, P, U32, P]),
+    "gs_rowwriter_rows_device_cuts": (I, [P, P, P, P, U32, P, P, P, P, U32, P, P, U32, P]),
     "gs_gz_open": (I, [C.c_char_p, I, C.POINTER(P)]),
     "gs_gz_read": (I, [P, U64, P, U64, C.POINTER(P), C.POINTER(U64)]),
     "gs_gz_free_buffer": (None, [P]),

@@ -115,15 +115,22 @@ __global__ void k_check_hits(const gs_hit *hits, uint64_t n, uint64_t n_rows, ui
 
 // the formatted rows of the last pass over `r`, in device memory (a pool block: pool_free)
 int format_rows(Ctx &c, gs_table *t, gs_reads *r, const gs_locrows *lr, uint32_t n_contigs, const char *const *contig_names, const uint8_t *names_base,
-                const uint64_t *name_off, const uint32_t *name_len, uint32_t n_names, const gs_batch *batch, uint8_t **d_text_out, uint64_t *n_bytes, uint64_t *n_rows_out) {
+                const uint64_t *name_off, const uint32_t *name_len, uint32_t n_names, const gs_batch *batch, uint8_t **d_text_out, uint64_t *n_bytes, uint64_t *n_rows_out,
+                const uint64_t *row_cuts, uint32_t n_cuts, uint64_t *byte_cuts) {
     *d_text_out = nullptr;
     *n_bytes = 0;
     *n_rows_out = 0;
+    for (uint32_t q = 0; q < n_cuts; q++) byte_cuts[q] = 0;
     const void *d_hits = nullptr;
     uint64_t n = 0;
     const int rc_hits = gs_tag_hits_device(t, r, &d_hits, &n);
     if (rc_hits != GS_OK && rc_hits != GS_E_KEYERROR) return rc_hits;  // (KeyError: the rows before the offending window are the output, kmerpos_annot3.nim:90)
     if (!n) return GS_OK;
+    for (uint32_t q = 0; q < n_cuts; q++)
+        if (row_cuts[q] > n || (q && row_cuts[q] < row_cuts[q - 1])) {
+            set_error("gs_rowwriter_rows_device_cuts: row cuts must ascend and end at or before the pass's %llu rows", (unsigned long long)n);
+            return GS_E_ARG;
+        }
     // the batch's read names and the contig names, back to back, with offsets
     const uint32_t n_reads = name_off ? n_names : (uint32_t)batch->len.size();
     std::vector<uint32_t> noff((size_t)n_reads + 1, 0), coff((size_t)n_contigs + 1, 0);
@@ -180,6 +187,9 @@ int format_rows(Ctx &c, gs_table *t, gs_reads *r, const gs_locrows *lr, uint32_t
     GSC_TRY(exclusive_sum(c, d_len, d_off, n + 1));
     uint64_t total = 0;
     GSC_TRY(c.fetch(&total, d_off + n));
+    for (uint32_t q = 0; q < n_cuts; q++)  // (a handful: the scatter chunks of --emulate-chunks)
+        GSC_HIP(hipMemcpyAsync(byte_cuts + q, d_off + row_cuts[q], sizeof(uint64_t), hipMemcpyDeviceToHost, c.st));
+    if (n_cuts) GSC_TRY(c.sync());
     uint8_t *d_text = static_cast<uint8_t *>(pool_alloc(c.device, std::max<uint64_t>(total, 1)));
     if (!d_text) return GS_E_NOMEM;
     hipLaunchKernelGGL(k_row_write, dim3(blocks_of(n, 64 * kFmtWaves)), dim3(64 * kFmtWaves), 0, c.st, a, d_off, d_text);
@@ -230,7 +240,17 @@ extern "C" {
 // is NULL, `batch`.
 int gs_rowwriter_rows_device(gs_rowwriter *w, gs_table *t, gs_reads *r, const gs_locrows *lr, uint32_t n_contigs, const char *const *contig_names,
                              const uint8_t *names_base, const uint64_t *name_off, const uint32_t *name_len, uint32_t n_names, const gs_batch *batch) {
-    if (!w || !t || !r || !lr || (n_contigs && !contig_names) || (!name_off && !batch) || (name_off && (!names_base || !name_len))) {
+    return gs_rowwriter_rows_device_cuts(w, t, r, lr, n_contigs, contig_names, names_base, name_off, name_len, n_names, batch, nullptr, 0, nullptr);
+}
+
+// ... and where in this call's text given rows start: byte_cuts[i] = bytes of the rows in front of row row_cuts[i] (ascending, at most the
+// pass's row count: that one gives the call's total).  What --emulate-chunks needs: a batch tagged in chunk-major order is written as one
+// text, and every scatter chunk's stretch of it is known (kmerpos_annot3.py run_chunked).
+int gs_rowwriter_rows_device_cuts(gs_rowwriter *w, gs_table *t, gs_reads *r, const gs_locrows *lr, uint32_t n_contigs, const char *const *contig_names,
+                                  const uint8_t *names_base, const uint64_t *name_off, const uint32_t *name_len, uint32_t n_names, const gs_batch *batch,
+                                  const uint64_t *row_cuts, uint32_t n_cuts, uint64_t *byte_cuts) {
+    if (!w || !t || !r || !lr || (n_contigs && !contig_names) || (!name_off && !batch) || (name_off && (!names_base || !name_len)) ||
+        (n_cuts && (!row_cuts || !byte_cuts))) {
         set_error("gs_rowwriter_rows_device: null argument");
         return GS_E_ARG;
     }
@@ -241,7 +261,7 @@ int gs_rowwriter_rows_device(gs_rowwriter *w, gs_table *t, gs_reads *r, const gs
     Ctx c(lr->device);
     uint8_t *d_text = nullptr;
     uint64_t total = 0, n = 0;
-    GSC_TRY(format_rows(c, t, r, lr, n_contigs, contig_names, names_base, name_off, name_len, n_names, batch, &d_text, &total, &n));
+    GSC_TRY(format_rows(c, t, r, lr, n_contigs, contig_names, names_base, name_off, name_len, n_names, batch, &d_text, &total, &n, row_cuts, n_cuts, byte_cuts));
     if (!n) return GS_OK;
     const double ms_format = ms_since(t_start);
     struct Free {

@@ -1162,6 +1162,16 @@ const uint32_t *gs_batch_len(const gs_batch *b) { return b->len.data(); }
 const char *gs_batch_name(const gs_batch *b, uint32_t r) {
     return r < b->name_off.size() ? b->names.data() + b->name_off[r] : nullptr;
 }
+int gs_batch_names(const gs_batch *b, const char **base, const uint64_t **off, uint64_t *bytes) {
+    if (!b || !base || !off || !bytes) {
+        set_error("gs_batch_names: null argument");
+        return GS_E_ARG;
+    }
+    *base = b->names.data();
+    *off = b->name_off.data();
+    *bytes = b->names.size();
+    return GS_OK;
+}
 
 }  // extern "C"
 

@@ -128,6 +128,18 @@ class ReadBatch:
         L = lib()
         return [L.gs_batch_name(self._h, i).decode() for i in range(self.n_reads)]
 
+    def names_blob(self):
+        """-> (bytes of all names as a uint8 view, start of every name uint64[n_reads], length of every name uint32[n_reads]):
+        what RowWriter.write_device takes as `names`, without a Python string per read (gs_batch_names)"""
+        base, off, nb = C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+        check(lib().gs_batch_names(self._h, C.byref(base), C.byref(off), C.byref(nb)))
+        if not self.n_reads or not nb.value:
+            return np.zeros(1, np.uint8), np.zeros(self.n_reads, np.uint64), np.zeros(self.n_reads, np.uint32)
+        blob = _view(base.value, nb.value, np.uint8)
+        o = _view(off.value, self.n_reads, np.uint64)
+        ends = np.append(o[1:], np.uint64(nb.value))
+        return blob, o, (ends - o - np.uint64(1)).astype(np.uint32)  # (every name is followed by its NUL)
+
     @classmethod
     def from_ascii(cls, seqs: Sequence[bytes]) -> "ReadBatch":
         off = np.zeros(len(seqs) + 1, dtype=np.uint64)
@@ -681,19 +693,25 @@ class RowWriter:
         else:
             check(lib().gs_rowwriter_rows(self._h, hits.ctypes.data, len(hits), db._h, None, None, None, reads._h))
 
-    def write_device(self, table: "DeviceTable", reads, locrows: "LocRows", contig_names: Sequence[str], names_of=None, names=None) -> None:
+    def write_device(self, table: "DeviceTable", reads, locrows: "LocRows", contig_names: Sequence[str], names_of=None, names=None, row_cuts=None):
         """The rows of the LAST pass over `reads` (DeviceReads), formatted on the device from its hit list where it lies
         (gs_rowwriter_rows_device).  Read names: from the text block a device-parsed batch came from; names_of: the ReadBatch the
-        reads came from when they were parsed on the host; names: (bytes as uint8 array, offsets uint64, lengths uint32) otherwise."""
+        reads came from when they were parsed on the host; names: (bytes as uint8 array, offsets uint64, lengths uint32) otherwise.
+        row_cuts (ascending row numbers of the pass): -> the bytes of this call's text in front of each of them (uint64 array)."""
         arr = (C.c_char_p * max(len(contig_names), 1))(*[c.encode() for c in contig_names])
         if names is None and getattr(reads, "_name_off", None) is not None:
             names = (np.frombuffer(reads._text, dtype=np.uint8), reads._name_off, reads._name_len)
+        cuts = np.ascontiguousarray(row_cuts if row_cuts is not None else [], np.uint64)
+        out = np.zeros(len(cuts), np.uint64)
+        pc, po = (cuts.ctypes.data, out.ctypes.data) if len(cuts) else (None, None)
         if names is not None:
             base, off, ln = (np.ascontiguousarray(names[0], np.uint8), np.ascontiguousarray(names[1], np.uint64), np.ascontiguousarray(names[2], np.uint32))
-            check(lib().gs_rowwriter_rows_device(self._h, table._h, reads._h, locrows._h, len(contig_names), arr, base.ctypes.data,
-                                                 off.ctypes.data, ln.ctypes.data, len(ln), None))
+            check(lib().gs_rowwriter_rows_device_cuts(self._h, table._h, reads._h, locrows._h, len(contig_names), arr, base.ctypes.data,
+                                                      off.ctypes.data, ln.ctypes.data, len(ln), None, pc, len(cuts), po))
         else:
-            check(lib().gs_rowwriter_rows_device(self._h, table._h, reads._h, locrows._h, len(contig_names), arr, None, None, None, 0, names_of._h))
+            check(lib().gs_rowwriter_rows_device_cuts(self._h, table._h, reads._h, locrows._h, len(contig_names), arr, None, None, None, 0,
+                                                      names_of._h, pc, len(cuts), po))
+        return out if row_cuts is not None else None
 
     def close(self) -> int:
         n = C.c_uint64(0)

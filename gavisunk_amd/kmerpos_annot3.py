@@ -421,6 +421,10 @@ def run(reads: str, kmers: str, locs: str, ofile: str, device: int = 0, batch_ba
 
 
 def run_chunked(reads: str, kmers: str, locs: str, ofile: str, nchunks: int, device: int = 0, batch_bases: int = 1 << 31) -> int:
+    """`--emulate-chunks N`.  Every device batch is tagged once, in chunk-major order; its rows are formatted on the device as ONE
+    text (gs_rowwriter_rows_device_cuts) into a spill file beside <out>, with the stretch of every scatter chunk known; at the end the
+    stretches are copied into <out> chunk by chunk (what `combine_ont` does with the per-chunk files, tagONT.smk:112-131).  Nothing
+    of a pass is held as Python objects per row or per read."""
     import numpy as np
 
     batches = _Prefetch(reads, batch_bases)
@@ -434,39 +438,71 @@ def run_chunked(reads: str, kmers: str, locs: str, ofile: str, nchunks: int, dev
     sys.stderr.write("FINISHED READING LOCS\n")
     table = engine.DeviceTable.from_db(db, device)
     carry = [_lib.GS_NONE] * nchunks          # per chunk: the location its reads so far carry (prevLoc of that chunk's run)
-    texts = [[] for _ in range(nchunks)]
+    pieces = [[] for _ in range(nchunks)]     # per chunk: (offset, bytes) of its stretches in the spill file, in batch order
+    spill = ofile + ".chunks.tmp"
     rec = 0                                   # records seen: record i goes to chunk i mod nchunks
+    at = 0                                    # bytes in the spill file
     rc = 0
-    for batch in batches:
-        n = batch.n_reads
-        chunk_of = (rec + np.arange(n, dtype=np.int64)) % nchunks
-        order = np.argsort(chunk_of, kind="stable").astype(np.uint32)  # chunk-major, file order inside a chunk
-        present = np.unique(chunk_of)
-        starts = np.searchsorted(chunk_of[order], present)              # tagging position of each present chunk's first read
-        dev = engine.DeviceReads.ordered(batch, order, db.k, device)
-        dev.set_seeds(starts, [carry[int(c)] for c in present])
-        st, hits, last, _ = engine.tag(table, dev)
-        seg = dev.segment_carries(table)  # seg[j] = carried up to starts[j] = what chunk present[j-1] carries now
-        for j, c in enumerate(present.tolist()):
-            carry[c] = int(seg[j + 1]) if j + 1 < len(present) else int(last)
-        names = batch.names
-        names_ord = [names[i] for i in order.tolist()]
-        bounds = np.searchsorted(hits["read"], np.append(starts, n))
-        for j, c in enumerate(present.tolist()):
-            texts[c].append(engine.format_sunkpos(hits[bounds[j]:bounds[j + 1]], names_ord, db))
-        dev.close()
-        batch.close()
-        rec += n
-        if st == _lib.GS_E_KEYERROR:
-            sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
-            rc = 1
-            break
-    with open(ofile, "w") as out:
-        for c in range(nchunks):
-            out.write("".join(texts[c]))
-    batches.close()
-    table.close()
-    db.close()
+    lr = None
+    try:
+        with engine.RowWriter(spill) as out:
+            for batch in batches:
+                n = batch.n_reads
+                chunk_of = (rec + np.arange(n, dtype=np.int64)) % nchunks
+                order = np.argsort(chunk_of, kind="stable").astype(np.uint32)  # chunk-major, file order inside a chunk
+                present = np.unique(chunk_of)
+                starts = np.searchsorted(chunk_of[order], present)              # tagging position of each present chunk's first read
+                dev = engine.DeviceReads.ordered(batch, order, db.k, device)
+                dev.set_seeds(starts, [carry[int(c)] for c in present])
+                st, hits, last, _ = engine.tag(table, dev)
+                seg = dev.segment_carries(table)  # seg[j] = carried up to starts[j] = what chunk present[j-1] carries now
+                for j, c in enumerate(present.tolist()):
+                    carry[c] = int(seg[j + 1]) if j + 1 < len(present) else int(last)
+                if len(hits):
+                    if lr is None:
+                        lr = engine.LocRows.from_db(db, device)
+                    blob, off, ln = batch.names_blob()
+                    bounds = np.searchsorted(hits["read"], np.append(starts, n)).astype(np.uint64)  # rows of every present chunk
+                    cuts = out.write_device(table, dev, lr, db.contigs, names=(blob, off[order], ln[order]), row_cuts=bounds)
+                    for j, c in enumerate(present.tolist()):
+                        if cuts[j + 1] > cuts[j]:
+                            pieces[c].append((at + int(cuts[j]), int(cuts[j + 1] - cuts[j])))
+                    at += int(cuts[-1])
+                dev.close()
+                batch.close()
+                rec += n
+                if st == _lib.GS_E_KEYERROR:
+                    sys.stderr.write("Error: unhandled exception: key not found [KeyError]\n")
+                    rc = 1
+                    break
+        with open(ofile, "wb") as dst, open(spill, "rb") as src:
+            for c in range(nchunks):
+                for off_b, n_b in pieces[c]:
+                    while n_b:
+                        try:
+                            m = os.sendfile(dst.fileno(), src.fileno(), off_b, min(n_b, 1 << 30))
+                        except (OSError, AttributeError):
+                            m = 0
+                        if m <= 0:  # (an output sendfile does not take: through a buffer)
+                            src.seek(off_b)
+                            buf = src.read(min(n_b, 1 << 24))
+                            if not buf:
+                                raise OSError("short read of " + spill)
+                            dst.write(buf)
+                            dst.flush()
+                            m = len(buf)
+                        off_b += m
+                        n_b -= m
+    finally:
+        try:
+            os.unlink(spill)
+        except OSError:
+            pass
+        if lr is not None:
+            lr.close()
+        batches.close()
+        table.close()
+        db.close()
     return rc
 
 

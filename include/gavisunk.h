@@ -106,6 +106,8 @@ uint64_t gs_batch_n_words(const gs_batch *b);
 const uint64_t *gs_batch_word_off(const gs_batch *b);
 const uint32_t *gs_batch_len(const gs_batch *b);
 const char *gs_batch_name(const gs_batch *b, uint32_t read);
+/* all names at once: NUL-terminated, back to back from *base; name r starts at (*off)[r]; *bytes = length of the whole blob */
+int gs_batch_names(const gs_batch *b, const char **base, const uint64_t **off, uint64_t *bytes);
 /* A batch from memory: ASCII bases of all reads back to back, off[n_reads+1] in bases.
  * Packing applies the `encode` table above. */
 int gs_batch_from_ascii(const uint8_t *seq, const uint64_t *off, uint32_t n_reads, gs_batch **out);
@@ -340,6 +342,12 @@ struct gs_locrows;
 int gs_rowwriter_rows_device(gs_rowwriter *w, gs_table *t, gs_reads *r, const struct gs_locrows *lr, uint32_t n_contigs,
                              const char *const *contig_names, const uint8_t *names_base, const uint64_t *name_off, const uint32_t *name_len,
                              uint32_t n_names, const gs_batch *batch);
+/* ... and where in this call's text given rows start: byte_cuts[i] = bytes of the rows in front of row row_cuts[i] of the pass
+ * (ascending, at most the pass's row count, which gives the call's total).  For --emulate-chunks (tagONT.smk:2-37,112-131 in one
+ * run): a batch tagged in chunk-major order is written as one text and every scatter chunk's stretch of it is known. */
+int gs_rowwriter_rows_device_cuts(gs_rowwriter *w, gs_table *t, gs_reads *r, const struct gs_locrows *lr, uint32_t n_contigs,
+                                  const char *const *contig_names, const uint8_t *names_base, const uint64_t *name_off, const uint32_t *name_len,
+                                  uint32_t n_names, const gs_batch *batch, const uint64_t *row_cuts, uint32_t n_cuts, uint64_t *byte_cuts);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU: read-sharded tagging, the SUNK table replicated.  One process per GPU; the data plane is

@@ -115,6 +115,19 @@ def test_cli_emulates_the_workflows_scatter_chunks(golden, name, batch_bases, tm
         assert rc == 0 and out.read_text() == c.text(run["out"]), f"{name}: {run['nchunks']} chunks"
 
 
+def test_cli_chunk_emulation_with_one_chunk_is_the_plain_run(golden, tmp_path):
+    """one scatter chunk = the plain command, also when it dies of the reference's KeyError half way (the rows before the
+    offending window are the output, exit code 1), and with names the device formatter takes from the batch's name blob"""
+    for name in ("kat2_missing", "kat1"):
+        c = golden(name)
+        run = c.meta["tag"][0]
+        a, b = tmp_path / f"{name}.plain", tmp_path / f"{name}.chunked"
+        rc_a = kmerpos_annot3.main([c.path(run["reads"]), c.path(run["db"]), c.path(run["loc"]), str(a)])
+        rc_b = kmerpos_annot3.main([c.path(run["reads"]), c.path(run["db"]), c.path(run["loc"]), str(b), "--emulate-chunks", "1"])
+        assert rc_a == rc_b == run["rc"] and a.read_bytes() == b.read_bytes()
+        assert not (tmp_path / f"{name}.chunked.chunks.tmp").exists()
+
+
 @pytest.mark.parametrize("k", [11, 16, 18, 20, 21, 23, 25, 27, 31, 32])
 @pytest.mark.parametrize("seed", [1, 2])
 def test_random_inputs_match_oracle(k, seed):
