@@ -71,6 +71,7 @@ SIGNATURES = {
     "gs_rowwriter_open": (I, [C.c_char_p, C.POINTER(P)]),
     "gs_rowwriter_rows": (I, [P, P, U64, P, P, P, P, P]),
     "gs_rowwriter_close": (I, [P, C.POINTER(U64)]),
+    "gs_rowwriter_rlen": (I, [P, P, U64, C.POINTER(U64)]),
     "gs_rowwriter_rows_device": (I, [P, P, P, P, U32, P, P, P, P, U32, P]),
     "gs_rowwriter_rows_device_cuts": (I, [P, P, P, P, U32, P, P, P, P, U32, P, P, U32, P]),
     "gs_gz_open": (I, [C.c_char_p, I, C.POINTER(P)]),

@@ -1341,6 +1341,89 @@ int gs_rowwriter_rows(gs_rowwriter *w, const gs_hit *hits, uint64_t n, const gs_
     w->rows += n;
     return GS_OK;
 }
+// `name \t len \n` (workflow/src/rlen.nim:13-14) for every record of a block of text that holds WHOLE records in one of the regular
+// forms -- FASTA (a '>' line, then sequence lines up to the next '>' line) or four-line FASTQ ('@' line, sequence, '+' line,
+// qualities as long as the sequence) -- appended to the writer's file.  The block is only scanned (memchr): no packing, no copy of
+// the bases.  Whatever the block-free reader (gs_fastx_*, kseq's rules) might read differently -- a sequence line that starts with
+// '>', '@' or '+', an empty sequence, a quality line of another length, text in front of the first header -- is not guessed at:
+// GS_E_IRREGULAR, and the caller reads the file from its start with gs_fastx_*.  *n_records = records of this block.
+int gs_rowwriter_rlen(gs_rowwriter *w, const uint8_t *text, uint64_t n, uint64_t *n_records) {
+    if (!w || (n && !text)) {
+        set_error("gs_rowwriter_rlen: null argument");
+        return GS_E_ARG;
+    }
+    if (n_records) *n_records = 0;
+    const char *p = reinterpret_cast<const char *>(text), *const e = p + n;
+    // a line [p, le) without its '\n' and a trailing '\r'; q = start of the next line
+    auto line = [&](const char *from, const char *&le, const char *&q) {
+        const char *nl = static_cast<const char *>(memchr(from, '\n', (size_t)(e - from)));
+        le = nl ? nl : e;
+        q = nl ? nl + 1 : e;
+        if (le > from && le[-1] == '\r') le--;
+    };
+    auto irregular = [&](const char *what) {
+        set_error("gs_rowwriter_rlen: %s", what);
+        return GS_E_IRREGULAR;
+    };
+    uint64_t recs = 0;
+    while (p < e) {
+        const char *le, *q;
+        line(p, le, q);
+        if (le == p) {  // (kseq skips empty lines between records)
+            p = q;
+            continue;
+        }
+        const char kind = *p;
+        if (kind != '>' && kind != '@') return irregular("text in front of a record header");
+        const char *nm = p + 1, *ne = nm;
+        while (ne < le && !isspace((unsigned char)*ne)) ne++;
+        p = q;
+        uint64_t len = 0;
+        if (kind == '@') {
+            if (p >= e) return irregular("a FASTQ record without its sequence line");
+            const char *se, *sq;
+            line(p, se, sq);
+            len = (uint64_t)(se - p);
+            if (!len || *p == '>' || *p == '@' || *p == '+') return irregular("a FASTQ sequence line that is empty or starts with > @ +");
+            p = sq;
+            if (p >= e) return irregular("a FASTQ record without its + line");
+            const char *pe, *pq;
+            line(p, pe, pq);
+            if (pe == p || *p != '+') return irregular("a FASTQ record whose third line is no + line (multi-line FASTQ?)");
+            p = pq;
+            const char *qe, *qq;
+            if (p >= e) return irregular("a FASTQ record without its quality line");
+            line(p, qe, qq);
+            if ((uint64_t)(qe - p) != len) return irregular("a FASTQ quality line as long as something else than the sequence");
+            p = qq;
+        } else {
+            while (p < e && *p != '>') {
+                const char *se, *sq;
+                line(p, se, sq);
+                if (se > p && (*p == '@' || *p == '+')) return irregular("a FASTA sequence line that starts with @ or +");
+                len += (uint64_t)(se - p);
+                p = sq;
+            }
+        }
+        const size_t nl = (size_t)(ne - nm), o = w->buf.size();
+        w->buf.resize(o + nl + 32);
+        char *d = w->buf.data() + o;
+        memcpy(d, nm, nl);
+        d += nl;
+        *d++ = '\t';
+        d = put_u64(d, len);
+        *d++ = '\n';
+        w->buf.resize((size_t)(d - w->buf.data()));
+        recs++;
+        if (w->buf.size() > (7u << 20) && !w->flush()) {
+            set_error("gs_rowwriter_rlen: write failed");
+            return GS_E_IO;
+        }
+    }
+    w->rows += recs;
+    if (n_records) *n_records = recs;
+    return GS_OK;
+}
 // flushes and closes; *rows_out = rows written
 int gs_rowwriter_close(gs_rowwriter *w, uint64_t *rows_out) {
     if (!w) return GS_OK;

@@ -713,6 +713,14 @@ class RowWriter:
                                                       names_of._h, pc, len(cuts), po))
         return out if row_cuts is not None else None
 
+    def rlen(self, text: np.ndarray) -> int:
+        """`name \\t len` for every record of a block of whole records in a regular form (gs_rowwriter_rlen); GsError with
+        GS_E_IRREGULAR otherwise.  -> records written"""
+        text = np.ascontiguousarray(text, np.uint8)
+        n = C.c_uint64(0)
+        check(lib().gs_rowwriter_rlen(self._h, text.ctypes.data if len(text) else None, len(text), C.byref(n)))
+        return n.value
+
     def close(self) -> int:
         n = C.c_uint64(0)
         if getattr(self, "_h", None):

@@ -334,6 +334,10 @@ int gs_rowwriter_open(const char *path, gs_rowwriter **out);
 int gs_rowwriter_rows(gs_rowwriter *w, const gs_hit *hits, uint64_t n, const gs_sunkdb *db, const uint8_t *names_base,
                       const uint64_t *name_off, const uint32_t *name_len, const gs_batch *batch);
 int gs_rowwriter_close(gs_rowwriter *w, uint64_t *rows_out);
+/* `name \t len` per record (workflow/src/rlen.nim:13-14, rule read_lengths, tagONT.smk:73) for a block of text holding whole records
+ * in a regular form (FASTA; four-line FASTQ), appended to the writer's file: a scan of the text, nothing packed or copied.
+ * GS_E_IRREGULAR for any text gs_fastx_* (kseq's rules) might read differently: the caller then reads the file with gs_fastx_*. */
+int gs_rowwriter_rlen(gs_rowwriter *w, const uint8_t *text, uint64_t n, uint64_t *n_records);
 /* The same bytes for the rows of the LAST PASS over `r`, whose hit list is still in device memory: measured, placed and written
  * as text by kernels (csrc/gs_format.hip; the loc record of a row is one 16-byte gather from `lr`), the finished text handed to the
  * file in 32 MiB pieces.  Names: (names_base + name_off[read], name_len[read]) for the n_names reads of the batch, or `batch` when

@@ -371,3 +371,51 @@ def test_inputs_that_can_be_read_only_once(tmp_path, monkeypatch):
     assert np.array_equal(got.row_start, want.row_start) and np.array_equal(got.row_group, want.row_group)
     got.close()
     want.close()
+
+
+def test_rlen_scanner_equals_the_record_reader(tmp_path, monkeypatch):
+    """rlen over text blocks (gs_rowwriter_rlen: a scan of names and line lengths) against the record reader with kseq's rules
+    (gs_fastx_*): the same file for every shape; regular shapes are taken by the scanner itself, anything kseq might read differently
+    is handed over (GS_E_IRREGULAR) -- never guessed at."""
+    import gzip
+
+    rng = np.random.default_rng(9)
+    seqs = [synth.codes_to_ascii(rng.integers(0, 4, int(n), dtype=np.uint8)) for n in rng.integers(1, 5000, 300)]
+    fq = b"".join(b"@r%d some comment\n%s\n+\n%s\n" % (i, s, bytes(rng.integers(33, 74, len(s), dtype=np.uint8))) for i, s in enumerate(seqs))
+    fa1 = b"".join(b">c%d\tdesc\n%s\n" % (i, s) for i, s in enumerate(seqs))
+    fa60 = b"".join(b">c%d\n" % i + b"".join(s[a:a + 60] + b"\n" for a in range(0, len(s), 60)) for i, s in enumerate(seqs))
+    regular = {
+        "fq": fq, "fq_crlf": fq.replace(b"\n", b"\r\n"), "fq_no_last_newline": fq[:-1], "fa_one_line": fa1, "fa_60": fa60,
+        "fa_crlf": fa60.replace(b"\n", b"\r\n"), "fa_empty_records": b">a\n>b x\nACGT\n>c\n", "fq_blank_between": fq.replace(b"\n@r7 ", b"\n\n@r7 "),
+        "empty": b"", "fq_gz": gzip.compress(fq * 3, 1), "fq_gz_members": gzip.compress(fq, 6) + gzip.compress(fq, 1),
+    }
+    irregular = {
+        "fq_multiline": b"@a\nACGT\nACGT\n+\nIIIIIIII\n@b\nAC\n+\nII\n", "fq_plus_with_name": None,  # (filled below: `+name` lines are regular)
+        "fq_empty_seq": b"@r\n\n+\n\n@s\nAC\n+\nII\n", "fq_qual_longer": b"@r\nACGT\n+\nIIIIII\n@s\nAC\n+\nII\n",
+        "junk_in_front": b"hello\n" + fq[:2000].rsplit(b"\n@", 1)[0] + b"\n", "fa_then_fq": b">a\nACGT\n@b\nAC\n+\nII\n",
+        "fq_truncated": fq[: len(fq) // 2], "header_mid_line": b"xx>a\nACGT\n>b\nAC\n", "fq_qual_starts_with_at": b"@r\nACGT\n+\n@III\n@s\nAC\n+\n@I\n",
+    }
+    regular["fq_plus_with_name"] = b"".join(b"@r%d\n%s\n+r%d\n%s\n" % (i, s, i, b"#" * len(s)) for i, s in enumerate(seqs[:50]))
+    del irregular["fq_plus_with_name"]
+    regular["fq_qual_starts_with_at"] = irregular.pop("fq_qual_starts_with_at")  # ('@' is a quality value: four-line records stay regular)
+    for name, data in {**regular, **irregular}.items():
+        p = tmp_path / (name + (".fq.gz" if "gz" in name else ".txt"))
+        p.write_bytes(data)
+        monkeypatch.setenv("GAVISUNK_RLEN", "reader")
+        assert rlen.main([str(p), str(tmp_path / "want")]) == 0
+        monkeypatch.delenv("GAVISUNK_RLEN")
+        assert rlen.main([str(p), str(tmp_path / "got")]) == 0
+        want = (tmp_path / "want").read_bytes()
+        assert (tmp_path / "got").read_bytes() == want, name
+        assert rlen._scan(str(p), str(tmp_path / "scan")) == (name in regular), name
+        if name in regular:
+            assert (tmp_path / "scan").read_bytes() == want
+    # blocks smaller than the file: cuts at record ends, every block scanned by itself
+    p = tmp_path / "big.fq"
+    p.write_bytes(fq * 4)
+    with engine.RowWriter(str(tmp_path / "blocks")) as out:
+        n = sum(out.rlen(np.frombuffer(b, dtype=np.uint8)) for b in engine.text_blocks(str(p), 50_000))
+    assert n == 4 * len(seqs)
+    monkeypatch.setenv("GAVISUNK_RLEN", "reader")
+    assert rlen.main([str(p), str(tmp_path / "want")]) == 0
+    assert (tmp_path / "blocks").read_bytes() == (tmp_path / "want").read_bytes()
