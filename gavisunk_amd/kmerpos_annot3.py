@@ -439,7 +439,15 @@ def run_chunked(reads: str, kmers: str, locs: str, ofile: str, nchunks: int, dev
     table = engine.DeviceTable.from_db(db, device)
     carry = [_lib.GS_NONE] * nchunks          # per chunk: the location its reads so far carry (prevLoc of that chunk's run)
     pieces = [[] for _ in range(nchunks)]     # per chunk: (offset, bytes) of its stretches in the spill file, in batch order
-    spill = ofile + ".chunks.tmp"
+    # the spill file: beside <out> (the same file system: what the scatter's per-chunk files would take), or in the temporary
+    # directory when <out> is no regular file (a FIFO, /dev/stdout) or its directory cannot be written to
+    import tempfile
+
+    where = os.path.dirname(os.path.abspath(ofile))
+    if not engine.is_regular_file(ofile) or not os.access(where, os.W_OK):
+        where = tempfile.gettempdir()
+    fd, spill = tempfile.mkstemp(prefix=os.path.basename(ofile) + ".", suffix=".chunks.tmp", dir=where)
+    os.close(fd)
     rec = 0                                   # records seen: record i goes to chunk i mod nchunks
     at = 0                                    # bytes in the spill file
     rc = 0

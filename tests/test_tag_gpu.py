@@ -2,6 +2,8 @@
 golden outputs of the reference's own binary, and the CPU oracle on seeded random inputs."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -125,7 +127,17 @@ def test_cli_chunk_emulation_with_one_chunk_is_the_plain_run(golden, tmp_path):
         rc_a = kmerpos_annot3.main([c.path(run["reads"]), c.path(run["db"]), c.path(run["loc"]), str(a)])
         rc_b = kmerpos_annot3.main([c.path(run["reads"]), c.path(run["db"]), c.path(run["loc"]), str(b), "--emulate-chunks", "1"])
         assert rc_a == rc_b == run["rc"] and a.read_bytes() == b.read_bytes()
-        assert not (tmp_path / f"{name}.chunked.chunks.tmp").exists()
+        assert not [f for f in os.listdir(tmp_path) if f.endswith(".chunks.tmp")]  # (the spill file is gone)
+    # <out> as a FIFO: the spill file goes to the temporary directory, the chunks' stretches are sent into the pipe
+    import threading
+
+    fifo, got = tmp_path / "out.fifo", []
+    os.mkfifo(fifo)
+    t = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()), daemon=True)
+    t.start()
+    assert kmerpos_annot3.main([c.path(run["reads"]), c.path(run["db"]), c.path(run["loc"]), str(fifo), "--emulate-chunks", "1"]) == 0
+    t.join(timeout=30)
+    assert got and got[0] == a.read_bytes()
 
 
 @pytest.mark.parametrize("k", [11, 16, 18, 20, 21, 23, 25, 27, 31, 32])
