@@ -89,4 +89,22 @@ for seed in 1 2 3 4 5 6 7 8 9 10 11 12; do
     tail -1 "$D/t.out"
 done
 unset GAVISUNK_LOC_THREADS
+# ---- rlen's record scanner (gs_rowwriter_rlen) over FASTQ / FASTA texts, truncations and damaged copies of them
+python3 - "$D" <<'PY'
+import os, sys
+import numpy as np
+d = sys.argv[1]
+rng = np.random.default_rng(11)
+lut = np.frombuffer(b"ACGT", np.uint8)
+seqs = [lut[rng.integers(0, 4, int(n), dtype=np.uint8)].tobytes() for n in rng.integers(1, 3000, 300)]
+fq = b"".join(b"@r%d c\n%s\n+\n%s\n" % (i, s, bytes(rng.integers(33, 74, len(s), dtype=np.uint8))) for i, s in enumerate(seqs))
+fa = b"".join(b">c%d\n" % i + b"".join(s[a:a + 60] + b"\n" for a in range(0, len(s), 60)) for i, s in enumerate(seqs))
+for name, t in (("fq", fq), ("fq_crlf", fq.replace(b"\n", b"\r\n")), ("fa", fa), ("fa_crlf", fa.replace(b"\n", b"\r\n")), ("nonl", fq[:-1]), ("empty", b""),
+                ("fq_small", fq[:fq.index(b"@r5 ")]), ("fa_small", fa[:fa.index(b">c12\n")])):  # (whole records: damaged copies of these are taken or refused byte by byte)
+    open(os.path.join(d, "rlen_" + name + ".txt"), "wb").write(t)
+PY
+for f in fq fq_crlf fa fa_crlf nonl empty fq_small fa_small; do
+    "$D/gz_asan_main" --rlen "$D/rlen_$f.txt" 2> "$D/r.err" || { cat "$D/r.err"; exit 1; }
+    if grep -q "ERROR: AddressSanitizer\|runtime error" "$D/r.err"; then cat "$D/r.err"; exit 1; fi
+done
 echo "gz_asan: all clean"

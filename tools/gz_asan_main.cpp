@@ -28,8 +28,59 @@ static int tables(const char *db, const char *loc) {
     return 0;
 }
 
+// `--rlen text`: the record scanner of rlen (gs_rowwriter_rlen) over a text, every one of a few hundred truncations of it and
+// damaged copies (a byte replaced by a newline, '@', '>', '+', '\r' or NUL): it may take a block or refuse it, never read outside it.
+// The copies are exact-size heap blocks, so that one byte beyond the text is a sanitizer report.
+static int rlen_scan(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return 2;
+    std::vector<uint8_t> t;
+    uint8_t buf[1 << 16];
+    for (size_t n; (n = fread(buf, 1, sizeof buf, f)) > 0;) t.insert(t.end(), buf, buf + n);
+    fclose(f);
+    gs_rowwriter *w = nullptr;
+    if (gs_rowwriter_open("/dev/null", &w) != GS_OK) return 2;
+    uint64_t taken = 0, refused = 0, recs = 0, x = 88172645463325252ull;
+    auto rnd = [&] {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    auto run = [&](const uint8_t *p, size_t n) {
+        uint8_t *c = n ? (uint8_t *)malloc(n) : nullptr;
+        if (n) memcpy(c, p, n);
+        uint64_t r = 0;
+        const int rc = gs_rowwriter_rlen(w, c, n, &r);
+        free(c);
+        if (rc == GS_OK) {
+            taken++;
+            recs += r;
+        } else {
+            refused++;
+        }
+    };
+    run(t.data(), t.size());
+    for (int i = 0; i < 400 && !t.empty(); i++) run(t.data(), (size_t)(rnd() % (t.size() + 1)));
+    const size_t head = t.size() < 20000 ? t.size() : 20000;  // (damaged copies of the head: short, many)
+    const uint8_t repl[6] = {'\n', '@', '>', '+', '\r', 0};
+    std::vector<uint8_t> d(t.begin(), t.begin() + (long)head);
+    for (int i = 0; i < 600 && head; i++) {
+        const size_t at = (size_t)(rnd() % head);
+        const uint8_t old = d[at];
+        d[at] = repl[rnd() % 6];
+        run(d.data(), head);
+        d[at] = old;
+    }
+    uint64_t rows = 0;
+    gs_rowwriter_close(w, &rows);
+    printf("ok rlen %s: %llu blocks taken (%llu records), %llu refused\n", path, (unsigned long long)taken, (unsigned long long)recs, (unsigned long long)refused);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc == 4 && !strcmp(argv[1], "--tables")) return tables(argv[2], argv[3]);
+    if (argc == 3 && !strcmp(argv[1], "--rlen")) return rlen_scan(argv[2]);
     if (argc < 4) {
         fprintf(stderr, "usage: gz_asan_main file.gz threads want_bytes\n");
         return 2;
