@@ -419,3 +419,33 @@ def test_rlen_scanner_equals_the_record_reader(tmp_path, monkeypatch):
     monkeypatch.setenv("GAVISUNK_RLEN", "reader")
     assert rlen.main([str(p), str(tmp_path / "want")]) == 0
     assert (tmp_path / "blocks").read_bytes() == (tmp_path / "want").read_bytes()
+
+
+def test_rlen_scanner_fuzz_slice(tmp_path, monkeypatch):
+    """small FASTQ / FASTA texts with random edits (newlines, record markers, CR, blanks, cuts): whenever the scanner takes a text,
+    its file equals the record reader's"""
+    rng = np.random.default_rng(123)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    repl = [b"\n", b"@", b">", b"+", b"\r", b" ", b"\t", b"\n\n", b"", b"\r\n", b"+\n", b"@x\n"]
+    taken = 0
+    for it in range(400):
+        seqs = [lut[rng.integers(0, 4, int(n), dtype=np.uint8)].tobytes() for n in rng.integers(1, 120, int(rng.integers(1, 8)))]
+        if it % 2:
+            t = b"".join(b"@r%d c\n%s\n+\n%s\n" % (i, s, bytes(rng.integers(33, 74, len(s), dtype=np.uint8))) for i, s in enumerate(seqs))
+        else:
+            w = int(rng.choice([0, 30]))
+            t = b"".join(b">c%d d\n" % i + (b"".join(s[a:a + w] + b"\n" for a in range(0, len(s), w)) if w else s + b"\n") for i, s in enumerate(seqs))
+        t = bytearray(t)
+        for _ in range(int(rng.integers(0, 3))):
+            at = int(rng.integers(0, len(t)))
+            t[at:at + 1] = repl[int(rng.integers(0, len(repl)))]
+        if it % 7 == 0:
+            t = t[: int(rng.integers(0, len(t) + 1))]
+        (tmp_path / "x.txt").write_bytes(bytes(t))
+        monkeypatch.setenv("GAVISUNK_RLEN", "reader")
+        assert rlen.main([str(tmp_path / "x.txt"), str(tmp_path / "want")]) == 0
+        monkeypatch.delenv("GAVISUNK_RLEN")
+        if rlen._scan(str(tmp_path / "x.txt"), str(tmp_path / "got")):
+            taken += 1
+            assert (tmp_path / "got").read_bytes() == (tmp_path / "want").read_bytes(), bytes(t)
+    assert 200 < taken < 400
