@@ -424,7 +424,7 @@ def digest(root):
             if f.endswith((".py", ".pyc")) or f == "MD5SUMS":
                 continue
             p = os.path.join(d, f)
-            if os.path.relpath(p, root).startswith(("pair_", "_shim", "config2_full")):  # made by make_golden_pair.py / make_golden_config2.py
+            if os.path.relpath(p, root).startswith(("pair_", "_shim", "config2_full", "badsunks")):  # made by make_golden_pair.py / _config2.py / _badsunks.py
                 continue
             out[os.path.relpath(p, root)] = hashlib.md5(open(p, "rb").read()).hexdigest()
     return out
