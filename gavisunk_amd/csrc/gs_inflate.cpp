@@ -399,8 +399,17 @@ inline int fast_symbols(const BlockCodes &bc, Bits &b, uint16_t *&o, uint16_t *o
         const uint16_t *r = w - dist;  // (behind the 32768 markers a distance never reaches before the buffer)
         if (dist >= 4) {
             for (uint32_t i = 0; i < len; i += 4) memcpy(w + i, r + i, 8);  // (up to 3 symbols of slack past the match: the margin holds them)
+        } else if (dist == 3) {
+            // a period of three symbols: four of the pattern per store, three of them kept (the same slack)
+            const uint64_t v = (uint64_t)r[0] | ((uint64_t)r[1] << 16) | ((uint64_t)r[2] << 32) | ((uint64_t)r[0] << 48);
+            for (uint32_t i = 0; i < len; i += 3) memcpy(w + i, &v, 8);
         } else {
-            for (uint32_t i = 0; i < len; i++) w[i] = r[i];
+            // runs and pairs (the quality line of `seqtk seq -F '#'` is one symbol repeated: half of a read file's text comes
+            // through here, 258 symbols to a match): the pattern from a register, four symbols per store -- symbol by symbol
+            // every load waited for the store before it
+            const uint64_t a = r[0], b = dist == 1 ? a : (uint64_t)r[1];
+            const uint64_t v = a | (b << 16) | (a << 32) | (b << 48);
+            for (uint32_t i = 0; i < len; i += 4) memcpy(w + i, &v, 8);
         }
         w += len;
     }

@@ -168,3 +168,26 @@ def test_bgzf_shaped_files_are_read_in_parallel_and_in_bounded_calls(tmp_path):
     assert b"".join(out) == text and len(text) > 20_000_000
     assert len(sizes) >= 4 and max(sizes) < 16 << 20, sizes  # (calls of about `want`, not one call of everything)
     assert used >= 2 * len(sizes)                             # (several pieces per call: the members were found)
+
+
+def test_runs_and_short_periods(tmp_path, monkeypatch):
+    """matches at distance 1, 2 and 3 (the quality line of `seqtk seq -F '#'`, dinucleotide and trinucleotide repeats) are written
+    from a register pattern, longer periods copied: the same bytes as zlib, whatever the level and the piece size"""
+    rnd = random.Random(7)
+    parts = []
+    for _ in range(30000):
+        k = rnd.randint(0, 4)
+        if k == 0:
+            parts.append(bytes([rnd.randint(33, 120)]) * rnd.randint(1, 600))
+        elif k < 4:
+            parts.append(bytes(rnd.choice(b"ACGT") for _ in range(k + 1 if k < 3 else rnd.randint(4, 9))) * rnd.randint(1, 200))
+        else:
+            parts.append(rnd.randbytes(rnd.randint(1, 50)))
+    data = b"".join(parts)
+    monkeypatch.setenv("GAVISUNK_GZ_PIECE_KB", "128")
+    for lvl in (1, 6, 9):
+        p = tmp_path / f"p{lvl}.gz"
+        p.write_bytes(_gz(data, lvl))
+        for threads in (1, 5):
+            got, used, _ = _inflate(str(p), threads, 1 << 20)
+            assert got == data and (threads == 1 or used > 1), (lvl, threads)
