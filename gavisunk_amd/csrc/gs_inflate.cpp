@@ -1078,6 +1078,14 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                 const size_t m = pc.n_out();
                 uint8_t *o = z->out.data() + base + out_off[c];
                 const uint8_t *w = win[c].data();
+                // a symbol -> its byte by ONE lookup: [0, 256) the byte itself, behind it the window before the piece.  Where the
+                // chain of copies is never cut (FASTA, reads shorter than the window: every base is a copy of an earlier one, back
+                // to the unknown window) nearly every symbol of a piece is a marker, and the test "byte or marker" per symbol
+                // cost more than the lookup
+                std::vector<uint8_t> lut((size_t)kMarker + kWindow);
+                for (uint32_t j = 0; j < kMarker; j++) lut[j] = (uint8_t)j;
+                memcpy(lut.data() + kMarker, w, kWindow);
+                const uint8_t *const lu = lut.data();
                 uint64_t nl = 0;
                 std::vector<SegCrc> &sg = segs[c];
                 size_t seg_lo = 0;
@@ -1094,23 +1102,19 @@ bool inflate_group(gs_gzfile *z, size_t piece_bytes, size_t want_pieces) {
                         for (; k + 16 <= t1; k += 16) {
                             const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k));
                             const __m128i b2 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k + 8));
+                            __m128i bytes;
                             if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(_mm_or_si128(a, b2), hi), _mm_setzero_si128())) != 0xFFFF) {
-                                for (size_t j = k; j < k + 16; j++) {  // a marker among them: one by one
-                                    const uint16_t v = s[j];
-                                    const uint8_t byte = v < kMarker ? (uint8_t)v : w[v - kMarker];
-                                    o[j] = byte;
-                                    nl += byte == '\n';
-                                }
-                                continue;
+                                for (size_t j = k; j < k + 16; j++) o[j] = lu[s[j]];  // a marker among them: sixteen lookups, no test
+                                bytes = _mm_loadu_si128(reinterpret_cast<const __m128i *>(o + k));
+                            } else {
+                                bytes = _mm_packus_epi16(a, b2);
+                                _mm_storeu_si128(reinterpret_cast<__m128i *>(o + k), bytes);
                             }
-                            const __m128i bytes = _mm_packus_epi16(a, b2);
-                            _mm_storeu_si128(reinterpret_cast<__m128i *>(o + k), bytes);
                             nl += (uint64_t)__builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(bytes, nlv)));
                         }
 #endif
                         for (; k < t1; k++) {
-                            const uint16_t v = s[k];
-                            const uint8_t byte = v < kMarker ? (uint8_t)v : w[v - kMarker];
+                            const uint8_t byte = lu[s[k]];
                             o[k] = byte;
                             nl += byte == '\n';
                         }
