@@ -67,7 +67,9 @@ enum : uint32_t { kOk = 0, kBadCode = 1, kBadDist = 2, kOverrun = 3, kBadStored 
 #ifndef GS_BGZF_WAVES_EU
 #define GS_BGZF_WAVES_EU 2
 #endif
+#ifndef GS_BGZF_OCC  // (the CPU stand-in of tools/hip_cpu has no such attribute)
 #define GS_BGZF_OCC __attribute__((amdgpu_waves_per_eu(GS_BGZF_WAVES_EU)))
+#endif
 constexpr int kLLBits = GS_BGZF_LL_BITS, kDBits = GS_BGZF_D_BITS;
 // Members per wavefront.  A lane's tables are 832 bytes of LDS, so a CU holds 192 members whatever this is.  Measured on blocks of
 // 2.3 - 3.1 GB (level 1): 64 and 32 members to a wave take 28 ms whatever the block's size -- one wave's own chain of instructions
@@ -788,6 +790,9 @@ __global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *text, const Memb
     if ((c ^ 0xFFFFFFFFu) != m.crc) atomicCAS(status, 0u, (mi << 4) | kBadCrc);
 }
 
+#ifndef GS_BGZF_NL_BLOCKS
+#define GS_BGZF_NL_BLOCKS 2048  // (a grid-stride kernel: the CPU stand-in of tools/hip_cpu runs it with a handful of blocks)
+#endif
 __global__ void k_count_newlines(const uint8_t *t, uint64_t n, unsigned long long *out) {
     uint32_t mine = 0;
     for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (uint64_t)gridDim.x * blockDim.x * 8) {
@@ -888,7 +893,11 @@ int walk_members(const uint8_t *buf, size_t n, bool at_eof, uint64_t text_at, ui
         if (t + m.isize > text_end) break;  // (the block is full: this member opens the next one)
         m.ooff = (uint32_t)t;
         t += m.isize;
-        if (m.isize) out.push_back(m);  // (the empty end-of-file member carries nothing)
+        // (bgzip's empty end-of-file member -- one empty fixed block, CRC 0 -- carries nothing.  Any other member that CLAIMS to be
+        // empty is decoded like the rest: a damaged ISIZE field over a member full of text must fail as it does under zlib, not
+        // drop the member's text silently)
+        const bool eof_marker = !m.isize && m.clen == 2 && buf[m.coff] == 0x03 && buf[m.coff + 1] == 0x00 && m.crc == 0;
+        if (!eof_marker) out.push_back(m);
         p += bsize;
     }
     *used = p;
@@ -1235,7 +1244,7 @@ int gs_bgzf_next(gs_bgzf *z, uint64_t want, gs_textstage **stage) {
     HIP_TRY(hipMemcpyAsync(&first, d_text, 1, hipMemcpyDeviceToHost, z->st));
     unsigned long long nl = 0;
     HIP_TRY(hipMemsetAsync(z->d_count, 0, sizeof(unsigned long long), z->st));
-    hipLaunchKernelGGL(k_count_newlines, dim3(2048), dim3(256), 0, z->st, d_text, n, z->d_count);
+    hipLaunchKernelGGL(k_count_newlines, dim3(GS_BGZF_NL_BLOCKS), dim3(256), 0, z->st, d_text, n, z->d_count);
     HIP_TRY(hipMemcpyAsync(&nl, z->d_count, sizeof nl, hipMemcpyDeviceToHost, z->st));
     HIP_TRY(hipStreamSynchronize(z->st));
     uint64_t cut = n;
