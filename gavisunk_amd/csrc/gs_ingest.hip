@@ -353,9 +353,10 @@ int gs_text_stage(int device, const uint8_t *text, uint64_t n_bytes, gs_textstag
     st->first = n_bytes ? text[0] : 0;
     const size_t n = st->n;
     if (const char *sk = getenv("GAVISUNK_TEST_STAGE_SKEW")) st->skew = (uint32_t)atoi(sk) & 15u;
-    st->d_text = stage_cache().get(device, n + st->skew, &st->cap);
+    // (+ 16: the line-start kernels read the text in aligned 16-byte chunks, the last of which may end behind the text's last byte)
+    st->d_text = stage_cache().get(device, n + st->skew + 16, &st->cap);
     if (!st->d_text) {
-        st->cap = std::max<size_t>(n + n / 8 + st->skew, 1);  // (a little room: the next block of a file is about this long)
+        st->cap = n + n / 8 + st->skew + 16;  // (a little room: the next block of a file is about this long)
         if (hipMalloc(reinterpret_cast<void **>(&st->d_text), st->cap) != hipSuccess) {
             delete st;
             set_error("gs_text_stage: out of device memory (%zu bytes)", n);

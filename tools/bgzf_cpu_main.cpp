@@ -47,6 +47,7 @@ static bool zlib_text(const char *path, std::string *out) {
 }
 
 int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     int bad = 0;
     for (int a = 1; a < argc; a++) {
         std::string want_text;

@@ -1,5 +1,5 @@
-// CPU stand-in for the slice of the HIP runtime that csrc/gs_bgzf.hip uses -- TEST INFRASTRUCTURE (tools/bgzf_cpu_asan.sh), never part
-// of the product library.  The GPU pool refuses sanitizer runs, and an out-of-bounds access of a kernel on a damaged `.gz` is at
+// CPU stand-in for the slice of the HIP runtime that csrc/gs_bgzf.hip and csrc/gs_ingest.hip use -- TEST INFRASTRUCTURE
+// (tools/bgzf_cpu_asan.sh, tools/ingest_cpu_asan.sh), never part of the product library.  The GPU pool refuses sanitizer runs, and an out-of-bounds access of a kernel on a damaged `.gz` is at
 // best silent there and at worst a fault that resets the node: with this header in front of the real one the SAME source file --
 // its host code and its kernels, unchanged -- compiles as plain C++ (clang++: the kernels use ext_vector_type) and runs under
 // AddressSanitizer + UBSan on the host:
@@ -79,6 +79,8 @@ inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
     memset(d, v, n);
     return hipSuccess;
 }
+inline hipError_t hipMemset(void *d, int v, size_t n) { return hipMemsetAsync(d, v, n, nullptr); }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipMemcpyFromSymbol(void *d, const void *sym, size_t n) {
     memcpy(d, sym, n);
     return hipSuccess;
@@ -184,21 +186,51 @@ void launch(K kernel, dim3 grid, dim3 block, A... args) {
 
 inline void __syncthreads() { hip_cpu::cur->sync(); }
 // (every thread of the block that has not returned takes part: the kernels here shuffle before any thread leaves)
-inline int __shfl_xor(int v, int lane_mask, int width = 64) {
+template <typename T, typename F>
+inline T hip_cpu_exchange(T v, F partner_of) {
+    static_assert(sizeof(T) <= 8, "32- and 64-bit values");
     hip_cpu::Block &b = *hip_cpu::cur;
     const unsigned me = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
-    b.xch[me] = (uint64_t)(uint32_t)v;
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    b.xch[me] = bits;
     b.sync();
-    const unsigned partner = (me & ~(unsigned)(width - 1)) | ((me ^ (unsigned)lane_mask) & (unsigned)(width - 1));
-    const int r = partner < b.threads ? (int)(uint32_t)b.xch[partner] : v;
+    const unsigned partner = partner_of(me);
+    T r = v;
+    if (partner < b.threads) memcpy(&r, &b.xch[partner], sizeof(T));
     b.sync();
     return r;
 }
+template <typename T>
+inline T __shfl_xor(T v, int lane_mask, int width = 64) {
+    return hip_cpu_exchange(v, [=](unsigned me) { return (me & ~(unsigned)(width - 1)) | ((me ^ (unsigned)lane_mask) & (unsigned)(width - 1)); });
+}
+template <typename T>
+inline T __shfl_up(T v, unsigned delta, int width = 64) {  // (a lane below `delta` keeps its own value)
+    return hip_cpu_exchange(v, [=](unsigned me) { return (me & (unsigned)(width - 1)) >= delta ? me - delta : me; });
+}
+inline int __popc(uint32_t v) { return __builtin_popcount(v); }
+inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
+struct alignas(16) uint4 {
+    uint32_t x, y, z, w;
+};
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 inline uint32_t __brev(uint32_t v) { return __builtin_bitreverse32(v); }
 inline unsigned long long wall_clock64() { return 0; }
 template <typename T>
 inline T atomicAdd(T *p, T v) {
     return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
+template <typename T>
+inline T atomicOr(T *p, T v) {
+    return __atomic_fetch_or(p, v, __ATOMIC_RELAXED);
+}
+template <typename T>
+inline T atomicMax(T *p, T v) {
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return old;
 }
 inline uint32_t atomicCAS(uint32_t *p, uint32_t expect, uint32_t v) {
     __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
