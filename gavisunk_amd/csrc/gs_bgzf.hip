@@ -1320,7 +1320,13 @@ int gs_textstage_names(const gs_textstage *stage, const uint64_t *name_off, cons
         return GS_E_ARG;
     }
     blob_off[0] = 0;
-    for (uint32_t i = 0; i < n; i++) blob_off[i + 1] = blob_off[i] + name_len[i];
+    for (uint32_t i = 0; i < n; i++) {
+        if (name_off[i] > stage->n || name_len[i] > stage->n - name_off[i]) {  // (the kernel below trusts them)
+            set_error("gs_textstage_names: name %u lies outside the staged text (%u bytes)", i, stage->n);
+            return GS_E_ARG;
+        }
+        blob_off[i + 1] = blob_off[i] + name_len[i];
+    }
     if (!n || !blob_off[n]) return GS_OK;
     if (!blob) {
         set_error("gs_textstage_names: null argument");
